@@ -1,0 +1,216 @@
+/*
+ * scarlet_amd.h -- C ABI of libscarlet_amd.so, the MI355X (gfx950) back end for
+ * the proximal-gradient fitting loop of pmelchior/scarlet.
+ *
+ * Plain C: pointers, sizes, POD structs.  All functions return 0 on success or a
+ * negative smi_status; smi_last_error() gives the message of the last failure on
+ * the calling thread.  Host pointers unless a parameter is named d_* (device).
+ * Handles are not thread-safe; one smi_batch lives on one GPU.
+ *
+ * The entry points replace these reference interfaces (paths relative to the
+ * reference checkout):
+ *
+ *   seam 1  scarlet/operators_pybind11.cc:234-260  (pybind11 module
+ *           `scarlet.operators_pybind11`, called from scarlet/operator.py:54-58
+ *           and scarlet/renderer.py:108-116)
+ *             prox_weighted_monotonic  -> smi_prox_weighted_monotonic_{f32,f64}
+ *             apply_filter             -> smi_apply_filter_{f32,f64}
+ *
+ *   seam 2  the optimizer call in scarlet/blend.py:165-180
+ *           (proxmin.adaprox(X, grad, step, prox=..., scheme="amsgrad",
+ *           prox_max_iter=10, M=, V=, Vhat=) together with the closures it is
+ *           given: Blend._loss_func blend.py:259-274, Blend.get_model
+ *           blend.py:200-244, Observation.get_log_likelihood
+ *           observation.py:147-170, ConvolutionRenderer renderer.py:247-259,
+ *           ConstraintChain constraint.py:76-80)
+ *             -> smi_batch_* : the same loop for a batch of independent blends,
+ *                resident on the device.
+ */
+#ifndef SCARLET_AMD_H
+#define SCARLET_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum smi_status {
+    SMI_OK = 0,
+    SMI_ERR_INVALID = -1,   /* bad argument (shape, NULL, out of range)            */
+    SMI_ERR_HIP = -2,       /* HIP runtime / rocFFT failure                        */
+    SMI_ERR_NO_DEVICE = -3, /* no usable GPU                                       */
+    SMI_ERR_ARITHMETIC = -4 /* a parameter became non-finite (model.py:153-165)    */
+} smi_status;
+
+const char *smi_last_error(void);
+int smi_device_count(void);
+/* "scarlet_amd <version> gfx950" */
+const char *smi_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * Seam 1: operators_pybind11 drop-ins.  Caller owns all buffers; flat_img and
+ * result are modified in place, like the Eigen::Ref arguments of the reference.
+ * ------------------------------------------------------------------------- */
+
+/* operators_pybind11.cc:14-36.  flat_img[n_pix]; weights[n_off][n_pix] row major;
+ * offsets[n_off]; dist_idx[n_idx] = sweep order (peak excluded).  Sequential
+ * (Gauss-Seidel) semantics are preserved exactly: the device kernel walks the
+ * levels of the dependency graph, which yields bit-identical results. */
+int smi_prox_weighted_monotonic_f32(float *flat_img, const float *weights,
+                                    const int32_t *offsets, int32_t n_off,
+                                    const int32_t *dist_idx, int32_t n_idx,
+                                    int32_t n_pix, float min_gradient);
+int smi_prox_weighted_monotonic_f64(double *flat_img, const double *weights,
+                                    const int32_t *offsets, int32_t n_off,
+                                    const int32_t *dist_idx, int32_t n_idx,
+                                    int32_t n_pix, double min_gradient);
+
+/* operators_pybind11.cc:39-56.  image[H][W], result[H][W]; taps given as in the
+ * reference: values[n_taps] and the four slice-bound vectors. */
+int smi_apply_filter_f32(const float *image, int32_t H, int32_t W,
+                         const float *values, int32_t n_taps,
+                         const int32_t *y_start, const int32_t *y_end,
+                         const int32_t *x_start, const int32_t *x_end,
+                         float *result);
+int smi_apply_filter_f64(const double *image, int32_t H, int32_t W,
+                         const double *values, int32_t n_taps,
+                         const int32_t *y_start, const int32_t *y_end,
+                         const int32_t *x_start, const int32_t *x_end,
+                         double *result);
+
+/* ------------------------------------------------------------------------- *
+ * Seam 2: batched proximal-gradient fit.
+ * ------------------------------------------------------------------------- */
+
+typedef struct smi_batch smi_batch;
+
+/* prox chain of a morphology (morphology.py:644-670): bit flags */
+enum {
+    SMI_PROX_MONOTONIC = 1,  /* MonotonicityConstraint (constraint.py:183-234)  */
+    SMI_PROX_SYMMETRY = 2,   /* SymmetryConstraint (constraint.py:262-273)      */
+    SMI_PROX_POSITIVE = 4,   /* PositivityConstraint (constraint.py:83-92)      */
+    SMI_PROX_CENTER_ON = 8,  /* CenterOnConstraint (constraint.py:276-287)      */
+    SMI_PROX_NORM_MAX = 16,  /* NormalizationConstraint("max") (95-114)         */
+    SMI_PROX_NORM_SUM = 32,  /* NormalizationConstraint("sum")                  */
+    SMI_PROX_L1 = 64,        /* L1Constraint -> proxmin prox_soft (134-145)     */
+    SMI_PROX_L0 = 128        /* L0Constraint -> proxmin prox_hard (117-130)     */
+};
+#define SMI_PROX_EXTENDED_SOURCE \
+    (SMI_PROX_MONOTONIC | SMI_PROX_POSITIVE | SMI_PROX_CENTER_ON | SMI_PROX_NORM_MAX)
+
+typedef struct smi_batch_desc {
+    int32_t n_blends;     /* independent scenes in the batch                       */
+    int32_t C, H, W;      /* model frame = observed frame (bands, rows, columns)   */
+    int32_t n_components; /* total over all blends                                 */
+    int32_t kernel_h;     /* difference-kernel stamp; 0 => NullRenderer            */
+    int32_t kernel_w;
+    int32_t kernel_bands; /* 1 (band shared) or C                                  */
+    int32_t kernel_per_blend; /* 0: one kernel set for the whole batch, 1: per blend */
+    int32_t fft_h;        /* FFT shape; 0 => reference rule fft.py:116-167         */
+    int32_t fft_w;
+    int32_t max_iter;     /* capacity of the per-blend loss history                */
+} smi_batch_desc;
+
+/* per component, all arrays of length n_components unless noted */
+typedef struct smi_components {
+    const int32_t *blend;       /* owning blend, non-decreasing                     */
+    const int32_t *origin_y;    /* box origin in frame pixels (may be negative)     */
+    const int32_t *origin_x;
+    const int32_t *box_h;
+    const int32_t *box_w;
+    const float *sed;           /* [n_components][C]                                */
+    const float *morph;         /* boxes packed back to back, row major             */
+    const float *sed_min_step;  /* [n_components][C]  (spectrum.py:56)              */
+    const float *sed_rel_step;  /* relative_step factor, 1e-2 in the reference      */
+    const float *morph_step;    /* constant step, 1e-2 (morphology.py:670)          */
+    const int32_t *prox_flags;  /* SMI_PROX_* of the morphology                     */
+    const int32_t *sweep_plan;  /* index into the plans added with                  */
+                                /* smi_batch_add_sweep_plan, -1 if not monotonic    */
+    const float *min_gradient;  /* MonotonicityConstraint.min_gradient              */
+    const float *l_thresh;      /* threshold for SMI_PROX_L1/L0 (absolute)          */
+    const float *morph_rel_step;/* step = max(morph_step, rel * mean(morph)); NULL=0 */
+                                /* (relative_step, parameter.py:126-129)            */
+} smi_components;
+
+int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out);
+int smi_batch_destroy(smi_batch *b);
+
+/* Monotonic operator tables exactly as operator.prox_weighted_monotonic binds them
+ * (operator.py:62-96): weights[8][h*w] (float64), offsets[8], dist_idx[n_idx].
+ * Returns the plan index (>= 0) or a negative status. */
+int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w,
+                             const double *weights, const int32_t *offsets,
+                             const int32_t *dist_idx, int32_t n_idx);
+
+/* data, weights: [n_blends][C][H][W] float32 (observation.py:52-57).  The _device
+ * form adopts device buffers (e.g. torch tensors) without copying; they must stay
+ * alive and unchanged while the batch uses them. */
+int smi_batch_set_observation(smi_batch *b, const float *data, const float *weights);
+int smi_batch_set_observation_device(smi_batch *b, const float *d_data,
+                                     const float *d_weights);
+/* kernel: [kernel_per_blend ? n_blends : 1][kernel_bands][kernel_h][kernel_w] */
+int smi_batch_set_kernel(smi_batch *b, const float *kernel);
+int smi_batch_set_components(smi_batch *b, const smi_components *comps);
+
+/* AMSGrad moments (blend.py:153-163), same packing as sed / morph; NULL = zeros */
+int smi_batch_set_moments(smi_batch *b, const float *m_sed, const float *v_sed,
+                          const float *vhat_sed, const float *m_morph,
+                          const float *v_morph, const float *vhat_morph);
+int smi_batch_get_moments(smi_batch *b, float *m_sed, float *v_sed, float *vhat_sed,
+                          float *m_morph, float *v_morph, float *vhat_morph);
+int smi_batch_get_parameters(smi_batch *b, float *sed, float *morph);
+int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph);
+
+/* HIP stream the batch launches on (hipStream_t as void*); NULL = default stream */
+int smi_batch_set_stream(smi_batch *b, void *stream);
+
+/* Blend.get_model + Observation.render + get_log_likelihood for every blend.
+ * Any output may be NULL.  model, rendered: [n_blends][C][H][W]; logL[n_blends]
+ * (includes -log_norm, observation.py:170-186). */
+int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL);
+
+/* Gradient of the loss (-logL) w.r.t. every sed and morphology at the current
+ * parameters; layout as sed / morph. */
+int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph);
+
+/* Run `n_iter` iterations of the adaprox loop on the device without host
+ * synchronisation; `it0` is the iteration counter of the first one (it = 0 takes
+ * a tenth of the step and sets vhat = v).  Convergence is evaluated per blend on
+ * the device when e_rel > 0: a blend stops after the update of the iteration in
+ * which  it > min_iter && |L[it] - L[it-1]| < e_rel |L[it]|  (blend.py:294-299).
+ * Asynchronous on the batch stream. */
+int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
+                   int32_t min_iter, int32_t prox_max_iter);
+
+/* Blocking.  n_active: blends still iterating; error: index of the first blend
+ * whose parameters became non-finite, or -1. */
+int smi_batch_status(smi_batch *b, int32_t *n_active, int32_t *first_error);
+
+/* Blend.fit for the whole batch: step() in chunks of `sync_every` iterations until
+ * max_iter or until every blend has converged.  n_iter[n_blends] receives the
+ * number of loss evaluations per blend (= len(blend.loss)). */
+int smi_batch_fit(smi_batch *b, int32_t max_iter, float e_rel, int32_t min_iter,
+                  int32_t prox_max_iter, int32_t sync_every, int32_t *n_iter);
+
+/* loss history: out[n_blends][capacity] (loss = -logL, blend.py:273); entries past
+ * a blend's n_iter are NaN. */
+int smi_batch_get_loss(smi_batch *b, double *out, int32_t capacity, int32_t *n_iter);
+
+/* Re-arm all blends (active, loss history cleared); parameters are kept. */
+int smi_batch_reset(smi_batch *b);
+
+/* Mean device time in milliseconds of the dominant kernel family per iteration,
+ * measured with hipEvents on the batch stream during the last smi_batch_step call
+ * when timing was enabled with smi_batch_enable_timing(b, 1).
+ * phase: 0 render, 1 forward conv, 2 residual, 3 adjoint conv, 4 update, 5 total */
+int smi_batch_enable_timing(smi_batch *b, int32_t on);
+int smi_batch_get_timing(smi_batch *b, double *ms_per_phase, int32_t n_phases);
+
+/* FFT shape actually used (fft_h, fft_w) */
+int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCARLET_AMD_H */

@@ -1,0 +1,287 @@
+"""Oracle: the proximal-gradient loop of ``Blend.fit`` on plain NumPy arrays.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+Scene description used here (no classes from the product):
+
+* ``Component``: spectrum ``sed`` (C,), morphology ``morph`` (h, w), spatial
+  ``origin`` (y0, x0) of the morphology box in model-frame pixels (may be
+  negative or overhang the frame, as in the reference), prox/step settings and
+  the AMSGrad moments of both parameters.
+* ``Scene``: frame shape (C, H, W), ``data``/``weights`` cubes, the difference
+  kernel stamp (Ck, P, P) with Ck in {1, C} or ``None`` for the NullRenderer.
+
+dtype behaviour follows NumPy promotion exactly as the reference does: the
+model cube is ``frame dtype`` (float32), morphologies are whatever the caller
+passes (float64 in the reference after initialisation), moments are float64
+(blend.py:155-160).
+"""
+
+import numpy as np
+
+from . import fftconv, proxops
+
+
+class Component:
+    def __init__(
+        self,
+        sed,
+        morph,
+        origin,
+        sed_min_step=0.0,
+        morph_step=1e-2,
+        monotonic="angle",
+        min_gradient=0.0,
+        symmetric=False,
+        sed_zero=1e-20,
+        source=None,
+    ):
+        self.sed = sed
+        self.morph = morph
+        self.origin = (int(origin[0]), int(origin[1]))
+        # spectrum.py:54-56 -- relative_step(factor=1e-2, minimum=min_step)
+        self.sed_min_step = sed_min_step
+        # morphology.py:670 -- constant step
+        self.morph_step = morph_step
+        self.monotonic = monotonic
+        self.min_gradient = min_gradient
+        self.symmetric = symmetric
+        self.sed_zero = sed_zero
+        # components with the same (not None) `source` id form one
+        # CombinedComponent, e.g. a MultiExtendedSource (source.py:615-717)
+        self.source = source
+        # blend.py:154-160: float64 zeros
+        self.m_sed = np.zeros(sed.shape)
+        self.v_sed = np.zeros(sed.shape)
+        self.vhat_sed = np.zeros(sed.shape)
+        self.m_morph = np.zeros(morph.shape)
+        self.v_morph = np.zeros(morph.shape)
+        self.vhat_morph = np.zeros(morph.shape)
+
+    def sed_step(self, it=0):
+        """``relative_step`` (parameter.py:126-129) with axis=None."""
+        return np.maximum(self.sed_min_step, 1e-2 * self.sed.mean())
+
+    def sed_prox(self, x, step):
+        """``PositivityConstraint(zero=1e-20)`` (spectrum.py:54)."""
+        return proxops.prox_positivity(x, step, self.sed_zero)
+
+    def morph_prox(self, x, step):
+        """ExtendedSourceMorphology chain (morphology.py:644-670)."""
+        return proxops.morph_chain(
+            x, step, self.monotonic, self.min_gradient, self.symmetric
+        )
+
+
+class Scene:
+    def __init__(self, frame_shape, data, weights, kernel, components, dtype=np.float32):
+        self.frame_shape = tuple(frame_shape)
+        self.dtype = dtype
+        self.data = data
+        self.weights = weights
+        self.kernel = kernel
+        self.components = list(components)
+        self.loss = []
+
+    # -- forward ---------------------------------------------------------
+
+    def box_slices(self, comp):
+        """``overlapped_slices(frame.bbox, comp.bbox)`` on the two spatial axes
+        (bbox.py:279-301; component.py:59-61)."""
+        H, W = self.frame_shape[1:]
+        h, w = comp.morph.shape
+        y0, x0 = comp.origin
+        ylo, yhi = max(y0, 0), min(y0 + h, H)
+        xlo, xhi = max(x0, 0), min(x0 + w, W)
+        yhi, xhi = max(yhi, ylo), max(xhi, xlo)
+        frame_sl = (slice(None), slice(ylo, yhi), slice(xlo, xhi))
+        box_sl = (slice(None), slice(ylo - y0, yhi - y0), slice(xlo - x0, xhi - x0))
+        return frame_sl, box_sl
+
+    def _groups(self):
+        groups = []
+        for c in self.components:
+            if groups and c.source is not None and groups[-1][0].source == c.source:
+                groups[-1].append(c)
+            else:
+                groups.append([c])
+        return groups
+
+    def get_model(self):
+        """``Blend.get_model`` (blend.py:200-244): scatter-add of every source's
+        boxed model into a zero cube of frame dtype.  A single component is the
+        outer product (component.py:160-164); a combined source first sums its
+        children in float64 over their common box (component.py:254-278)."""
+        full = np.zeros(self.frame_shape, dtype=self.dtype)
+        H, W = self.frame_shape[1:]
+        for group in self._groups():
+            if len(group) == 1:
+                c = group[0]
+                boxed = c.sed[:, None, None] * c.morph[None, :, :]
+                fs, bs = self.box_slices(c)
+                full[fs] += boxed[bs]
+                continue
+            y0 = min(c.origin[0] for c in group)
+            x0 = min(c.origin[1] for c in group)
+            y1 = max(c.origin[0] + c.morph.shape[0] for c in group)
+            x1 = max(c.origin[1] + c.morph.shape[1] for c in group)
+            summed = np.zeros((self.frame_shape[0], y1 - y0, x1 - x0))
+            for c in group:
+                oy, ox = c.origin[0] - y0, c.origin[1] - x0
+                h, w = c.morph.shape
+                summed[:, oy : oy + h, ox : ox + w] += c.sed[:, None, None] * c.morph[None]
+            ylo, yhi = max(y0, 0), min(y1, H)
+            xlo, xhi = max(x0, 0), min(x1, W)
+            if yhi > ylo and xhi > xlo:
+                full[:, ylo:yhi, xlo:xhi] += summed[:, ylo - y0 : yhi - y0, xlo - x0 : xhi - x0]
+        return full
+
+    def render(self, model):
+        """``Observation.render`` for NullRenderer / ConvolutionRenderer with
+        identical model and data footprints (renderer.py:86-94, 247-259)."""
+        if self.kernel is None:
+            return model
+        return fftconv.convolve(model, self.kernel, axes=(1, 2))
+
+    def render_adjoint(self, grad):
+        if self.kernel is None:
+            return grad
+        return fftconv.convolve_adjoint(grad, self.kernel, axes=(1, 2))
+
+    @property
+    def log_norm(self):
+        """``Observation.log_norm`` (observation.py:172-186)."""
+        import numpy.ma as ma
+
+        # observation.py:116-124: masked array, zeros of the weights masked
+        noise_rms = 1 / np.sqrt(ma.masked_equal(self.weights, 0))
+        n = np.prod(self.data.shape) - noise_rms.mask.sum()
+        with np.errstate(divide="ignore"):
+            return n / 2 * np.log(2 * np.pi) + np.log(noise_rms).sum()
+
+    def log_likelihood(self, rendered):
+        """``Observation.get_log_likelihood`` (observation.py:147-170)."""
+        return -self.log_norm - np.sum(self.weights * (rendered - self.data) ** 2) / 2
+
+    # -- gradient --------------------------------------------------------
+
+    def model_gradient(self, rendered):
+        """d(-logL)/d(model cube): ``w (m - d)`` pulled back through the
+        renderer (lite/models.py:537-545)."""
+        return self.render_adjoint(self.weights * (rendered - self.data))
+
+    def parameter_gradients(self, G):
+        """Per component d(-logL)/d(sed), d(-logL)/d(morph): slice ``G`` into
+        the box (zero where the box overhangs the frame; blend.py:30-46), then
+        ``sum_yx G*morph`` and ``sum_c sed*G`` (lite/models.py:206-216)."""
+        out = []
+        for c in self.components:
+            h, w = c.morph.shape
+            boxed = np.zeros((self.frame_shape[0], h, w), dtype=np.float64)
+            fs, bs = self.box_slices(c)
+            boxed[bs] = G[fs]
+            g_sed = np.einsum("cyx,yx->c", boxed, c.morph)
+            g_morph = np.einsum("c,cyx->yx", c.sed, boxed)
+            out.append((g_sed, g_morph))
+        return out
+
+    def loss_and_gradients(self):
+        """One evaluation of ``Blend._loss_func`` (blend.py:259-274) and of its
+        gradient; appends the loss like the reference does."""
+        model = self.get_model()
+        rendered = self.render(model)
+        loss = -self.log_likelihood(rendered)
+        self.loss.append(loss)
+        G = self.model_gradient(rendered)
+        return loss, self.parameter_gradients(G)
+
+    # -- optimizer -------------------------------------------------------
+
+    def step(self, it, e_rel, prox_max_iter=10, b1=0.9, b2=0.999, eps=1e-8):
+        """One iteration of ``proxmin.adaprox`` as configured at
+        blend.py:165-180 (amsgrad, prox_max_iter=10)."""
+        _, grads = self.loss_and_gradients()
+        # all steps are evaluated on the pre-update parameters (blend.py:135-138)
+        alphas = [(c.sed_step(it), c.morph_step) for c in self.components]
+        for c, (g_sed, g_morph), (a_sed, a_morph) in zip(self.components, grads, alphas):
+            adaprox_update(
+                it, c.sed, g_sed, c.m_sed, c.v_sed, c.vhat_sed, a_sed, c.sed_prox,
+                e_rel, prox_max_iter, b1, b2, eps,
+            )
+            adaprox_update(
+                it, c.morph, g_morph, c.m_morph, c.v_morph, c.vhat_morph, a_morph,
+                c.morph_prox, e_rel, prox_max_iter, b1, b2, eps,
+            )
+
+    def check_parameters(self):
+        """``Model.check_parameters`` (model.py:153-165)."""
+        for k, c in enumerate(self.components):
+            if not (np.isfinite(c.sed).all() and np.isfinite(c.morph).all()):
+                raise ArithmeticError("component {} is not finite".format(k))
+
+    def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, prox_max_iter=10):
+        """``Blend.fit`` (blend.py:85-198) without box resizing.
+
+        Iteration order follows the reference authors' own loop
+        (lite/models.py:589-624): gradient (loss appended) -> parameter updates
+        -> convergence test ``it > min_iter and |dL| < e_rel |L|``.  The
+        position of proxmin's callback inside ``adaprox`` is third-party code
+        (parity unpinned, see oracle/__init__.py).
+
+        Returns ``(len(loss), logL[-1])`` like blend.py:194.
+        """
+        it = 0
+        while it < max_iter:
+            self.step(it, e_rel, prox_max_iter)
+            self.check_parameters()
+            if it > min_iter and abs(self.loss[-1] - self.loss[-2]) < e_rel * abs(
+                self.loss[-1]
+            ):
+                break
+            it += 1
+        return len(self.loss), -self.loss[-1]
+
+
+def l2sq(x):
+    """``proxmin.utils.l2sq``: squared Euclidean norm."""
+    return (x**2).sum()
+
+
+def amsgrad_phi_psi(it, g, m, v, vhat, b1, b2, eps):
+    """AMSGrad moments (Reddi, Kale & Kumar 2018) as used by
+    ``proxmin.algorithms._amsgrad_phi_psi``: no bias correction, ``vhat = v``
+    on the first iteration, floor ``eps`` under the square root.
+    In-place on ``m, v, vhat`` (warm start, blend.py:153-163)."""
+    m[:] = (1 - b1) * g + b1 * m
+    v[:] = (1 - b2) * (g**2) + b2 * v
+    if it == 0:
+        vhat[:] = v
+    else:
+        vhat[:] = np.maximum(vhat, v)
+    psi = np.sqrt(np.maximum(vhat, eps)) if eps > 0 else np.sqrt(vhat)
+    return m, psi
+
+
+def adaprox_update(it, x, g, m, v, vhat, alpha, prox, e_rel, prox_max_iter=10,
+                   b1=0.9, b2=0.999, eps=1e-8):
+    """Inner update of one parameter (lite/parameters.py:274-305): gradient
+    step ``x -= alpha phi/psi`` (a tenth of it on the first iteration), then
+    up to ``prox_max_iter`` proximal sub-iterations in the metric ``psi`` with
+    step ``gamma = alpha / max(psi)``, stopped when the relative squared
+    change drops to ``e_rel**2``.  ``x`` is updated in place."""
+    phi, psi = amsgrad_phi_psi(it, g, m, v, vhat, b1, b2, eps)
+    if it > 0:
+        x -= alpha * phi / psi
+    else:
+        x -= alpha * phi / psi / 10
+    if prox is not None:
+        z = x.copy()
+        gamma = alpha / np.max(psi)
+        for _tau in range(1, prox_max_iter + 1):
+            z_new = prox(z - gamma / alpha * psi * (z - x), gamma)
+            converged = l2sq(z_new - z) <= e_rel**2 * l2sq(z)
+            z = z_new
+            if converged:
+                break
+        x[...] = z
+    return x

@@ -1,0 +1,291 @@
+"""Generate the golden vectors under ``tests/golden/`` by RUNNING THE REFERENCE.
+
+BUILD-CONTAINER TOOLING: needs ``/root/reference`` (read-only checkout of
+pmelchior/scarlet).  Run from the repo root::
+
+    python -m oracle.refshim.make_golden
+
+Everything written is *data* (inputs and the reference's outputs on them);
+no reference source travels.  The two small input files are the reference's
+own MIT-licensed sample scenes (``data/hsc_cosmos_35.npz``,
+``data/psf_unmatched_sim.npz``), reduced to the arrays the path uses.
+
+Vectors (names follow SURVEY.md section 8c):
+
+* ``operator_tables.npz``  (G10) ``operator.getRadialMonotonicWeights`` and
+  ``operator.sort_by_radius`` run unmodified, several shapes x weightings.
+* ``fft_psf.npz``          (G2)  ``match_psf`` / ``convolve`` on Gaussian PSFs.
+* ``render_loss.npz``      (G3)  the reference's tests/test_observation.py scene.
+* ``hsc_cosmos_35.npz``    (G6/G8) quickstart scene up to the first gradient:
+  inputs, the reference's initial sources, model cube, rendered cube, logL,
+  diff kernel, and central finite differences of the reference's float64
+  forward log-likelihood along random parameter directions.
+* ``psf_unmatched.npz``    cfg 4: per-band PSF diff kernel + render of a fixed
+  model cube.
+* ``synthetic_cfg2.npz``   cfg 2: reference forward (model, rendered, logL) on
+  the seeded synthetic 5x128x128 scene of ``scarlet_amd.synthetic``.
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def operator_tables(scarlet):
+    out = {}
+    shapes = [(5, 5), (7, 9), (21, 21), (31, 31), (41, 41), (31, 41), (22, 30)]
+    for shape in shapes:
+        center = (shape[0] // 2, shape[1] // 2)
+        tag = "{}x{}".format(*shape)
+        didx = scarlet.operator.sort_by_radius(shape, center)
+        out["didx_" + tag] = didx.astype(np.int32)
+        for mode in ("flat", "angle", "nearest"):
+            w = scarlet.operator.getRadialMonotonicWeights(shape, mode, center)
+            out["w_{}_{}".format(mode, tag)] = w
+    # one sweep through the reference's cached Python operator per weighting
+    rng = np.random.default_rng(7)
+    for shape in [(21, 21), (31, 41)]:
+        tag = "{}x{}".format(*shape)
+        x0 = rng.random(shape)
+        out["sweep_in_" + tag] = x0
+        for mode, g in (("flat", 0.1), ("angle", 0.0), ("nearest", 0.0), ("angle", 0.25)):
+            c = scarlet.MonotonicityConstraint(neighbor_weight=mode, min_gradient=g)
+            out["sweep_{}_{}_{}".format(mode, g, tag)] = c(x0.copy(), 0)
+    np.savez_compressed(os.path.join(OUT, "operator_tables.npz"), **out)
+
+
+def fft_psf(scarlet):
+    fft = scarlet.fft
+    p1 = scarlet.GaussianPSF(1, boxsize=41).get_model()
+    p2 = scarlet.GaussianPSF(2, boxsize=41).get_model()
+    p123 = scarlet.GaussianPSF((1, 2, 3), boxsize=41).get_model()
+    k12 = fft.match_psf(fft.Fourier(p2), fft.Fourier(p1))
+    img2 = fft.convolve(fft.Fourier(p1), k12)
+    k21 = fft.match_psf(fft.Fourier(p1), fft.Fourier(p2))
+    kmulti = fft.match_psf(fft.Fourier(p123), fft.Fourier(p1))
+    imulti = fft.convolve(kmulti, fft.Fourier(p1))
+    # float32 cube x per-band kernel, axes (1,2): the renderer's call shape
+    rng = np.random.default_rng(11)
+    cube = rng.random((3, 30, 37)).astype(np.float32)
+    kern = kmulti.image.astype(np.float32)
+    conv = fft.convolve(fft.Fourier(cube), fft.Fourier(kern), axes=(1, 2)).image
+    shapes = np.array(
+        [
+            fft._get_fft_shape((5, 58, 48), (5, 43, 43), 3, (1, 2)),
+            fft._get_fft_shape((5, 128, 128), (1, 41, 41), 3, (1, 2)),
+            fft._get_fft_shape((6, 40, 59), (6, 31, 31), 3, (1, 2)),
+            fft._get_fft_shape((1, 43, 43), (1, 9, 9), 10, (-2, -1)),
+            fft._get_fft_shape((2, 30, 30), (2, 10, 12), 3, (1, 2)),
+        ]
+    )
+    np.savez_compressed(
+        os.path.join(OUT, "fft_psf.npz"),
+        psf1=p1, psf2=p2, psf123=p123,
+        k12=k12.image, img2=img2.image, k21=k21.image,
+        kmulti=kmulti.image, imulti=imulti.image,
+        cube=cube, kern=kern, conv=conv, fft_shapes=shapes,
+        shift_in=cube[0], shift_out=fft.shift(cube[0], (0.3, -1.7), return_Fourier=False),
+    )
+
+
+def render_loss(scarlet):
+    """tests/test_observation.py:13-47 scene, outputs stored."""
+    shape0 = (3, 13, 13)
+    model_psf = scarlet.GaussianPSF(0.9, boxsize=shape0[1])
+    mimg = model_psf.get_model()
+    shape = (3, 43, 43)
+    channels = np.arange(shape[0])
+    frame = scarlet.Frame(shape, psf=model_psf, channels=channels)
+    origin = (0, shape[1] // 2 - shape0[1] // 2, shape[2] // 2 - shape0[2] // 2)
+    bbox = scarlet.Box(shape0, origin=origin)
+    model = np.zeros(shape)
+    bbox.insert_into(model, np.stack([mimg[0]] * 3, axis=0))
+    psf = scarlet.GaussianPSF([2.1, 1.1, 3.5], boxsize=shape[1])
+    images = np.ones(shape)
+    obs = scarlet.Observation(images, psf=psf, channels=channels)
+    obs.match(frame)
+    rendered = obs.render(model)
+    np.savez_compressed(
+        os.path.join(OUT, "render_loss.npz"),
+        model_psf=mimg, obs_psf=psf.get_model(), model=model, images=images,
+        diff_kernel=obs.renderer.diff_kernel.image, rendered=rendered,
+        logL=obs.get_log_likelihood(model), log_norm=obs.log_norm,
+    )
+
+
+def _sources_to_arrays(sources, scarlet):
+    """Flatten sources into components; `source_of` keeps the grouping (a
+    MultiExtendedSource sums its children in float64 first, component.py:254-278)."""
+    seds, morphs, origins, min_steps, source_of = [], [], [], [], []
+    for i, src in enumerate(sources):
+        comps = [src] if isinstance(src, scarlet.FactorizedComponent) else list(src.children)
+        for comp in comps:
+            spectrum, morphology = comp.children
+            seds.append(np.array(spectrum.parameters[0]))
+            morphs.append(np.array(morphology.parameters[0]))
+            origins.append(morphology.bbox.origin[-2:])
+            step = spectrum.parameters[0].step
+            min_steps.append(np.asarray(step.keywords["minimum"]))
+            source_of.append(i)
+    return seds, morphs, origins, min_steps, source_of
+
+
+def _forward(blend, obs, params):
+    model = blend.get_model(*params)
+    return model, obs.get_log_likelihood(model)
+
+
+def hsc_cosmos_35(scarlet):
+    from scarlet.initialization import init_all_sources
+
+    d = np.load("/root/reference/data/hsc_cosmos_35.npz")
+    images = d["images"]
+    filters = [str(f) for f in d["filters"]]
+    weights = 1 / d["variance"]
+    psfs = d["psfs"]
+    centers = [(s["y"], s["x"]) for s in d["catalog"]]
+
+    def build(dtype):
+        model_psf = scarlet.GaussianPSF(sigma=(0.8,) * len(filters))
+        frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters, dtype=dtype)
+        obs = scarlet.Observation(
+            images, psf=scarlet.ImagePSF(psfs), weights=weights, channels=filters
+        ).match(frame)
+        sources, skipped = init_all_sources(
+            frame, centers, obs, max_components=2, min_snr=50, thresh=1,
+            fallback=True, silent=True, set_spectra=True,
+        )
+        return model_psf, frame, obs, sources, skipped
+
+    model_psf, frame, obs, sources, skipped = build(np.float32)
+    blend = scarlet.Blend(sources, obs)
+    model = blend.get_model()
+    rendered = obs.render(model)
+    logL = obs.get_log_likelihood(model)
+    seds, morphs, origins, min_steps, source_of = _sources_to_arrays(sources, scarlet)
+
+    out = dict(
+        images=images, weights=weights.astype(np.float32), psfs=psfs,
+        centers=np.array(centers), model_psf=model_psf.get_model(),
+        diff_kernel=obs.renderer.diff_kernel.image,
+        model=model, rendered=rendered, logL=logL, log_norm=obs.log_norm,
+        n_comp=len(seds), n_skipped=len(skipped), source_of=np.array(source_of),
+        noise_rms_mean=np.array(np.mean(obs.noise_rms, axis=(1, 2))),
+    )
+    for k, (s, m, o, ms) in enumerate(zip(seds, morphs, origins, min_steps)):
+        out["sed_%d" % k] = s
+        out["morph_%d" % k] = m
+        out["origin_%d" % k] = np.array(o)
+        out["min_step_%d" % k] = ms
+
+    # finite differences of the reference's forward in float64
+    _, frame64, obs64, sources64, _ = build(np.float64)
+    blend64 = scarlet.Blend(sources64, obs64)
+    params = [np.array(p, dtype=np.float64) for p in blend64.parameters]
+    rng = np.random.default_rng(3)
+    n_dir = 6
+    fd = np.zeros(n_dir)
+    dirs = []
+    for j in range(n_dir):
+        direction = []
+        for p in params:
+            if p.shape == (2,):  # the unused `shift` parameters
+                direction.append(np.zeros_like(p))
+            else:
+                direction.append(rng.standard_normal(p.shape))
+        eps = 1e-6
+        plus = [p + eps * t for p, t in zip(params, direction)]
+        minus = [p - eps * t for p, t in zip(params, direction)]
+        lp = _forward(blend64, obs64, plus)[1]
+        lm = _forward(blend64, obs64, minus)[1]
+        fd[j] = (lp - lm) / (2 * eps)
+        dirs.append([t for t in direction if t.shape != (2,)])
+    out["fd_dlogL"] = fd
+    s64, m64, _, _, _ = _sources_to_arrays(sources64, scarlet)
+    for k in range(len(s64)):
+        out["sed64_%d" % k] = s64[k]
+        out["morph64_%d" % k] = m64[k]
+    for j, dl in enumerate(dirs):
+        for i, t in enumerate(dl):
+            # order: (sed_0, morph_0, sed_1, morph_1, ...)
+            out["dir%d_%d" % (j, i)] = t.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "hsc_cosmos_35.npz"), **out)
+    print("hsc_cosmos_35: %d components, logL=%.3f" % (len(seds), logL))
+
+
+def psf_unmatched(scarlet):
+    d = np.load("/root/reference/data/psf_unmatched_sim.npz")
+    images = d["images"]
+    psfs = d["psfs"]
+    filters = [str(f) for f in d["filters"]]
+    model_psf = scarlet.GaussianPSF(sigma=(0.9,) * len(filters))
+    frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters)
+    weights = np.ones_like(images) / 2**2
+    obs = scarlet.Observation(
+        images, psf=scarlet.ImagePSF(psfs), weights=weights, channels=filters
+    ).match(frame)
+    rng = np.random.default_rng(5)
+    model = (rng.random(images.shape) * (rng.random(images.shape) > 0.9)).astype(np.float32)
+    rendered = obs.render(model)
+    np.savez_compressed(
+        os.path.join(OUT, "psf_unmatched.npz"),
+        images=images, psfs=psfs, model_psf=model_psf.get_model(),
+        diff_kernel=obs.renderer.diff_kernel.image, model=model, rendered=rendered,
+        logL=obs.get_log_likelihood(model), log_norm=obs.log_norm,
+    )
+
+
+def synthetic_cfg2(scarlet):
+    sys.path.insert(0, REPO)
+    from scarlet_amd import synthetic
+
+    sc = synthetic.make_blend(seed=1234)
+    filters = list("grizy")
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5)
+    frame = scarlet.Frame(sc["data"].shape, psf=model_psf, channels=filters)
+    obs = scarlet.Observation(
+        sc["data"], psf=scarlet.ImagePSF(sc["obs_psf"]), weights=sc["weights"], channels=filters
+    ).match(frame)
+    comps = []
+    for k in range(len(sc["seds"])):
+        h, w = sc["morphs"][k].shape
+        box = scarlet.Box((5, h, w), origin=(0,) + tuple(sc["origins"][k]))
+        spec = scarlet.TabulatedSpectrum(frame, sc["seds"][k].copy(), bbox=box[0])
+        morph = scarlet.ImageMorphology(frame, sc["morphs"][k].copy(), bbox=box[1:])
+        comps.append(scarlet.FactorizedComponent(frame, spec, morph))
+    blend = scarlet.Blend(comps, obs)
+    model = blend.get_model()
+    rendered = obs.render(model)
+    np.savez_compressed(
+        os.path.join(OUT, "synthetic_cfg2.npz"),
+        diff_kernel=obs.renderer.diff_kernel.image,
+        model=model, rendered=rendered,
+        logL=obs.get_log_likelihood(model), log_norm=obs.log_norm,
+        data_checksum=np.float64(sc["data"].astype(np.float64).sum()),
+    )
+
+
+def main(which=None):
+    from oracle.refshim.load_reference import load
+
+    scarlet = load()
+    os.makedirs(OUT, exist_ok=True)
+    jobs = dict(
+        operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
+        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched,
+        synthetic_cfg2=synthetic_cfg2,
+    )
+    for name, fn in jobs.items():
+        if which and name not in which:
+            continue
+        fn(scarlet)
+        print("wrote", name)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,174 @@
+"""ctypes binding of ``libscarlet_amd.so`` (C ABI in ``include/scarlet_amd.h``).
+
+There is no CPU fallback: if the library is missing or no GPU is visible the
+calls raise.  ``import torch`` happens first on purpose -- torch ships its own
+HIP runtime / rocFFT with the same SONAMEs as /opt/rocm, and loading it first
+makes this library resolve against the copies that are already in the process
+(one HIP runtime per process).
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscarlet_amd.so")
+
+PROX_MONOTONIC = 1
+PROX_SYMMETRY = 2
+PROX_POSITIVE = 4
+PROX_CENTER_ON = 8
+PROX_NORM_MAX = 16
+PROX_NORM_SUM = 32
+PROX_L1 = 64
+PROX_L0 = 128
+PROX_EXTENDED_SOURCE = PROX_MONOTONIC | PROX_POSITIVE | PROX_CENTER_ON | PROX_NORM_MAX
+
+ERR_ARITHMETIC = -4
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+class BatchDesc(ctypes.Structure):
+    _fields_ = [
+        (name, ctypes.c_int32)
+        for name in (
+            "n_blends", "C", "H", "W", "n_components", "kernel_h", "kernel_w",
+            "kernel_bands", "kernel_per_blend", "fft_h", "fft_w", "max_iter",
+        )
+    ]
+
+
+class Components(ctypes.Structure):
+    _fields_ = [
+        ("blend", c_i32p), ("origin_y", c_i32p), ("origin_x", c_i32p),
+        ("box_h", c_i32p), ("box_w", c_i32p), ("sed", c_f32p), ("morph", c_f32p),
+        ("sed_min_step", c_f32p), ("sed_rel_step", c_f32p), ("morph_step", c_f32p),
+        ("prox_flags", c_i32p), ("sweep_plan", c_i32p), ("min_gradient", c_f32p),
+        ("l_thresh", c_f32p), ("morph_rel_step", c_f32p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/scarlet_amd.h declares
+SYMBOLS = {
+    "smi_last_error": (ctypes.c_char_p, []),
+    "smi_device_count": (ctypes.c_int, []),
+    "smi_version": (ctypes.c_char_p, []),
+    "smi_prox_weighted_monotonic_f32": (
+        ctypes.c_int,
+        [c_f32p, c_f32p, c_i32p, ctypes.c_int32, c_i32p, ctypes.c_int32, ctypes.c_int32,
+         ctypes.c_float],
+    ),
+    "smi_prox_weighted_monotonic_f64": (
+        ctypes.c_int,
+        [c_f64p, c_f64p, c_i32p, ctypes.c_int32, c_i32p, ctypes.c_int32, ctypes.c_int32,
+         ctypes.c_double],
+    ),
+    "smi_apply_filter_f32": (
+        ctypes.c_int,
+        [c_f32p, ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_int32, c_i32p, c_i32p,
+         c_i32p, c_i32p, c_f32p],
+    ),
+    "smi_apply_filter_f64": (
+        ctypes.c_int,
+        [c_f64p, ctypes.c_int32, ctypes.c_int32, c_f64p, ctypes.c_int32, c_i32p, c_i32p,
+         c_i32p, c_i32p, c_f64p],
+    ),
+    "smi_batch_create": (
+        ctypes.c_int,
+        [ctypes.POINTER(BatchDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)],
+    ),
+    "smi_batch_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "smi_batch_add_sweep_plan": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_f64p, c_i32p, c_i32p,
+         ctypes.c_int32],
+    ),
+    "smi_batch_set_observation": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
+    "smi_batch_set_observation_device": (
+        ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    ),
+    "smi_batch_set_kernel": (ctypes.c_int, [ctypes.c_void_p, c_f32p]),
+    "smi_batch_set_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Components)]),
+    "smi_batch_set_moments": (ctypes.c_int, [ctypes.c_void_p] + [c_f32p] * 6),
+    "smi_batch_get_moments": (ctypes.c_int, [ctypes.c_void_p] + [c_f32p] * 6),
+    "smi_batch_get_parameters": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
+    "smi_batch_set_parameters": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
+    "smi_batch_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "smi_batch_forward": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f64p]),
+    "smi_batch_gradient": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
+    "smi_batch_step": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int32,
+         ctypes.c_int32],
+    ),
+    "smi_batch_status": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
+    "smi_batch_fit": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_int32, ctypes.c_int32,
+         ctypes.c_int32, c_i32p],
+    ),
+    "smi_batch_get_loss": (ctypes.c_int, [ctypes.c_void_p, c_f64p, ctypes.c_int32, c_i32p]),
+    "smi_batch_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "smi_batch_enable_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "smi_batch_get_timing": (ctypes.c_int, [ctypes.c_void_p, c_f64p, ctypes.c_int32]),
+    "smi_batch_fft_shape": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
+}
+
+_lib = None
+
+
+class ScarletAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ScarletAmdError(
+                "{} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C scarlet_amd/csrc` (there is no CPU fallback)".format(
+                    LIB_PATH
+                )
+            )
+        try:
+            import torch  # noqa: F401  (see module docstring)
+        except ImportError:
+            pass
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    """Turn a negative smi_status into an exception (ArithmeticError for
+    non-finite parameters, as the reference's Model.check_parameters)."""
+    if status < 0:
+        msg = load().smi_last_error().decode()
+        if status == ERR_ARITHMETIC:
+            raise ArithmeticError(msg)
+        raise ScarletAmdError("libscarlet_amd: {} (status {})".format(msg, status))
+    return status
+
+
+def ptr(arr, ctype):
+    if arr is None:
+        return None
+    return arr.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)

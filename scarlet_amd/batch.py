@@ -1,0 +1,314 @@
+"""``BlendBatch``: many independent blends fitted together on one GPU.
+
+This is the batched form of ``Blend.fit`` (reference blend.py:85-198) that the
+benchmark and the multi-GPU driver use; ``scarlet_amd.Blend.fit`` is a batch of
+one.  All arithmetic happens in ``libscarlet_amd.so`` (HIP); this class only
+packs NumPy arrays for the C ABI.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib, operator
+
+
+class ComponentSpec:
+    """Plain description of one factorized component for the device loop."""
+
+    def __init__(self, sed, morph, origin, sed_min_step=0.0, sed_rel_step=1e-2,
+                 morph_step=1e-2, morph_rel_step=0.0, prox_flags=_lib.PROX_EXTENDED_SOURCE,
+                 neighbor_weight="angle", min_gradient=0.0, l_thresh=0.0):
+        self.sed = np.asarray(sed, dtype=np.float32)
+        self.morph = np.ascontiguousarray(morph, dtype=np.float32)
+        self.origin = (int(origin[0]), int(origin[1]))
+        self.sed_min_step = np.broadcast_to(
+            np.asarray(sed_min_step, dtype=np.float32), self.sed.shape
+        )
+        self.sed_rel_step = float(sed_rel_step)
+        self.morph_step = float(morph_step)
+        self.morph_rel_step = float(morph_rel_step)
+        self.prox_flags = int(prox_flags)
+        self.neighbor_weight = neighbor_weight
+        self.min_gradient = float(min_gradient)
+        self.l_thresh = float(l_thresh)
+
+
+class BlendBatch:
+    """A batch of blends sharing the frame shape ``(C, H, W)``.
+
+    Parameters
+    ----------
+    data, weights: (n_blends, C, H, W) float32 arrays
+    components: list (one entry per blend) of lists of ``ComponentSpec``
+    kernel: difference kernel, ``None`` (NullRenderer), ``(Ck, P, P)`` shared by
+        all blends, or ``(n_blends, Ck, P, P)``; Ck in {1, C}
+    max_iter: capacity of the loss history
+    fft_shape: ``None`` for the reference's rule (fft.py:116-167) or (Fy, Fx)
+    device: GPU index
+    """
+
+    def __init__(self, data, weights, components, kernel=None, max_iter=200,
+                 fft_shape=None, device=0):
+        lib = _lib.load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        data = _lib.f32(data)
+        weights = _lib.f32(weights)
+        assert data.ndim == 4 and data.shape == weights.shape
+        nb, C, H, W = data.shape
+        assert len(components) == nb
+        self.n_blends, self.C, self.H, self.W = nb, C, H, W
+        self.n_comp_per_blend = [len(c) for c in components]
+        flat = [c for blend in components for c in blend]
+        self.n_components = len(flat)
+        self.max_iter = int(max_iter)
+
+        desc = _lib.BatchDesc()
+        desc.n_blends, desc.C, desc.H, desc.W = nb, C, H, W
+        desc.n_components = len(flat)
+        desc.max_iter = self.max_iter
+        if kernel is not None:
+            kernel = _lib.f32(kernel)
+            per_blend = kernel.ndim == 4
+            kb = kernel.shape[-3]
+            assert kb in (1, C)
+            if per_blend:
+                assert kernel.shape[0] == nb
+            desc.kernel_h, desc.kernel_w = kernel.shape[-2:]
+            desc.kernel_bands, desc.kernel_per_blend = kb, int(per_blend)
+        if fft_shape is not None:
+            desc.fft_h, desc.fft_w = int(fft_shape[0]), int(fft_shape[1])
+        _lib.check(lib.smi_batch_create(ctypes.byref(desc), int(device), ctypes.byref(self._h)))
+
+        # monotonicity plans, one per (box shape, weighting)
+        plan_ids = {}
+        for c in flat:
+            if c.prox_flags & _lib.PROX_MONOTONIC:
+                key = (c.morph.shape, c.neighbor_weight)
+                if key not in plan_ids:
+                    wts, off, didx = operator.monotonic_tables(c.morph.shape, c.neighbor_weight)
+                    plan_ids[key] = _lib.check(
+                        lib.smi_batch_add_sweep_plan(
+                            self._h, c.morph.shape[0], c.morph.shape[1],
+                            _lib.ptr(wts, ctypes.c_double), _lib.ptr(off, ctypes.c_int32),
+                            _lib.ptr(didx, ctypes.c_int32), didx.size,
+                        )
+                    )
+        self._shapes = [c.morph.shape for c in flat]
+        self._morph_offsets = np.concatenate(
+            [[0], np.cumsum([s[0] * s[1] for s in self._shapes])]
+        ).astype(np.int64)
+
+        arrays = dict(
+            blend=_lib.i32(np.repeat(np.arange(nb), self.n_comp_per_blend)),
+            origin_y=_lib.i32([c.origin[0] for c in flat]),
+            origin_x=_lib.i32([c.origin[1] for c in flat]),
+            box_h=_lib.i32([s[0] for s in self._shapes]),
+            box_w=_lib.i32([s[1] for s in self._shapes]),
+            sed=_lib.f32(np.stack([c.sed for c in flat]) if flat else np.zeros((0, C))),
+            morph=_lib.f32(
+                np.concatenate([c.morph.reshape(-1) for c in flat]) if flat else np.zeros(0)
+            ),
+            sed_min_step=_lib.f32(
+                np.stack([c.sed_min_step for c in flat]) if flat else np.zeros((0, C))
+            ),
+            sed_rel_step=_lib.f32([c.sed_rel_step for c in flat]),
+            morph_step=_lib.f32([c.morph_step for c in flat]),
+            prox_flags=_lib.i32([c.prox_flags for c in flat]),
+            sweep_plan=_lib.i32(
+                [
+                    plan_ids.get((c.morph.shape, c.neighbor_weight), -1)
+                    if c.prox_flags & _lib.PROX_MONOTONIC else -1
+                    for c in flat
+                ]
+            ),
+            min_gradient=_lib.f32([c.min_gradient for c in flat]),
+            l_thresh=_lib.f32([c.l_thresh for c in flat]),
+            morph_rel_step=_lib.f32([c.morph_rel_step for c in flat]),
+        )
+        comps = _lib.Components()
+        for name, ctype in _lib.Components._fields_:
+            setattr(comps, name, arrays[name].ctypes.data_as(ctype))
+        _lib.check(lib.smi_batch_set_components(self._h, ctypes.byref(comps)))
+        _lib.check(
+            lib.smi_batch_set_observation(
+                self._h, _lib.ptr(data, ctypes.c_float), _lib.ptr(weights, ctypes.c_float)
+            )
+        )
+        if kernel is not None:
+            _lib.check(lib.smi_batch_set_kernel(self._h, _lib.ptr(kernel, ctypes.c_float)))
+
+    # -- lifetime ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.smi_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -----------------------------------------------------------
+    def _split_morphs(self, flat):
+        return [
+            flat[self._morph_offsets[k] : self._morph_offsets[k + 1]].reshape(self._shapes[k])
+            for k in range(self.n_components)
+        ]
+
+    @property
+    def fft_shape(self):
+        fy, fx = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self._lib.smi_batch_fft_shape(self._h, ctypes.byref(fy), ctypes.byref(fx)))
+        return fy.value, fx.value
+
+    def set_stream(self, stream_handle):
+        """Launch on the given HIP stream (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        _lib.check(self._lib.smi_batch_set_stream(self._h, ctypes.c_void_p(stream_handle)))
+
+    def set_observation_device(self, data_ptr, weights_ptr):
+        """Adopt device-resident data/weights (e.g. ``tensor.data_ptr()``)."""
+        _lib.check(
+            self._lib.smi_batch_set_observation_device(
+                self._h, ctypes.c_void_p(data_ptr), ctypes.c_void_p(weights_ptr)
+            )
+        )
+
+    # -- forward / gradient --------------------------------------------------
+    def forward(self, model=True, rendered=True):
+        """``(model, rendered, logL)`` for every blend: Blend.get_model,
+        Observation.render, Observation.get_log_likelihood."""
+        shape = (self.n_blends, self.C, self.H, self.W)
+        m = np.empty(shape, dtype=np.float32) if model else None
+        r = np.empty(shape, dtype=np.float32) if rendered else None
+        logL = np.empty(self.n_blends, dtype=np.float64)
+        _lib.check(
+            self._lib.smi_batch_forward(
+                self._h, _lib.ptr(m, ctypes.c_float), _lib.ptr(r, ctypes.c_float),
+                _lib.ptr(logL, ctypes.c_double),
+            )
+        )
+        return m, r, logL
+
+    def gradient(self):
+        """Gradient of ``-logL``: (g_sed (n_components, C), list of g_morph)."""
+        g_sed = np.empty((self.n_components, self.C), dtype=np.float32)
+        g_morph = np.empty(int(self._morph_offsets[-1]), dtype=np.float32)
+        _lib.check(
+            self._lib.smi_batch_gradient(
+                self._h, _lib.ptr(g_sed, ctypes.c_float), _lib.ptr(g_morph, ctypes.c_float)
+            )
+        )
+        return g_sed, self._split_morphs(g_morph)
+
+    # -- optimisation --------------------------------------------------------
+    def step(self, it0, n_iter, e_rel=0.0, min_iter=1, prox_max_iter=10):
+        """``n_iter`` asynchronous iterations starting at counter ``it0``;
+        ``e_rel=0`` disables the convergence test (fixed-iteration timing)."""
+        _lib.check(
+            self._lib.smi_batch_step(self._h, it0, n_iter, e_rel, min_iter, prox_max_iter)
+        )
+
+    def status(self):
+        """(number of blends still iterating, first non-finite blend or -1); blocks."""
+        a, e = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self._lib.smi_batch_status(self._h, ctypes.byref(a), ctypes.byref(e)))
+        return a.value, e.value
+
+    def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, prox_max_iter=10, sync_every=10):
+        """Fit every blend; returns ``(n_iter, logL)`` arrays like the tuple
+        ``Blend.fit`` returns (blend.py:194)."""
+        if max_iter > self.max_iter:
+            raise ValueError("max_iter exceeds the loss-history capacity of this batch")
+        n_iter = np.zeros(self.n_blends, dtype=np.int32)
+        _lib.check(
+            self._lib.smi_batch_fit(
+                self._h, max_iter, e_rel, min_iter, prox_max_iter, sync_every,
+                _lib.ptr(n_iter, ctypes.c_int32),
+            )
+        )
+        loss = self.loss_history()
+        last = np.array([loss[b][n_iter[b] - 1] if n_iter[b] else np.nan
+                         for b in range(self.n_blends)])
+        return n_iter, -last
+
+    def loss_history(self):
+        """List (per blend) of the recorded losses (= -logL, blend.py:273)."""
+        out = np.empty((self.n_blends, self.max_iter), dtype=np.float64)
+        n = np.zeros(self.n_blends, dtype=np.int32)
+        _lib.check(
+            self._lib.smi_batch_get_loss(
+                self._h, _lib.ptr(out, ctypes.c_double), self.max_iter,
+                _lib.ptr(n, ctypes.c_int32),
+            )
+        )
+        return [out[b, : min(n[b], self.max_iter)].copy() for b in range(self.n_blends)]
+
+    def reset(self):
+        _lib.check(self._lib.smi_batch_reset(self._h))
+
+    # -- parameters and optimizer state ---------------------------------------
+    def parameters(self):
+        """(seds (n_components, C), list of morphologies)."""
+        sed = np.empty((self.n_components, self.C), dtype=np.float32)
+        morph = np.empty(int(self._morph_offsets[-1]), dtype=np.float32)
+        _lib.check(
+            self._lib.smi_batch_get_parameters(
+                self._h, _lib.ptr(sed, ctypes.c_float), _lib.ptr(morph, ctypes.c_float)
+            )
+        )
+        return sed, self._split_morphs(morph)
+
+    def set_parameters(self, seds=None, morphs=None):
+        sed = None if seds is None else _lib.f32(seds)
+        morph = None if morphs is None else _lib.f32(
+            np.concatenate([np.asarray(m).reshape(-1) for m in morphs])
+        )
+        _lib.check(
+            self._lib.smi_batch_set_parameters(
+                self._h, _lib.ptr(sed, ctypes.c_float), _lib.ptr(morph, ctypes.c_float)
+            )
+        )
+
+    def moments(self):
+        """AMSGrad state: dict with m/v/vhat for seds (arrays) and morphs (lists)."""
+        ns, nm = (self.n_components, self.C), int(self._morph_offsets[-1])
+        bufs = [np.empty(ns, dtype=np.float32) for _ in range(3)] + [
+            np.empty(nm, dtype=np.float32) for _ in range(3)
+        ]
+        _lib.check(
+            self._lib.smi_batch_get_moments(self._h, *[_lib.ptr(b, ctypes.c_float) for b in bufs])
+        )
+        return dict(
+            m_sed=bufs[0], v_sed=bufs[1], vhat_sed=bufs[2],
+            m_morph=self._split_morphs(bufs[3]), v_morph=self._split_morphs(bufs[4]),
+            vhat_morph=self._split_morphs(bufs[5]),
+        )
+
+    def set_moments(self, m_sed=None, v_sed=None, vhat_sed=None, m_morph=None, v_morph=None,
+                    vhat_morph=None):
+        def pack(x, is_morph):
+            if x is None:
+                return None
+            if is_morph:
+                return _lib.f32(np.concatenate([np.asarray(m).reshape(-1) for m in x]))
+            return _lib.f32(x)
+
+        arrs = [pack(m_sed, 0), pack(v_sed, 0), pack(vhat_sed, 0), pack(m_morph, 1),
+                pack(v_morph, 1), pack(vhat_morph, 1)]
+        _lib.check(
+            self._lib.smi_batch_set_moments(self._h, *[_lib.ptr(a, ctypes.c_float) for a in arrs])
+        )
+
+    # -- timing ----------------------------------------------------------------
+    def enable_timing(self, on=True):
+        _lib.check(self._lib.smi_batch_enable_timing(self._h, int(on)))
+
+    def timing(self):
+        """Mean ms per iteration of (render, conv, residual, conv^T, update, total)
+        of the last timed ``step`` call."""
+        out = np.zeros(6, dtype=np.float64)
+        _lib.check(self._lib.smi_batch_get_timing(self._h, _lib.ptr(out, ctypes.c_double), 6))
+        return dict(zip(("render", "conv", "residual", "conv_adj", "update", "total"), out))

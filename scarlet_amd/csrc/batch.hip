@@ -1,0 +1,841 @@
+// C ABI of libscarlet_amd.so (declared in include/scarlet_amd.h): a batch of
+// independent blends resident on one GPU and the proximal-gradient loop over it.
+//
+// Per iteration (the body of the proxmin.adaprox loop called at
+// scarlet/blend.py:165-180):
+//   render      Blend.get_model                       blend.py:200-244
+//   conv        ConvolutionRenderer (FFT, cached K^)  renderer.py:247-259, fft.py:368-396
+//   residual    -logL and w (m - d)                   observation.py:147-170
+//   finalize    loss history + convergence test       blend.py:273, 294-299
+//   conv^T      same transforms with conj(K^)         (vjp of fft.py:316-331)
+//   update      gradient gather + AMSGrad + prox      lite/parameters.py:274-305
+//
+// FFT path: rocFFT batched 2-D real transforms over (blend, band).  The image is
+// placed at the origin of the zero-padded (Fy, Fx) buffer and the kernel stamp is
+// wrapped with its centre on index 0, which is the same linear convolution the
+// reference gets with _pad / ifftshift / fftshift / _centered, without the shift
+// copies.  The kernel spectrum is computed once (the reference recomputes it in
+// every call, fft.py:387-388).
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "common.h"
+
+namespace smi {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+static int next_fast_len(int n) {
+    for (;; ++n) {
+        int m = n;
+        for (int p : {2, 3, 5})
+            while (m % p == 0) m /= p;
+        if (m == 1) return n;
+    }
+}
+
+// fft.py:116-167 for axes (1, 2) of a (C, H, W) cube and a (Ck, ph, pw) kernel
+static void reference_fft_shape(int H, int W, int ph, int pw, int *Fy, int *Fx) {
+    int fy = next_fast_len(H + ph + 3), fx = next_fast_len(W + pw + 3);
+    while (fx % 2) fx = next_fast_len(fx + 1);
+    if (ph % 2 == 0)
+        while (fy % 2) fy = next_fast_len(fy + 1);
+    *Fy = fy;
+    *Fx = fx;
+}
+
+#define SMI_FFT(expr)                                                          \
+    do {                                                                       \
+        rocfft_status _s = (expr);                                             \
+        if (_s != rocfft_status_success) {                                     \
+            smi::set_error(std::string(#expr) + ": rocfft status " +           \
+                           std::to_string((int)_s));                           \
+            return SMI_ERR_HIP;                                                \
+        }                                                                      \
+    } while (0)
+
+template <typename T>
+static hipError_t dev_alloc(T **p, size_t n) {
+    return hipMalloc(reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T));
+}
+
+}  // namespace smi
+
+using namespace smi;
+
+struct smi_batch {
+    smi_batch_desc d{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool null_renderer = false;
+    int Fy = 0, Fx = 0, Fxh = 0;
+    // FFT work cubes
+    float *P = nullptr, *Q = nullptr;
+    float2 *S = nullptr, *Khat = nullptr;
+    void *work = nullptr;
+    rocfft_plan plan_fwd = nullptr, plan_inv = nullptr;
+    rocfft_execution_info info = nullptr;
+    // observation
+    float *data = nullptr, *weights = nullptr;
+    bool own_obs = false;
+    double *log_norm = nullptr;
+    // components
+    int32_t *comp_start = nullptr, *c_blend = nullptr, *c_oy = nullptr, *c_ox = nullptr,
+            *c_h = nullptr, *c_w = nullptr, *c_flags = nullptr, *c_plan = nullptr;
+    int64_t *c_moff = nullptr;
+    float *c_sed_min_step = nullptr, *c_sed_rel = nullptr, *c_morph_step = nullptr,
+          *c_morph_rel = nullptr, *c_min_grad = nullptr, *c_lthresh = nullptr;
+    float *sed = nullptr, *morph = nullptr;
+    float *mom[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *g_sed = nullptr, *g_morph = nullptr;
+    int64_t n_morph = 0;
+    bool have_components = false, have_obs = false, have_kernel = false;
+    // per blend
+    int32_t *state = nullptr, *zero_state = nullptr, *n_loss = nullptr, *status_out = nullptr;
+    double *loss_hist = nullptr, *last_loss = nullptr, *loss_partial = nullptr;
+    // plans
+    std::vector<SweepPlanDev> plans;
+    SweepPlanDev *d_plans = nullptr;
+    int max_levels = 0;
+    BatchView view{};
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> events;
+    double phase_ms[6] = {0, 0, 0, 0, 0, 0};
+    int timed_iters = 0;
+};
+
+namespace {
+
+void refresh_view(smi_batch *b) {
+    BatchView &v = b->view;
+    v.nb = b->d.n_blends;
+    v.C = b->d.C;
+    v.H = b->d.H;
+    v.W = b->d.W;
+    v.Fy = b->Fy;
+    v.Fx = b->Fx;
+    v.n_comp = b->d.n_components;
+    v.comp_start = b->comp_start;
+    v.c_blend = b->c_blend;
+    v.c_oy = b->c_oy;
+    v.c_ox = b->c_ox;
+    v.c_h = b->c_h;
+    v.c_w = b->c_w;
+    v.c_flags = b->c_flags;
+    v.c_plan = b->c_plan;
+    v.c_moff = b->c_moff;
+    v.c_sed_min_step = b->c_sed_min_step;
+    v.c_sed_rel = b->c_sed_rel;
+    v.c_morph_step = b->c_morph_step;
+    v.c_morph_rel = b->c_morph_rel;
+    v.c_min_grad = b->c_min_grad;
+    v.c_lthresh = b->c_lthresh;
+    v.sed = b->sed;
+    v.morph = b->morph;
+    v.m_sed = b->mom[0];
+    v.v_sed = b->mom[1];
+    v.vh_sed = b->mom[2];
+    v.m_morph = b->mom[3];
+    v.v_morph = b->mom[4];
+    v.vh_morph = b->mom[5];
+    v.data = b->data;
+    v.weights = b->weights;
+    v.log_norm = b->log_norm;
+    v.state = b->state;
+    v.n_loss = b->n_loss;
+    v.loss_hist = b->loss_hist;
+    v.hist_cap = b->d.max_iter;
+    v.last_loss = b->last_loss;
+    v.loss_partial = b->loss_partial;
+    v.n_partial = (b->d.H * b->d.W + 255) / 256;
+    v.plans = b->d_plans;
+    v.max_levels = b->max_levels;
+}
+
+int ready(smi_batch *b) {
+    SMI_REQUIRE(b != nullptr, "null batch");
+    SMI_REQUIRE(b->have_components, "smi_batch_set_components has not been called");
+    SMI_REQUIRE(b->have_obs, "smi_batch_set_observation has not been called");
+    SMI_REQUIRE(b->null_renderer || b->have_kernel, "smi_batch_set_kernel has not been called");
+    SMI_HIP(hipSetDevice(b->device));
+    return SMI_OK;
+}
+
+int fft_exec(smi_batch *b, rocfft_plan plan, void *in, void *out) {
+    void *ins[1] = {in}, *outs[1] = {out};
+    SMI_FFT(rocfft_execute(plan, ins, outs, b->info));
+    return SMI_OK;
+}
+
+// rendered = model (*) kernel, or its transpose; in: P, out: Q
+int convolve(smi_batch *b, const BatchView &v, int conj) {
+    if (b->null_renderer) return SMI_OK;
+    int rc = fft_exec(b, b->plan_fwd, b->P, b->S);
+    if (rc) return rc;
+    launch_cmul(b->S, b->Khat, v.nb, v.C, (int64_t)b->Fy * b->Fxh, b->d.kernel_bands,
+                b->d.kernel_per_blend, conj, v.state, b->stream);
+    return fft_exec(b, b->plan_inv, b->S, b->Q);
+}
+
+BatchView unmasked_view(smi_batch *b) {
+    BatchView v = b->view;
+    v.state = b->zero_state;
+    return v;
+}
+
+int upload_plans(smi_batch *b) {
+    if (b->d_plans) {
+        SMI_HIP(hipFree(b->d_plans));
+        b->d_plans = nullptr;
+    }
+    if (!b->plans.empty()) {
+        SMI_HIP(dev_alloc(&b->d_plans, b->plans.size()));
+        SMI_HIP(hipMemcpy(b->d_plans, b->plans.data(), b->plans.size() * sizeof(SweepPlanDev),
+                          hipMemcpyHostToDevice));
+    }
+    refresh_view(b);
+    return SMI_OK;
+}
+
+template <typename T>
+int upload(T **dst, const T *src, size_t n) {
+    if (*dst) {
+        SMI_HIP(hipFree(*dst));
+        *dst = nullptr;
+    }
+    SMI_HIP(dev_alloc(dst, n));
+    if (n) SMI_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return SMI_OK;
+}
+
+template <typename T>
+int seam1_sweep(T *flat_img, const T *weights, const int32_t *offsets, int32_t n_off,
+                const int32_t *dist_idx, int32_t n_idx, int32_t n_pix, T min_gradient) {
+    SMI_REQUIRE(flat_img && weights && offsets && (dist_idx || n_idx == 0), "null argument");
+    SMI_REQUIRE(n_pix > 0 && n_off > 0 && n_idx >= 0, "bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device available");
+        return SMI_ERR_NO_DEVICE;
+    }
+    std::vector<double> w64((size_t)n_off * n_pix);
+    for (size_t i = 0; i < w64.size(); ++i) w64[i] = (double)weights[i];
+    SweepPlanHost plan;
+    if (!build_sweep_plan(n_pix, w64.data(), offsets, n_off, dist_idx, n_idx, &plan))
+        return SMI_ERR_INVALID;
+    return sweep_host_buffers<T>(flat_img, n_pix, plan, min_gradient);
+}
+
+template <typename T>
+int seam1_filter(const T *image, int32_t H, int32_t W, const T *values, int32_t n_taps,
+                 const int32_t *ys, const int32_t *ye, const int32_t *xs, const int32_t *xe,
+                 T *result) {
+    SMI_REQUIRE(image && values && ys && ye && xs && xe && result, "null argument");
+    SMI_REQUIRE(H > 0 && W > 0 && n_taps >= 0, "bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device available");
+        return SMI_ERR_NO_DEVICE;
+    }
+    return apply_filter_host_buffers<T>(image, H, W, values, n_taps, ys, ye, xs, xe, result);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *smi_last_error(void) { return g_error.c_str(); }
+
+const char *smi_version(void) { return "scarlet_amd 0.1 gfx950"; }
+
+int smi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int smi_prox_weighted_monotonic_f32(float *flat_img, const float *weights,
+                                    const int32_t *offsets, int32_t n_off,
+                                    const int32_t *dist_idx, int32_t n_idx, int32_t n_pix,
+                                    float min_gradient) {
+    return seam1_sweep<float>(flat_img, weights, offsets, n_off, dist_idx, n_idx, n_pix,
+                              min_gradient);
+}
+int smi_prox_weighted_monotonic_f64(double *flat_img, const double *weights,
+                                    const int32_t *offsets, int32_t n_off,
+                                    const int32_t *dist_idx, int32_t n_idx, int32_t n_pix,
+                                    double min_gradient) {
+    return seam1_sweep<double>(flat_img, weights, offsets, n_off, dist_idx, n_idx, n_pix,
+                               min_gradient);
+}
+int smi_apply_filter_f32(const float *image, int32_t H, int32_t W, const float *values,
+                         int32_t n_taps, const int32_t *y_start, const int32_t *y_end,
+                         const int32_t *x_start, const int32_t *x_end, float *result) {
+    return seam1_filter<float>(image, H, W, values, n_taps, y_start, y_end, x_start, x_end,
+                               result);
+}
+int smi_apply_filter_f64(const double *image, int32_t H, int32_t W, const double *values,
+                         int32_t n_taps, const int32_t *y_start, const int32_t *y_end,
+                         const int32_t *x_start, const int32_t *x_end, double *result) {
+    return seam1_filter<double>(image, H, W, values, n_taps, y_start, y_end, x_start, x_end,
+                                result);
+}
+
+int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
+    SMI_REQUIRE(desc && out, "null argument");
+    SMI_REQUIRE(desc->n_blends > 0 && desc->n_blends <= 65535, "n_blends must be in [1, 65535]");
+    SMI_REQUIRE(desc->C > 0 && desc->C <= 64, "C must be in [1, 64]");
+    SMI_REQUIRE(desc->H > 0 && desc->W > 0, "empty frame");
+    SMI_REQUIRE(desc->n_components >= 0, "negative component count");
+    SMI_REQUIRE(desc->max_iter > 0, "max_iter must be positive");
+    SMI_REQUIRE((desc->kernel_h == 0) == (desc->kernel_w == 0), "kernel_h/kernel_w mismatch");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device available");
+        return SMI_ERR_NO_DEVICE;
+    }
+    SMI_REQUIRE(device >= 0 && device < ndev, "device index out of range");
+    SMI_HIP(hipSetDevice(device));
+
+    smi_batch *b = new smi_batch();
+    b->d = *desc;
+    b->device = device;
+    b->null_renderer = desc->kernel_h == 0;
+    const int nb = desc->n_blends, C = desc->C, H = desc->H, W = desc->W;
+    if (b->null_renderer) {
+        b->Fy = H;
+        b->Fx = W;
+    } else {
+        SMI_REQUIRE(desc->kernel_bands == 1 || desc->kernel_bands == C,
+                    "kernel_bands must be 1 or C");
+        if (desc->fft_h > 0 && desc->fft_w > 0) {
+            // alias-free 'same' output needs F >= N + P/2 (image at the origin)
+            SMI_REQUIRE(desc->fft_h >= H + desc->kernel_h / 2 && desc->fft_w >= W + desc->kernel_w / 2,
+                        "fft shape too small for an alias-free convolution");
+            SMI_REQUIRE(desc->fft_w % 2 == 0, "fft_w must be even");
+            b->Fy = desc->fft_h;
+            b->Fx = desc->fft_w;
+        } else {
+            reference_fft_shape(H, W, desc->kernel_h, desc->kernel_w, &b->Fy, &b->Fx);
+        }
+    }
+    b->Fxh = b->Fx / 2 + 1;
+    const size_t n_real = (size_t)nb * C * b->Fy * b->Fx;
+    SMI_HIP(dev_alloc(&b->P, n_real));
+    SMI_HIP(hipMemset(b->P, 0, n_real * sizeof(float)));
+    if (b->null_renderer) {
+        b->Q = b->P;
+    } else {
+        const size_t n_cplx = (size_t)nb * C * b->Fy * b->Fxh;
+        SMI_HIP(dev_alloc(&b->Q, n_real));
+        SMI_HIP(hipMemset(b->Q, 0, n_real * sizeof(float)));
+        SMI_HIP(dev_alloc(&b->S, n_cplx));
+        SMI_FFT(rocfft_setup());
+        const size_t lengths[2] = {(size_t)b->Fx, (size_t)b->Fy};
+        SMI_FFT(rocfft_plan_create(&b->plan_fwd, rocfft_placement_notinplace,
+                                   rocfft_transform_type_real_forward, rocfft_precision_single,
+                                   2, lengths, (size_t)nb * C, nullptr));
+        SMI_FFT(rocfft_plan_create(&b->plan_inv, rocfft_placement_notinplace,
+                                   rocfft_transform_type_real_inverse, rocfft_precision_single,
+                                   2, lengths, (size_t)nb * C, nullptr));
+        size_t w1 = 0, w2 = 0;
+        SMI_FFT(rocfft_plan_get_work_buffer_size(b->plan_fwd, &w1));
+        SMI_FFT(rocfft_plan_get_work_buffer_size(b->plan_inv, &w2));
+        const size_t wb = w1 > w2 ? w1 : w2;
+        SMI_FFT(rocfft_execution_info_create(&b->info));
+        if (wb) {
+            SMI_HIP(hipMalloc(&b->work, wb));
+            SMI_FFT(rocfft_execution_info_set_work_buffer(b->info, b->work, wb));
+        }
+    }
+    SMI_HIP(dev_alloc(&b->state, nb));
+    SMI_HIP(dev_alloc(&b->zero_state, nb));
+    SMI_HIP(dev_alloc(&b->n_loss, nb));
+    SMI_HIP(dev_alloc(&b->status_out, 2));
+    SMI_HIP(dev_alloc(&b->loss_hist, (size_t)nb * desc->max_iter));
+    SMI_HIP(dev_alloc(&b->last_loss, nb));
+    SMI_HIP(dev_alloc(&b->log_norm, nb));
+    SMI_HIP(dev_alloc(&b->loss_partial, (size_t)nb * ((H * W + 255) / 256)));
+    SMI_HIP(hipMemset(b->state, 0, nb * sizeof(int32_t)));
+    SMI_HIP(hipMemset(b->zero_state, 0, nb * sizeof(int32_t)));
+    SMI_HIP(hipMemset(b->n_loss, 0, nb * sizeof(int32_t)));
+    SMI_HIP(hipMemset(b->last_loss, 0, nb * sizeof(double)));
+    refresh_view(b);
+    *out = b;
+    return SMI_OK;
+}
+
+int smi_batch_destroy(smi_batch *b) {
+    if (!b) return SMI_OK;
+    (void)hipSetDevice(b->device);
+    (void)hipDeviceSynchronize();
+    if (b->plan_fwd) rocfft_plan_destroy(b->plan_fwd);
+    if (b->plan_inv) rocfft_plan_destroy(b->plan_inv);
+    if (b->info) rocfft_execution_info_destroy(b->info);
+    for (auto &pl : b->plans) {
+        (void)hipFree(pl.level_start);
+        (void)hipFree(pl.pix);
+        (void)hipFree(pl.cnt);
+        (void)hipFree(pl.nbr);
+        (void)hipFree(pl.wt);
+    }
+    void *bufs[] = {b->P, b->null_renderer ? nullptr : (void *)b->Q, b->S, b->Khat, b->work,
+                    b->own_obs ? b->data : nullptr, b->own_obs ? b->weights : nullptr,
+                    b->log_norm, b->comp_start, b->c_blend, b->c_oy, b->c_ox, b->c_h, b->c_w,
+                    b->c_flags, b->c_plan, b->c_moff, b->c_sed_min_step, b->c_sed_rel,
+                    b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
+                    b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
+                    b->g_sed, b->g_morph, b->state, b->zero_state, b->n_loss, b->status_out,
+                    b->loss_hist, b->last_loss, b->loss_partial, b->d_plans};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    for (auto e : b->events) (void)hipEventDestroy(e);
+    delete b;
+    return SMI_OK;
+}
+
+int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *weights,
+                             const int32_t *offsets, const int32_t *dist_idx, int32_t n_idx) {
+    SMI_REQUIRE(b && weights && offsets, "null argument");
+    SMI_REQUIRE(h > 0 && w > 0, "empty box");
+    SMI_HIP(hipSetDevice(b->device));
+    SweepPlanHost hp;
+    if (!build_sweep_plan(h * w, weights, offsets, 8, dist_idx, n_idx, &hp)) return SMI_ERR_INVALID;
+    SweepPlanDev dp;
+    dp.h = h;
+    dp.w = w;
+    dp.n_entries = hp.n_entries;
+    dp.max_terms = hp.max_terms;
+    dp.n_levels = (int32_t)hp.level_start.size() - 1;
+    std::vector<float> wt(hp.wt.size());
+    for (size_t i = 0; i < wt.size(); ++i) wt[i] = (float)hp.wt[i];
+    int rc;
+    if ((rc = upload(&dp.level_start, hp.level_start.data(), hp.level_start.size()))) return rc;
+    if ((rc = upload(&dp.pix, hp.pix.data(), hp.pix.size()))) return rc;
+    if ((rc = upload(&dp.cnt, hp.cnt.data(), hp.cnt.size()))) return rc;
+    if ((rc = upload(&dp.nbr, hp.nbr.data(), hp.nbr.size()))) return rc;
+    if ((rc = upload(&dp.wt, wt.data(), wt.size()))) return rc;
+    b->plans.push_back(dp);
+    if (dp.n_levels > b->max_levels) b->max_levels = dp.n_levels;
+    if ((rc = upload_plans(b))) return rc;
+    return (int)b->plans.size() - 1;
+}
+
+int smi_batch_set_observation(smi_batch *b, const float *data, const float *weights) {
+    SMI_REQUIRE(b && data && weights, "null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    const size_t n = (size_t)b->d.n_blends * b->d.C * b->d.H * b->d.W;
+    if (!b->own_obs) b->data = b->weights = nullptr;
+    int rc;
+    if ((rc = upload(&b->data, data, n))) return rc;
+    if ((rc = upload(&b->weights, weights, n))) return rc;
+    b->own_obs = true;
+    launch_log_norm(b->weights, b->log_norm, b->d.n_blends, (int64_t)b->d.C * b->d.H * b->d.W,
+                    b->stream);
+    b->have_obs = true;
+    refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_set_observation_device(smi_batch *b, const float *d_data, const float *d_weights) {
+    SMI_REQUIRE(b && d_data && d_weights, "null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    if (b->own_obs) {
+        (void)hipFree(b->data);
+        (void)hipFree(b->weights);
+        b->own_obs = false;
+    }
+    b->data = const_cast<float *>(d_data);
+    b->weights = const_cast<float *>(d_weights);
+    launch_log_norm(b->weights, b->log_norm, b->d.n_blends, (int64_t)b->d.C * b->d.H * b->d.W,
+                    b->stream);
+    b->have_obs = true;
+    refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
+    SMI_REQUIRE(b && kernel, "null argument");
+    SMI_REQUIRE(!b->null_renderer, "batch was created without a kernel (NullRenderer)");
+    SMI_HIP(hipSetDevice(b->device));
+    const int n_img = (b->d.kernel_per_blend ? b->d.n_blends : 1) * b->d.kernel_bands;
+    const int ph = b->d.kernel_h, pw = b->d.kernel_w;
+    SMI_REQUIRE(ph <= b->Fy && pw <= b->Fx, "kernel larger than the FFT shape");
+    const size_t n_real = (size_t)n_img * b->Fy * b->Fx, n_cplx = (size_t)n_img * b->Fy * b->Fxh;
+    float *d_kern = nullptr, *d_pad = nullptr;
+    int rc;
+    if ((rc = upload(&d_kern, kernel, (size_t)n_img * ph * pw))) return rc;
+    SMI_HIP(dev_alloc(&d_pad, n_real));
+    SMI_HIP(hipMemsetAsync(d_pad, 0, n_real * sizeof(float), b->stream));
+    const float scale = 1.0f / ((float)b->Fy * (float)b->Fx);
+    launch_wrap_kernel(d_kern, d_pad, n_img, ph, pw, b->Fy, b->Fx, scale, b->stream);
+    if (!b->Khat) SMI_HIP(dev_alloc(&b->Khat, n_cplx));
+    rocfft_plan plan = nullptr;
+    const size_t lengths[2] = {(size_t)b->Fx, (size_t)b->Fy};
+    SMI_FFT(rocfft_plan_create(&plan, rocfft_placement_notinplace,
+                               rocfft_transform_type_real_forward, rocfft_precision_single, 2,
+                               lengths, (size_t)n_img, nullptr));
+    size_t wb = 0;
+    SMI_FFT(rocfft_plan_get_work_buffer_size(plan, &wb));
+    rocfft_execution_info info = nullptr;
+    SMI_FFT(rocfft_execution_info_create(&info));
+    void *work = nullptr;
+    if (wb) {
+        SMI_HIP(hipMalloc(&work, wb));
+        SMI_FFT(rocfft_execution_info_set_work_buffer(info, work, wb));
+    }
+    SMI_FFT(rocfft_execution_info_set_stream(info, b->stream));
+    void *ins[1] = {d_pad}, *outs[1] = {b->Khat};
+    SMI_FFT(rocfft_execute(plan, ins, outs, info));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    rocfft_execution_info_destroy(info);
+    rocfft_plan_destroy(plan);
+    if (work) (void)hipFree(work);
+    (void)hipFree(d_pad);
+    (void)hipFree(d_kern);
+    b->have_kernel = true;
+    return SMI_OK;
+}
+
+int smi_batch_set_components(smi_batch *b, const smi_components *c) {
+    SMI_REQUIRE(b && c, "null argument");
+    SMI_REQUIRE(c->blend && c->origin_y && c->origin_x && c->box_h && c->box_w && c->sed &&
+                    c->morph && c->sed_min_step && c->morph_step && c->prox_flags,
+                "missing component array");
+    SMI_HIP(hipSetDevice(b->device));
+    const int n = b->d.n_components, nb = b->d.n_blends, C = b->d.C;
+    std::vector<int32_t> start(nb + 1, 0);
+    std::vector<int64_t> moff(n + 1, 0);
+    int max_pix = 1, prev = 0;
+    for (int k = 0; k < n; ++k) {
+        SMI_REQUIRE(c->blend[k] >= prev && c->blend[k] < nb, "components must be grouped by blend");
+        SMI_REQUIRE(c->box_h[k] > 0 && c->box_w[k] > 0, "empty component box");
+        prev = c->blend[k];
+        start[c->blend[k] + 1]++;
+        const int64_t np = (int64_t)c->box_h[k] * c->box_w[k];
+        SMI_REQUIRE(np * 16 + 2048 <= 160 * 1024, "component box too large (LDS-resident update)");
+        moff[k + 1] = moff[k] + np;
+        if (np > max_pix) max_pix = (int)np;
+        if (c->prox_flags[k] & SMI_PROX_MONOTONIC) {
+            const int pid = c->sweep_plan ? c->sweep_plan[k] : -1;
+            SMI_REQUIRE(pid >= 0 && pid < (int)b->plans.size(), "monotonic component without sweep plan");
+            SMI_REQUIRE(b->plans[pid].h == c->box_h[k] && b->plans[pid].w == c->box_w[k],
+                        "sweep plan shape does not match the component box");
+        }
+    }
+    for (int i = 0; i < nb; ++i) start[i + 1] += start[i];
+    b->n_morph = moff[n];
+    b->view.max_box_pixels = max_pix;
+
+    std::vector<float> zeros_n(n, 0.f), rel(n, 1e-2f);
+    std::vector<int32_t> noplan(n, -1);
+    int rc;
+#define UP(field, src, count) \
+    if ((rc = upload(&b->field, src, (size_t)(count)))) return rc
+    UP(comp_start, start.data(), nb + 1);
+    UP(c_blend, c->blend, n);
+    UP(c_oy, c->origin_y, n);
+    UP(c_ox, c->origin_x, n);
+    UP(c_h, c->box_h, n);
+    UP(c_w, c->box_w, n);
+    UP(c_flags, c->prox_flags, n);
+    UP(c_plan, c->sweep_plan ? c->sweep_plan : noplan.data(), n);
+    UP(c_moff, moff.data(), n + 1);
+    UP(c_sed_min_step, c->sed_min_step, (size_t)n * C);
+    UP(c_sed_rel, c->sed_rel_step ? c->sed_rel_step : rel.data(), n);
+    UP(c_morph_step, c->morph_step, n);
+    UP(c_morph_rel, c->morph_rel_step ? c->morph_rel_step : zeros_n.data(), n);
+    UP(c_min_grad, c->min_gradient ? c->min_gradient : zeros_n.data(), n);
+    UP(c_lthresh, c->l_thresh ? c->l_thresh : zeros_n.data(), n);
+    UP(sed, c->sed, (size_t)n * C);
+    UP(morph, c->morph, (size_t)b->n_morph);
+#undef UP
+    for (int i = 0; i < 6; ++i) {
+        const size_t cnt = i < 3 ? (size_t)n * C : (size_t)b->n_morph;
+        if (b->mom[i]) SMI_HIP(hipFree(b->mom[i]));
+        SMI_HIP(dev_alloc(&b->mom[i], cnt));
+        SMI_HIP(hipMemset(b->mom[i], 0, (cnt ? cnt : 1) * sizeof(float)));
+    }
+    if (b->g_sed) SMI_HIP(hipFree(b->g_sed));
+    if (b->g_morph) SMI_HIP(hipFree(b->g_morph));
+    SMI_HIP(dev_alloc(&b->g_sed, (size_t)n * C));
+    SMI_HIP(dev_alloc(&b->g_morph, (size_t)b->n_morph));
+    b->have_components = true;
+    const int keep = b->view.max_box_pixels;
+    refresh_view(b);
+    b->view.max_box_pixels = keep;
+    return SMI_OK;
+}
+
+int smi_batch_set_moments(smi_batch *b, const float *m_sed, const float *v_sed,
+                          const float *vhat_sed, const float *m_morph, const float *v_morph,
+                          const float *vhat_morph) {
+    SMI_REQUIRE(b && b->have_components, "components not set");
+    SMI_HIP(hipSetDevice(b->device));
+    const float *src[6] = {m_sed, v_sed, vhat_sed, m_morph, v_morph, vhat_morph};
+    for (int i = 0; i < 6; ++i) {
+        const size_t cnt = i < 3 ? (size_t)b->d.n_components * b->d.C : (size_t)b->n_morph;
+        if (src[i])
+            SMI_HIP(hipMemcpy(b->mom[i], src[i], cnt * sizeof(float), hipMemcpyHostToDevice));
+        else
+            SMI_HIP(hipMemset(b->mom[i], 0, (cnt ? cnt : 1) * sizeof(float)));
+    }
+    return SMI_OK;
+}
+
+int smi_batch_get_moments(smi_batch *b, float *m_sed, float *v_sed, float *vhat_sed,
+                          float *m_morph, float *v_morph, float *vhat_morph) {
+    SMI_REQUIRE(b && b->have_components, "components not set");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    float *dst[6] = {m_sed, v_sed, vhat_sed, m_morph, v_morph, vhat_morph};
+    for (int i = 0; i < 6; ++i) {
+        const size_t cnt = i < 3 ? (size_t)b->d.n_components * b->d.C : (size_t)b->n_morph;
+        if (dst[i]) SMI_HIP(hipMemcpy(dst[i], b->mom[i], cnt * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return SMI_OK;
+}
+
+int smi_batch_get_parameters(smi_batch *b, float *sed, float *morph) {
+    SMI_REQUIRE(b && b->have_components, "components not set");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    if (sed)
+        SMI_HIP(hipMemcpy(sed, b->sed, (size_t)b->d.n_components * b->d.C * sizeof(float),
+                          hipMemcpyDeviceToHost));
+    if (morph)
+        SMI_HIP(hipMemcpy(morph, b->morph, (size_t)b->n_morph * sizeof(float),
+                          hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+
+int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph) {
+    SMI_REQUIRE(b && b->have_components, "components not set");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    if (sed)
+        SMI_HIP(hipMemcpy(b->sed, sed, (size_t)b->d.n_components * b->d.C * sizeof(float),
+                          hipMemcpyHostToDevice));
+    if (morph)
+        SMI_HIP(hipMemcpy(b->morph, morph, (size_t)b->n_morph * sizeof(float),
+                          hipMemcpyHostToDevice));
+    return SMI_OK;
+}
+
+int smi_batch_set_stream(smi_batch *b, void *stream) {
+    SMI_REQUIRE(b, "null batch");
+    b->stream = reinterpret_cast<hipStream_t>(stream);
+    if (b->info) SMI_FFT(rocfft_execution_info_set_stream(b->info, b->stream));
+    return SMI_OK;
+}
+
+int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL) {
+    int rc = ready(b);
+    if (rc) return rc;
+    const BatchView v = unmasked_view(b);
+    const int nb = v.nb, C = v.C, H = v.H, W = v.W;
+    const size_t n_out = (size_t)nb * C * H * W;
+    launch_render(v, b->P, b->stream);
+    float *tmp = nullptr;
+    if (model || rendered) SMI_HIP(dev_alloc(&tmp, n_out));
+    if (model) {
+        launch_crop(b->P, tmp, nb * C, H, W, b->Fy, b->Fx, b->stream);
+        SMI_HIP(hipMemcpyAsync(model, tmp, n_out * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+        SMI_HIP(hipStreamSynchronize(b->stream));
+    }
+    if ((rc = convolve(b, v, 0))) return rc;
+    if (rendered) {
+        launch_crop(b->Q, tmp, nb * C, H, W, b->Fy, b->Fx, b->stream);
+        SMI_HIP(hipMemcpyAsync(rendered, tmp, n_out * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+        SMI_HIP(hipStreamSynchronize(b->stream));
+    }
+    if (tmp) (void)hipFree(tmp);
+    if (logL) {
+        launch_residual(v, b->Q, b->P, b->stream);
+        std::vector<double> part((size_t)nb * v.n_partial), ln(nb);
+        SMI_HIP(hipMemcpyAsync(part.data(), b->loss_partial, part.size() * sizeof(double),
+                               hipMemcpyDeviceToHost, b->stream));
+        SMI_HIP(hipMemcpyAsync(ln.data(), b->log_norm, nb * sizeof(double), hipMemcpyDeviceToHost,
+                               b->stream));
+        SMI_HIP(hipStreamSynchronize(b->stream));
+        for (int i = 0; i < nb; ++i) {
+            double t = 0.0;
+            for (int j = 0; j < v.n_partial; ++j) t += part[(size_t)i * v.n_partial + j];
+            logL[i] = -(ln[i] + 0.5 * t);
+        }
+    }
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
+    int rc = ready(b);
+    if (rc) return rc;
+    const BatchView v = unmasked_view(b);
+    launch_render(v, b->P, b->stream);
+    if ((rc = convolve(b, v, 0))) return rc;
+    launch_residual(v, b->Q, b->P, b->stream);
+    if ((rc = convolve(b, v, 1))) return rc;
+    if ((rc = launch_update(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_morph, 1, b->stream))) return rc;
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    if (g_sed)
+        SMI_HIP(hipMemcpy(g_sed, b->g_sed, (size_t)v.n_comp * v.C * sizeof(float),
+                          hipMemcpyDeviceToHost));
+    if (g_morph)
+        SMI_HIP(hipMemcpy(g_morph, b->g_morph, (size_t)b->n_morph * sizeof(float),
+                          hipMemcpyDeviceToHost));
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32_t min_iter,
+                   int32_t prox_max_iter) {
+    int rc = ready(b);
+    if (rc) return rc;
+    SMI_REQUIRE(n_iter >= 0 && it0 >= 0 && prox_max_iter >= 0, "bad iteration arguments");
+    const BatchView &v = b->view;
+    const int check = e_rel > 0.f;
+    const bool timing = b->timing;
+    if (timing) {
+        const size_t need = (size_t)n_iter * 6;
+        while (b->events.size() < need) {
+            hipEvent_t e;
+            SMI_HIP(hipEventCreate(&e));
+            b->events.push_back(e);
+        }
+    }
+    for (int i = 0; i < n_iter; ++i) {
+        const int it = it0 + i;
+        hipEvent_t *ev = timing ? &b->events[(size_t)i * 6] : nullptr;
+        if (ev) SMI_HIP(hipEventRecord(ev[0], b->stream));
+        launch_render(v, b->P, b->stream);
+        if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
+        if ((rc = convolve(b, v, 0))) return rc;
+        if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
+        launch_residual(v, b->Q, b->P, b->stream);
+        launch_finalize(v, it, e_rel, min_iter, check, b->stream);
+        if (ev) SMI_HIP(hipEventRecord(ev[3], b->stream));
+        if ((rc = convolve(b, v, 1))) return rc;
+        if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
+        if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, b->stream)))
+            return rc;
+        if (check) launch_advance(v, b->stream);
+        if (ev) SMI_HIP(hipEventRecord(ev[5], b->stream));
+    }
+    SMI_HIP(hipGetLastError());
+    if (timing && n_iter > 0) {
+        SMI_HIP(hipStreamSynchronize(b->stream));
+        for (int p = 0; p < 6; ++p) b->phase_ms[p] = 0.0;
+        for (int i = 0; i < n_iter; ++i) {
+            hipEvent_t *ev = &b->events[(size_t)i * 6];
+            for (int p = 0; p < 5; ++p) {
+                float ms = 0.f;
+                SMI_HIP(hipEventElapsedTime(&ms, ev[p], ev[p + 1]));
+                b->phase_ms[p] += ms;
+            }
+            float tot = 0.f;
+            SMI_HIP(hipEventElapsedTime(&tot, ev[0], ev[5]));
+            b->phase_ms[5] += tot;
+        }
+        for (int p = 0; p < 6; ++p) b->phase_ms[p] /= n_iter;
+        b->timed_iters = n_iter;
+    }
+    return SMI_OK;
+}
+
+int smi_batch_status(smi_batch *b, int32_t *n_active, int32_t *first_error) {
+    SMI_REQUIRE(b, "null batch");
+    SMI_HIP(hipSetDevice(b->device));
+    launch_count_active(b->state, b->d.n_blends, b->status_out, b->stream);
+    int32_t out[2] = {0, -1};
+    SMI_HIP(hipMemcpyAsync(out, b->status_out, sizeof(out), hipMemcpyDeviceToHost, b->stream));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipGetLastError());
+    if (n_active) *n_active = out[0];
+    if (first_error) *first_error = out[1];
+    return SMI_OK;
+}
+
+int smi_batch_fit(smi_batch *b, int32_t max_iter, float e_rel, int32_t min_iter,
+                  int32_t prox_max_iter, int32_t sync_every, int32_t *n_iter) {
+    int rc = ready(b);
+    if (rc) return rc;
+    SMI_REQUIRE(max_iter >= 0, "negative max_iter");
+    if (sync_every <= 0) sync_every = 10;
+    int it = 0;
+    while (it < max_iter) {
+        const int chunk = std::min(sync_every, max_iter - it);
+        if ((rc = smi_batch_step(b, it, chunk, e_rel, min_iter, prox_max_iter))) return rc;
+        it += chunk;
+        int32_t active = 0, err = -1;
+        if ((rc = smi_batch_status(b, &active, &err))) return rc;
+        if (err >= 0) {
+            set_error("blend " + std::to_string(err) + ": parameters are not finite");
+            return SMI_ERR_ARITHMETIC;
+        }
+        if (active == 0) break;
+    }
+    if (n_iter) {
+        SMI_HIP(hipMemcpy(n_iter, b->n_loss, b->d.n_blends * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return SMI_OK;
+}
+
+int smi_batch_get_loss(smi_batch *b, double *out, int32_t capacity, int32_t *n_iter) {
+    SMI_REQUIRE(b, "null batch");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int nb = b->d.n_blends, cap = b->d.max_iter;
+    std::vector<int32_t> n(nb);
+    SMI_HIP(hipMemcpy(n.data(), b->n_loss, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_iter) std::memcpy(n_iter, n.data(), nb * sizeof(int32_t));
+    if (out) {
+        SMI_REQUIRE(capacity > 0, "capacity must be positive");
+        std::vector<double> hist((size_t)nb * cap);
+        SMI_HIP(hipMemcpy(hist.data(), b->loss_hist, hist.size() * sizeof(double),
+                          hipMemcpyDeviceToHost));
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        for (int i = 0; i < nb; ++i)
+            for (int j = 0; j < capacity; ++j)
+                out[(size_t)i * capacity + j] =
+                    (j < n[i] && j < cap) ? hist[(size_t)i * cap + j] : nan;
+    }
+    return SMI_OK;
+}
+
+int smi_batch_reset(smi_batch *b) {
+    SMI_REQUIRE(b, "null batch");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int nb = b->d.n_blends;
+    SMI_HIP(hipMemset(b->state, 0, nb * sizeof(int32_t)));
+    SMI_HIP(hipMemset(b->n_loss, 0, nb * sizeof(int32_t)));
+    SMI_HIP(hipMemset(b->last_loss, 0, nb * sizeof(double)));
+    return SMI_OK;
+}
+
+int smi_batch_enable_timing(smi_batch *b, int32_t on) {
+    SMI_REQUIRE(b, "null batch");
+    b->timing = on != 0;
+    return SMI_OK;
+}
+
+int smi_batch_get_timing(smi_batch *b, double *ms_per_phase, int32_t n_phases) {
+    SMI_REQUIRE(b && ms_per_phase, "null argument");
+    for (int p = 0; p < n_phases && p < 6; ++p) ms_per_phase[p] = b->phase_ms[p];
+    return SMI_OK;
+}
+
+int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w) {
+    SMI_REQUIRE(b, "null batch");
+    if (fft_h) *fft_h = b->Fy;
+    if (fft_w) *fft_w = b->Fx;
+    return SMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// Internal declarations shared by the translation units of libscarlet_amd.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/scarlet_amd.h"
+
+namespace smi {
+
+void set_error(const std::string &msg);
+
+#define SMI_HIP(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            smi::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));     \
+            return SMI_ERR_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define SMI_REQUIRE(cond, msg)                                                     \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            smi::set_error(std::string(msg) + " (" #cond ")");                     \
+            return SMI_ERR_INVALID;                                                \
+        }                                                                          \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Level-ordered plan of one monotonic operator (one box shape x weighting).
+//
+// The reference walks the pixels one after another in order of increasing
+// radius and clips each against the weighted mean of its neighbours nearer the
+// peak (operators_pybind11.cc:14-36).  Pixels whose inputs are all final can be
+// processed together: the plan groups the sweep order into levels of the
+// read/write dependency graph, so that a wavefront handles one level per step
+// and still reproduces the sequential result bit for bit.
+//
+// Entry e (level major):  pix[e] target pixel, cnt[e] number of terms,
+// nbr[j*E+e] / wt[j*E+e] the j-th term in ascending neighbour order.
+// ---------------------------------------------------------------------------
+struct SweepPlanHost {
+    int32_t h = 0, w = 0;
+    int32_t n_entries = 0;  // E
+    int32_t max_terms = 0;  // D
+    std::vector<int32_t> level_start;  // n_levels + 1
+    std::vector<int32_t> pix;          // E
+    std::vector<int32_t> cnt;          // E
+    std::vector<int32_t> nbr;          // D * E
+    std::vector<double> wt;            // D * E
+};
+
+// Build the plan from the tables the reference binds (operator.py:62-96).
+// Returns false (with set_error) on malformed input.
+bool build_sweep_plan(int32_t n_pix, const double *weights, const int32_t *offsets,
+                      int32_t n_off, const int32_t *dist_idx, int32_t n_idx,
+                      SweepPlanHost *out);
+
+struct SweepPlanDev {
+    int32_t h = 0, w = 0, n_entries = 0, max_terms = 0, n_levels = 0;
+    int32_t *level_start = nullptr;
+    int32_t *pix = nullptr;
+    int32_t *cnt = nullptr;
+    int32_t *nbr = nullptr;
+    float *wt = nullptr;
+};
+
+// ---------------------------------------------------------------------------
+// kernel launchers (kernels.hip)
+// ---------------------------------------------------------------------------
+
+struct BatchView {
+    int32_t nb, C, H, W, Fy, Fx;  // Fy=H, Fx=W for the NullRenderer
+    int32_t n_comp;
+    // components (device, SoA)
+    const int32_t *comp_start;  // nb + 1
+    const int32_t *c_blend, *c_oy, *c_ox, *c_h, *c_w, *c_flags, *c_plan;
+    const int64_t *c_moff;  // n_comp + 1 offsets into the packed morph arrays
+    const float *c_sed_min_step, *c_sed_rel, *c_morph_step, *c_morph_rel;
+    const float *c_min_grad, *c_lthresh;
+    float *sed, *morph;  // parameters
+    float *m_sed, *v_sed, *vh_sed, *m_morph, *v_morph, *vh_morph;
+    // observation
+    const float *data, *weights;
+    const double *log_norm;  // nb
+    // per blend state
+    int32_t *state;       // 0 active, 1 last iteration, 2 done, 3 non-finite
+    int32_t *n_loss;      // losses recorded
+    double *loss_hist;    // nb * hist_cap
+    int32_t hist_cap;
+    double *last_loss;    // nb
+    double *loss_partial; // nb * n_partial
+    int32_t n_partial;
+    // sweep plans
+    const SweepPlanDev *plans;  // device array
+    int32_t max_box_pixels;
+    int32_t max_levels;  // over all plans
+};
+
+void launch_render(const BatchView &v, float *P, hipStream_t s);
+void launch_residual(const BatchView &v, const float *Q, float *R, hipStream_t s);
+void launch_finalize(const BatchView &v, int32_t it, float e_rel, int32_t min_iter,
+                     int32_t check, hipStream_t s);
+void launch_advance(const BatchView &v, hipStream_t s);
+void launch_cmul(float2 *S, const float2 *K, int32_t nb, int32_t C, int64_t plane,
+                 int32_t k_bands, int32_t k_per_blend, int32_t conj,
+                 const int32_t *state, hipStream_t s);
+int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
+                  int32_t prox_max_iter, float *g_sed_out, float *g_morph_out,
+                  int32_t grad_only, hipStream_t s);
+void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
+                     hipStream_t s);
+void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,
+                        int32_t pw, int32_t Fy, int32_t Fx, float scale, hipStream_t s);
+void launch_crop(const float *P, float *out, int32_t n_img, int32_t H, int32_t W,
+                 int32_t Fy, int32_t Fx, hipStream_t s);
+void launch_count_active(const int32_t *state, int32_t nb, int32_t *out, hipStream_t s);
+
+template <typename T>
+int sweep_host_buffers(T *flat_img, int32_t n_pix, const SweepPlanHost &plan, T min_gradient);
+template <typename T>
+int apply_filter_host_buffers(const T *image, int32_t H, int32_t W, const T *values,
+                              int32_t n_taps, const int32_t *ys, const int32_t *ye,
+                              const int32_t *xs, const int32_t *xe, T *result);
+
+}  // namespace smi

@@ -1,0 +1,657 @@
+// HIP kernels (gfx950 / CDNA4, wave64) of the proximal-gradient loop.
+//
+// Everything here is HBM/LDS-bound element-wise, stencil and reduction work; no
+// MFMA.  Conventions: one thread per frame pixel with the band loop inside (so a
+// morphology value is fetched once for all bands and every global access is
+// coalesced along x); one wavefront per component for the parameter update, with
+// the morphology, the metric and the proximal iterate resident in LDS.
+#include <math.h>
+
+#include "common.h"
+
+namespace smi {
+
+namespace {
+
+constexpr int kBandChunk = 8;
+constexpr int kPixBlock = 256;
+constexpr float kB1 = 0.9f, kB2 = 0.999f, kEps = 1e-8f;  // lite/parameters.py:194
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_or(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Blend.get_model (blend.py:200-244, component.py:160-164): scatter-add of the
+// boxed outer products sed (x) morph, written straight into the zero-padded FFT
+// input cube P[nb][C][Fy][Fx] (image at the origin; the padding stays zero).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kPixBlock) void render_kernel(BatchView v, float *P) {
+    const int b = blockIdx.y;
+    if (v.state[b] >= 2) return;
+    const int pix = blockIdx.x * kPixBlock + threadIdx.x;
+    const int y = pix / v.W, x = pix - y * v.W;
+    const bool inside = pix < v.H * v.W;
+    const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
+    for (int c0 = 0; c0 < v.C; c0 += kBandChunk) {
+        float acc[kBandChunk];
+#pragma unroll
+        for (int j = 0; j < kBandChunk; ++j) acc[j] = 0.f;
+        const int nc = min(kBandChunk, v.C - c0);
+        for (int k = cs; k < ce; ++k) {
+            const int yy = y - v.c_oy[k], xx = x - v.c_ox[k];
+            const int w = v.c_w[k];
+            if (inside && (unsigned)yy < (unsigned)v.c_h[k] && (unsigned)xx < (unsigned)w) {
+                const float mv = v.morph[v.c_moff[k] + (int64_t)yy * w + xx];
+                const float *sed = v.sed + (int64_t)k * v.C + c0;
+#pragma unroll
+                for (int j = 0; j < kBandChunk; ++j)
+                    if (j < nc) acc[j] = fmaf(sed[j], mv, acc[j]);
+            }
+        }
+        if (inside) {
+#pragma unroll
+            for (int j = 0; j < kBandChunk; ++j)
+                if (j < nc)
+                    P[(((int64_t)b * v.C + c0 + j) * v.Fy + y) * v.Fx + x] = acc[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Observation.get_log_likelihood (observation.py:147-170) and the upstream
+// gradient w (m - d) (lite/models.py:537-545), fused: reads the rendered cube
+// Q, data and weights once, writes the residual into the zero-padded cube R and
+// one partial sum of w (m-d)^2 per block.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kPixBlock) void residual_kernel(BatchView v, const float *Q,
+                                                             float *R) {
+    const int b = blockIdx.y;
+    if (v.state[b] >= 2) return;
+    const int pix = blockIdx.x * kPixBlock + threadIdx.x;
+    const int y = pix / v.W, x = pix - y * v.W;
+    const bool inside = pix < v.H * v.W;
+    double acc = 0.0;
+    if (inside) {
+        for (int c = 0; c < v.C; ++c) {
+            const int64_t iF = (((int64_t)b * v.C + c) * v.Fy + y) * v.Fx + x;
+            const int64_t iD = (((int64_t)b * v.C + c) * v.H + y) * v.W + x;
+            const float diff = Q[iF] - v.data[iD];
+            const float r = v.weights[iD] * diff;
+            R[iF] = r;
+            acc += (double)(r * diff);
+        }
+    }
+    acc = wave_sum(acc);
+    __shared__ double part[kPixBlock / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < kPixBlock / 64; ++i) t += part[i];
+        v.loss_partial[(int64_t)b * v.n_partial + blockIdx.x] = t;
+    }
+}
+
+// loss bookkeeping + convergence test of Blend._callback (blend.py:294-299)
+__global__ __launch_bounds__(64) void finalize_kernel(BatchView v, int it, float e_rel,
+                                                      int min_iter, int check) {
+    const int b = blockIdx.x;
+    if (v.state[b] >= 2) return;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < v.n_partial; i += 64)
+        t += v.loss_partial[(int64_t)b * v.n_partial + i];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) {
+        const double loss = v.log_norm[b] + 0.5 * t;
+        const int n = v.n_loss[b];
+        const double prev = v.last_loss[b];
+        if (n < v.hist_cap) v.loss_hist[(int64_t)b * v.hist_cap + n] = loss;
+        v.n_loss[b] = n + 1;
+        v.last_loss[b] = loss;
+        if (check && n >= 1 && it > min_iter && fabs(loss - prev) < (double)e_rel * fabs(loss))
+            v.state[b] = 1;  // this iteration's update is the last one
+    }
+}
+
+__global__ void advance_kernel(int32_t *state, int nb) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb && state[b] == 1) state[b] = 2;
+}
+
+__global__ void count_active_kernel(const int32_t *state, int nb, int32_t *out) {
+    // out[0] = blends still iterating, out[1] = first non-finite blend or -1
+    int active = 0, err = 0x7fffffff;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        active += state[b] < 2;
+        if (state[b] == 3) err = min(err, b);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        active += __shfl_xor(active, o, 64);
+        err = min(err, __shfl_xor(err, o, 64));
+    }
+    if (threadIdx.x == 0) {
+        out[0] = active;
+        out[1] = err == 0x7fffffff ? -1 : err;
+    }
+}
+
+// S *= K  or  S *= conj(K), K broadcast over blends and/or bands
+__global__ __launch_bounds__(256) void cmul_kernel(float2 *S, const float2 *K, int C,
+                                                   int64_t plane, int k_bands,
+                                                   int k_per_blend, int conj,
+                                                   const int32_t *state) {
+    const int tiles = (int)((plane + 255) / 256);
+    const int bc = blockIdx.x / tiles;
+    const int b = bc / C, c = bc - b * C;
+    if (state[b] >= 2) return;
+    const int64_t i = (int64_t)(blockIdx.x - bc * tiles) * 256 + threadIdx.x;
+    if (i >= plane) return;
+    const int kb = k_per_blend ? b : 0, kc = k_bands == 1 ? 0 : c;
+    const float2 k = K[((int64_t)kb * k_bands + kc) * plane + i];
+    float2 s = S[(int64_t)bc * plane + i];
+    const float ki = conj ? -k.y : k.y;
+    S[(int64_t)bc * plane + i] = make_float2(s.x * k.x - s.y * ki, s.x * ki + s.y * k.x);
+}
+
+// ---------------------------------------------------------------------------
+// Monotonic sweep on an LDS-resident image, one wavefront, level by level.
+// Separate multiply and add (no FMA contraction): bit-identical to the
+// reference's sequential loop (operators_pybind11.cc:14-36).
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T mul_rn(T a, T b);
+template <>
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+template <>
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+template <typename T>
+__device__ __forceinline__ T add_rn(T a, T b);
+template <>
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+template <>
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+template <typename T, typename W>
+__device__ __forceinline__ void sweep_levels(T *img, const int32_t *level_start, int n_levels,
+                                             int E, const int32_t *pix, const int32_t *cnt,
+                                             const int32_t *nbr, const W *wt,
+                                             T one_minus_g, int lane) {
+    for (int l = 0; l < n_levels; ++l) {
+        const int s = level_start[l], e = level_start[l + 1];
+        for (int q = s + lane; q < e; q += 64) {
+            const int p = pix[q];
+            const int n = cnt[q];
+            T ref = 0;
+            for (int j = 0; j < n; ++j)
+                ref = add_rn(ref, mul_rn(img[nbr[(int64_t)j * E + q]], (T)wt[(int64_t)j * E + q]));
+            const T lim = mul_rn(ref, one_minus_g);
+            if (lim < img[p]) img[p] = lim;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-component gradient, AMSGrad step and proximal sub-iterations: the body
+// of proxmin.adaprox as mirrored at lite/parameters.py:274-305, for the two
+// parameters (spectrum, morphology image) of one FactorizedComponent.
+// One wavefront per component; G is the gradient image d(-logL)/d(model).
+// ---------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+
+__global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G, int it,
+                                                    float e_rel, int prox_max_iter,
+                                                    float *g_sed_out, float *g_morph_out,
+                                                    int grad_only) {
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int b = v.c_blend[k];
+    if (!grad_only && v.state[b] >= 2) return;
+    const int C = v.C;
+    const int h = v.c_h[k], w = v.c_w[k], N = h * w;
+    const int oy = v.c_oy[k], ox = v.c_ox[k];
+    const int64_t moff = v.c_moff[k];
+    const int npad = (v.max_box_pixels + 3) & ~3;
+    float *xs = lds_dyn;       // x after the gradient step
+    float *rs = xs + npad;     // psi / max(psi)
+    float *zs = rs + npad;     // current proximal iterate
+    float *us = zs + npad;     // candidate (and g_morph before that)
+    int32_t *lvl = reinterpret_cast<int32_t *>(us + npad);  // level_start of the plan
+
+    const float *morph = v.morph + moff;
+    const float *sed = v.sed + (int64_t)k * C;
+
+    // ---- gradient: slice G into the box; sum_c sed G and sum_yx G morph ----
+    float g_sed = 0.f;  // lane c keeps band c
+    for (int c0 = 0; c0 < C; c0 += kBandChunk) {
+        const int nc = min(kBandChunk, C - c0);
+        float acc[kBandChunk];
+#pragma unroll
+        for (int j = 0; j < kBandChunk; ++j) acc[j] = 0.f;
+        for (int i = lane; i < N; i += 64) {
+            const int y = i / w, x = i - y * w;
+            const int fy = y + oy, fx = x + ox;
+            float gm = c0 == 0 ? 0.f : us[i];
+            if ((unsigned)fy < (unsigned)v.H && (unsigned)fx < (unsigned)v.W) {
+                const float mv = morph[i];
+                const float *g = G + (((int64_t)b * C + c0) * v.Fy + fy) * v.Fx + fx;
+#pragma unroll
+                for (int j = 0; j < kBandChunk; ++j)
+                    if (j < nc) {
+                        const float gv = g[(int64_t)j * v.Fy * v.Fx];
+                        gm = fmaf(sed[c0 + j], gv, gm);
+                        acc[j] = fmaf(gv, mv, acc[j]);
+                    }
+            }
+            us[i] = gm;
+        }
+#pragma unroll
+        for (int j = 0; j < kBandChunk; ++j)
+            if (j < nc) {
+                const float t = wave_sum(acc[j]);
+                if (lane == c0 + j) g_sed = t;
+            }
+    }
+    __syncthreads();
+    if (grad_only) {
+        if (lane < C) g_sed_out[(int64_t)k * C + lane] = g_sed;
+        for (int i = lane; i < N; i += 64) g_morph_out[moff + i] = us[i];
+        return;
+    }
+
+    int bad = 0;
+    const float e2 = e_rel * e_rel;
+
+    // ---- spectrum (spectrum.py:54-56): relative step, positivity 1e-20 ----
+    {
+        const bool on = lane < C;
+        const float s = on ? sed[lane] : 0.f;
+        const float mean = wave_sum(s) / (float)C;
+        const int64_t idx = (int64_t)k * C + lane;
+        float psi = 0.f, x = s;
+        if (on) {
+            const float alpha = fmaxf(v.c_sed_min_step[idx], v.c_sed_rel[k] * mean);
+            const float m = (1.f - kB1) * g_sed + kB1 * v.m_sed[idx];
+            const float vv = (1.f - kB2) * g_sed * g_sed + kB2 * v.v_sed[idx];
+            const float vh = it == 0 ? vv : fmaxf(v.vh_sed[idx], vv);
+            v.m_sed[idx] = m;
+            v.v_sed[idx] = vv;
+            v.vh_sed[idx] = vh;
+            psi = sqrtf(fmaxf(vh, kEps));
+            float upd = alpha * m / psi;
+            if (it == 0) upd /= 10.f;  // lite/parameters.py:288-291
+            x = s - upd;
+        }
+        const float pmax = wave_max(psi);
+        const float ratio = on ? psi / pmax : 0.f;
+        float z = x;
+        for (int tau = 0; tau < prox_max_iter; ++tau) {
+            const float zn = on ? fmaxf(z - ratio * (z - x), 1e-20f) : 0.f;
+            const float d2 = wave_sum((zn - z) * (zn - z));
+            const float z2 = wave_sum(z * z);
+            z = zn;
+            if (d2 <= e2 * z2) break;
+        }
+        if (on) {
+            v.sed[idx] = z;
+            bad |= !isfinite(z);
+        }
+    }
+
+    // ---- morphology image --------------------------------------------------
+    const int flags = v.c_flags[k];
+    const int plan_id = v.c_plan[k];
+    float msum = 0.f;
+    for (int i = lane; i < N; i += 64) msum += morph[i];
+    const float mmean = wave_sum(msum) / (float)N;
+    const float alpha = fmaxf(v.c_morph_step[k], v.c_morph_rel[k] * mmean);
+    float pmax = 0.f;
+    for (int i = lane; i < N; i += 64) {
+        const float g = us[i];
+        const float m = (1.f - kB1) * g + kB1 * v.m_morph[moff + i];
+        const float vv = (1.f - kB2) * g * g + kB2 * v.v_morph[moff + i];
+        const float vh = it == 0 ? vv : fmaxf(v.vh_morph[moff + i], vv);
+        v.m_morph[moff + i] = m;
+        v.v_morph[moff + i] = vv;
+        v.vh_morph[moff + i] = vh;
+        const float psi = sqrtf(fmaxf(vh, kEps));
+        float upd = alpha * m / psi;
+        if (it == 0) upd /= 10.f;
+        const float x = morph[i] - upd;
+        xs[i] = x;
+        zs[i] = x;
+        rs[i] = psi;
+        pmax = fmaxf(pmax, psi);
+    }
+    pmax = wave_max(pmax);
+
+    const bool monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
+    SweepPlanDev pl;
+    if (monotonic) {
+        pl = v.plans[plan_id];
+        for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
+    }
+    const float one_minus_g = 1.f - v.c_min_grad[k];
+    const int ctr = (h / 2) * w + (w / 2);
+    __syncthreads();
+    for (int i = lane; i < N; i += 64) rs[i] = rs[i] / pmax;
+
+    for (int tau = 0; tau < prox_max_iter; ++tau) {
+        for (int i = lane; i < N; i += 64) us[i] = zs[i] - rs[i] * (zs[i] - xs[i]);
+        __syncthreads();
+        // ConstraintChain (constraint.py:76-80) in the order of morphology.py:644-670
+        if (monotonic)
+            sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
+                                       pl.nbr, pl.wt, one_minus_g, lane);
+        if (flags & SMI_PROX_SYMMETRY) {
+            // prox_soft_symmetry, strength 1 (operator.py:274-293): even axes are
+            // padded by one trailing zero before the 180-degree rotation
+            const int hp = h + !(h & 1), wp = w + !(w & 1);
+            for (int i = lane; i < N; i += 64) {
+                const int y = i / w, x = i - y * w;
+                const int py = hp - 1 - y, px = wp - 1 - x;
+                const bool has = py < h && px < w;
+                const int j = py * w + px;
+                if (!has) {
+                    us[i] = 0.5f * us[i];
+                } else if (j >= i) {
+                    const float a = 0.5f * (us[i] + us[j]);
+                    us[i] = a;
+                    us[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+        if (flags & (SMI_PROX_L1 | SMI_PROX_L0)) {
+            const float t = v.c_lthresh[k];
+            for (int i = lane; i < N; i += 64) {
+                const float u = us[i];
+                if (flags & SMI_PROX_L1)
+                    us[i] = copysignf(fmaxf(fabsf(u) - t, 0.f), u);
+                else if (fabsf(u) < t)
+                    us[i] = 0.f;
+            }
+        }
+        float mx = -INFINITY, sm = 0.f;
+        for (int i = lane; i < N; i += 64) {
+            float u = us[i];
+            if (flags & SMI_PROX_POSITIVE) u = fmaxf(u, 0.f);
+            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = fmaxf(u, 1e-6f);
+            us[i] = u;
+            mx = fmaxf(mx, u);
+            sm += u;
+        }
+        float div = 1.f;
+        if (flags & SMI_PROX_NORM_MAX) div = wave_max(mx);
+        if (flags & SMI_PROX_NORM_SUM) div = wave_sum(sm);
+        float d2 = 0.f, z2 = 0.f;
+        for (int i = lane; i < N; i += 64) {
+            const float u = (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM)) ? us[i] / div : us[i];
+            const float z = zs[i];
+            d2 += (u - z) * (u - z);
+            z2 += z * z;
+            zs[i] = u;
+        }
+        d2 = wave_sum(d2);
+        z2 = wave_sum(z2);
+        __syncthreads();
+        if (d2 <= e2 * z2) break;
+    }
+    for (int i = lane; i < N; i += 64) {
+        const float z = zs[i];
+        v.morph[moff + i] = z;
+        bad |= !isfinite(z);
+    }
+    if (wave_or(bad) && lane == 0) atomicExch(&v.state[b], 3);  // model.py:153-165
+}
+
+// log_norm of Observation (observation.py:172-186): D/2 ln(2 pi) + sum ln(1/sqrt(w))
+__global__ __launch_bounds__(256) void log_norm_kernel(const float *weights, double *out,
+                                                       int64_t n) {
+    const int b = blockIdx.x;
+    double cnt = 0.0, sl = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float wv = weights[(int64_t)b * n + i];
+        if (wv != 0.f) {
+            cnt += 1.0;
+            sl += log((double)wv);
+        }
+    }
+    cnt = wave_sum(cnt);
+    sl = wave_sum(sl);
+    __shared__ double pc[4], ps[4];
+    if ((threadIdx.x & 63) == 0) {
+        pc[threadIdx.x >> 6] = cnt;
+        ps[threadIdx.x >> 6] = sl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double c = pc[0] + pc[1] + pc[2] + pc[3];
+        const double s = ps[0] + ps[1] + ps[2] + ps[3];
+        out[b] = 0.5 * c * 1.8378770664093453 - 0.5 * s;  // ln(2 pi)
+    }
+}
+
+// kernel stamp -> FFT input with the stamp centre (ph/2, pw/2) at index (0,0),
+// wrapped around (the layout the reference reaches with _pad + ifftshift,
+// fft.py:255-273), scaled by 1/(Fy Fx) for the unnormalised inverse transform
+__global__ void wrap_kernel_kernel(const float *kern, float *out, int ph, int pw, int Fy,
+                                   int Fx, float scale) {
+    const int img = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ph * pw) return;
+    const int ky = i / pw, kx = i - ky * pw;
+    int ty = ky - ph / 2, tx = kx - pw / 2;
+    if (ty < 0) ty += Fy;
+    if (tx < 0) tx += Fx;
+    out[((int64_t)img * Fy + ty) * Fx + tx] = kern[(int64_t)img * ph * pw + i] * scale;
+}
+
+__global__ void crop_kernel(const float *P, float *out, int H, int W, int Fy, int Fx) {
+    const int img = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    out[(int64_t)img * H * W + i] = P[((int64_t)img * Fy + y) * Fx + x];
+}
+
+// ---- seam 1 kernels --------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void sweep_kernel(T *img, int n_pix, const int32_t *level_start,
+                                                   int n_levels, int E, const int32_t *pix,
+                                                   const int32_t *cnt, const int32_t *nbr,
+                                                   const T *wt, T one_minus_g) {
+    T *buf = reinterpret_cast<T *>(lds_dyn);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n_pix; i += 64) buf[i] = img[i];
+    __syncthreads();
+    sweep_levels<T, T>(buf, level_start, n_levels, E, pix, cnt, nbr, wt, one_minus_g, lane);
+    for (int i = lane; i < n_pix; i += 64) img[i] = buf[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void apply_filter_kernel(const T *image, int H, int W,
+                                                           const T *values, int n_taps,
+                                                           const int32_t *ys, const int32_t *ye,
+                                                           const int32_t *xs, const int32_t *xe,
+                                                           T *result) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    T acc = 0;
+    for (int n = 0; n < n_taps; ++n) {
+        const int r = y - ys[n], c = x - xs[n];
+        if (r >= 0 && c >= 0 && r < H - ys[n] - ye[n] && c < W - xs[n] - xe[n])
+            acc = add_rn(acc, mul_rn(values[n], image[(int64_t)(r + ye[n]) * W + c + xe[n]]));
+    }
+    result[i] = acc;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline int pix_blocks(const BatchView &v) {
+    return (v.H * v.W + kPixBlock - 1) / kPixBlock;
+}
+
+void launch_render(const BatchView &v, float *P, hipStream_t s) {
+    hipLaunchKernelGGL(render_kernel, dim3(pix_blocks(v), v.nb), dim3(kPixBlock), 0, s, v, P);
+}
+
+void launch_residual(const BatchView &v, const float *Q, float *R, hipStream_t s) {
+    hipLaunchKernelGGL(residual_kernel, dim3(pix_blocks(v), v.nb), dim3(kPixBlock), 0, s, v, Q, R);
+}
+
+void launch_finalize(const BatchView &v, int32_t it, float e_rel, int32_t min_iter,
+                     int32_t check, hipStream_t s) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(v.nb), dim3(64), 0, s, v, it, e_rel, min_iter,
+                       check);
+}
+
+void launch_advance(const BatchView &v, hipStream_t s) {
+    hipLaunchKernelGGL(advance_kernel, dim3((v.nb + 255) / 256), dim3(256), 0, s, v.state, v.nb);
+}
+
+void launch_count_active(const int32_t *state, int32_t nb, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(64), 0, s, state, nb, out);
+}
+
+void launch_cmul(float2 *S, const float2 *K, int32_t nb, int32_t C, int64_t plane,
+                 int32_t k_bands, int32_t k_per_blend, int32_t conj, const int32_t *state,
+                 hipStream_t s) {
+    const unsigned tiles = (unsigned)((plane + 255) / 256);
+    hipLaunchKernelGGL(cmul_kernel, dim3(tiles * (unsigned)(nb * C)), dim3(256), 0, s, S, K, C,
+                       plane, k_bands, k_per_blend, conj, state);
+}
+
+static size_t update_lds_bytes(const BatchView &v) {
+    const size_t npad = (v.max_box_pixels + 3) & ~3;
+    return 4 * npad * sizeof(float) + (size_t)(v.max_levels + 2) * sizeof(int32_t);
+}
+
+int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
+                  int32_t prox_max_iter, float *g_sed_out, float *g_morph_out,
+                  int32_t grad_only, hipStream_t s) {
+    const size_t lds = update_lds_bytes(v);
+    SMI_REQUIRE(lds <= 160 * 1024, "component box too large for the LDS-resident update");
+    static size_t configured = 0;
+    if (lds > configured) {
+        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(update_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(update_kernel, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
+                       prox_max_iter, g_sed_out, g_morph_out, grad_only);
+    return SMI_OK;
+}
+
+void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(log_norm_kernel, dim3(nb), dim3(256), 0, s, weights, log_norm, n);
+}
+
+void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph, int32_t pw,
+                        int32_t Fy, int32_t Fx, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(wrap_kernel_kernel, dim3((ph * pw + 255) / 256, n_img), dim3(256), 0, s,
+                       kern, out, ph, pw, Fy, Fx, scale);
+}
+
+void launch_crop(const float *P, float *out, int32_t n_img, int32_t H, int32_t W, int32_t Fy,
+                 int32_t Fx, hipStream_t s) {
+    hipLaunchKernelGGL(crop_kernel, dim3((H * W + 255) / 256, n_img), dim3(256), 0, s, P, out, H,
+                       W, Fy, Fx);
+}
+
+// ---- seam 1: host-buffer entry points --------------------------------------
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)); }
+    hipError_t upload(const T *h, size_t n) {
+        hipError_t e = alloc(n > 0 ? n : 1);
+        if (e != hipSuccess || n == 0) return e;
+        return hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+template <typename T>
+int sweep_host_buffers(T *flat_img, int32_t n_pix, const SweepPlanHost &plan, T min_gradient) {
+    const size_t lds = (size_t)n_pix * sizeof(T);
+    SMI_REQUIRE(lds <= 160 * 1024, "prox_weighted_monotonic: image does not fit the 160 KiB LDS");
+    if (plan.n_entries == 0) return SMI_OK;
+    DevBuf<T> d_img, d_wt;
+    DevBuf<int32_t> d_ls, d_pix, d_cnt, d_nbr;
+    std::vector<T> wt(plan.wt.size());
+    for (size_t i = 0; i < wt.size(); ++i) wt[i] = (T)plan.wt[i];
+    SMI_HIP(d_img.upload(flat_img, n_pix));
+    SMI_HIP(d_wt.upload(wt.data(), wt.size()));
+    SMI_HIP(d_ls.upload(plan.level_start.data(), plan.level_start.size()));
+    SMI_HIP(d_pix.upload(plan.pix.data(), plan.pix.size()));
+    SMI_HIP(d_cnt.upload(plan.cnt.data(), plan.cnt.size()));
+    SMI_HIP(d_nbr.upload(plan.nbr.data(), plan.nbr.size()));
+    auto kern = sweep_kernel<T>;
+    SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const T omg = (T)1 - min_gradient;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64), lds, 0, d_img.p, n_pix, d_ls.p,
+                       (int)plan.level_start.size() - 1, plan.n_entries, d_pix.p, d_cnt.p,
+                       d_nbr.p, d_wt.p, omg);
+    SMI_HIP(hipGetLastError());
+    SMI_HIP(hipMemcpy(flat_img, d_img.p, (size_t)n_pix * sizeof(T), hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+template int sweep_host_buffers<float>(float *, int32_t, const SweepPlanHost &, float);
+template int sweep_host_buffers<double>(double *, int32_t, const SweepPlanHost &, double);
+
+template <typename T>
+int apply_filter_host_buffers(const T *image, int32_t H, int32_t W, const T *values,
+                              int32_t n_taps, const int32_t *ys, const int32_t *ye,
+                              const int32_t *xs, const int32_t *xe, T *result) {
+    DevBuf<T> d_img, d_val, d_out;
+    DevBuf<int32_t> d_ys, d_ye, d_xs, d_xe;
+    const size_t n = (size_t)H * W;
+    SMI_HIP(d_img.upload(image, n));
+    SMI_HIP(d_val.upload(values, n_taps));
+    SMI_HIP(d_ys.upload(ys, n_taps));
+    SMI_HIP(d_ye.upload(ye, n_taps));
+    SMI_HIP(d_xs.upload(xs, n_taps));
+    SMI_HIP(d_xe.upload(xe, n_taps));
+    SMI_HIP(d_out.alloc(n));
+    hipLaunchKernelGGL(apply_filter_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0,
+                       d_img.p, H, W, d_val.p, n_taps, d_ys.p, d_ye.p, d_xs.p, d_xe.p, d_out.p);
+    SMI_HIP(hipGetLastError());
+    SMI_HIP(hipMemcpy(result, d_out.p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+template int apply_filter_host_buffers<float>(const float *, int32_t, int32_t, const float *,
+                                              int32_t, const int32_t *, const int32_t *,
+                                              const int32_t *, const int32_t *, float *);
+template int apply_filter_host_buffers<double>(const double *, int32_t, int32_t, const double *,
+                                               int32_t, const int32_t *, const int32_t *,
+                                               const int32_t *, const int32_t *, double *);
+
+}  // namespace smi

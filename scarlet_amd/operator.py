@@ -1,0 +1,225 @@
+"""Proximal-operator factories with the reference's ``scarlet.operator`` names.
+
+The monotonicity tables are built here on the host (once per box shape, like
+the reference does in Python, operator.py:62-96, 591-667); the sweep itself runs
+on the GPU through the C ABI (``smi_prox_weighted_monotonic_*`` for stand-alone
+calls, the fused update kernel inside ``Blend.fit``).
+"""
+
+from functools import partial
+
+import numpy as np
+
+from . import _lib
+
+# order of the 8 neighbours in every (8, N) table (reference operator.py:84)
+NEIGHBOR_COORDS = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
+
+
+def _center_or_default(shape, center):
+    if center is None:
+        return (shape[0] - 1) >> 1, (shape[1] - 1) >> 1
+    return int(center[0]), int(center[1])
+
+
+def sort_by_radius(shape, center=None):
+    """Flat indices of an image of ``shape`` ordered by distance from ``center``."""
+    cy, cx = _center_or_default(shape, center)
+    yy = (np.arange(shape[0]) - cy)[:, None]
+    xx = (np.arange(shape[1]) - cx)[None, :]
+    return np.argsort(np.sqrt(xx**2 + yy**2).reshape(-1))
+
+
+def getOffsets(width, coords=None):
+    """Flat-index offsets of the neighbours and the slice pairs that align a
+    vector with its shifted copy (reference operator.py:512-527)."""
+    if coords is None:
+        coords = NEIGHBOR_COORDS
+    offsets = [width * y + x for y, x in coords]
+    slices = [slice(None, s) if s < 0 else slice(s, None) for s in offsets]
+    slicesInv = [slice(-s, None) if s < 0 else slice(None, -s) for s in offsets]
+    return offsets, slices, slicesInv
+
+
+def diagonalizeArray(arr, shape=None, dtype=np.float64):
+    """(8, N) table of every pixel's neighbour values and the mask of
+    neighbours that do not exist (reference operator.py:530-572)."""
+    if shape is None:
+        height, width = arr.shape
+        data = arr.reshape(-1)
+    elif arr.ndim == 1:
+        height, width = shape
+        data = arr
+    else:
+        raise ValueError("Expected either a 2D array or a 1D array and a shape")
+    n = height * width
+    table = np.zeros((8, n), dtype=dtype)
+    missing = np.ones((8, n), dtype=bool)
+    yy, xx = np.divmod(np.arange(n), width)
+    for i, (dy, dx) in enumerate(NEIGHBOR_COORDS):
+        ok = (yy + dy >= 0) & (yy + dy < height) & (xx + dx >= 0) & (xx + dx < width)
+        # the reference also fills the row-wrapped entries with data; they are masked
+        off = dy * width + dx
+        src = np.arange(n) + off
+        inside = (src >= 0) & (src < n)
+        table[i, inside] = data[src[inside]]
+        missing[i] = ~ok
+    return table, missing
+
+
+def getRadialMonotonicWeights(shape, neighbor_weight="flat", center=None):
+    """(8, N) float64 weights of the radial monotonicity operator.
+
+    For pixel p and neighbour direction i the weight is non-zero only when that
+    neighbour lies inside the image and strictly nearer the peak.  'angle'
+    uses the cosine of the angle between the directions p->peak and
+    p->neighbour, normalised to unit sum; 'flat' gives all such neighbours equal
+    weight; 'nearest' keeps the single best aligned one
+    (same tables as reference operator.py:591-667).
+    """
+    assert neighbor_weight in ["flat", "angle", "nearest"]
+    h, w = shape
+    if center is None:
+        center = ((h - 1) // 2, (w - 1) // 2)
+    py, px = int(center[0]), int(center[1])
+    Y = (np.arange(h) - py)[:, None] * np.ones((1, w), dtype=int)
+    X = (np.arange(w) - px)[None, :] * np.ones((h, 1), dtype=int)
+    r2 = X * X + Y * Y
+    to_peak = np.arctan2(-Y, -X)
+    cosw = np.zeros((8, h, w))
+    for i, (dy, dx) in enumerate(NEIGHBOR_COORDS):
+        ny, nx = Y + dy, X + dx
+        inside = (ny + py >= 0) & (ny + py < h) & (nx + px >= 0) & (nx + px < w)
+        nearer = (nx * nx + ny * ny) < r2
+        valid = inside & nearer
+        cosw[i][valid] = np.cos(to_peak[valid] - np.arctan2(float(dy), float(dx)))
+    cosw = cosw.reshape(8, h * w)
+    if neighbor_weight == "nearest":
+        out = np.zeros_like(cosw)
+        out[np.argmax(cosw, axis=0), np.arange(h * w)] = 1
+        out[:, py * w + px] = 0
+        return out
+    if neighbor_weight == "flat":
+        cosw[cosw != 0] = 1
+    total = cosw.sum(axis=0)
+    total[total == 0] = 1
+    return cosw / total[None, :]
+
+
+def _native_sweep(X, weights, offsets, didx, min_gradient):
+    """``operators_pybind11.prox_weighted_monotonic`` through the C ABI, in place."""
+    lib = _lib.load()
+    if not X.flags.c_contiguous:
+        raise ValueError("prox_weighted_monotonic needs a C-contiguous array")
+    flat = X.reshape(-1)
+    off = _lib.i32(offsets)
+    idx = _lib.i32(didx)
+    if flat.dtype == np.float32:
+        wts = np.ascontiguousarray(weights, dtype=np.float32)
+        fn, ct, mg = lib.smi_prox_weighted_monotonic_f32, _lib.ctypes.c_float, float(min_gradient)
+    elif flat.dtype == np.float64:
+        wts = np.ascontiguousarray(weights, dtype=np.float64)
+        fn, ct, mg = lib.smi_prox_weighted_monotonic_f64, _lib.ctypes.c_double, float(min_gradient)
+    else:
+        raise TypeError("prox_weighted_monotonic: float32 or float64 array required")
+    _lib.check(
+        fn(_lib.ptr(flat, ct), _lib.ptr(wts, ct), _lib.ptr(off, _lib.ctypes.c_int32), off.size,
+           _lib.ptr(idx, _lib.ctypes.c_int32), idx.size, flat.size, mg)
+    )
+    return X
+
+
+def _prox_weighted_monotonic(X, step, weights, didx, offsets, min_gradient=0.1):
+    """Force a radially monotonic profile; ``X`` is modified in place."""
+    return _native_sweep(X, weights, offsets, didx, min_gradient)
+
+
+def prox_weighted_monotonic(shape, neighbor_weight="flat", min_gradient=0.1, center=None):
+    """Build the monotonicity operator for images of ``shape``
+    (reference operator.py:62-96).  Returns ``f(X, step) -> X``."""
+    height, width = shape
+    didx = sort_by_radius(shape, center)
+    offsets = np.array([width * y + x for y, x in NEIGHBOR_COORDS])
+    weights = getRadialMonotonicWeights(shape, neighbor_weight=neighbor_weight, center=center)
+    return partial(
+        _prox_weighted_monotonic,
+        weights=weights,
+        didx=didx[1:],
+        offsets=offsets,
+        min_gradient=min_gradient,
+    )
+
+
+def monotonic_tables(shape, neighbor_weight, center=None):
+    """(weights, offsets, didx without the peak) as int32/float64 arrays for the
+    C ABI (``smi_batch_add_sweep_plan``)."""
+    if center is None:
+        center = (shape[0] // 2, shape[1] // 2)
+    weights = np.ascontiguousarray(
+        getRadialMonotonicWeights(shape, neighbor_weight, center), dtype=np.float64
+    )
+    offsets = np.array([shape[1] * y + x for y, x in NEIGHBOR_COORDS], dtype=np.int32)
+    didx = sort_by_radius(shape, center)[1:].astype(np.int32)
+    return weights, offsets, didx
+
+
+def get_center(image, center, radius=1):
+    """Brightest pixel within ``radius`` of ``center`` (reference operator.py:99-129)."""
+    cy, cx = int(center[0]), int(center[1])
+    y0, x0 = max(cy - radius, 0), max(cx - radius, 0)
+    patch = image[y0 : cy + radius + 1, x0 : cx + radius + 1]
+    dy, dx = np.unravel_index(np.argmax(patch), patch.shape)
+    return y0 + dy, x0 + dx
+
+
+def prox_sdss_symmetry(X, step):
+    """Minimum of each pixel and its 180-degree partner, in place."""
+    X[:] = np.minimum(X, X[::-1, ::-1])
+    return X
+
+
+def prox_soft_symmetry(X, step, strength=1):
+    """Blend ``X`` with its 180-degree rotation; even axes get one trailing
+    zero before rotating (reference operator.py:274-293)."""
+    h, w = X.shape
+    padded = np.zeros((h + (h % 2 == 0), w + (w % 2 == 0)), dtype=X.dtype)
+    padded[:h, :w] = X
+    out = 0.5 * strength * (padded + padded[::-1, ::-1]) + (1 - strength) * padded
+    return out[:h, :w]
+
+
+def uncentered_operator(X, func, center=None, fill=None, **kwargs):
+    """Apply ``func`` to the largest sub-array of ``X`` that is centred on
+    ``center`` (reference operator.py:207-260)."""
+    if center is None:
+        py, px = np.unravel_index(np.argmax(X), X.shape)
+    else:
+        py, px = int(center[0]), int(center[1])
+    cy, cx = np.array(X.shape) // 2
+    if py == cy and px == cx:
+        return func(X, **kwargs)
+    dy, dx = int(2 * (py - cy)), int(2 * (px - cx))
+    if not X.shape[0] % 2:
+        dy += 1
+    if not X.shape[1] % 2:
+        dx += 1
+    ysl = slice(dy, None) if dy > 0 else (slice(None, dy) if dy < 0 else slice(None))
+    xsl = slice(dx, None) if dx > 0 else (slice(None, dx) if dx < 0 else slice(None))
+    if fill is not None:
+        out = np.ones(X.shape, X.dtype) * fill
+        out[ysl, xsl] = func(X[ysl, xsl], **kwargs)
+        X[:] = out
+    else:
+        X[ysl, xsl] = func(X[ysl, xsl], **kwargs)
+    return X
+
+
+def prox_uncentered_symmetry(X, step, center=None, algorithm="sdss", fill=None, strength=0.5):
+    """Symmetry about an off-centre peak (reference operator.py:328-400)."""
+    if algorithm == "sdss":
+        return uncentered_operator(X, prox_sdss_symmetry, center, step=step, fill=fill)
+    if algorithm == "soft":
+        return uncentered_operator(
+            X, prox_soft_symmetry, center, step=step, strength=strength, fill=fill
+        )
+    raise ValueError("algorithm must be 'sdss' or 'soft', got {}".format(algorithm))

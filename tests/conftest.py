@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def hsc():
+    return golden("hsc_cosmos_35")
+
+
+def hsc_scene(g, dtype64=False):
+    """oracle.pgm.Scene of the quickstart blend from the golden fixture."""
+    from oracle import pgm
+
+    n = int(g["n_comp"])
+    comps = []
+    for k in range(n):
+        sed = g["sed64_%d" % k] if dtype64 else g["sed_%d" % k]
+        morph = g["morph64_%d" % k] if dtype64 else g["morph_%d" % k]
+        comps.append(
+            pgm.Component(sed.copy(), morph.copy(), g["origin_%d" % k],
+                          sed_min_step=g["min_step_%d" % k], source=int(g["source_of"][k]))
+        )
+    dt = np.float64 if dtype64 else np.float32
+    images = g["images"].astype(dt)
+    weights = g["weights"].astype(dt)
+    kernel = g["diff_kernel"].astype(dt)
+    return pgm.Scene(images.shape, images, weights, kernel, comps, dtype=dt)
