@@ -176,12 +176,14 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph);
 
 /* Run `n_iter` iterations of the adaprox loop on the device without host
  * synchronisation; `it0` is the iteration counter of the first one (it = 0 takes
- * a tenth of the step and sets vhat = v).  Convergence is evaluated per blend on
- * the device when e_rel > 0: a blend stops after the update of the iteration in
- * which  it > min_iter && |L[it] - L[it-1]| < e_rel |L[it]|  (blend.py:294-299).
+ * a tenth of the step and sets vhat = v).  `e_rel` is the relative tolerance of
+ * the proximal sub-iterations (lite/parameters.py:297-303) and, when
+ * `check_convergence` != 0, of the per-blend stopping rule evaluated on the device:
+ * a blend stops after the update of the iteration in which
+ *   it > min_iter && |L[it] - L[it-1]| < e_rel |L[it]|        (blend.py:294-299).
  * Asynchronous on the batch stream. */
 int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
-                   int32_t min_iter, int32_t prox_max_iter);
+                   int32_t min_iter, int32_t prox_max_iter, int32_t check_convergence);
 
 /* Blocking.  n_active: blends still iterating; error: index of the first blend
  * whose parameters became non-finite, or -1. */

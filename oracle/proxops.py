@@ -67,8 +67,8 @@ def _diagonalize(arr2d):
             diag[i, -off:] = flat[:off]
             mask[i, -off:] = False
         else:
-            diag[i, : n - off] = flat[off:]
-            mask[i, : n - off] = False
+            diag[i, :-off] = flat[off:]
+            mask[i, :-off] = False
     # wrapped "neighbours" of edge pixels (operator.py:561-570)
     mask[0][np.arange(1, h) * w] = True
     mask[2][np.arange(h) * w - 1] = True

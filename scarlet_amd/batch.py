@@ -204,11 +204,16 @@ class BlendBatch:
         return g_sed, self._split_morphs(g_morph)
 
     # -- optimisation --------------------------------------------------------
-    def step(self, it0, n_iter, e_rel=0.0, min_iter=1, prox_max_iter=10):
-        """``n_iter`` asynchronous iterations starting at counter ``it0``;
-        ``e_rel=0`` disables the convergence test (fixed-iteration timing)."""
+    def step(self, it0, n_iter, e_rel=1e-3, min_iter=1, prox_max_iter=10,
+             check_convergence=False):
+        """``n_iter`` asynchronous iterations starting at counter ``it0``.
+        ``e_rel`` is the tolerance of the proximal sub-iterations and, with
+        ``check_convergence``, of the per-blend stopping rule (off by default:
+        fixed-iteration runs)."""
         _lib.check(
-            self._lib.smi_batch_step(self._h, it0, n_iter, e_rel, min_iter, prox_max_iter)
+            self._lib.smi_batch_step(
+                self._h, it0, n_iter, e_rel, min_iter, prox_max_iter, int(check_convergence)
+            )
         )
 
     def status(self):

@@ -694,12 +694,12 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
 }
 
 int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32_t min_iter,
-                   int32_t prox_max_iter) {
+                   int32_t prox_max_iter, int32_t check_convergence) {
     int rc = ready(b);
     if (rc) return rc;
     SMI_REQUIRE(n_iter >= 0 && it0 >= 0 && prox_max_iter >= 0, "bad iteration arguments");
     const BatchView &v = b->view;
-    const int check = e_rel > 0.f;
+    const int check = check_convergence != 0;
     const bool timing = b->timing;
     if (timing) {
         const size_t need = (size_t)n_iter * 6;
@@ -770,7 +770,7 @@ int smi_batch_fit(smi_batch *b, int32_t max_iter, float e_rel, int32_t min_iter,
     int it = 0;
     while (it < max_iter) {
         const int chunk = std::min(sync_every, max_iter - it);
-        if ((rc = smi_batch_step(b, it, chunk, e_rel, min_iter, prox_max_iter))) return rc;
+        if ((rc = smi_batch_step(b, it, chunk, e_rel, min_iter, prox_max_iter, 1))) return rc;
         it += chunk;
         int32_t active = 0, err = -1;
         if ((rc = smi_batch_status(b, &active, &err))) return rc;

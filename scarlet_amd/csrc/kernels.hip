@@ -32,6 +32,9 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// np.maximum semantics: a NaN in the data propagates (fmaxf would drop it)
+__device__ __forceinline__ float max_nan(float a, float b) { return a != a ? a : fmaxf(a, b); }
+
 __device__ __forceinline__ int wave_or(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         const float ratio = on ? psi / pmax : 0.f;
         float z = x;
         for (int tau = 0; tau < prox_max_iter; ++tau) {
-            const float zn = on ? fmaxf(z - ratio * (z - x), 1e-20f) : 0.f;
+            const float zn = on ? max_nan(z - ratio * (z - x), 1e-20f) : 0.f;
             const float d2 = wave_sum((zn - z) * (zn - z));
             const float z2 = wave_sum(z * z);
             z = zn;
@@ -394,8 +397,8 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         float mx = -INFINITY, sm = 0.f;
         for (int i = lane; i < N; i += 64) {
             float u = us[i];
-            if (flags & SMI_PROX_POSITIVE) u = fmaxf(u, 0.f);
-            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = fmaxf(u, 1e-6f);
+            if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
+            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, 1e-6f);
             us[i] = u;
             mx = fmaxf(mx, u);
             sm += u;

@@ -1,0 +1,373 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real
+MI355X.  Tolerance: 1e-5 relative (float32), as BASELINE.json's north_star
+states; integer/index work and the monotonic sweep / apply_filter are bit exact.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+from conftest import golden, hsc_scene
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def rel_err(a, b):
+    return np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def assert_loss_close(loss, ref_loss, log_norm, rtol=RTOL):
+    """loss = log_norm + chi2/2 can pass through zero: compare the chi2 part"""
+    a = np.asarray(loss, dtype=np.float64) - log_norm
+    b = np.asarray(ref_loss, dtype=np.float64) - log_norm
+    assert a.shape == b.shape
+    assert np.all(np.abs(a - b) <= rtol * np.abs(b)), (a, b)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import scarlet_amd
+    from scarlet_amd import _lib
+
+    _lib.load()
+    assert _lib.load().smi_device_count() >= 1
+    return scarlet_amd
+
+
+# ---------------------------------------------------------------- seam 1
+MODES = [("flat", 0.1), ("angle", 0.0), ("nearest", 0.0), ("angle", 0.25)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(5, 5), (21, 21), (41, 41), (31, 41), (22, 30), (81, 81)])
+def test_sweep_bit_exact(amd, dtype, shape):
+    from oracle import proxops
+
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    for mode, g in MODES:
+        w, didx, off = proxops.monotonic_operator(shape, mode, (shape[0] // 2, shape[1] // 2))
+        x0 = rng.random(shape).astype(dtype)
+        want = proxops.sweep(x0.copy(), w, off, didx, g)
+        got = amd.operator._native_sweep(x0.copy(), w, off, didx, g)
+        assert_array_equal(got, want)
+
+
+def test_sweep_reference_known_answers(amd):
+    """reference tests/test_constraint.py:92-135 through the product classes"""
+    from test_oracle_golden import MONO_NEAREST, MONO_ANGLE, MONO_ANGLE_G25
+
+    X = np.arange(25, dtype=float).reshape(5, 5)
+    for mode, g, truth in (("nearest", 0, MONO_NEAREST), ("angle", 0, MONO_ANGLE),
+                           ("angle", 0.25, MONO_ANGLE_G25)):
+        c = amd.MonotonicityConstraint(neighbor_weight=mode, min_gradient=g)
+        np.testing.assert_almost_equal(c(X.copy(), 0), truth)
+
+
+def test_sweep_golden_from_reference(amd):
+    g = golden("operator_tables")
+    for tag in ("21x21", "31x41"):
+        x0 = g["sweep_in_" + tag]
+        for mode, gr in MODES:
+            c = amd.MonotonicityConstraint(neighbor_weight=mode, min_gradient=gr)
+            assert_array_equal(c(x0.copy(), 0), g["sweep_{}_{}_{}".format(mode, gr, tag)])
+
+
+def test_sweep_empty_and_degenerate(amd):
+    from oracle import proxops
+
+    # 1x1 image: empty sweep order
+    x = np.array([[3.0]])
+    w, didx, off = proxops.monotonic_operator((1, 1), "angle", (0, 0))
+    assert didx.size == 0
+    assert_array_equal(amd.operator._native_sweep(x.copy(), w, off, didx, 0.0), x)
+    # a single row
+    w, didx, off = proxops.monotonic_operator((1, 9), "flat", (0, 4))
+    x = np.arange(9, dtype=np.float64)[None]
+    want = proxops.sweep(x.copy(), w, off, didx, 0.1)
+    assert_array_equal(amd.operator._native_sweep(x.copy(), w, off, didx, 0.1), want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_apply_filter_bit_exact(amd, dtype):
+    from oracle import fftconv, proxops
+    from scarlet_amd import _lib
+
+    rng = np.random.default_rng(1)
+    img = rng.standard_normal((40, 59)).astype(dtype)
+    ker = rng.standard_normal((7, 5)).astype(dtype)
+    ys, ye, xs, xe = fftconv.filter_bounds(ker)
+    vals = np.ascontiguousarray(ker.reshape(-1))
+    want = np.empty_like(img)
+    lib = proxops._lib()
+    ofn = lib.oracle_apply_filter_f32 if dtype == np.float32 else lib.oracle_apply_filter_f64
+    ofn.restype = None
+    vp = ctypes.c_void_p
+    ofn(img.ctypes.data_as(vp), 40, 59, vals.ctypes.data_as(vp), vals.size,
+        ys.ctypes.data_as(vp), ye.ctypes.data_as(vp), xs.ctypes.data_as(vp),
+        xe.ctypes.data_as(vp), want.ctypes.data_as(vp))
+    got = np.empty_like(img)
+    ct = ctypes.c_float if dtype == np.float32 else ctypes.c_double
+    fn = _lib.load().smi_apply_filter_f32 if dtype == np.float32 else _lib.load().smi_apply_filter_f64
+    _lib.check(fn(_lib.ptr(img, ct), 40, 59, _lib.ptr(vals, ct), vals.size,
+                  _lib.ptr(ys, ctypes.c_int32), _lib.ptr(ye, ctypes.c_int32),
+                  _lib.ptr(xs, ctypes.c_int32), _lib.ptr(xe, ctypes.c_int32), _lib.ptr(got, ct)))
+    assert_array_equal(got, want)
+    assert_allclose(got, fftconv.apply_filter(img, ker), rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- seam 2
+def hsc_batch(amd, g, **kw):
+    n = int(g["n_comp"])
+    comps = [
+        amd.ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
+                          sed_min_step=g["min_step_%d" % k])
+        for k in range(n)
+    ]
+    return amd.BlendBatch(g["images"][None], g["weights"][None], [comps],
+                          kernel=g["diff_kernel"], **kw)
+
+
+def test_hsc_forward_vs_golden_and_oracle(amd, hsc):
+    batch = hsc_batch(amd, hsc)
+    assert batch.fft_shape == (108, 96)  # fft.py:116-167 on (58,48)+(43,43)+3
+    model, rendered, logL = batch.forward()
+    assert rel_err(model[0], hsc["model"]) < RTOL
+    assert rel_err(rendered[0], hsc["rendered"]) < RTOL
+    chi2_ref = -(float(hsc["logL"]) + float(hsc["log_norm"]))
+    sc = hsc_scene(hsc)
+    chi2 = -(logL[0] + sc.log_norm)
+    assert abs(chi2 - chi2_ref) < RTOL * abs(chi2_ref)
+    assert abs(logL[0] - float(hsc["logL"])) < 1e-5 * abs(float(hsc["logL"]))
+
+
+def grad_scales(sc):
+    """sum |G||morph| and sum |sed||G| per component: the magnitudes the float32
+    sums are taken over (the gradients themselves cancel to much less)"""
+    model = sc.get_model()
+    G = np.abs(sc.model_gradient(sc.render(model)))
+    out = []
+    for c in sc.components:
+        h, w = c.morph.shape
+        boxed = np.zeros((sc.frame_shape[0], h, w))
+        fs, bs = sc.box_slices(c)
+        boxed[bs] = G[fs]
+        out.append((np.einsum("cyx,yx->c", boxed, np.abs(c.morph)).max(),
+                    np.einsum("c,cyx->yx", np.abs(c.sed), boxed).max()))
+    return out
+
+
+def test_hsc_gradient_vs_oracle(amd, hsc):
+    batch = hsc_batch(amd, hsc)
+    g_sed, g_morph = batch.gradient()
+    sc = hsc_scene(hsc)
+    _, grads = sc.loss_and_gradients()
+    for k, ((gs, gm), (s_sed, s_morph)) in enumerate(zip(grads, grad_scales(sc))):
+        assert np.abs(g_sed[k] - gs).max() < RTOL * s_sed, k
+        assert np.abs(g_morph[k] - gm).max() < RTOL * s_morph, k
+
+
+def test_hsc_steps_vs_oracle(amd, hsc):
+    n_it = 5
+    batch = hsc_batch(amd, hsc, max_iter=16)
+    batch.step(0, n_it, e_rel=1e-3)
+    sed, morphs = batch.parameters()
+    mom = batch.moments()
+    sc = hsc_scene(hsc)
+    for it in range(n_it):
+        sc.step(it, 1e-3)
+    loss = batch.loss_history()[0]
+    assert_loss_close(loss, sc.loss, sc.log_norm)
+    for k, c in enumerate(sc.components):
+        assert rel_err(sed[k], c.sed) < 1e-4, k
+        assert np.abs(morphs[k] - c.morph).max() < 1e-4, k
+        assert rel_err(mom["m_sed"][k], c.m_sed) < 1e-3
+        assert rel_err(mom["v_morph"][k], c.v_morph) < 1e-3
+
+
+def test_first_step_exact_structure(amd, hsc):
+    """one iteration from identical state: every parameter within 1e-5"""
+    batch = hsc_batch(amd, hsc, max_iter=4)
+    batch.step(0, 1, e_rel=1e-3)
+    sed, morphs = batch.parameters()
+    sc = hsc_scene(hsc)
+    sc.step(0, 1e-3)
+    for k, c in enumerate(sc.components):
+        assert rel_err(sed[k], c.sed) < RTOL, k
+        assert np.abs(morphs[k] - c.morph).max() < RTOL, k
+        assert morphs[k].max() == 1.0 and morphs[k].min() >= 0.0
+
+
+def test_hsc_fit_converges_like_oracle(amd, hsc):
+    batch = hsc_batch(amd, hsc, max_iter=100)
+    n_iter, logL = batch.fit(max_iter=100, e_rel=1e-4)
+    sc = hsc_scene(hsc)
+    n_ref, logL_ref = sc.fit(max_iter=100, e_rel=1e-4)
+    loss = batch.loss_history()[0]
+    assert len(loss) == n_iter[0]
+    # trajectories pass through min/max branches: compare the likelihood reached
+    chi2 = lambda l: l - sc.log_norm  # noqa: E731
+    assert abs(chi2(-logL[0]) - chi2(-logL_ref)) < 2e-3 * abs(chi2(-logL_ref))
+    assert abs(int(n_iter[0]) - n_ref) <= max(3, n_ref // 10)
+    assert -loss[-1] > -loss[0]
+
+
+def test_synthetic_batch_vs_oracle(amd):
+    from oracle import pgm
+    from scarlet_amd import synthetic
+
+    kern = synthetic.psfs()
+    scenes = [synthetic.make_blend(1234 + b, kernel=kern) for b in range(3)]
+    comps = [
+        [amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                           sed_min_step=s["noise_rms"]) for k in range(10)]
+        for s in scenes
+    ]
+    data = np.stack([s["data"] for s in scenes])
+    weights = np.stack([s["weights"] for s in scenes])
+    batch = amd.BlendBatch(data, weights, comps, kernel=kern[2], max_iter=8)
+    assert batch.fft_shape == (180, 180)
+    g = golden("synthetic_cfg2")
+    model, rendered, logL = batch.forward()
+    assert rel_err(model[0], g["model"]) < RTOL
+    assert rel_err(rendered[0], g["rendered"]) < RTOL
+    batch.step(0, 3, e_rel=1e-3)
+    sed, morphs = batch.parameters()
+    losses = batch.loss_history()
+    for b, s in enumerate(scenes):
+        sc = pgm.Scene(
+            s["data"].shape, s["data"], s["weights"], s["diff_kernel"],
+            [pgm.Component(s["seds"][k].copy(), s["morphs"][k].copy(), s["origins"][k],
+                           sed_min_step=s["noise_rms"]) for k in range(10)],
+        )
+        for it in range(3):
+            sc.step(it, 1e-3)
+        assert_loss_close(losses[b], sc.loss, sc.log_norm)
+        for k, c in enumerate(sc.components):
+            assert rel_err(sed[b * 10 + k], c.sed) < 1e-4
+            assert np.abs(morphs[b * 10 + k] - c.morph).max() < 1e-4
+
+
+def test_null_renderer_vs_oracle(amd):
+    from oracle import pgm
+    from scarlet_amd import synthetic
+
+    s = synthetic.make_blend(99)
+    comps = [amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                               sed_min_step=s["noise_rms"]) for k in range(10)]
+    batch = amd.BlendBatch(s["data"][None], s["weights"][None], [comps], kernel=None, max_iter=8)
+    sc = pgm.Scene(
+        s["data"].shape, s["data"], s["weights"], None,
+        [pgm.Component(s["seds"][k].copy(), s["morphs"][k].copy(), s["origins"][k],
+                       sed_min_step=s["noise_rms"]) for k in range(10)],
+    )
+    model, rendered, logL = batch.forward()
+    assert_array_equal(model, rendered)
+    assert rel_err(model[0], sc.get_model()) < RTOL
+    batch.step(0, 2, e_rel=0.0)  # tolerance 0: always prox_max_iter sub-iterations
+    for it in range(2):
+        sc.step(it, 0.0)
+    assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm)
+
+
+def test_per_band_kernel_and_ragged_boxes(amd):
+    """cfg 4 shapes: (6,40,59) frame, (6,31,31) kernel, boxes overhanging the frame"""
+    from oracle import pgm
+
+    g = golden("psf_unmatched")
+    rng = np.random.default_rng(8)
+    C, H, W = g["images"].shape
+    specs, ocomps = [], []
+    for (h, w), (oy, ox) in (((21, 21), (-6, 13)), ((31, 31), (20, 40)), ((15, 23), (5, -4)),
+                             ((11, 11), (35, 55))):
+        morph = rng.random((h, w)).astype(np.float32)
+        morph /= morph.max()
+        sed = rng.uniform(0.5, 2, C).astype(np.float32)
+        specs.append(amd.ComponentSpec(sed, morph, (oy, ox), sed_min_step=0.01))
+        ocomps.append(pgm.Component(sed.copy(), morph.copy(), (oy, ox), sed_min_step=0.01))
+    w = np.full(g["images"].shape, 0.25, dtype=np.float32)
+    w[:, :3, :] = 0  # masked rows: log_norm must skip them
+    batch = amd.BlendBatch(g["images"][None], w[None], [specs], kernel=g["diff_kernel"], max_iter=4)
+    assert batch.fft_shape == (75, 96)
+    sc = pgm.Scene(g["images"].shape, g["images"], w, g["diff_kernel"], ocomps)
+    model, rendered, logL = batch.forward()
+    ref_model = sc.get_model()
+    assert rel_err(model[0], ref_model) < RTOL
+    assert rel_err(rendered[0], sc.render(ref_model)) < RTOL
+    assert abs(logL[0] - sc.log_likelihood(sc.render(ref_model))) < RTOL * abs(logL[0])
+    g_sed, g_morph = batch.gradient()
+    _, grads = sc.loss_and_gradients()
+    for k, ((gs, gm), (s_sed, s_morph)) in enumerate(zip(grads, grad_scales(sc))):
+        assert np.abs(g_sed[k] - gs).max() < RTOL * s_sed, k
+        assert np.abs(g_morph[k] - gm).max() < RTOL * s_morph, k
+    # reference render of a fixed cube with the per-band kernel (golden from the reference)
+    spec = [amd.ComponentSpec(np.eye(C, dtype=np.float32)[c], g["model"][c], (0, 0),
+                              prox_flags=0) for c in range(C)]
+    b2 = amd.BlendBatch(g["images"][None], w[None], [spec], kernel=g["diff_kernel"], max_iter=2)
+    _, rendered, _ = b2.forward()
+    assert np.abs(rendered[0] - g["rendered"]).max() < RTOL * np.abs(g["rendered"]).max()
+
+
+def test_convolution_properties_full_size(amd):
+    """size-independent properties at the benchmark shape (5x128x128, F=180x180):
+    linearity, and <A x, y> = <x, A^T y> with the gradient path as A^T"""
+    from scarlet_amd import synthetic
+
+    obs, model_psf, diff = synthetic.psfs()
+    rng = np.random.default_rng(5)
+    C, H, W, T = 5, 128, 128, 64
+    x = rng.standard_normal((C, H, W)).astype(np.float32)
+    y = rng.standard_normal((C, H, W)).astype(np.float32)
+    eye = np.eye(C, dtype=np.float32)
+    tiles = [(c, ty, tx) for c in range(C) for ty in range(0, H, T) for tx in range(0, W, T)]
+
+    def specs(cube):
+        # the cube as unit-sed components, one 64x64 tile each
+        return [amd.ComponentSpec(eye[c], cube[c, ty:ty + T, tx:tx + T], (ty, tx), prox_flags=0)
+                for c, ty, tx in tiles]
+
+    def untile(parts):
+        out = np.zeros((C, H, W), dtype=np.float64)
+        for (c, ty, tx), p in zip(tiles, parts):
+            out[c, ty:ty + T, tx:tx + T] = p
+        return out
+
+    def render(cube, data=None):
+        d = np.zeros((1, C, H, W), np.float32) if data is None else data[None]
+        b = amd.BlendBatch(d, np.ones((1, C, H, W), np.float32), [specs(cube)], kernel=diff,
+                           max_iter=2)
+        return b, b.forward()[1][0]
+
+    _, ax = render(x)
+    _, ay = render(y)
+    _, axy = render(x + 2 * y)
+    assert rel_err(axy, ax.astype(np.float64) + 2.0 * ay) < RTOL
+    # with unit weights the gradient wrt the tiles is A^T (A x - y)
+    b, _ = render(x, data=y)
+    _, g_morph = b.gradient()
+    at_r = untile(g_morph)
+    r = (ax - y).astype(np.float32)
+    lhs = np.sum(r.astype(np.float64) * render(r)[1])   # <r, A r>
+    rhs = np.sum(at_r * r)                               # <A^T r, r>
+    assert abs(lhs - rhs) < 1e-4 * abs(lhs)
+
+
+def test_convergence_freezes_blend_and_error_flag(amd, hsc):
+    batch = hsc_batch(amd, hsc, max_iter=60)
+    n_iter, _ = batch.fit(max_iter=60, e_rel=1e-2)  # loose: converges early
+    assert n_iter[0] < 60
+    sed0, _ = batch.parameters()
+    batch.step(int(n_iter[0]), 3, e_rel=1e-2, check_convergence=True)  # frozen
+    sed1, _ = batch.parameters()
+    assert_array_equal(sed0, sed1)
+    assert batch.status()[0] == 0
+    # non-finite input -> ArithmeticError (model.py:153-165)
+    bad = hsc_batch(amd, hsc, max_iter=12)
+    seds, morphs = bad.parameters()
+    seds[0, 0] = np.nan
+    bad.set_parameters(seds, morphs)
+    with pytest.raises(ArithmeticError):
+        bad.fit(max_iter=10, e_rel=1e-4)
