@@ -1,0 +1,198 @@
+"""Benchmark: PGM iterations/sec over batched blends (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one proximal-gradient iteration (render -> FFT convolution -> weighted
+residual/loss -> adjoint convolution -> gradient gather -> AMSGrad -> prox chain)
+of EVERY blend of the rank's batch.  Workload = BASELINE.json configs[2]'s batch
+of 1024 synthetic 5-band 128x128 blends with 10 ExtendedSource components each
+(SURVEY.md section 8d), per GPU (weak scaling: rank r fits seeds
+1234 + 1024 r + b).  Inputs are resident in HBM before the timed region.
+
+Output: ONE JSON line on rank 0 with the contract's fields plus
+  roofline     algorithmic bytes per blend-iteration x blend-iterations / device time
+               of the timed region (HIP events on the batch stream), against 8 TB/s
+  cpu_baseline the CPU oracle (NumPy/C port of the reference loop) timed on this
+               host, single thread, on a bounded sample of the same workload.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# SURVEY.md section 8d / BASELINE.md section 3: algorithmic bytes per blend-iteration
+BYTES_FFT_PATH = 6_669_760
+BYTES_NULL_PATH = 1_194_880
+HBM_PEAK_GBS = 8000.0
+
+
+def build_scenes(n_blends, seed0, device=0):
+    """Synthetic scenes; the noiseless truth is rendered on the GPU."""
+    from scarlet_amd import synthetic
+
+    kern = synthetic.psfs()
+    return kern, synthetic.make_batch(range(seed0, seed0 + n_blends), kernel=kern, device=device)
+
+
+def cpu_baseline(scenes, n_blends, n_iter, e_rel):
+    """Time the oracle (port of the reference loop) on the host: `n_blends` blends x
+    `n_iter` iterations, one thread.  The oracle is only the thing being timed as the
+    CPU baseline here; it is never part of the GPU path."""
+    from oracle import pgm
+
+    t0 = time.perf_counter()
+    done = 0
+    for s in scenes[:n_blends]:
+        sc = pgm.Scene(
+            s["data"].shape, s["data"], s["weights"], s["diff_kernel"],
+            [pgm.Component(s["seds"][k].copy(), s["morphs"][k].copy(), s["origins"][k],
+                           sed_min_step=s["noise_rms"]) for k in range(len(s["morphs"]))],
+        )
+        for it in range(n_iter):
+            sc.step(it, e_rel)
+            done += 1
+    dt = time.perf_counter() - t0
+    return done / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--blends", type=int, default=1024, help="blends per GPU")
+    ap.add_argument("--null-renderer", action="store_true", help="ablation: no PSF convolution")
+    ap.add_argument("--fft", type=int, nargs=2, default=None, help="override FFT shape")
+    ap.add_argument("--cpu-blends", type=int, default=16)
+    ap.add_argument("--cpu-iters", type=int, default=150)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="print the per-phase device times")
+    args = ap.parse_args()
+
+    import torch
+    from scarlet_amd import BlendBatch, ComponentSpec, dist as sdist
+
+    rank, local_rank, world = sdist.init_process_group()
+    assert world == args.gpus, "launch with torchrun --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    e_rel = 1e-3  # Blend.fit default; tolerance of the prox sub-iterations
+
+    nb = args.blends
+    kern, scenes = build_scenes(nb, 1234 + rank * nb, device=local_rank)
+
+    comps = [
+        [ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k], sed_min_step=s["noise_rms"])
+         for k in range(len(s["morphs"]))]
+        for s in scenes
+    ]
+    data = np.stack([s["data"] for s in scenes])
+    weights = np.stack([s["weights"] for s in scenes])
+    total_it = args.warmup + args.steps
+    batch = BlendBatch(
+        data, weights, comps, kernel=None if args.null_renderer else kern[2],
+        max_iter=total_it + 1, fft_shape=args.fft, device=local_rank,
+    )
+    stream = torch.cuda.Stream(device=local_rank)
+    batch.set_stream(stream.cuda_stream)
+
+    # warm-up iterations 0 .. W-1 (untimed), then K timed iterations of the same fit
+    batch.step(0, args.warmup, e_rel=e_rel, check_convergence=False)
+    torch.cuda.synchronize()
+    sdist.barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    batch.step(args.warmup, args.steps, e_rel=e_rel, check_convergence=False)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    sdist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = sdist.max_over_ranks(elapsed)
+    dev_ms = ev0.elapsed_time(ev1)
+
+    active, err = batch.status()
+    assert err < 0, "non-finite parameters in blend %d" % err
+    loss = batch.loss_history()
+    n_iter = np.array([len(l) for l in loss], dtype=np.int32)
+    logL = np.array([-l[-1] for l in loss])
+    n_iter_all, logL_all = sdist.gather_results(n_iter, logL)  # the only collective
+
+    phases = None
+    if args.phases or rank == 0:
+        batch.enable_timing(True)
+        batch.step(total_it, min(5, args.steps), e_rel=e_rel, check_convergence=False)
+        phases = {k: round(v, 4) for k, v in batch.timing().items()}
+        batch.enable_timing(False)
+
+    if rank == 0:
+        blend_iters = world * nb * args.steps
+        value = blend_iters / elapsed
+        bytes_per = BYTES_NULL_PATH if args.null_renderer else BYTES_FFT_PATH
+        ms_iter = dev_ms / args.steps  # one "launch" = one iteration of the whole batch
+        achieved = bytes_per * nb / (ms_iter * 1e-3) / 1e9
+        line = {
+            "metric": "PGM iters/sec over batched blends; achieved HBM GB/s vs roofline",
+            "value": round(value, 1),
+            "unit": "blend-iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[2] batch on one GPU: %d independent 5-band 128x128 blends "
+                            "per GPU, 10 ExtendedSource components (41x41) each, %s" % (
+                                nb, "NullRenderer ablation" if args.null_renderer
+                                else "ConvolutionRenderer FFT %dx%d" % batch.fft_shape),
+                "blends_per_gpu": nb,
+                "components_per_blend": 10,
+                "parallelism": "blend-sharded x%d, no data-path collective" % world,
+                "mean_logL": float(np.mean(logL_all)),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "kernel": "one PGM iteration of the batch (all kernels of the step)",
+                "bytes_per_blend_iteration": bytes_per,
+                "ms_per_launch": round(ms_iter, 4),
+                "phases_ms": phases,
+            },
+        }
+        if not args.no_cpu:
+            v, dt = cpu_baseline(scenes, args.cpu_blends, args.cpu_iters, e_rel)
+            line["cpu_baseline"] = {
+                "value": round(v, 2),
+                "unit": "blend-iterations/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "%d blends x %d iterations of the same workload, NumPy/C oracle, "
+                          "1 thread, %.1f s" % (args.cpu_blends, args.cpu_iters, dt),
+            }
+        print(json.dumps(line), flush=True)
+    batch.close()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,14 +32,7 @@ def _place(cube, sed, morph, origin):
     )
 
 
-def make_blend(seed=1234, kernel=None, n_sources=K):
-    """One synthetic scene.  Returns a dict with ``data``, ``weights`` (C,H,W)
-    float32, the truth (``true_seds``, ``true_morphs``), the perturbed
-    initial parameters (``seds`` (K,C) float32, ``morphs`` list of (41,41)
-    float32, ``origins`` (K,2) int), ``obs_psf``, ``model_psf``, ``diff_kernel``
-    and ``noise_rms`` (C,)."""
-    rng = np.random.default_rng(seed)
-    obs_psf, model_psf, diff = psfs() if kernel is None else kernel
+def _draw_truth(rng, n_sources):
     centers = rng.integers(20, 108, size=(n_sources, 2))
     yy, xx = np.mgrid[:BOX, :BOX] - BOX // 2
     true_seds, true_morphs, origins = [], [], []
@@ -51,12 +44,13 @@ def make_blend(seed=1234, kernel=None, n_sources=K):
         true_morphs.append((morph / morph.max()).astype(np.float32))
         true_seds.append(rng.uniform(1, 5, size=C).astype(np.float32))
         origins.append(centers[k] - BOX // 2)
-    truth = np.zeros((C, H, W), dtype=np.float32)
-    for sed, morph, origin in zip(true_seds, true_morphs, origins):
-        _place(truth, sed, morph, origin)
-    rendered = fft.convolve(fft.Fourier(truth), fft.Fourier(diff), axes=(1, 2)).image
-    data = (rendered + rng.normal(0, NOISE, size=truth.shape)).astype(np.float32)
-    weights = np.full(truth.shape, 1 / NOISE**2, dtype=np.float32)
+    return true_seds, true_morphs, origins
+
+
+def _finish(rng, rendered, true_seds, true_morphs, origins, kernel):
+    obs_psf, model_psf, diff = kernel
+    data = (rendered + rng.normal(0, NOISE, size=rendered.shape)).astype(np.float32)
+    weights = np.full(rendered.shape, 1 / NOISE**2, dtype=np.float32)
     seds, morphs = [], []
     for sed, morph in zip(true_seds, true_morphs):
         seds.append((sed * rng.uniform(0.7, 1.3, size=C)).astype(np.float32))
@@ -68,3 +62,48 @@ def make_blend(seed=1234, kernel=None, n_sources=K):
         obs_psf=obs_psf, model_psf=model_psf, diff_kernel=diff,
         noise_rms=np.full(C, NOISE, dtype=np.float32),
     )
+
+
+def make_blend(seed=1234, kernel=None, n_sources=K):
+    """One synthetic scene, rendered on the host.  Returns a dict with ``data``,
+    ``weights`` (C,H,W) float32, the truth (``true_seds``, ``true_morphs``), the
+    perturbed initial parameters (``seds`` (K,C) float32, ``morphs`` list of
+    (41,41) float32, ``origins`` (K,2) int), ``obs_psf``, ``model_psf``,
+    ``diff_kernel`` and ``noise_rms`` (C,)."""
+    rng = np.random.default_rng(seed)
+    kernel = psfs() if kernel is None else kernel
+    true_seds, true_morphs, origins = _draw_truth(rng, n_sources)
+    truth = np.zeros((C, H, W), dtype=np.float32)
+    for sed, morph, origin in zip(true_seds, true_morphs, origins):
+        _place(truth, sed, morph, origin)
+    rendered = fft.convolve(fft.Fourier(truth), fft.Fourier(kernel[2]), axes=(1, 2)).image
+    return _finish(rng, rendered, true_seds, true_morphs, origins, kernel)
+
+
+def make_batch(seeds, kernel=None, n_sources=K, device=0, chunk=256):
+    """The same scenes as ``make_blend`` for many seeds, with the noiseless truth
+    rendered on the GPU (model render + PSF convolution of the device path), so
+    that setting up a 1024-blend benchmark takes seconds.  Same random stream per
+    seed as ``make_blend``; data agree to float32 rounding."""
+    from .batch import BlendBatch, ComponentSpec
+
+    kernel = psfs() if kernel is None else kernel
+    seeds = list(seeds)
+    rngs = [np.random.default_rng(s) for s in seeds]
+    truths = [_draw_truth(r, n_sources) for r in rngs]
+    scenes = []
+    zeros = np.zeros((min(chunk, len(seeds)), C, H, W), dtype=np.float32)
+    for lo in range(0, len(seeds), chunk):
+        part = truths[lo : lo + chunk]
+        comps = [
+            [ComponentSpec(sed, morph, origin, prox_flags=0)
+             for sed, morph, origin in zip(*t)]
+            for t in part
+        ]
+        z = zeros[: len(part)]
+        batch = BlendBatch(z, z + 1, comps, kernel=kernel[2], max_iter=1, device=device)
+        _, rendered, _ = batch.forward(model=False)
+        batch.close()
+        for i, t in enumerate(part):
+            scenes.append(_finish(rngs[lo + i], rendered[i], *t, kernel))
+    return scenes

@@ -371,3 +371,16 @@ def test_convergence_freezes_blend_and_error_flag(amd, hsc):
     bad.set_parameters(seds, morphs)
     with pytest.raises(ArithmeticError):
         bad.fit(max_iter=10, e_rel=1e-4)
+
+
+def test_make_batch_matches_host_generator(amd):
+    from scarlet_amd import synthetic
+
+    kern = synthetic.psfs()
+    gpu = synthetic.make_batch([1234, 77], kernel=kern)
+    for s, seed in zip(gpu, (1234, 77)):
+        host = synthetic.make_blend(seed, kernel=kern)
+        assert np.abs(s["data"] - host["data"]).max() < 1e-5 * np.abs(host["data"]).max()
+        assert_array_equal(s["seds"], host["seds"])
+        assert_array_equal(np.array(s["morphs"]), np.array(host["morphs"]))
+        assert_array_equal(s["origins"], host["origins"])
