@@ -155,6 +155,9 @@ void refresh_view(smi_batch *b) {
     v.n_partial = (b->d.H * b->d.W + 255) / 256;
     v.plans = b->d_plans;
     v.max_levels = b->max_levels;
+    v.fast_plans = 1;
+    for (const auto &pl : b->plans)
+        if (!pl.slots) v.fast_plans = 0;
 }
 
 int ready(smi_batch *b) {
@@ -383,6 +386,7 @@ int smi_batch_destroy(smi_batch *b) {
         (void)hipFree(pl.cnt);
         (void)hipFree(pl.nbr);
         (void)hipFree(pl.wt);
+        if (pl.slots) (void)hipFree(pl.slots);
     }
     void *bufs[] = {b->P, b->null_renderer ? nullptr : (void *)b->Q, b->S, b->Khat, b->work,
                     b->own_obs ? b->data : nullptr, b->own_obs ? b->weights : nullptr,
@@ -420,6 +424,35 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
     if ((rc = upload(&dp.cnt, hp.cnt.data(), hp.cnt.size()))) return rc;
     if ((rc = upload(&dp.nbr, hp.nbr.data(), hp.nbr.size()))) return rc;
     if ((rc = upload(&dp.wt, wt.data(), wt.size()))) return rc;
+    if (hp.max_terms <= 4 && h * w < 65536) {
+        // slot layout of the fast update kernel: every level padded to 64-lane steps
+        std::vector<SweepSlotEntry> slots;
+        for (int l = 0; l < dp.n_levels; ++l) {
+            const int s0 = hp.level_start[l], s1 = hp.level_start[l + 1];
+            for (int base = s0; base < s1; base += 64) {
+                for (int lane = 0; lane < 64; ++lane) {
+                    SweepSlotEntry e{};
+                    const int q = base + lane;
+                    if (q < s1) {
+                        const int p = hp.pix[q], n = hp.cnt[q];
+                        uint32_t nb4[4] = {(uint32_t)p, (uint32_t)p, (uint32_t)p, (uint32_t)p};
+                        for (int j = 0; j < n; ++j) {
+                            nb4[j] = (uint32_t)hp.nbr[(size_t)j * hp.n_entries + q];
+                            e.w[j] = (float)hp.wt[(size_t)j * hp.n_entries + q];
+                        }
+                        e.pc = p | (n << 16);
+                        e.n01 = nb4[0] | (nb4[1] << 16);
+                        e.n23 = nb4[2] | (nb4[3] << 16);
+                    } else {
+                        e.pc = -1;
+                    }
+                    slots.push_back(e);
+                }
+            }
+        }
+        dp.n_slots = (int32_t)(slots.size() / 64);
+        if ((rc = upload(&dp.slots, slots.data(), slots.size()))) return rc;
+    }
     b->plans.push_back(dp);
     if (dp.n_levels > b->max_levels) b->max_levels = dp.n_levels;
     if ((rc = upload_plans(b))) return rc;

@@ -60,8 +60,20 @@ bool build_sweep_plan(int32_t n_pix, const double *weights, const int32_t *offse
                       int32_t n_off, const int32_t *dist_idx, int32_t n_idx,
                       SweepPlanHost *out);
 
+// One lane's work in one 64-wide step of the sweep (fast path, <= 4 terms,
+// < 65536 pixels): pc = pixel | n_terms << 16 (or -1: idle lane), n01 / n23 =
+// neighbour pixel indices packed two per word, w = weights.
+struct alignas(16) SweepSlotEntry {
+    int32_t pc;
+    uint32_t n01, n23;
+    int32_t pad;
+    float w[4];
+};
+
 struct SweepPlanDev {
     int32_t h = 0, w = 0, n_entries = 0, max_terms = 0, n_levels = 0;
+    int32_t n_slots = 0;
+    SweepSlotEntry *slots = nullptr;  // nullptr when the plan does not fit the fast path
     int32_t *level_start = nullptr;
     int32_t *pix = nullptr;
     int32_t *cnt = nullptr;
@@ -99,6 +111,7 @@ struct BatchView {
     const SweepPlanDev *plans;  // device array
     int32_t max_box_pixels;
     int32_t max_levels;  // over all plans
+    int32_t fast_plans;  // every plan has the slot layout
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);

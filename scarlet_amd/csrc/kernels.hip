@@ -221,47 +221,51 @@ __device__ __forceinline__ void sweep_levels(T *img, const int32_t *level_start,
 // ---------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
 
-__global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G, int it,
-                                                    float e_rel, int prox_max_iter,
-                                                    float *g_sed_out, float *g_morph_out,
-                                                    int grad_only) {
-    const int k = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int b = v.c_blend[k];
-    if (!grad_only && v.state[b] >= 2) return;
-    const int C = v.C;
-    const int h = v.c_h[k], w = v.c_w[k], N = h * w;
-    const int oy = v.c_oy[k], ox = v.c_ox[k];
-    const int64_t moff = v.c_moff[k];
-    const int npad = (v.max_box_pixels + 3) & ~3;
-    float *xs = lds_dyn;       // x after the gradient step
-    float *rs = xs + npad;     // psi / max(psi)
-    float *zs = rs + npad;     // current proximal iterate
-    float *us = zs + npad;     // candidate (and g_morph before that)
-    int32_t *lvl = reinterpret_cast<int32_t *>(us + npad);  // level_start of the plan
+struct CompCtx {
+    int k, b, C, h, w, N, oy, ox, lane;
+    int64_t moff;
+    const float *morph, *sed;
+};
 
-    const float *morph = v.morph + moff;
-    const float *sed = v.sed + (int64_t)k * C;
+__device__ __forceinline__ CompCtx comp_ctx(const BatchView &v) {
+    CompCtx c;
+    c.k = blockIdx.x;
+    c.lane = threadIdx.x;
+    c.b = v.c_blend[c.k];
+    c.C = v.C;
+    c.h = v.c_h[c.k];
+    c.w = v.c_w[c.k];
+    c.N = c.h * c.w;
+    c.oy = v.c_oy[c.k];
+    c.ox = v.c_ox[c.k];
+    c.moff = v.c_moff[c.k];
+    c.morph = v.morph + c.moff;
+    c.sed = v.sed + (int64_t)c.k * c.C;
+    return c;
+}
 
-    // ---- gradient: slice G into the box; sum_c sed G and sum_yx G morph ----
-    float g_sed = 0.f;  // lane c keeps band c
-    for (int c0 = 0; c0 < C; c0 += kBandChunk) {
-        const int nc = min(kBandChunk, C - c0);
+// slice G into the box (zero outside the frame, blend.py:30-46); us[i] = sum_c sed G,
+// return (in lane c) sum_yx G[c] morph  (lite/models.py:206-216)
+__device__ __forceinline__ float gather_gradient(const BatchView &v, const CompCtx &c,
+                                                 const float *G, float *us) {
+    float g_sed = 0.f;
+    for (int c0 = 0; c0 < c.C; c0 += kBandChunk) {
+        const int nc = min(kBandChunk, c.C - c0);
         float acc[kBandChunk];
 #pragma unroll
         for (int j = 0; j < kBandChunk; ++j) acc[j] = 0.f;
-        for (int i = lane; i < N; i += 64) {
-            const int y = i / w, x = i - y * w;
-            const int fy = y + oy, fx = x + ox;
+        for (int i = c.lane; i < c.N; i += 64) {
+            const int y = i / c.w, x = i - y * c.w;
+            const int fy = y + c.oy, fx = x + c.ox;
             float gm = c0 == 0 ? 0.f : us[i];
             if ((unsigned)fy < (unsigned)v.H && (unsigned)fx < (unsigned)v.W) {
-                const float mv = morph[i];
-                const float *g = G + (((int64_t)b * C + c0) * v.Fy + fy) * v.Fx + fx;
+                const float mv = c.morph[i];
+                const float *g = G + (((int64_t)c.b * c.C + c0) * v.Fy + fy) * v.Fx + fx;
 #pragma unroll
                 for (int j = 0; j < kBandChunk; ++j)
                     if (j < nc) {
                         const float gv = g[(int64_t)j * v.Fy * v.Fx];
-                        gm = fmaf(sed[c0 + j], gv, gm);
+                        gm = fmaf(c.sed[c0 + j], gv, gm);
                         acc[j] = fmaf(gv, mv, acc[j]);
                     }
             }
@@ -271,75 +275,126 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         for (int j = 0; j < kBandChunk; ++j)
             if (j < nc) {
                 const float t = wave_sum(acc[j]);
-                if (lane == c0 + j) g_sed = t;
+                if (c.lane == c0 + j) g_sed = t;
             }
     }
+    return g_sed;
+}
+
+// spectrum (spectrum.py:54-56): relative step, AMSGrad, positivity at 1e-20.
+// Returns non-zero if the new value is not finite.
+__device__ __forceinline__ int update_spectrum(const BatchView &v, const CompCtx &c, float g_sed,
+                                               int it, float e2, int prox_max_iter) {
+    const bool on = c.lane < c.C;
+    const float s = on ? c.sed[c.lane] : 0.f;
+    const float mean = wave_sum(s) / (float)c.C;
+    const int64_t idx = (int64_t)c.k * c.C + c.lane;
+    float psi = 0.f, x = s;
+    if (on) {
+        const float alpha = fmaxf(v.c_sed_min_step[idx], v.c_sed_rel[c.k] * mean);
+        const float m = (1.f - kB1) * g_sed + kB1 * v.m_sed[idx];
+        const float vv = (1.f - kB2) * g_sed * g_sed + kB2 * v.v_sed[idx];
+        const float vh = it == 0 ? vv : fmaxf(v.vh_sed[idx], vv);
+        v.m_sed[idx] = m;
+        v.v_sed[idx] = vv;
+        v.vh_sed[idx] = vh;
+        psi = sqrtf(fmaxf(vh, kEps));
+        float upd = alpha * m / psi;
+        if (it == 0) upd /= 10.f;  // lite/parameters.py:288-291
+        x = s - upd;
+    }
+    const float pmax = wave_max(psi);
+    const float ratio = on ? psi / pmax : 0.f;
+    float z = x;
+    for (int tau = 0; tau < prox_max_iter; ++tau) {
+        const float zn = on ? max_nan(z - ratio * (z - x), 1e-20f) : 0.f;
+        const float d2 = wave_sum((zn - z) * (zn - z));
+        const float z2 = wave_sum(z * z);
+        z = zn;
+        if (d2 <= e2 * z2) break;
+    }
+    if (on) v.sed[idx] = z;
+    return on && !isfinite(z);
+}
+
+// the element-wise members of the chain that act on the LDS image `us` before the
+// final positivity / centre / normalisation pass (constraint.py:262-273, 117-145)
+__device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCtx &c, int flags,
+                                                         float lthresh) {
+    const int h = c.h, w = c.w, N = c.N, lane = c.lane;
+    if (flags & SMI_PROX_SYMMETRY) {
+        // prox_soft_symmetry, strength 1 (operator.py:274-293): even axes are
+        // padded by one trailing zero before the 180-degree rotation
+        const int hp = h + !(h & 1), wp = w + !(w & 1);
+        for (int i = lane; i < N; i += 64) {
+            const int y = i / w, x = i - y * w;
+            const int py = hp - 1 - y, px = wp - 1 - x;
+            const bool has = py < h && px < w;
+            const int j = py * w + px;
+            if (!has) {
+                us[i] = 0.5f * us[i];
+            } else if (j >= i) {
+                const float a = 0.5f * (us[i] + us[j]);
+                us[i] = a;
+                us[j] = a;
+            }
+        }
+        __syncthreads();
+    }
+    if (flags & (SMI_PROX_L1 | SMI_PROX_L0)) {
+        for (int i = lane; i < N; i += 64) {
+            const float u = us[i];
+            if (flags & SMI_PROX_L1)
+                us[i] = copysignf(fmaxf(fabsf(u) - lthresh, 0.f), u);
+            else if (fabsf(u) < lthresh)
+                us[i] = 0.f;
+        }
+    }
+}
+
+// -- generic variant: everything in LDS, plans with any number of terms -----
+__global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G, int it,
+                                                    float e_rel, int prox_max_iter,
+                                                    float *g_sed_out, float *g_morph_out,
+                                                    int grad_only) {
+    const CompCtx c = comp_ctx(v);
+    if (!grad_only && v.state[c.b] >= 2) return;
+    const int lane = c.lane, N = c.N;
+    const int npad = (v.max_box_pixels + 3) & ~3;
+    float *xs = lds_dyn;       // x after the gradient step
+    float *rs = xs + npad;     // psi / max(psi)
+    float *zs = rs + npad;     // current proximal iterate
+    float *us = zs + npad;     // candidate (and g_morph before that)
+    int32_t *lvl = reinterpret_cast<int32_t *>(us + npad);  // level_start of the plan
+
+    const float g_sed = gather_gradient(v, c, G, us);
     __syncthreads();
     if (grad_only) {
-        if (lane < C) g_sed_out[(int64_t)k * C + lane] = g_sed;
-        for (int i = lane; i < N; i += 64) g_morph_out[moff + i] = us[i];
+        if (lane < c.C) g_sed_out[(int64_t)c.k * c.C + lane] = g_sed;
+        for (int i = lane; i < N; i += 64) g_morph_out[c.moff + i] = us[i];
         return;
     }
-
-    int bad = 0;
     const float e2 = e_rel * e_rel;
+    int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter);
 
-    // ---- spectrum (spectrum.py:54-56): relative step, positivity 1e-20 ----
-    {
-        const bool on = lane < C;
-        const float s = on ? sed[lane] : 0.f;
-        const float mean = wave_sum(s) / (float)C;
-        const int64_t idx = (int64_t)k * C + lane;
-        float psi = 0.f, x = s;
-        if (on) {
-            const float alpha = fmaxf(v.c_sed_min_step[idx], v.c_sed_rel[k] * mean);
-            const float m = (1.f - kB1) * g_sed + kB1 * v.m_sed[idx];
-            const float vv = (1.f - kB2) * g_sed * g_sed + kB2 * v.v_sed[idx];
-            const float vh = it == 0 ? vv : fmaxf(v.vh_sed[idx], vv);
-            v.m_sed[idx] = m;
-            v.v_sed[idx] = vv;
-            v.vh_sed[idx] = vh;
-            psi = sqrtf(fmaxf(vh, kEps));
-            float upd = alpha * m / psi;
-            if (it == 0) upd /= 10.f;  // lite/parameters.py:288-291
-            x = s - upd;
-        }
-        const float pmax = wave_max(psi);
-        const float ratio = on ? psi / pmax : 0.f;
-        float z = x;
-        for (int tau = 0; tau < prox_max_iter; ++tau) {
-            const float zn = on ? max_nan(z - ratio * (z - x), 1e-20f) : 0.f;
-            const float d2 = wave_sum((zn - z) * (zn - z));
-            const float z2 = wave_sum(z * z);
-            z = zn;
-            if (d2 <= e2 * z2) break;
-        }
-        if (on) {
-            v.sed[idx] = z;
-            bad |= !isfinite(z);
-        }
-    }
-
-    // ---- morphology image --------------------------------------------------
-    const int flags = v.c_flags[k];
-    const int plan_id = v.c_plan[k];
+    const int flags = v.c_flags[c.k];
+    const int plan_id = v.c_plan[c.k];
     float msum = 0.f;
-    for (int i = lane; i < N; i += 64) msum += morph[i];
-    const float mmean = wave_sum(msum) / (float)N;
-    const float alpha = fmaxf(v.c_morph_step[k], v.c_morph_rel[k] * mmean);
+    for (int i = lane; i < N; i += 64) msum += c.morph[i];
+    const float alpha = fmaxf(v.c_morph_step[c.k], v.c_morph_rel[c.k] * (wave_sum(msum) / (float)N));
     float pmax = 0.f;
     for (int i = lane; i < N; i += 64) {
         const float g = us[i];
-        const float m = (1.f - kB1) * g + kB1 * v.m_morph[moff + i];
-        const float vv = (1.f - kB2) * g * g + kB2 * v.v_morph[moff + i];
-        const float vh = it == 0 ? vv : fmaxf(v.vh_morph[moff + i], vv);
-        v.m_morph[moff + i] = m;
-        v.v_morph[moff + i] = vv;
-        v.vh_morph[moff + i] = vh;
+        const float m = (1.f - kB1) * g + kB1 * v.m_morph[c.moff + i];
+        const float vv = (1.f - kB2) * g * g + kB2 * v.v_morph[c.moff + i];
+        const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
+        v.m_morph[c.moff + i] = m;
+        v.v_morph[c.moff + i] = vv;
+        v.vh_morph[c.moff + i] = vh;
         const float psi = sqrtf(fmaxf(vh, kEps));
         float upd = alpha * m / psi;
         if (it == 0) upd /= 10.f;
-        const float x = morph[i] - upd;
+        const float x = c.morph[i] - upd;
         xs[i] = x;
         zs[i] = x;
         rs[i] = psi;
@@ -353,8 +408,8 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         pl = v.plans[plan_id];
         for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
     }
-    const float one_minus_g = 1.f - v.c_min_grad[k];
-    const int ctr = (h / 2) * w + (w / 2);
+    const float one_minus_g = 1.f - v.c_min_grad[c.k];
+    const int ctr = (c.h / 2) * c.w + (c.w / 2);
     __syncthreads();
     for (int i = lane; i < N; i += 64) rs[i] = rs[i] / pmax;
 
@@ -365,35 +420,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         if (monotonic)
             sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
                                        pl.nbr, pl.wt, one_minus_g, lane);
-        if (flags & SMI_PROX_SYMMETRY) {
-            // prox_soft_symmetry, strength 1 (operator.py:274-293): even axes are
-            // padded by one trailing zero before the 180-degree rotation
-            const int hp = h + !(h & 1), wp = w + !(w & 1);
-            for (int i = lane; i < N; i += 64) {
-                const int y = i / w, x = i - y * w;
-                const int py = hp - 1 - y, px = wp - 1 - x;
-                const bool has = py < h && px < w;
-                const int j = py * w + px;
-                if (!has) {
-                    us[i] = 0.5f * us[i];
-                } else if (j >= i) {
-                    const float a = 0.5f * (us[i] + us[j]);
-                    us[i] = a;
-                    us[j] = a;
-                }
-            }
-            __syncthreads();
-        }
-        if (flags & (SMI_PROX_L1 | SMI_PROX_L0)) {
-            const float t = v.c_lthresh[k];
-            for (int i = lane; i < N; i += 64) {
-                const float u = us[i];
-                if (flags & SMI_PROX_L1)
-                    us[i] = copysignf(fmaxf(fabsf(u) - t, 0.f), u);
-                else if (fabsf(u) < t)
-                    us[i] = 0.f;
-            }
-        }
+        chain_symmetry_threshold(us, c, flags, v.c_lthresh[c.k]);
         float mx = -INFINITY, sm = 0.f;
         for (int i = lane; i < N; i += 64) {
             float u = us[i];
@@ -421,10 +448,166 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     }
     for (int i = lane; i < N; i += 64) {
         const float z = zs[i];
-        v.morph[moff + i] = z;
+        v.morph[c.moff + i] = z;
         bad |= !isfinite(z);
     }
-    if (wave_or(bad) && lane == 0) atomicExch(&v.state[b], 3);  // model.py:153-165
+    if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
+}
+
+// -- fast variant --------------------------------------------------------------
+// Boxes of at most 64*NPL pixels and plans with at most 4 terms per pixel (the
+// reference's 'flat' / 'angle' / 'nearest' tables): x, psi/max(psi) and the
+// iterate z live in registers (lane l owns pixels l, l+64, ...); only the image
+// being swept is in LDS, so ~16 waves fit a CU.  The sweep plan is stored as
+// 64-wide slots (one 32-byte entry per lane, two coalesced dwordx4 loads) and the
+// next slot is fetched while the current one is processed.
+__device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slots, int n_slots,
+                                            float one_minus_g, int lane) {
+    const int4 *meta = reinterpret_cast<const int4 *>(slots);
+    const float4 *wts = reinterpret_cast<const float4 *>(slots);
+    int4 a = meta[(int64_t)lane * 2];
+    float4 wv = wts[(int64_t)lane * 2 + 1];
+    for (int s = 0; s < n_slots; ++s) {
+        int4 an = a;
+        float4 wn = wv;
+        if (s + 1 < n_slots) {
+            an = meta[((int64_t)(s + 1) * 64 + lane) * 2];
+            wn = wts[((int64_t)(s + 1) * 64 + lane) * 2 + 1];
+        }
+        if (a.x >= 0) {
+            const int p = a.x & 0xffff, n = a.x >> 16;
+            const float cur = us[p];
+            const float u0 = us[a.y & 0xffff], u1 = us[(unsigned)a.y >> 16];
+            const float u2 = us[a.z & 0xffff], u3 = us[(unsigned)a.z >> 16];
+            float ref = 0.f;
+            if (n > 0) ref = __fadd_rn(ref, __fmul_rn(u0, wv.x));
+            if (n > 1) ref = __fadd_rn(ref, __fmul_rn(u1, wv.y));
+            if (n > 2) ref = __fadd_rn(ref, __fmul_rn(u2, wv.z));
+            if (n > 3) ref = __fadd_rn(ref, __fmul_rn(u3, wv.w));
+            const float lim = __fmul_rn(ref, one_minus_g);
+            if (lim < cur) us[p] = lim;
+        }
+        __syncthreads();
+        a = an;
+        wv = wn;
+    }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float *G, int it,
+                                                        float e_rel, int prox_max_iter) {
+    const CompCtx c = comp_ctx(v);
+    if (v.state[c.b] >= 2) return;
+    const int lane = c.lane, N = c.N;
+    float *us = lds_dyn;
+
+    const float g_sed = gather_gradient(v, c, G, us);
+    __syncthreads();
+    const float e2 = e_rel * e_rel;
+    int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter);
+
+    const int flags = v.c_flags[c.k];
+    const int plan_id = v.c_plan[c.k];
+    float xs[NPL], rs[NPL], zs[NPL];
+    float msum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int i = lane + 64 * j;
+        zs[j] = i < N ? c.morph[i] : 0.f;
+        msum += zs[j];
+    }
+    const float alpha = fmaxf(v.c_morph_step[c.k], v.c_morph_rel[c.k] * (wave_sum(msum) / (float)N));
+    float pmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int i = lane + 64 * j;
+        xs[j] = 0.f;
+        rs[j] = 0.f;
+        if (i < N) {
+            const float g = us[i];
+            const float m = (1.f - kB1) * g + kB1 * v.m_morph[c.moff + i];
+            const float vv = (1.f - kB2) * g * g + kB2 * v.v_morph[c.moff + i];
+            const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
+            v.m_morph[c.moff + i] = m;
+            v.v_morph[c.moff + i] = vv;
+            v.vh_morph[c.moff + i] = vh;
+            const float psi = sqrtf(fmaxf(vh, kEps));
+            float upd = alpha * m / psi;
+            if (it == 0) upd /= 10.f;
+            xs[j] = zs[j] - upd;
+            zs[j] = xs[j];
+            rs[j] = psi;
+            pmax = fmaxf(pmax, psi);
+        }
+    }
+    pmax = wave_max(pmax);
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) rs[j] = rs[j] / pmax;
+
+    const bool monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
+    const SweepSlotEntry *slots = nullptr;
+    int n_slots = 0;
+    if (monotonic) {
+        slots = v.plans[plan_id].slots;
+        n_slots = v.plans[plan_id].n_slots;
+    }
+    const float one_minus_g = 1.f - v.c_min_grad[c.k];
+    const int ctr = (c.h / 2) * c.w + (c.w / 2);
+    const float lthresh = v.c_lthresh[c.k];
+    __syncthreads();
+
+    for (int tau = 0; tau < prox_max_iter; ++tau) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int i = lane + 64 * j;
+            if (i < N) us[i] = zs[j] - rs[j] * (zs[j] - xs[j]);
+        }
+        __syncthreads();
+        if (monotonic) sweep_slots(us, slots, n_slots, one_minus_g, lane);
+        chain_symmetry_threshold(us, c, flags, lthresh);
+        float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int i = lane + 64 * j;
+            if (i < N) {
+                float u = us[i];
+                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
+                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, 1e-6f);
+                mx = fmaxf(mx, u);
+                sm += u;
+            }
+        }
+        float div = 1.f;
+        if (flags & SMI_PROX_NORM_MAX) div = wave_max(mx);
+        if (flags & SMI_PROX_NORM_SUM) div = wave_sum(sm);
+        float d2 = 0.f, z2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int i = lane + 64 * j;
+            if (i < N) {
+                float u = us[i];  // second read instead of NPL more registers
+                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
+                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, 1e-6f);
+                if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM)) u = u / div;
+                d2 += (u - zs[j]) * (u - zs[j]);
+                z2 += zs[j] * zs[j];
+                zs[j] = u;
+            }
+        }
+        d2 = wave_sum(d2);
+        z2 = wave_sum(z2);
+        __syncthreads();
+        if (d2 <= e2 * z2) break;
+    }
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int i = lane + 64 * j;
+        if (i < N) {
+            v.morph[c.moff + i] = zs[j];
+            bad |= !isfinite(zs[j]);
+        }
+    }
+    if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
 }
 
 // log_norm of Observation (observation.py:172-186): D/2 ln(2 pi) + sum ln(1/sqrt(w))
@@ -553,9 +736,32 @@ static size_t update_lds_bytes(const BatchView &v) {
     return 4 * npad * sizeof(float) + (size_t)(v.max_levels + 2) * sizeof(int32_t);
 }
 
+template <int NPL>
+static void launch_update_reg(const BatchView &v, const float *G, int32_t it, float e_rel,
+                              int32_t prox_max_iter, hipStream_t s) {
+    const size_t lds = (size_t)((v.max_box_pixels + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL(update_kernel_reg<NPL>, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
+                       prox_max_iter);
+}
+
 int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
                   int32_t prox_max_iter, float *g_sed_out, float *g_morph_out,
                   int32_t grad_only, hipStream_t s) {
+    if (v.n_comp == 0) return SMI_OK;
+    if (!grad_only && v.fast_plans && v.max_box_pixels <= 64 * 59) {
+        const int n = v.max_box_pixels;
+        if (n <= 64 * 7)
+            launch_update_reg<7>(v, G, it, e_rel, prox_max_iter, s);
+        else if (n <= 64 * 16)
+            launch_update_reg<16>(v, G, it, e_rel, prox_max_iter, s);
+        else if (n <= 64 * 27)
+            launch_update_reg<27>(v, G, it, e_rel, prox_max_iter, s);
+        else if (n <= 64 * 42)
+            launch_update_reg<42>(v, G, it, e_rel, prox_max_iter, s);
+        else
+            launch_update_reg<59>(v, G, it, e_rel, prox_max_iter, s);
+        return SMI_OK;
+    }
     const size_t lds = update_lds_bytes(v);
     SMI_REQUIRE(lds <= 160 * 1024, "component box too large for the LDS-resident update");
     static size_t configured = 0;
