@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--blends", type=int, default=1024, help="blends per GPU")
     ap.add_argument("--null-renderer", action="store_true", help="ablation: no PSF convolution")
     ap.add_argument("--fft", type=int, nargs=2, default=None, help="override FFT shape")
+    ap.add_argument("--conv-path", default="auto", choices=["auto", "rocfft", "fused"])
     ap.add_argument("--cpu-blends", type=int, default=16)
     ap.add_argument("--cpu-iters", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true")
@@ -98,7 +99,7 @@ def main():
     total_it = args.warmup + args.steps
     batch = BlendBatch(
         data, weights, comps, kernel=None if args.null_renderer else kern[2],
-        max_iter=total_it + 1, fft_shape=args.fft, device=local_rank,
+        max_iter=total_it + 1, fft_shape=args.fft, device=local_rank, conv_path=args.conv_path,
     )
     stream = torch.cuda.Stream(device=local_rank)
     batch.set_stream(stream.cuda_stream)

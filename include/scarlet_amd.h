@@ -110,6 +110,10 @@ typedef struct smi_batch_desc {
     int32_t fft_h;        /* FFT shape; 0 => reference rule fft.py:116-167         */
     int32_t fft_w;
     int32_t max_iter;     /* capacity of the per-blend loss history                */
+    int32_t conv_path;    /* 0 auto: LDS-resident fused convolution kernel when the  */
+                          /*   padded band fits the LDS, else rocFFT;                */
+                          /* 1 rocFFT pipeline (reference FFT shape by default);     */
+                          /* 2 fused kernel or fail                                  */
 } smi_batch_desc;
 
 /* per component, all arrays of length n_components unless noted */

@@ -37,7 +37,7 @@ class BatchDesc(ctypes.Structure):
         (name, ctypes.c_int32)
         for name in (
             "n_blends", "C", "H", "W", "n_components", "kernel_h", "kernel_w",
-            "kernel_bands", "kernel_per_blend", "fft_h", "fft_w", "max_iter",
+            "kernel_bands", "kernel_per_blend", "fft_h", "fft_w", "max_iter", "conv_path",
         )
     ]
 

@@ -44,12 +44,16 @@ class BlendBatch:
     kernel: difference kernel, ``None`` (NullRenderer), ``(Ck, P, P)`` shared by
         all blends, or ``(n_blends, Ck, P, P)``; Ck in {1, C}
     max_iter: capacity of the loss history
-    fft_shape: ``None`` for the reference's rule (fft.py:116-167) or (Fy, Fx)
+    fft_shape: ``None`` or (Fy, Fx); any alias-free shape gives the same linear
+        convolution as the reference's (fft.py:116-167)
+    conv_path: "auto" (fused LDS-resident convolution kernel when the padded band
+        fits the LDS, otherwise rocFFT), "rocfft" (rocFFT pipeline with the
+        reference's FFT shape by default) or "fused"
     device: GPU index
     """
 
     def __init__(self, data, weights, components, kernel=None, max_iter=200,
-                 fft_shape=None, device=0):
+                 fft_shape=None, device=0, conv_path="auto"):
         lib = _lib.load()
         self._lib = lib
         self._h = ctypes.c_void_p()
@@ -79,6 +83,7 @@ class BlendBatch:
             desc.kernel_bands, desc.kernel_per_blend = kb, int(per_blend)
         if fft_shape is not None:
             desc.fft_h, desc.fft_w = int(fft_shape[0]), int(fft_shape[1])
+        desc.conv_path = {"auto": 0, "rocfft": 1, "fused": 2}[conv_path]
         _lib.check(lib.smi_batch_create(ctypes.byref(desc), int(device), ctypes.byref(self._h)))
 
         # monotonicity plans, one per (box shape, weighting)

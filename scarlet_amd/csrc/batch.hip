@@ -18,6 +18,7 @@
 // every call, fft.py:387-388).
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -72,7 +73,10 @@ struct smi_batch {
     int device = 0;
     hipStream_t stream = nullptr;
     bool null_renderer = false;
-    int Fy = 0, Fx = 0, Fxh = 0;
+    bool fused = false;       // LDS-resident convolution kernel instead of rocFFT
+    int Fy = 0, Fx = 0, Fxh = 0;  // FFT shape
+    int Py = 0, Px = 0;           // row/plane strides of the P / Q cubes
+    float2 *Kt = nullptr;         // kernel spectrum in the fused kernel's order
     // FFT work cubes
     float *P = nullptr, *Q = nullptr;
     float2 *S = nullptr, *Khat = nullptr;
@@ -117,8 +121,8 @@ void refresh_view(smi_batch *b) {
     v.C = b->d.C;
     v.H = b->d.H;
     v.W = b->d.W;
-    v.Fy = b->Fy;
-    v.Fx = b->Fx;
+    v.Fy = b->Py;
+    v.Fx = b->Px;
     v.n_comp = b->d.n_components;
     v.comp_start = b->comp_start;
     v.c_blend = b->c_blend;
@@ -152,7 +156,7 @@ void refresh_view(smi_batch *b) {
     v.hist_cap = b->d.max_iter;
     v.last_loss = b->last_loss;
     v.loss_partial = b->loss_partial;
-    v.n_partial = (b->d.H * b->d.W + 255) / 256;
+    v.n_partial = b->fused ? b->d.C : (b->d.H * b->d.W + 255) / 256;
     v.plans = b->d_plans;
     v.max_levels = b->max_levels;
     v.fast_plans = 1;
@@ -178,6 +182,10 @@ int fft_exec(smi_batch *b, rocfft_plan plan, void *in, void *out) {
 // rendered = model (*) kernel, or its transpose; in: P, out: Q
 int convolve(smi_batch *b, const BatchView &v, int conj) {
     if (b->null_renderer) return SMI_OK;
+    if (b->fused) {
+        set_error("internal: rocFFT convolution requested on the fused path");
+        return SMI_ERR_INVALID;
+    }
     int rc = fft_exec(b, b->plan_fwd, b->P, b->S);
     if (rc) return rc;
     launch_cmul(b->S, b->Khat, v.nb, v.C, (int64_t)b->Fy * b->Fxh, b->d.kernel_bands,
@@ -323,22 +331,37 @@ int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
             SMI_REQUIRE(desc->fft_w % 2 == 0, "fft_w must be even");
             b->Fy = desc->fft_h;
             b->Fx = desc->fft_w;
+            b->fused = desc->conv_path != 1 && fused_conv_instantiated(b->Fy, b->Fx);
         } else {
-            reference_fft_shape(H, W, desc->kernel_h, desc->kernel_w, &b->Fy, &b->Fx);
+            const int fy = fused_conv_length(H + desc->kernel_h / 2);
+            const int fx = fused_conv_length(W + desc->kernel_w / 2);
+            if (desc->conv_path != 1 && fy && fx && fused_conv_instantiated(fy, fx)) {
+                b->fused = true;
+                b->Fy = fy;
+                b->Fx = fx;
+            } else {
+                reference_fft_shape(H, W, desc->kernel_h, desc->kernel_w, &b->Fy, &b->Fx);
+            }
         }
+        SMI_REQUIRE(desc->conv_path != 2 || b->fused, "fused convolution not available for this shape");
     }
     b->Fxh = b->Fx / 2 + 1;
-    const size_t n_real = (size_t)nb * C * b->Fy * b->Fx;
+    const bool padded = !b->null_renderer && !b->fused;
+    b->Py = padded ? b->Fy : H;
+    b->Px = padded ? b->Fx : W;
+    const size_t n_real = (size_t)nb * C * b->Py * b->Px;
     SMI_HIP(dev_alloc(&b->P, n_real));
     SMI_HIP(hipMemset(b->P, 0, n_real * sizeof(float)));
     if (b->null_renderer) {
         b->Q = b->P;
     } else {
-        const size_t n_cplx = (size_t)nb * C * b->Fy * b->Fxh;
         SMI_HIP(dev_alloc(&b->Q, n_real));
         SMI_HIP(hipMemset(b->Q, 0, n_real * sizeof(float)));
-        SMI_HIP(dev_alloc(&b->S, n_cplx));
         SMI_FFT(rocfft_setup());
+    }
+    if (padded) {
+        const size_t n_cplx = (size_t)nb * C * b->Fy * b->Fxh;
+        SMI_HIP(dev_alloc(&b->S, n_cplx));
         const size_t lengths[2] = {(size_t)b->Fx, (size_t)b->Fy};
         SMI_FFT(rocfft_plan_create(&b->plan_fwd, rocfft_placement_notinplace,
                                    rocfft_transform_type_real_forward, rocfft_precision_single,
@@ -363,7 +386,7 @@ int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
     SMI_HIP(dev_alloc(&b->loss_hist, (size_t)nb * desc->max_iter));
     SMI_HIP(dev_alloc(&b->last_loss, nb));
     SMI_HIP(dev_alloc(&b->log_norm, nb));
-    SMI_HIP(dev_alloc(&b->loss_partial, (size_t)nb * ((H * W + 255) / 256)));
+    SMI_HIP(dev_alloc(&b->loss_partial, (size_t)nb * std::max(C, (H * W + 255) / 256)));
     SMI_HIP(hipMemset(b->state, 0, nb * sizeof(int32_t)));
     SMI_HIP(hipMemset(b->zero_state, 0, nb * sizeof(int32_t)));
     SMI_HIP(hipMemset(b->n_loss, 0, nb * sizeof(int32_t)));
@@ -388,7 +411,7 @@ int smi_batch_destroy(smi_batch *b) {
         (void)hipFree(pl.wt);
         if (pl.slots) (void)hipFree(pl.slots);
     }
-    void *bufs[] = {b->P, b->null_renderer ? nullptr : (void *)b->Q, b->S, b->Khat, b->work,
+    void *bufs[] = {b->P, b->null_renderer ? nullptr : (void *)b->Q, b->S, b->Khat, b->Kt, b->work,
                     b->own_obs ? b->data : nullptr, b->own_obs ? b->weights : nullptr,
                     b->log_norm, b->comp_start, b->c_blend, b->c_oy, b->c_ox, b->c_h, b->c_w,
                     b->c_flags, b->c_plan, b->c_moff, b->c_sed_min_step, b->c_sed_rel,
@@ -531,6 +554,14 @@ int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
     if (work) (void)hipFree(work);
     (void)hipFree(d_pad);
     (void)hipFree(d_kern);
+    if (b->fused) {
+        // the fused kernel wants [img][pos_y(ky)][kx]; the 1/2 of its Hermitian row
+        // separation is folded into the spectrum as well
+        if (!b->Kt) SMI_HIP(dev_alloc(&b->Kt, n_cplx));
+        if ((rc = launch_permute_kernel_spectrum(b->Khat, b->Kt, n_img, b->Fy, b->Fx, 0.5f, b->stream)))
+            return rc;
+        SMI_HIP(hipStreamSynchronize(b->stream));
+    }
     b->have_kernel = true;
     return SMI_OK;
 }
@@ -677,19 +708,26 @@ int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL)
     float *tmp = nullptr;
     if (model || rendered) SMI_HIP(dev_alloc(&tmp, n_out));
     if (model) {
-        launch_crop(b->P, tmp, nb * C, H, W, b->Fy, b->Fx, b->stream);
+        launch_crop(b->P, tmp, nb * C, H, W, b->Py, b->Px, b->stream);
         SMI_HIP(hipMemcpyAsync(model, tmp, n_out * sizeof(float), hipMemcpyDeviceToHost, b->stream));
         SMI_HIP(hipStreamSynchronize(b->stream));
     }
-    if ((rc = convolve(b, v, 0))) return rc;
+    if (b->fused) {
+        // mode 1: rendered cube to Q (compact) and the loss partials
+        if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
+                                    b->d.kernel_per_blend, b->Q, 1, b->stream)))
+            return rc;
+    } else if ((rc = convolve(b, v, 0))) {
+        return rc;
+    }
     if (rendered) {
-        launch_crop(b->Q, tmp, nb * C, H, W, b->Fy, b->Fx, b->stream);
+        launch_crop(b->Q, tmp, nb * C, H, W, b->Py, b->Px, b->stream);
         SMI_HIP(hipMemcpyAsync(rendered, tmp, n_out * sizeof(float), hipMemcpyDeviceToHost, b->stream));
         SMI_HIP(hipStreamSynchronize(b->stream));
     }
     if (tmp) (void)hipFree(tmp);
     if (logL) {
-        launch_residual(v, b->Q, b->P, b->stream);
+        if (!b->fused) launch_residual(v, b->Q, b->P, b->stream);
         std::vector<double> part((size_t)nb * v.n_partial), ln(nb);
         SMI_HIP(hipMemcpyAsync(part.data(), b->loss_partial, part.size() * sizeof(double),
                                hipMemcpyDeviceToHost, b->stream));
@@ -710,10 +748,16 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     int rc = ready(b);
     if (rc) return rc;
     const BatchView v = unmasked_view(b);
-    launch_render(v, b->P, b->stream);
-    if ((rc = convolve(b, v, 0))) return rc;
-    launch_residual(v, b->Q, b->P, b->stream);
-    if ((rc = convolve(b, v, 1))) return rc;
+    if (b->fused) {
+        if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
+                                    b->d.kernel_per_blend, b->Q, 0, b->stream)))
+            return rc;
+    } else {
+        launch_render(v, b->P, b->stream);
+        if ((rc = convolve(b, v, 0))) return rc;
+        launch_residual(v, b->Q, b->P, b->stream);
+        if ((rc = convolve(b, v, 1))) return rc;
+    }
     if ((rc = launch_update(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_morph, 1, b->stream))) return rc;
     SMI_HIP(hipStreamSynchronize(b->stream));
     if (g_sed)
@@ -746,15 +790,27 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
         const int it = it0 + i;
         hipEvent_t *ev = timing ? &b->events[(size_t)i * 6] : nullptr;
         if (ev) SMI_HIP(hipEventRecord(ev[0], b->stream));
-        launch_render(v, b->P, b->stream);
-        if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
-        if ((rc = convolve(b, v, 0))) return rc;
-        if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
-        launch_residual(v, b->Q, b->P, b->stream);
-        launch_finalize(v, it, e_rel, min_iter, check, b->stream);
-        if (ev) SMI_HIP(hipEventRecord(ev[3], b->stream));
-        if ((rc = convolve(b, v, 1))) return rc;
-        if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
+        if (b->fused) {
+            // render + conv + residual/loss + conv^T in one LDS-resident kernel
+            if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
+            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
+                                        b->d.kernel_per_blend, b->Q, 0, b->stream)))
+                return rc;
+            if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
+            launch_finalize(v, it, e_rel, min_iter, check, b->stream);
+            if (ev) SMI_HIP(hipEventRecord(ev[3], b->stream));
+            if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
+        } else {
+            launch_render(v, b->P, b->stream);
+            if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
+            if ((rc = convolve(b, v, 0))) return rc;
+            if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
+            launch_residual(v, b->Q, b->P, b->stream);
+            launch_finalize(v, it, e_rel, min_iter, check, b->stream);
+            if (ev) SMI_HIP(hipEventRecord(ev[3], b->stream));
+            if ((rc = convolve(b, v, 1))) return rc;
+            if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
+        }
         if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, b->stream)))
             return rc;
         if (check) launch_advance(v, b->stream);

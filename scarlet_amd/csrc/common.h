@@ -133,6 +133,15 @@ void launch_crop(const float *P, float *out, int32_t n_img, int32_t H, int32_t W
                  int32_t Fy, int32_t Fx, hipStream_t s);
 void launch_count_active(const int32_t *state, int32_t nb, int32_t *out, hipStream_t s);
 
+// fused LDS-resident convolution (fused_conv.hip)
+bool fused_conv_supported(int Fy, int Fx);
+bool fused_conv_instantiated(int Fy, int Fx);
+int fused_conv_length(int n);
+int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float2 *Kt, int k_bands,
+                      int k_per_blend, float *out, int mode, hipStream_t s);
+int launch_permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int n_img, int Fy, int Fx,
+                                   float scale, hipStream_t s);
+
 template <typename T>
 int sweep_host_buffers(T *flat_img, int32_t n_pix, const SweepPlanHost &plan, T min_gradient);
 template <typename T>

@@ -1,0 +1,398 @@
+// LDS-resident PSF convolution + likelihood for one (blend, band) per workgroup.
+//
+// Replaces, for frames whose padded band fits the 160 KiB LDS of a CU, the chain
+//   render -> rocFFT R2C -> x K^ -> rocFFT C2R -> residual/loss -> rocFFT R2C ->
+//   x conj(K^) -> rocFFT C2R
+// (renderer.py:247-259 / fft.py:368-396 forward, its transpose backward,
+// observation.py:147-170 in between) by ONE kernel that keeps the half-spectrum of
+// the band in LDS from the first row transform to the last: per blend-iteration the
+// only HBM traffic left is data + weights (read once), the morphologies (L2) and the
+// gradient image (written once).
+//
+// Layout: T[kx][y], kx in [0, FX/2], column stride SY = FY + 1 complex (odd, so that
+// 32 lanes working on 32 different columns hit 32 different 8-byte bank pairs).
+// 1-D transforms of length F = F1 * 16 are two in-place passes (radix F1 over stride
+// 16, radix 16 over contiguous blocks); the forward transform leaves the spectrum in
+// the digit-swapped order pos(k1 + F1 k2) = 16 k1 + k2, the inverse starts from it,
+// so no transposition pass is ever needed; the kernel spectrum K^ is stored in the
+// same order.  Rows are transformed two at a time (row 2j + i row 2j+1) and
+// separated by Hermitian symmetry; zero padding is never stored for the columns.
+#include "common.h"
+#include "fft_regs.h"
+
+namespace smi {
+
+using fftk::cadd;
+using fftk::cmul;
+using fftk::cmulc;
+using fftk::csub;
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kF2 = 16;      // second radix of every 1-D transform
+constexpr int kPairs = 32;   // row pairs per chunk (64 rows)
+
+template <int FY1, int FX1>
+struct Cfg {
+    static constexpr int FY = FY1 * kF2, FX = FX1 * kF2;
+    static constexpr int NKX = FX / 2 + 1;
+    static constexpr int SY = FY + 1;  // column stride of T (complex), odd
+    static constexpr int SX = FX + 1;  // row-pair stride of the scratch (complex), odd
+    static constexpr size_t lds_bytes =
+        sizeof(float2) * ((size_t)NKX * SY + (size_t)kPairs * SX + FY + FX);
+};
+
+// ---- one radix-F1 pass over elements a[16 n1 + n2] -----------------------------
+// forward: A[k1] = w_F^(n2 k1) DFT_F1(x)[k1] written to a[16 k1 + n2]; inputs with
+// index >= valid are taken as zero.  inverse: plain inverse DFT_F1.
+template <int F1, bool INV>
+__device__ __forceinline__ void pass_stride(float2 *a, int n2, const float2 *tw, int valid) {
+    float2 v[F1];
+#pragma unroll
+    for (int n1 = 0; n1 < F1; ++n1) {
+        const int idx = kF2 * n1 + n2;
+        v[n1] = (INV || idx < valid) ? a[idx] : make_float2(0.f, 0.f);
+    }
+    fftk::Dft<F1, INV>::run(v);
+#pragma unroll
+    for (int k1 = 0; k1 < F1; ++k1) {
+        if (!INV && k1 > 0) v[k1] = cmul(v[k1], tw[n2 * k1]);
+        a[kF2 * k1 + n2] = v[k1];
+    }
+}
+
+// ---- radix-16 pass over the contiguous block a[16 k1 .. 16 k1 + 15] ---------------
+template <bool INV>
+__device__ __forceinline__ void pass_block(float2 *a, int k1, const float2 *tw) {
+    float2 v[kF2];
+#pragma unroll
+    for (int j = 0; j < kF2; ++j) v[j] = a[kF2 * k1 + j];
+    fftk::Dft<kF2, INV>::run(v);
+#pragma unroll
+    for (int j = 0; j < kF2; ++j) {
+        if (INV && j > 0) v[j] = cmulc(v[j], tw[j * k1]);
+        a[kF2 * k1 + j] = v[j];
+    }
+}
+
+// position of natural frequency k in the digit-swapped order of a length F1*16 transform
+template <int F1>
+__device__ __forceinline__ int pos(int k) {
+    return kF2 * (k % F1) + k / F1;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *part) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < kThreads / 64; ++i) t += part[i];
+    return t;
+}
+
+template <int FY1, int FX1>
+struct Conv {
+    using C = Cfg<FY1, FX1>;
+    float2 *T, *Z, *twy, *twx;
+    int tid;
+
+    // column transforms fused with the spectral product:
+    //   T <- IFFT_y( FFT_y(T) * K )   for every column kx, K in digit-swapped order
+    __device__ __forceinline__ void columns(const float2 *Kt, int H, bool conj) {
+        for (int b = tid; b < C::NKX * kF2; b += kThreads) {
+            const int kx = b % C::NKX, n2 = b / C::NKX;
+            pass_stride<FY1, false>(T + kx * C::SY, n2, twy, H);
+        }
+        __syncthreads();
+        for (int b = tid; b < C::NKX * FY1; b += kThreads) {
+            const int kx = b % C::NKX, k1 = b / C::NKX;
+            float2 *a = T + kx * C::SY + kF2 * k1;
+            float2 v[kF2];
+#pragma unroll
+            for (int j = 0; j < kF2; ++j) v[j] = a[j];
+            fftk::Dft<kF2, false>::run(v);
+#pragma unroll
+            for (int j = 0; j < kF2; ++j) {
+                const float2 kv = Kt[(int64_t)(kF2 * k1 + j) * C::NKX + kx];
+                v[j] = conj ? cmulc(v[j], kv) : cmul(v[j], kv);
+            }
+            fftk::Dft<kF2, true>::run(v);
+#pragma unroll
+            for (int j = 0; j < kF2; ++j) {
+                if (j > 0) v[j] = cmulc(v[j], twy[j * k1]);
+                a[j] = v[j];
+            }
+        }
+        __syncthreads();
+        for (int b = tid; b < C::NKX * kF2; b += kThreads) {
+            const int kx = b % C::NKX, n2 = b / C::NKX;
+            pass_stride<FY1, true>(T + kx * C::SY, n2, twy, C::FY);
+        }
+        __syncthreads();
+    }
+
+    // forward row transforms of the chunk in Z (pairs of real rows as re/im) and
+    // Hermitian separation into T[kx][y0 + 2j], T[kx][y0 + 2j + 1]
+    __device__ __forceinline__ void rows_forward(int y0, int W) {
+        for (int b = tid; b < kPairs * kF2; b += kThreads)
+            pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
+        __syncthreads();
+        for (int b = tid; b < kPairs * FX1; b += kThreads)
+            pass_block<false>(Z + (b % kPairs) * C::SX, b / kPairs, twx);
+        __syncthreads();
+        for (int b = tid; b < C::NKX * kPairs; b += kThreads) {
+            const int j = b % kPairs, kx = b / kPairs;
+            const int y = y0 + 2 * j;
+            if (y + 1 < C::FY) {
+                const float2 *z = Z + j * C::SX;
+                const float2 za = z[pos<FX1>(kx)];
+                const float2 zb = z[pos<FX1>((C::FX - kx) % C::FX)];
+                // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^)
+                float2 *t = T + kx * C::SY + y;
+                t[0] = make_float2(za.x + zb.x, za.y - zb.y);
+                t[1] = make_float2(za.y + zb.y, zb.x - za.x);
+            }
+        }
+        __syncthreads();
+    }
+
+    // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
+    __device__ __forceinline__ void rows_inverse(int y0) {
+        for (int b = tid; b < C::NKX * kPairs; b += kThreads) {
+            const int j = b % kPairs, kx = b / kPairs;
+            const int y = y0 + 2 * j;
+            float2 xa = make_float2(0.f, 0.f), xb = xa;
+            if (y + 1 < C::FY) {
+                const float2 *t = T + kx * C::SY + y;
+                xa = t[0];
+                xb = t[1];
+            }
+            float2 *z = Z + j * C::SX;
+            z[pos<FX1>(kx)] = make_float2(xa.x - xb.y, xa.y + xb.x);  // Xa + i Xb
+            if (kx != 0 && 2 * kx != C::FX)                           // conj(Xa) + i conj(Xb)
+                z[pos<FX1>(C::FX - kx)] = make_float2(xa.x + xb.y, xb.x - xa.y);
+        }
+        __syncthreads();
+        for (int b = tid; b < kPairs * FX1; b += kThreads)
+            pass_block<true>(Z + (b % kPairs) * C::SX, b / kPairs, twx);
+        __syncthreads();
+        for (int b = tid; b < kPairs * kF2; b += kThreads)
+            pass_stride<FX1, true>(Z + (b % kPairs) * C::SX, b / kPairs, twx, C::FX);
+        __syncthreads();
+    }
+};
+
+// element (row r of the chunk, column x) of the pair-packed scratch
+__device__ __forceinline__ float &zref(float2 *Z, int SX, int r, int x) {
+    float2 &e = Z[(r >> 1) * SX + x];
+    return (r & 1) ? e.y : e.x;
+}
+
+extern __shared__ __attribute__((aligned(16))) float2 lds_conv[];
+
+// mode 0: full (writes the gradient image G[nb][C][H][W] and the loss partial)
+// mode 1: forward only (writes the rendered cube instead and the loss partial)
+template <int FY1, int FX1>
+__global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const float2 *Kt,
+                                                              int k_bands, int k_per_blend,
+                                                              float *out, int mode) {
+    using C = Cfg<FY1, FX1>;
+    // XCD-aware placement: consecutive logical ids (the bands of one blend) share an
+    // XCD and therefore its L2 (morphologies, data of neighbouring bands)
+    const int total = gridDim.x;
+    int lid = blockIdx.x;
+    if (total % 8 == 0) lid = (blockIdx.x % 8) * (total / 8) + blockIdx.x / 8;
+    const int b = lid / v.C, c = lid - b * v.C;
+    if (v.state[b] >= 2) return;
+    const int tid = threadIdx.x;
+    const int H = v.H, W = v.W;
+
+    Conv<FY1, FX1> cv;
+    cv.T = lds_conv;
+    cv.Z = cv.T + C::NKX * C::SY;
+    cv.twy = cv.Z + kPairs * C::SX;
+    cv.twx = cv.twy + C::FY;
+    cv.tid = tid;
+    for (int j = tid; j < C::FY; j += kThreads) {
+        float s, co;
+        sincospif(2.0f * (float)j / (float)C::FY, &s, &co);
+        cv.twy[j] = make_float2(co, -s);
+    }
+    for (int j = tid; j < C::FX; j += kThreads) {
+        float s, co;
+        sincospif(2.0f * (float)j / (float)C::FX, &s, &co);
+        cv.twx[j] = make_float2(co, -s);
+    }
+    const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
+                               C::FY * C::NKX;
+    const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
+    const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
+    __syncthreads();
+
+    // ---- A: render (blend.py:200-244) and forward row transforms ----------------
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int y0 = ch * 2 * kPairs;
+        for (int i = tid; i < 2 * kPairs * C::FX; i += kThreads) {
+            const int r = i / C::FX, x = i - r * C::FX;
+            const int y = y0 + r;
+            float acc = 0.f;
+            if (x < W && y < H) {
+                for (int k = cs; k < ce; ++k) {
+                    const int yy = y - v.c_oy[k], xx = x - v.c_ox[k];
+                    const int w = v.c_w[k];
+                    if ((unsigned)yy < (unsigned)v.c_h[k] && (unsigned)xx < (unsigned)w)
+                        acc = fmaf(v.sed[(int64_t)k * v.C + c],
+                                   v.morph[v.c_moff[k] + (int64_t)yy * w + xx], acc);
+                }
+            }
+            zref(cv.Z, C::SX, r, x) = acc;
+        }
+        __syncthreads();
+        cv.rows_forward(y0, W);
+    }
+    // ---- B: columns, x K^ --------------------------------------------------------
+    cv.columns(K, H, false);
+    // ---- C: rendered rows -> residual, loss, forward rows of the residual ------------
+    double loss = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int y0 = ch * 2 * kPairs;
+        cv.rows_inverse(y0);
+        for (int i = tid; i < 2 * kPairs * C::FX; i += kThreads) {
+            const int r = i / C::FX, x = i - r * C::FX;
+            const int y = y0 + r;
+            float &slot = zref(cv.Z, C::SX, r, x);
+            float res = 0.f;
+            if (x < W && y < H) {
+                const int64_t iD = (((int64_t)b * v.C + c) * H + y) * W + x;
+                const float m = slot;
+                if (mode == 1) out[iD] = m;
+                const float diff = m - v.data[iD];
+                res = v.weights[iD] * diff;
+                loss += (double)(res * diff);
+            }
+            slot = res;
+        }
+        __syncthreads();
+        cv.rows_forward(y0, W);
+    }
+    {
+        double *part = reinterpret_cast<double *>(cv.Z);  // Z is free between stages
+        const double t = block_sum(loss, part);
+        if (tid == 0) v.loss_partial[(int64_t)b * v.n_partial + c] = t;
+        __syncthreads();
+    }
+    if (mode == 1) return;
+    // ---- B': columns, x conj(K^) ---------------------------------------------------
+    cv.columns(K, H, true);
+    // ---- D: gradient image rows -----------------------------------------------------
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int y0 = ch * 2 * kPairs;
+        cv.rows_inverse(y0);
+        for (int i = tid; i < 2 * kPairs * W; i += kThreads) {
+            const int r = i / W, x = i - r * W;
+            const int y = y0 + r;
+            if (y < H) out[(((int64_t)b * v.C + c) * H + y) * W + x] = zref(cv.Z, C::SX, r, x);
+        }
+        __syncthreads();
+    }
+}
+
+// natural-order spectrum (rocFFT, [img][ky][kx]) -> [img][pos_y(ky)][kx], scaled
+template <int FY1>
+__global__ void permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int NKX, float scale) {
+    constexpr int FY = FY1 * kF2;
+    const int img = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= FY * NKX) return;
+    const int ky = i / NKX, kx = i - ky * NKX;
+    const float2 k = Khat[(int64_t)img * FY * NKX + i];
+    Kt[((int64_t)img * FY + pos<FY1>(ky)) * NKX + kx] = make_float2(k.x * scale, k.y * scale);
+}
+
+template <int FY1, int FX1>
+int launch_impl(const BatchView &v, const float2 *Kt, int k_bands, int k_per_blend, float *out,
+                int mode, hipStream_t s) {
+    using C = Cfg<FY1, FX1>;
+    auto kern = fused_conv_kernel<FY1, FX1>;
+    static bool configured = false;
+    if (!configured) {
+        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)C::lds_bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(v.nb * v.C), dim3(kThreads), C::lds_bytes, s, v, Kt, k_bands,
+                       k_per_blend, out, mode);
+    return SMI_OK;
+}
+
+}  // namespace
+
+// supported (FY, FX): multiples of 16 with first radix in {4,5,6,8,10}; LDS must fit
+bool fused_conv_supported(int Fy, int Fx) {
+    auto ok = [](int f) { return f == 64 || f == 80 || f == 96 || f == 128 || f == 160; };
+    if (!ok(Fy) || !ok(Fx)) return false;
+    const size_t lds = sizeof(float2) * ((size_t)(Fx / 2 + 1) * (Fy + 1) +
+                                         (size_t)kPairs * (Fx + 1) + Fy + Fx);
+    return lds <= 160 * 1024;
+}
+
+// smallest supported length >= n, or 0
+int fused_conv_length(int n) {
+    for (int f : {64, 80, 96, 128, 160})
+        if (f >= n) return f;
+    return 0;
+}
+
+#define SMI_FUSED_DISPATCH(FN, ...)                                             \
+    switch (Fy / 16 * 100 + Fx / 16) {                                          \
+        case 404: return FN<4, 4>(__VA_ARGS__);                                 \
+        case 405: return FN<4, 5>(__VA_ARGS__);                                 \
+        case 505: return FN<5, 5>(__VA_ARGS__);                                 \
+        case 504: return FN<5, 4>(__VA_ARGS__);                                 \
+        case 506: return FN<5, 6>(__VA_ARGS__);                                 \
+        case 605: return FN<6, 5>(__VA_ARGS__);                                 \
+        case 606: return FN<6, 6>(__VA_ARGS__);                                 \
+        case 808: return FN<8, 8>(__VA_ARGS__);                                 \
+        case 810: return FN<8, 10>(__VA_ARGS__);                                \
+        case 1008: return FN<10, 8>(__VA_ARGS__);                               \
+        case 1010: return FN<10, 10>(__VA_ARGS__);                              \
+        default: break;                                                         \
+    }
+
+bool fused_conv_instantiated(int Fy, int Fx) {
+    switch (Fy / 16 * 100 + Fx / 16) {
+        case 404: case 405: case 505: case 504: case 506: case 605: case 606:
+        case 808: case 810: case 1008: case 1010:
+            return fused_conv_supported(Fy, Fx);
+        default:
+            return false;
+    }
+}
+
+int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float2 *Kt, int k_bands,
+                      int k_per_blend, float *out, int mode, hipStream_t s) {
+    SMI_FUSED_DISPATCH(launch_impl, v, Kt, k_bands, k_per_blend, out, mode, s)
+    set_error("fused convolution: FFT shape not instantiated");
+    return SMI_ERR_INVALID;
+}
+
+int launch_permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int n_img, int Fy, int Fx,
+                                   float scale, hipStream_t s) {
+    const int NKX = Fx / 2 + 1;
+    const dim3 grid((Fy * NKX + 255) / 256, n_img);
+    switch (Fy / 16) {
+        case 4: hipLaunchKernelGGL(permute_kernel_spectrum<4>, grid, dim3(256), 0, s, Khat, Kt, NKX, scale); break;
+        case 5: hipLaunchKernelGGL(permute_kernel_spectrum<5>, grid, dim3(256), 0, s, Khat, Kt, NKX, scale); break;
+        case 6: hipLaunchKernelGGL(permute_kernel_spectrum<6>, grid, dim3(256), 0, s, Khat, Kt, NKX, scale); break;
+        case 8: hipLaunchKernelGGL(permute_kernel_spectrum<8>, grid, dim3(256), 0, s, Khat, Kt, NKX, scale); break;
+        case 10: hipLaunchKernelGGL(permute_kernel_spectrum<10>, grid, dim3(256), 0, s, Khat, Kt, NKX, scale); break;
+        default:
+            set_error("permute_kernel_spectrum: unsupported FFT height");
+            return SMI_ERR_INVALID;
+    }
+    return SMI_OK;
+}
+
+}  // namespace smi

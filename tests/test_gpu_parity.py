@@ -120,6 +120,9 @@ def test_apply_filter_bit_exact(amd, dtype):
 
 
 # ---------------------------------------------------------------- seam 2
+PATHS = ["rocfft", "fused"]
+
+
 def hsc_batch(amd, g, **kw):
     n = int(g["n_comp"])
     comps = [
@@ -131,9 +134,12 @@ def hsc_batch(amd, g, **kw):
                           kernel=g["diff_kernel"], **kw)
 
 
-def test_hsc_forward_vs_golden_and_oracle(amd, hsc):
-    batch = hsc_batch(amd, hsc)
-    assert batch.fft_shape == (108, 96)  # fft.py:116-167 on (58,48)+(43,43)+3
+@pytest.mark.parametrize("path", PATHS)
+def test_hsc_forward_vs_golden_and_oracle(amd, hsc, path):
+    batch = hsc_batch(amd, hsc, conv_path=path)
+    # rocFFT path: the reference's shape (fft.py:116-167 on (58,48)+(43,43)+3);
+    # fused path: the smallest alias-free supported shape >= N + P//2
+    assert batch.fft_shape == ((108, 96) if path == "rocfft" else (80, 80))
     model, rendered, logL = batch.forward()
     assert rel_err(model[0], hsc["model"]) < RTOL
     assert rel_err(rendered[0], hsc["rendered"]) < RTOL
@@ -160,8 +166,9 @@ def grad_scales(sc):
     return out
 
 
-def test_hsc_gradient_vs_oracle(amd, hsc):
-    batch = hsc_batch(amd, hsc)
+@pytest.mark.parametrize("path", PATHS)
+def test_hsc_gradient_vs_oracle(amd, hsc, path):
+    batch = hsc_batch(amd, hsc, conv_path=path)
     g_sed, g_morph = batch.gradient()
     sc = hsc_scene(hsc)
     _, grads = sc.loss_and_gradients()
@@ -170,9 +177,10 @@ def test_hsc_gradient_vs_oracle(amd, hsc):
         assert np.abs(g_morph[k] - gm).max() < RTOL * s_morph, k
 
 
-def test_hsc_steps_vs_oracle(amd, hsc):
+@pytest.mark.parametrize("path", PATHS)
+def test_hsc_steps_vs_oracle(amd, hsc, path):
     n_it = 5
-    batch = hsc_batch(amd, hsc, max_iter=16)
+    batch = hsc_batch(amd, hsc, max_iter=16, conv_path=path)
     batch.step(0, n_it, e_rel=1e-3)
     sed, morphs = batch.parameters()
     mom = batch.moments()
@@ -188,9 +196,10 @@ def test_hsc_steps_vs_oracle(amd, hsc):
         assert rel_err(mom["v_morph"][k], c.v_morph) < 1e-3
 
 
-def test_first_step_exact_structure(amd, hsc):
+@pytest.mark.parametrize("path", PATHS)
+def test_first_step_exact_structure(amd, hsc, path):
     """one iteration from identical state: every parameter within 1e-5"""
-    batch = hsc_batch(amd, hsc, max_iter=4)
+    batch = hsc_batch(amd, hsc, max_iter=4, conv_path=path)
     batch.step(0, 1, e_rel=1e-3)
     sed, morphs = batch.parameters()
     sc = hsc_scene(hsc)
@@ -201,8 +210,9 @@ def test_first_step_exact_structure(amd, hsc):
         assert morphs[k].max() == 1.0 and morphs[k].min() >= 0.0
 
 
-def test_hsc_fit_converges_like_oracle(amd, hsc):
-    batch = hsc_batch(amd, hsc, max_iter=100)
+@pytest.mark.parametrize("path", PATHS)
+def test_hsc_fit_converges_like_oracle(amd, hsc, path):
+    batch = hsc_batch(amd, hsc, max_iter=100, conv_path=path)
     n_iter, logL = batch.fit(max_iter=100, e_rel=1e-4)
     sc = hsc_scene(hsc)
     n_ref, logL_ref = sc.fit(max_iter=100, e_rel=1e-4)
@@ -215,7 +225,8 @@ def test_hsc_fit_converges_like_oracle(amd, hsc):
     assert -loss[-1] > -loss[0]
 
 
-def test_synthetic_batch_vs_oracle(amd):
+@pytest.mark.parametrize("path", PATHS)
+def test_synthetic_batch_vs_oracle(amd, path):
     from oracle import pgm
     from scarlet_amd import synthetic
 
@@ -228,8 +239,8 @@ def test_synthetic_batch_vs_oracle(amd):
     ]
     data = np.stack([s["data"] for s in scenes])
     weights = np.stack([s["weights"] for s in scenes])
-    batch = amd.BlendBatch(data, weights, comps, kernel=kern[2], max_iter=8)
-    assert batch.fft_shape == (180, 180)
+    batch = amd.BlendBatch(data, weights, comps, kernel=kern[2], max_iter=8, conv_path=path)
+    assert batch.fft_shape == ((180, 180) if path == "rocfft" else (160, 160))
     g = golden("synthetic_cfg2")
     model, rendered, logL = batch.forward()
     assert rel_err(model[0], g["model"]) < RTOL
@@ -273,7 +284,8 @@ def test_null_renderer_vs_oracle(amd):
     assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm)
 
 
-def test_per_band_kernel_and_ragged_boxes(amd):
+@pytest.mark.parametrize("path", PATHS)
+def test_per_band_kernel_and_ragged_boxes(amd, path):
     """cfg 4 shapes: (6,40,59) frame, (6,31,31) kernel, boxes overhanging the frame"""
     from oracle import pgm
 
@@ -290,8 +302,9 @@ def test_per_band_kernel_and_ragged_boxes(amd):
         ocomps.append(pgm.Component(sed.copy(), morph.copy(), (oy, ox), sed_min_step=0.01))
     w = np.full(g["images"].shape, 0.25, dtype=np.float32)
     w[:, :3, :] = 0  # masked rows: log_norm must skip them
-    batch = amd.BlendBatch(g["images"][None], w[None], [specs], kernel=g["diff_kernel"], max_iter=4)
-    assert batch.fft_shape == (75, 96)
+    batch = amd.BlendBatch(g["images"][None], w[None], [specs], kernel=g["diff_kernel"], max_iter=4,
+                           conv_path=path)
+    assert batch.fft_shape == ((75, 96) if path == "rocfft" else (64, 80))
     sc = pgm.Scene(g["images"].shape, g["images"], w, g["diff_kernel"], ocomps)
     model, rendered, logL = batch.forward()
     ref_model = sc.get_model()
@@ -306,12 +319,14 @@ def test_per_band_kernel_and_ragged_boxes(amd):
     # reference render of a fixed cube with the per-band kernel (golden from the reference)
     spec = [amd.ComponentSpec(np.eye(C, dtype=np.float32)[c], g["model"][c], (0, 0),
                               prox_flags=0) for c in range(C)]
-    b2 = amd.BlendBatch(g["images"][None], w[None], [spec], kernel=g["diff_kernel"], max_iter=2)
+    b2 = amd.BlendBatch(g["images"][None], w[None], [spec], kernel=g["diff_kernel"], max_iter=2,
+                        conv_path=path)
     _, rendered, _ = b2.forward()
     assert np.abs(rendered[0] - g["rendered"]).max() < RTOL * np.abs(g["rendered"]).max()
 
 
-def test_convolution_properties_full_size(amd):
+@pytest.mark.parametrize("path", PATHS)
+def test_convolution_properties_full_size(amd, path):
     """size-independent properties at the benchmark shape (5x128x128, F=180x180):
     linearity, and <A x, y> = <x, A^T y> with the gradient path as A^T"""
     from scarlet_amd import synthetic
@@ -338,7 +353,7 @@ def test_convolution_properties_full_size(amd):
     def render(cube, data=None):
         d = np.zeros((1, C, H, W), np.float32) if data is None else data[None]
         b = amd.BlendBatch(d, np.ones((1, C, H, W), np.float32), [specs(cube)], kernel=diff,
-                           max_iter=2)
+                           max_iter=2, conv_path=path)
         return b, b.forward()[1][0]
 
     _, ax = render(x)
