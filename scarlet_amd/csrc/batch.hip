@@ -77,6 +77,7 @@ struct smi_batch {
     int Fy = 0, Fx = 0, Fxh = 0;  // FFT shape
     int Py = 0, Px = 0;           // row/plane strides of the P / Q cubes
     float2 *Kt = nullptr;         // kernel spectrum in the fused kernel's order
+    long long *dbg = nullptr;     // optional stage time stamps of workgroup 0 (debug)
     // FFT work cubes
     float *P = nullptr, *Q = nullptr;
     float2 *S = nullptr, *Khat = nullptr;
@@ -715,7 +716,7 @@ int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL)
     if (b->fused) {
         // mode 1: rendered cube to Q (compact) and the loss partials
         if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
-                                    b->d.kernel_per_blend, b->Q, 1, b->stream)))
+                                    b->d.kernel_per_blend, b->Q, 1, nullptr, b->stream)))
             return rc;
     } else if ((rc = convolve(b, v, 0))) {
         return rc;
@@ -750,7 +751,7 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     const BatchView v = unmasked_view(b);
     if (b->fused) {
         if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
-                                    b->d.kernel_per_blend, b->Q, 0, b->stream)))
+                                    b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
             return rc;
     } else {
         launch_render(v, b->P, b->stream);
@@ -794,7 +795,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
             // render + conv + residual/loss + conv^T in one LDS-resident kernel
             if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
             if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
-                                        b->d.kernel_per_blend, b->Q, 0, b->stream)))
+                                        b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
                 return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
             launch_finalize(v, it, e_rel, min_iter, check, b->stream);
@@ -917,6 +918,22 @@ int smi_batch_enable_timing(smi_batch *b, int32_t on) {
 int smi_batch_get_timing(smi_batch *b, double *ms_per_phase, int32_t n_phases) {
     SMI_REQUIRE(b && ms_per_phase, "null argument");
     for (int p = 0; p < n_phases && p < 6; ++p) ms_per_phase[p] = b->phase_ms[p];
+    return SMI_OK;
+}
+
+// development aid (not in the public header): shader-clock stamps of the fused
+// kernel's stages in workgroup 0 of the last launch
+int smi_debug_fused_stamps(smi_batch *b, long long *out6) {
+    SMI_REQUIRE(b && out6, "null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    if (!b->dbg) {
+        SMI_HIP(dev_alloc(&b->dbg, 8));
+        SMI_HIP(hipMemset(b->dbg, 0, 8 * sizeof(long long)));
+        std::memset(out6, 0, 6 * sizeof(long long));
+        return SMI_OK;
+    }
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipMemcpy(out6, b->dbg, 6 * sizeof(long long), hipMemcpyDeviceToHost));
     return SMI_OK;
 }
 

@@ -100,34 +100,53 @@ struct Conv {
     // column transforms fused with the spectral product:
     //   T <- IFFT_y( FFT_y(T) * K )   for every column kx, K in digit-swapped order
     __device__ __forceinline__ void columns(const float2 *Kt, int H, bool conj) {
-        for (int b = tid; b < C::NKX * kF2; b += kThreads) {
-            const int kx = b % C::NKX, n2 = b / C::NKX;
+        // items (kx, n2) resp. (kx, k1), kx fastest: flat index tid + i * kThreads,
+        // advanced without divisions
+        constexpr int dq = kThreads / C::NKX, dr = kThreads % C::NKX;
+        const int kx0 = tid % C::NKX, q0 = tid / C::NKX;
+        for (int kx = kx0, n2 = q0; n2 < kF2;) {
             pass_stride<FY1, false>(T + kx * C::SY, n2, twy, H);
+            kx += dr;
+            n2 += dq;
+            if (kx >= C::NKX) {
+                kx -= C::NKX;
+                ++n2;
+            }
         }
         __syncthreads();
-        for (int b = tid; b < C::NKX * FY1; b += kThreads) {
-            const int kx = b % C::NKX, k1 = b / C::NKX;
+        for (int kx = kx0, k1 = q0; k1 < FY1;) {
             float2 *a = T + kx * C::SY + kF2 * k1;
-            float2 v[kF2];
+            const float2 *kp = Kt + (int64_t)(kF2 * k1) * C::NKX + kx;
+            float2 v[kF2], kv[kF2];
+#pragma unroll
+            for (int j = 0; j < kF2; ++j) kv[j] = kp[j * C::NKX];
 #pragma unroll
             for (int j = 0; j < kF2; ++j) v[j] = a[j];
             fftk::Dft<kF2, false>::run(v);
 #pragma unroll
-            for (int j = 0; j < kF2; ++j) {
-                const float2 kv = Kt[(int64_t)(kF2 * k1 + j) * C::NKX + kx];
-                v[j] = conj ? cmulc(v[j], kv) : cmul(v[j], kv);
-            }
+            for (int j = 0; j < kF2; ++j) v[j] = conj ? cmulc(v[j], kv[j]) : cmul(v[j], kv[j]);
             fftk::Dft<kF2, true>::run(v);
 #pragma unroll
             for (int j = 0; j < kF2; ++j) {
                 if (j > 0) v[j] = cmulc(v[j], twy[j * k1]);
                 a[j] = v[j];
             }
+            kx += dr;
+            k1 += dq;
+            if (kx >= C::NKX) {
+                kx -= C::NKX;
+                ++k1;
+            }
         }
         __syncthreads();
-        for (int b = tid; b < C::NKX * kF2; b += kThreads) {
-            const int kx = b % C::NKX, n2 = b / C::NKX;
+        for (int kx = kx0, n2 = q0; n2 < kF2;) {
             pass_stride<FY1, true>(T + kx * C::SY, n2, twy, C::FY);
+            kx += dr;
+            n2 += dq;
+            if (kx >= C::NKX) {
+                kx -= C::NKX;
+                ++n2;
+            }
         }
         __syncthreads();
     }
@@ -196,7 +215,8 @@ extern __shared__ __attribute__((aligned(16))) float2 lds_conv[];
 template <int FY1, int FX1>
 __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const float2 *Kt,
                                                               int k_bands, int k_per_blend,
-                                                              float *out, int mode) {
+                                                              float *out, int mode,
+                                                              long long *dbg) {
     using C = Cfg<FY1, FX1>;
     // XCD-aware placement: consecutive logical ids (the bands of one blend) share an
     // XCD and therefore its L2 (morphologies, data of neighbouring bands)
@@ -206,6 +226,9 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     const int b = lid / v.C, c = lid - b * v.C;
     if (v.state[b] >= 2) return;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kXIter = (C::FX + 63) / 64;
     const int H = v.H, W = v.W;
 
     Conv<FY1, FX1> cv;
@@ -229,49 +252,95 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
     const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
     __syncthreads();
+#define SMI_STAMP(i) if (dbg && tid == 0 && blockIdx.x == 0) dbg[i] = clock64()
+    SMI_STAMP(0);
 
     // ---- A: render (blend.py:200-244) and forward row transforms ----------------
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int y0 = ch * 2 * kPairs;
-        for (int i = tid; i < 2 * kPairs * C::FX; i += kThreads) {
-            const int r = i / C::FX, x = i - r * C::FX;
-            const int y = y0 + r;
-            float acc = 0.f;
-            if (x < W && y < H) {
-                for (int k = cs; k < ce; ++k) {
-                    const int yy = y - v.c_oy[k], xx = x - v.c_ox[k];
-                    const int w = v.c_w[k];
-                    if ((unsigned)yy < (unsigned)v.c_h[k] && (unsigned)xx < (unsigned)w)
-                        acc = fmaf(v.sed[(int64_t)k * v.C + c],
-                                   v.morph[v.c_moff[k] + (int64_t)yy * w + xx], acc);
+        // component-major scatter-add into the (zeroed) chunk: each box row is a
+        // contiguous run in memory, so the morphology loads are coalesced, and every
+        // pixel still accumulates its components in ascending order
+        for (int i = tid; i < kPairs * C::SX; i += kThreads) cv.Z[i] = make_float2(0.f, 0.f);
+        __syncthreads();
+        for (int k = cs; k < ce; ++k) {
+            const int oy = v.c_oy[k], ox = v.c_ox[k], w = v.c_w[k];
+            const int r_lo = max(y0, oy), r_hi = min(min(y0 + 2 * kPairs, H), oy + v.c_h[k]);
+            const int x_lo = max(0, ox), x_hi = min(W, ox + w);
+            const int ncols = x_hi - x_lo, npx = (r_hi - r_lo) * ncols;
+            if (r_hi <= r_lo || ncols <= 0) continue;  // wave-uniform
+            const float sed = v.sed[(int64_t)k * v.C + c];
+            const float *mbase = v.morph + v.c_moff[k];
+            for (int p0 = tid; p0 < npx; p0 += 4 * kThreads) {
+                float mv[4];
+                int rr[4], xx[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + u * kThreads;
+                    const int ry = p / ncols;
+                    rr[u] = r_lo + ry;
+                    xx[u] = x_lo + (p - ry * ncols);
+                    mv[u] = p < npx ? mbase[(int64_t)(rr[u] - oy) * w + (xx[u] - ox)] : 0.f;
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p0 + u * kThreads < npx) {
+                        float &slot = zref(cv.Z, C::SX, rr[u] - y0, xx[u]);
+                        slot = fmaf(sed, mv[u], slot);
+                    }
             }
-            zref(cv.Z, C::SX, r, x) = acc;
+            __syncthreads();
         }
         __syncthreads();
         cv.rows_forward(y0, W);
     }
+    SMI_STAMP(1);
     // ---- B: columns, x K^ --------------------------------------------------------
     cv.columns(K, H, false);
+    SMI_STAMP(2);
     // ---- C: rendered rows -> residual, loss, forward rows of the residual ------------
     double loss = 0.0;
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int y0 = ch * 2 * kPairs;
-        cv.rows_inverse(y0);
-        for (int i = tid; i < 2 * kPairs * C::FX; i += kThreads) {
-            const int r = i / C::FX, x = i - r * C::FX;
-            const int y = y0 + r;
-            float &slot = zref(cv.Z, C::SX, r, x);
-            float res = 0.f;
-            if (x < W && y < H) {
-                const int64_t iD = (((int64_t)b * v.C + c) * H + y) * W + x;
-                const float m = slot;
-                if (mode == 1) out[iD] = m;
-                const float diff = m - v.data[iD];
-                res = v.weights[iD] * diff;
-                loss += (double)(res * diff);
+        // data / weights of the chunk are fetched before the inverse row transforms so
+        // that their HBM latency hides behind them
+        constexpr int kRows = 2 * kPairs / (kThreads / 64);
+        float dpre[kRows][kXIter], wpre[kRows][kXIter];
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int y = y0 + wave + j * (kThreads / 64);
+#pragma unroll
+            for (int q = 0; q < kXIter; ++q) {
+                const int x = lane + 64 * q;
+                dpre[j][q] = 0.f;
+                wpre[j][q] = 0.f;
+                if (x < W && y < H) {
+                    const int64_t iD = (((int64_t)b * v.C + c) * H + y) * W + x;
+                    dpre[j][q] = v.data[iD];
+                    wpre[j][q] = v.weights[iD];
+                }
             }
-            slot = res;
+        }
+        cv.rows_inverse(y0);
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int r = wave + j * (kThreads / 64);
+            const int y = y0 + r;
+#pragma unroll
+            for (int q = 0; q < kXIter; ++q) {
+                const int x = lane + 64 * q;
+                if (x >= C::FX) continue;
+                float &slot = zref(cv.Z, C::SX, r, x);
+                float res = 0.f;
+                if (x < W && y < H) {
+                    const float m = slot;
+                    if (mode == 1) out[(((int64_t)b * v.C + c) * H + y) * W + x] = m;
+                    const float diff = m - dpre[j][q];
+                    res = wpre[j][q] * diff;
+                    loss += (double)(res * diff);
+                }
+                slot = res;
+            }
         }
         __syncthreads();
         cv.rows_forward(y0, W);
@@ -282,20 +351,28 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         if (tid == 0) v.loss_partial[(int64_t)b * v.n_partial + c] = t;
         __syncthreads();
     }
+    SMI_STAMP(3);
     if (mode == 1) return;
     // ---- B': columns, x conj(K^) ---------------------------------------------------
     cv.columns(K, H, true);
+    SMI_STAMP(4);
     // ---- D: gradient image rows -----------------------------------------------------
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int y0 = ch * 2 * kPairs;
         cv.rows_inverse(y0);
-        for (int i = tid; i < 2 * kPairs * W; i += kThreads) {
-            const int r = i / W, x = i - r * W;
+        for (int r = wave; r < 2 * kPairs; r += kThreads / 64) {
             const int y = y0 + r;
-            if (y < H) out[(((int64_t)b * v.C + c) * H + y) * W + x] = zref(cv.Z, C::SX, r, x);
+            if (y >= H) break;
+#pragma unroll
+            for (int q = 0; q < kXIter; ++q) {
+                const int x = lane + 64 * q;
+                if (x < W) out[(((int64_t)b * v.C + c) * H + y) * W + x] = zref(cv.Z, C::SX, r, x);
+            }
         }
         __syncthreads();
     }
+    SMI_STAMP(5);
+#undef SMI_STAMP
 }
 
 // natural-order spectrum (rocFFT, [img][ky][kx]) -> [img][pos_y(ky)][kx], scaled
@@ -312,7 +389,7 @@ __global__ void permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int NKX,
 
 template <int FY1, int FX1>
 int launch_impl(const BatchView &v, const float2 *Kt, int k_bands, int k_per_blend, float *out,
-                int mode, hipStream_t s) {
+                int mode, long long *dbg, hipStream_t s) {
     using C = Cfg<FY1, FX1>;
     auto kern = fused_conv_kernel<FY1, FX1>;
     static bool configured = false;
@@ -323,7 +400,7 @@ int launch_impl(const BatchView &v, const float2 *Kt, int k_bands, int k_per_ble
         configured = true;
     }
     hipLaunchKernelGGL(kern, dim3(v.nb * v.C), dim3(kThreads), C::lds_bytes, s, v, Kt, k_bands,
-                       k_per_blend, out, mode);
+                       k_per_blend, out, mode, dbg);
     return SMI_OK;
 }
 
@@ -372,8 +449,8 @@ bool fused_conv_instantiated(int Fy, int Fx) {
 }
 
 int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float2 *Kt, int k_bands,
-                      int k_per_blend, float *out, int mode, hipStream_t s) {
-    SMI_FUSED_DISPATCH(launch_impl, v, Kt, k_bands, k_per_blend, out, mode, s)
+                      int k_per_blend, float *out, int mode, long long *dbg, hipStream_t s) {
+    SMI_FUSED_DISPATCH(launch_impl, v, Kt, k_bands, k_per_blend, out, mode, dbg, s)
     set_error("fused convolution: FFT shape not instantiated");
     return SMI_ERR_INVALID;
 }
