@@ -25,6 +25,19 @@ from .parameter import Parameter, relative_step  # noqa: F401
 from .prior import Prior  # noqa: F401
 from .psf import PSF, ImagePSF, FunctionPSF, GaussianPSF, MoffatPSF  # noqa: F401
 from .batch import BlendBatch, ComponentSpec  # noqa: F401
+from .frame import Frame  # noqa: F401
+from .observation import Observation  # noqa: F401
+from .renderer import Renderer, NullRenderer, ConvolutionRenderer  # noqa: F401
+from .spectrum import Spectrum, TabulatedSpectrum  # noqa: F401
+from .morphology import Morphology, ImageMorphology, ExtendedSourceMorphology  # noqa: F401
+from .component import (  # noqa: F401
+    Component,
+    FactorizedComponent,
+    CubeComponent,
+    CombinedComponent,
+)
+from .blend import Blend  # noqa: F401
+from .model import Model, UpdateException  # noqa: F401
 from . import fft, operator, synthetic  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,248 @@
+"""``Blend``: the scene and its fit (reference scarlet/blend.py:49-308).
+
+``fit`` keeps the reference's signature, return value and side effects (parameter
+values updated in place, ``m / v / vhat / std`` on every ``Parameter``,
+``blend.loss``), but the whole proximal-gradient loop -- what the reference
+delegates to ``proxmin.adaprox`` with autograd gradients (blend.py:165-180) --
+runs on the GPU through ``libscarlet_amd.so``.  The host only steps in every 10
+iterations for the box-resizing hook (``src.update()``, blend.py:284-292).
+"""
+
+import logging
+from functools import partial
+
+import numpy as np
+import numpy.ma as ma
+
+from . import _lib
+from .batch import BlendBatch, ComponentSpec
+from .bbox import overlapped_slices
+from .component import CombinedComponent, FactorizedComponent
+from .constraint import PositivityConstraint, device_flags
+from .model import UpdateException
+from .parameter import relative_step
+from .renderer import ConvolutionRenderer, NullRenderer
+
+logger = logging.getLogger("scarlet_amd.blend")
+
+
+def _flatten(sources):
+    """FactorizedComponents of the scene in parameter order."""
+    out = []
+    for src in sources:
+        if isinstance(src, FactorizedComponent):
+            out.append(src)
+        elif isinstance(src, CombinedComponent):
+            if src.operation != "add":
+                raise NotImplementedError("CombinedComponent('multiply') is not supported")
+            out.extend(_flatten(src.children))
+        else:
+            raise NotImplementedError(
+                "{} cannot be fitted on the device (only factorized components)".format(
+                    type(src).__name__
+                )
+            )
+    return out
+
+
+def _step_rule(step, what):
+    """(constant, relative factor, minimum) of a Parameter.step."""
+    if isinstance(step, partial) and step.func is relative_step:
+        kw = step.keywords
+        if kw.get("axis") is not None or step.args:
+            raise NotImplementedError("relative_step along an axis is not supported")
+        return 0.0, float(kw.get("factor", 0.1)), kw.get("minimum", 0)
+    if step is relative_step:
+        return 0.0, 0.1, 0
+    if callable(step):
+        raise NotImplementedError("custom step callables for {} cannot run on the device".format(what))
+    return float(step), 0.0, 0
+
+
+class Blend(CombinedComponent):
+    """Collection of sources fitted jointly to one observation."""
+
+    def __init__(self, sources, observations):
+        self.sources = sources if hasattr(sources, "__iter__") else (sources,)
+        self.observations = observations if hasattr(observations, "__iter__") else (observations,)
+        super().__init__(self.sources)
+        self.loss = []
+
+    # ------------------------------------------------------------------ device
+    def _observation(self):
+        if len(self.observations) != 1:
+            raise NotImplementedError("fitting several observations at once is not supported yet")
+        obs = self.observations[0]
+        r = obs.renderer
+        if type(r) not in (NullRenderer, ConvolutionRenderer):
+            raise NotImplementedError(
+                "renderer {} cannot run on the device".format(type(r).__name__)
+            )
+        if r.channel_map is not None or tuple(obs.shape) != tuple(self.frame.shape):
+            raise NotImplementedError(
+                "observations must cover the model frame with identical channels"
+            )
+        if obs.parameters:
+            raise NotImplementedError("parameterised renderers are not supported")
+        return obs
+
+    def _specs(self, comps):
+        specs = []
+        for comp in comps:
+            spectrum, morphology = comp.children
+            sed = spectrum.parameters[0]
+            image = morphology.parameters[0]
+            if getattr(morphology, "shifting", False):
+                raise NotImplementedError("shifting morphologies are not supported yet")
+            if sed.prior is not None or image.prior is not None:
+                raise NotImplementedError("priors are not supported on the device")
+            if sed.fixed or image.fixed:
+                raise NotImplementedError("fixed parameters are not supported on the device")
+            s_const, s_rel, s_min = _step_rule(sed.step, "spectrum")
+            if not (isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20):
+                raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
+            m_const, m_rel, m_min = _step_rule(image.step, "morphology")
+            flags = device_flags(image.constraint)
+            if flags["zero"] != 0:
+                raise NotImplementedError("PositivityConstraint(zero != 0) on a morphology")
+            specs.append(
+                ComponentSpec(
+                    np.asarray(sed), np.asarray(image), morphology.bbox.origin[-2:],
+                    sed_min_step=np.maximum(np.asarray(s_min, dtype=np.float64), s_const),
+                    sed_rel_step=s_rel,
+                    morph_step=max(m_const, float(np.max(m_min))),
+                    morph_rel_step=m_rel,
+                    prox_flags=flags["flags"],
+                    neighbor_weight=flags["neighbor_weight"] or "angle",
+                    min_gradient=flags["min_gradient"],
+                    l_thresh=flags["l_thresh"],
+                )
+            )
+        return specs
+
+    def _build_batch(self, comps, capacity):
+        obs = self._observation()
+        kernel = None
+        if isinstance(obs.renderer, ConvolutionRenderer):
+            kernel = np.ascontiguousarray(obs.renderer.diff_kernel.image, dtype=np.float32)
+        batch = BlendBatch(
+            np.asarray(obs.data, dtype=np.float32)[None],
+            np.asarray(obs.weights, dtype=np.float32)[None],
+            [self._specs(comps)], kernel=kernel, max_iter=max(capacity, 1),
+        )
+        params = [(c.children[0].parameters[0], c.children[1].parameters[0]) for c in comps]
+        if all(p.m is not None and p.v is not None and p.vhat is not None
+               for pair in params for p in pair):
+            batch.set_moments(
+                m_sed=np.stack([s.m for s, _ in params]),
+                v_sed=np.stack([s.v for s, _ in params]),
+                vhat_sed=np.stack([s.vhat for s, _ in params]),
+                m_morph=[i.m for _, i in params],
+                v_morph=[i.v for _, i in params],
+                vhat_morph=[i.vhat for _, i in params],
+            )
+        return batch
+
+    @staticmethod
+    def _download(batch, comps):
+        """Device -> the Parameters (values in place, moments as float64 arrays)."""
+        seds, morphs = batch.parameters()
+        mom = batch.moments()
+        for k, comp in enumerate(comps):
+            sed = comp.children[0].parameters[0]
+            image = comp.children[1].parameters[0]
+            sed[...] = seds[k]
+            image[...] = morphs[k]
+            sed.m, sed.v, sed.vhat = (mom[n][k].astype(np.float64) for n in ("m_sed", "v_sed", "vhat_sed"))
+            image.m, image.v, image.vhat = (
+                mom[n][k].astype(np.float64) for n in ("m_morph", "v_morph", "vhat_morph")
+            )
+
+    # --------------------------------------------------------------------- fit
+    def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, noise_factor=0, **alg_kwargs):
+        """Fit all sources to the observation.
+
+        Returns ``(number of loss evaluations, final logL)`` like the reference
+        (blend.py:194).  Iteration order: gradient at the current parameters
+        (loss appended), AMSGrad + proximal update of every parameter, every 10
+        iterations the resize hook, then the convergence test
+        ``it > min_iter and |dL| < e_rel |L|``."""
+        if noise_factor:
+            raise NotImplementedError("noise_factor > 0 is not supported")
+        scheme = alg_kwargs.pop("scheme", "amsgrad")
+        prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
+        if scheme != "amsgrad":
+            raise NotImplementedError("only scheme='amsgrad' runs on the device")
+        if alg_kwargs:
+            raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
+
+        it = 0
+        while it < max_iter:
+            comps = _flatten(self.sources)
+            batch = self._build_batch(comps, max_iter - it)
+            restart = False
+            try:
+                local = 0  # adaprox's own counter, restarts after every resize
+                while it + local < max_iter and not restart:
+                    # the resize hook fires after the update of local iterations 10, 20, ...
+                    # i.e. once 11, 21, ... iterations of this batch are done
+                    next_hook = 11 if local == 0 else ((local - 1) // 10 + 1) * 10 + 1
+                    n = min(next_hook - local, max_iter - it - local)
+                    batch.step(local, n, e_rel=e_rel, min_iter=min_iter,
+                               prox_max_iter=prox_max_iter, check_convergence=True)
+                    active, err = batch.status()
+                    done = len(batch.loss_history()[0])
+                    if err >= 0:
+                        self.loss.extend(batch.loss_history()[0])
+                        self._download(batch, comps)
+                        raise ArithmeticError("parameters of the blend are not finite")
+                    hook = done == local + n and done > 1 and (done - 1) % 10 == 0
+                    local = done
+                    if hook:
+                        self._download(batch, comps)
+                        for src in self.sources:
+                            try:
+                                src.update()
+                            except UpdateException:
+                                restart = True
+                    if active == 0 and not restart:
+                        break
+                self.loss.extend(batch.loss_history()[0])
+                if not restart:
+                    self._download(batch, comps)
+            finally:
+                batch.close()
+            if not restart:
+                break
+            it = len(self.loss)
+
+        logger.info("scarlet ran for {0} iterations to logL = {1}".format(
+            len(self.loss), -self.loss[-1]))
+        for p in self.parameters:
+            if p.v is not None:
+                p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))  # rough estimate, blend.py:189-192
+        return len(self.loss), -self.loss[-1]
+
+    # ------------------------------------------------------------------- model
+    def get_model(self, *parameters, frame=None):
+        """(C, H, W) model cube: every source's boxed model added into a zero cube
+        of the frame's dtype (host evaluation for inspection; blend.py:200-244)."""
+        models = self.get_models_of_children(*parameters, frame=None)
+        if frame is None:
+            frame = self.frame
+        full = np.zeros(frame.shape, dtype=frame.dtype)
+        for src, model in zip(self.sources, models):
+            if frame == self.frame:
+                fs, ms = src._model_frame_slices, src._model_slices
+            else:
+                fs, ms = overlapped_slices(frame.bbox, src.bbox)
+            full[fs] += model[ms]
+        return full
+
+    @property
+    def log_likelihood(self):
+        return -np.array(self.loss)
+
+    @property
+    def bbox(self):
+        return self.frame.bbox

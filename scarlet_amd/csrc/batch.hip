@@ -583,7 +583,6 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         prev = c->blend[k];
         start[c->blend[k] + 1]++;
         const int64_t np = (int64_t)c->box_h[k] * c->box_w[k];
-        SMI_REQUIRE(np * 16 + 2048 <= 160 * 1024, "component box too large (LDS-resident update)");
         moff[k + 1] = moff[k] + np;
         if (np > max_pix) max_pix = (int)np;
         if (c->prox_flags[k] & SMI_PROX_MONOTONIC) {

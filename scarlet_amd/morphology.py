@@ -1,0 +1,162 @@
+"""Image morphologies of factorized components (reference
+scarlet/morphology.py:26-207, 607-688).  Parametric profiles (Gaussian, Spergel,
+point source, starlet) are outside the scope of this package."""
+
+import numpy as np
+import numpy.ma as ma
+
+from .bbox import Box, overlapped_slices
+from .constraint import (
+    CenterOnConstraint,
+    ConstraintChain,
+    MonotonicityConstraint,
+    NormalizationConstraint,
+    PositivityConstraint,
+    SymmetryConstraint,
+)
+from .frame import Frame
+from .model import Model, UpdateException
+from .parameter import Parameter, relative_step
+
+
+def get_minimal_boxsize(size, min_size=21, increment=10):
+    """Smallest odd box size ``min_size + k * increment`` that holds ``size``
+    pixels (reference initialization.py:173-177)."""
+    boxsize = min_size
+    while boxsize < size:
+        boxsize += increment
+    return boxsize
+
+
+class Morphology(Model):
+    def __init__(self, frame, *parameters, bbox=None):
+        assert isinstance(frame, Frame)
+        self.frame = frame
+        if bbox is None:
+            bbox = frame.bbox
+        assert isinstance(bbox, Box)
+        self.bbox = bbox
+        super().__init__(*parameters)
+
+    def shrink_box(self, image, thresh=0):
+        """Peel off empty borders; adopt the next smaller standard box size."""
+        size = max(image.shape)
+        dist = 0
+        while (
+            np.all(image[dist, :] <= thresh)
+            and np.all(image[-dist - 1, :] <= thresh)
+            and np.all(image[:, dist] <= thresh)
+            and np.all(image[:, -dist - 1] <= thresh)
+        ):
+            dist += 1
+        newsize = get_minimal_boxsize(size - 2 * dist)
+        if newsize < size:
+            dist = (size - newsize) // 2
+            self.bbox.origin = tuple(o + dist for o in self.bbox.origin)
+            self.bbox.shape = (newsize, newsize)
+
+
+class ImageMorphology(Morphology):
+    """Free-form image morphology inside ``bbox``."""
+
+    def __init__(self, frame, image, bbox=None, shifting=False, shift=None, resizing=True):
+        if isinstance(image, Parameter):
+            assert image.name == "image"
+        else:
+            image = Parameter(image, name="image", step=relative_step,
+                              constraint=PositivityConstraint())
+        if bbox is None:
+            assert frame.bbox[1:].shape == image.shape
+            bbox = Box(image.shape)
+        else:
+            assert bbox.shape == image.shape
+        if shifting:
+            raise NotImplementedError("shifting=True (Fourier sub-pixel shifts) is not supported yet")
+        self.resizing = resizing
+        self.shifting = shifting
+        if shift is None:
+            # kept for parameter-order compatibility with the reference, which creates
+            # this unused 2-vector for every image morphology (morphology.py:113)
+            shift = Parameter(np.zeros(2), name="shift", step=1e-2, fixed=self.shifting)
+        else:
+            assert shift.shape == (2,)
+            if not isinstance(shift, Parameter):
+                shift = Parameter(shift, name="shift", step=1e-2)
+        super().__init__(frame, image, shift, bbox=bbox)
+
+    def get_model(self, *parameters):
+        return self.get_parameter(0, *parameters)
+
+    def update(self):
+        """Every 10 iterations: shrink the box when all edges are empty, grow it
+        when the next Adam step pulls flux over an edge; the optimizer state is
+        sliced / padded along and the step halved (reference morphology.py:132-207)."""
+        image = self._parameters[0]
+        if not self.resizing or image.fixed:
+            return
+        bbox = self.bbox.copy()
+        self.shrink_box(image)
+        if bbox != self.bbox:
+            sl, _ = overlapped_slices(bbox, self.bbox)
+
+            def cut(a):
+                return a[sl] if a is not None else None
+
+            image = Parameter(image[sl], name=image.name, prior=image.prior,
+                              constraint=image.constraint, step=image.step / 2,
+                              fixed=image.fixed, m=cut(image.m), v=cut(image.v),
+                              vhat=cut(image.vhat))
+            self._parameters = (image,) + self._parameters[1:]
+            raise UpdateException
+        if image.m is not None:
+            gu = -image.m / np.sqrt(np.sqrt(ma.masked_equal(image.v, 0))) * image.step
+            pull = gu * (image > 0)
+            edge_pull = np.array((pull[:, 0].mean(), pull[:, -1].mean(),
+                                  pull[0, :].mean(), pull[-1, :].mean()))
+            if np.any(edge_pull > 0.1):
+                size = max(bbox.shape)
+                newsize = get_minimal_boxsize(size + 1)
+                pad = (newsize - size) // 2
+
+                def grow(a):
+                    return np.pad(a, pad, mode="constant") if a is not None else None
+
+                image = Parameter(np.pad(image, pad, mode="linear_ramp"), name=image.name,
+                                  prior=image.prior, constraint=image.constraint,
+                                  step=image.step / 2, fixed=image.fixed, m=grow(image.m),
+                                  v=grow(image.v), vhat=grow(image.vhat))
+                self._parameters = (image,) + self._parameters[1:]
+                self.bbox.origin = tuple(o - pad for o in self.bbox.origin)
+                self.bbox.shape = (newsize, newsize)
+                raise UpdateException
+
+
+class ExtendedSourceMorphology(ImageMorphology):
+    """Image morphology for galaxies: monotonic from the centre (``monotonic`` in
+    'flat' / 'angle' / 'nearest' or None), optionally symmetric, positive, centre
+    pixel kept on, normalised to unit maximum; step 1e-2."""
+
+    def __init__(self, frame, center, image, bbox=None, monotonic="angle", symmetric=False,
+                 min_grad=0, shifting=False, resizing=True):
+        constraints = []
+        if monotonic is True:
+            monotonic = "angle"
+        elif monotonic is False:
+            monotonic = None
+        if monotonic is not None:
+            constraints.append(
+                MonotonicityConstraint(neighbor_weight=monotonic, min_gradient=min_grad)
+            )
+        if symmetric:
+            constraints.append(SymmetryConstraint())
+        constraints += [PositivityConstraint(), CenterOnConstraint(),
+                        NormalizationConstraint("max")]
+        image = Parameter(image, name="image", step=1e-2, constraint=ConstraintChain(*constraints))
+        self.pixel_center = np.round(center).astype("int")
+        self.shift = None
+        super().__init__(frame, image, bbox=bbox, shifting=shifting, shift=None,
+                         resizing=resizing)
+
+    @property
+    def center(self):
+        return self.pixel_center

@@ -1,0 +1,106 @@
+"""Observations: data, weights and the renderer that maps the model onto them
+(reference scarlet/observation.py)."""
+
+import numpy as np
+import numpy.ma as ma
+
+from . import _lib
+from .bbox import overlapped_slices
+from .frame import Frame
+from .renderer import ConvolutionRenderer, NullRenderer, Renderer
+
+
+def _device_render(renderer, model):
+    """``model`` (C, H, W) convolved with the renderer's difference kernel on
+    the GPU: the cube is presented to the batch as C unit-spectrum components."""
+    from .batch import BlendBatch, ComponentSpec
+
+    model_ = np.ascontiguousarray(renderer.map_channels(model), dtype=np.float32)
+    C, H, W = model_.shape
+    eye = np.eye(C, dtype=np.float32)
+    comps = [ComponentSpec(eye[c], model_[c], (0, 0), prox_flags=0) for c in range(C)]
+    zeros = np.zeros((1, C, H, W), dtype=np.float32)
+    kernel = np.ascontiguousarray(renderer.diff_kernel.image, dtype=np.float32)
+    batch = BlendBatch(zeros, zeros + 1, [comps], kernel=kernel, max_iter=1)
+    try:
+        _, rendered, _ = batch.forward(model=False)
+    finally:
+        batch.close()
+    out = rendered[0].astype(renderer.data_frame.dtype, copy=False)
+    data_sl, model_sl = renderer.slices
+    if out[model_sl].shape == tuple(renderer.data_frame.shape):
+        return out[model_sl]
+    matched = np.zeros(renderer.data_frame.shape, dtype=renderer.data_frame.dtype)
+    matched[data_sl] = out[model_sl]
+    return matched
+
+
+class Observation(Frame):
+    """Data cube (channels, Ny, Nx) with inverse-variance ``weights`` (zero for
+    masked pixels), ``psf`` and ``channels``."""
+
+    def __init__(self, data, channels, psf=None, weights=None, wcs=None, padding=10):
+        super().__init__(data.shape, wcs=wcs, psf=psf, channels=channels, dtype=data.dtype)
+        self.data = data
+        self.weights = np.ones(data.shape, dtype=data.dtype) if weights is None else weights
+        assert self.weights.shape == self.data.shape, "Weights needs to have same shape as data"
+        self._padding = padding
+
+    def match(self, model_frame, renderer=None):
+        """Set up the mapping from ``model_frame`` to this observation: cast the
+        data to the model dtype and choose the renderer (same PSF object ->
+        ``NullRenderer``; otherwise ``ConvolutionRenderer``).  Returns ``self``."""
+        self.model_frame = model_frame
+        if self.dtype != model_frame.dtype:
+            self.dtype = model_frame.dtype
+            self.data = self.data.astype(model_frame.dtype)
+            if type(self.weights) is np.ndarray:
+                self.weights = self.weights.astype(model_frame.dtype)
+        if renderer is None:
+            if self.psf is model_frame.psf:
+                self.renderer = NullRenderer(self, model_frame)
+            else:
+                assert self.psf is not None and model_frame.psf is not None
+                self.renderer = ConvolutionRenderer(self, model_frame, convolution_type="fft")
+        else:
+            assert isinstance(renderer, Renderer)
+            self.renderer = renderer
+        return self
+
+    @property
+    def noise_rms(self):
+        if not hasattr(self, "_noise_rms"):
+            self._noise_rms = 1 / np.sqrt(ma.masked_equal(self.weights, 0))
+            ma.set_fill_value(self._noise_rms, np.inf)
+        return self._noise_rms
+
+    @property
+    def parameters(self):
+        return self.renderer.parameters
+
+    def render(self, model, *parameters):
+        """Model cube mapped into the observation frame (on the GPU)."""
+        return self.renderer(model, *parameters)
+
+    def get_log_likelihood(self, model, *parameters, noise_factor=0):
+        """``-log_norm - sum w (render(model) - data)^2 / 2``."""
+        if noise_factor > 0:
+            raise NotImplementedError("noise_factor > 0 (random noise injection) is not supported")
+        model_ = self.render(model, *parameters)
+        return -self.log_norm - np.sum(self.weights * (model_ - self.data) ** 2) / 2
+
+    @property
+    def log_norm(self):
+        if not hasattr(self, "_log_norm"):
+            n = np.prod(self.data.shape) - self.noise_rms.mask.sum()
+            with np.errstate(divide="ignore"):
+                self._log_norm = n / 2 * np.log(2 * np.pi) + np.log(self.noise_rms).sum()
+        return self._log_norm
+
+    def _to_frame(self, frame, data=None):
+        frame_sl, obs_sl = overlapped_slices(frame.bbox, self.bbox)
+        if data is None:
+            data = self.data
+        out = np.zeros(frame.shape, dtype=getattr(frame, "dtype", data.dtype))
+        out[frame_sl] = data[obs_sl]
+        return out

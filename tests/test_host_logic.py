@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference interface (no GPU): boxes, FFT utilities,
+PSFs, monotonicity tables, constraints and their translation to the device chain.
+The expectations are the reference's own tests (tests/test_bbox.py, test_fft.py,
+test_component.py, test_constraint.py) and the golden vectors."""
+
+import pickle
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_almost_equal, assert_array_equal
+
+import scarlet_amd as scarlet
+from scarlet_amd import _lib, fft, operator
+from scarlet_amd.constraint import device_flags
+from conftest import golden
+from oracle import fftconv, proxops
+
+
+def test_box_algebra():
+    # reference tests/test_bbox.py
+    box = scarlet.Box((3, 4), origin=(1, 2))
+    assert box.D == 2 and box.start == (1, 2) and box.stop == (4, 6)
+    assert box.bounds == ((1, 4), (2, 6)) and box.slices == (slice(1, 4), slice(2, 6))
+    assert scarlet.Box.from_bounds((1, 4), (2, 6)) == box
+    assert (box | scarlet.Box((2, 2), origin=(0, 0))) == scarlet.Box((4, 6), origin=(0, 0))
+    assert (box & scarlet.Box((3, 3), origin=(2, 3))) == scarlet.Box((2, 3), origin=(2, 3))
+    assert (box & scarlet.Box((1, 1), origin=(9, 9))).shape == (0, 0)
+    assert box + 2 == scarlet.Box((3, 4), origin=(3, 4))
+    assert box - (1, 2) == scarlet.Box((3, 4))
+    assert scarlet.Box((5,)) @ box == scarlet.Box((5, 3, 4), origin=(0, 1, 2))
+    assert box.contains((1, 2)) and not box.contains((4, 2))
+    img = np.arange(30).reshape(5, 6)
+    sub = scarlet.Box((3, 3), origin=(-1, 4)).extract_from(img)
+    assert_array_equal(sub, [[0, 0, 0], [4, 5, 0], [10, 11, 0]])
+    x = np.zeros((5, 6))
+    x[2:, 3:] = 1
+    assert scarlet.Box.from_data(x) == scarlet.Box((3, 3), origin=(2, 3))
+    f_sl, b_sl = scarlet.overlapped_slices(scarlet.Box((5, 6)), scarlet.Box((3, 3), origin=(-1, 4)))
+    assert f_sl == (slice(0, 2), slice(4, 6)) and b_sl == (slice(1, 3), slice(0, 2))
+
+
+def test_fft_centering_conventions():
+    # reference tests/test_fft.py:12-80
+    a_pad = fft._pad(np.ones((1, 1)), (5, 4))
+    truth = np.zeros((5, 4))
+    truth[2, 2] = 1
+    assert_array_equal(a_pad, truth)
+    a0 = np.arange(10).reshape(5, 2)
+    a_pad = fft._pad(a0, (9, 11))
+    assert_array_equal(a_pad, fftconv.pad_to(a0, (9, 11)))
+    assert_array_equal(fft._centered(a_pad, (5, 2)), a0)
+    assert fft._get_fft_shape((5, 58, 48), (5, 43, 43), 3, (1, 2)) == [108, 96]
+    assert fft._get_fft_shape((5, 128, 128), (1, 41, 41), 3, (1, 2)) == [180, 180]
+    assert fft._get_fft_shape((6, 40, 59), (6, 31, 31), 3, (1, 2)) == [75, 96]
+    for n in (1, 7, 97, 172, 1000):
+        assert fft.next_fast_len(n) == fftconv.next_fast_len(n)
+
+
+def test_fft_psf_matching_like_reference():
+    # reference tests/test_fft.py:91-123 + golden outputs of the reference
+    g = golden("fft_psf")
+    psf1 = fft.Fourier(scarlet.GaussianPSF(1, boxsize=41).get_model())
+    psf2 = fft.Fourier(scarlet.GaussianPSF(2, boxsize=41).get_model())
+    assert_allclose(psf1.image, g["psf1"], atol=1e-15)
+    k12 = fft.match_psf(psf2, psf1)
+    assert_almost_equal(fft.convolve(psf1, k12).image, psf2.image)
+    assert_allclose(k12.image, g["k12"], atol=1e-12)
+    k21 = fft.match_psf(psf1, psf2)
+    assert_almost_equal(fft.convolve(psf2, k21).image, psf1.image)
+    psf123 = fft.Fourier(scarlet.GaussianPSF((1, 2, 3), boxsize=41).get_model())
+    assert_allclose(psf123.image, g["psf123"], atol=1e-15)
+    km = fft.match_psf(psf123, psf1)
+    assert_almost_equal(psf123.image, fft.convolve(km, psf1).image)
+    for img in fft.convolve(fft.match_psf(psf1, psf123), psf123).image:
+        assert_almost_equal(img, psf1.image[0])
+    assert_allclose(fft.shift(g["shift_in"], (0.3, -1.7), return_Fourier=False), g["shift_out"],
+                    atol=1e-6)
+    assert_allclose(fft.convolve(g["cube"], g["kern"], axes=(1, 2), return_Fourier=False),
+                    g["conv"], atol=1e-6)
+
+
+def test_diff_kernel_matches_reference_golden(hsc):
+    psf = scarlet.ImagePSF(hsc["psfs"].copy())
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5)
+    assert_allclose(model_psf.get_model(), hsc["model_psf"], atol=1e-15)
+    frame = scarlet.Frame(hsc["images"].shape, psf=model_psf, channels=list("grizy"))
+    obs = scarlet.Observation(hsc["images"], psf=psf, weights=hsc["weights"],
+                              channels=list("grizy")).match(frame)
+    assert isinstance(obs.renderer, scarlet.ConvolutionRenderer)
+    assert_allclose(obs.renderer.diff_kernel.image, hsc["diff_kernel"], atol=1e-7)
+    assert_allclose(obs.log_norm, hsc["log_norm"], rtol=1e-7)
+    assert_allclose(np.array(np.mean(obs.noise_rms, axis=(1, 2))), hsc["noise_rms_mean"], rtol=1e-6)
+    same = scarlet.Observation(hsc["images"], psf=model_psf, channels=list("grizy")).match(frame)
+    assert isinstance(same.renderer, scarlet.NullRenderer)
+
+
+def test_monotonic_tables_match_reference():
+    g = golden("operator_tables")
+    for key in g.files:
+        if key.startswith("w_"):
+            _, mode, tag = key.split("_")
+            h, w = map(int, tag.split("x"))
+            mine = operator.getRadialMonotonicWeights((h, w), mode, (h // 2, w // 2))
+            assert_allclose(mine, g[key], rtol=0, atol=1e-15)
+        elif key.startswith("didx_"):
+            h, w = map(int, key[5:].split("x"))
+            assert_array_equal(operator.sort_by_radius((h, w), (h // 2, w // 2)), g[key])
+    # default centre and the helper tables of the reference API
+    assert_allclose(operator.getRadialMonotonicWeights((7, 9), "angle"),
+                    proxops.radial_monotonic_weights((7, 9), "angle"), atol=1e-15)
+    table, missing = operator.diagonalizeArray(np.arange(12.0).reshape(3, 4))
+    ref_table, ref_missing = proxops._diagonalize(np.arange(12.0).reshape(3, 4))
+    assert_array_equal(missing, ref_missing)
+    assert_array_equal(table[~missing], ref_table[~ref_missing])
+    offsets, sl, sl_inv = operator.getOffsets(4)
+    assert offsets == [-5, -4, -3, -1, 1, 3, 4, 5]
+
+
+def test_elementwise_constraints_like_reference():
+    # reference tests/test_constraint.py:9-71, 137-171
+    rng = np.random.default_rng(0)
+    X = rng.random(100) - 0.5
+    assert np.all(scarlet.PositivityConstraint()(X, 0) >= 0)
+    assert np.all(scarlet.PositivityConstraint(zero=0.1)(X, 0) >= 0.1)
+    Y = rng.random(100)
+    assert_almost_equal(scarlet.NormalizationConstraint("sum")(Y.copy(), 0), Y / Y.sum())
+    assert_almost_equal(scarlet.NormalizationConstraint("max")(Y.copy(), 0), Y / Y.max())
+    step, thresh = 0.5, 0.25
+    for typ, t in (("relative", thresh * step), ("absolute", thresh)):
+        out = scarlet.L0Constraint(thresh=thresh, type=typ)(X.copy(), step)
+        mask = np.abs(X) < t
+        assert np.all(out[mask] == 0)
+        assert_array_equal(out[~mask], X[~mask])
+        out = scarlet.L1Constraint(thresh=thresh, type=typ)(X.copy(), step)
+        assert np.all(out[mask] == 0)
+        assert_array_equal(np.abs(out[~mask]), np.abs(np.abs(X[~mask]) - t))
+    Z = np.arange(25, dtype=float).reshape(5, 5)
+    assert_almost_equal(scarlet.SymmetryConstraint()(Z.copy(), 0), np.full((5, 5), 12.0))
+    assert_almost_equal(scarlet.SymmetryConstraint(strength=0.5)(Z.copy(), 0), Z * 0.5 + 6)
+    assert scarlet.CenterOnConstraint()(np.zeros((5, 5)), 0)[2, 2] > 0
+    np.random.seed(0)
+    noise = np.random.rand(21, 21) * 2
+    signal = np.zeros(noise.shape)
+    psf = scarlet.GaussianPSF(sigma=1, boxsize=21).get_model()
+    signal[7:14, 7:14] = psf[0, 7:14, 7:14]
+    Xn = signal + noise
+    out = scarlet.ThresholdConstraint()(Xn.copy(), 0)
+    mask = Xn < 0.05704869232578929
+    assert np.all(out[mask] == 0)
+    assert_array_equal(out[~mask], Xn[~mask])
+
+
+def test_device_chain_translation():
+    frame = scarlet.Frame((2, 30, 30), channels=[0, 1], psf=scarlet.GaussianPSF(0.8))
+    morph = scarlet.ExtendedSourceMorphology(frame, (15, 15), np.ones((21, 21)),
+                                             bbox=scarlet.Box((21, 21), origin=(5, 5)))
+    f = device_flags(morph.parameters[0].constraint)
+    assert f["flags"] == _lib.PROX_EXTENDED_SOURCE
+    assert f["neighbor_weight"] == "angle" and f["min_gradient"] == 0
+    sym = scarlet.ExtendedSourceMorphology(frame, (15, 15), np.ones((21, 21)),
+                                           bbox=scarlet.Box((21, 21), origin=(5, 5)),
+                                           monotonic="flat", symmetric=True, min_grad=0.1)
+    f = device_flags(sym.parameters[0].constraint)
+    assert f["flags"] == _lib.PROX_EXTENDED_SOURCE | _lib.PROX_SYMMETRY
+    assert f["neighbor_weight"] == "flat" and f["min_gradient"] == 0.1
+    assert device_flags(scarlet.PositivityConstraint())["flags"] == _lib.PROX_POSITIVE
+    assert device_flags(None)["flags"] == 0
+    with pytest.raises(NotImplementedError):
+        device_flags(scarlet.ConstraintChain(scarlet.PositivityConstraint(),
+                                             scarlet.MonotonicityConstraint()))
+    with pytest.raises(NotImplementedError):
+        device_flags(scarlet.Constraint(lambda x, s: x))
+
+
+def test_component_placement_like_reference():
+    # reference tests/test_component.py
+    frame = scarlet.Frame((10, 20, 30), channels=np.arange(10))
+    shape, on, origin = (5, 4, 6), (1, 2, 3), (2, 3, 4)
+    sed = np.zeros(5)
+    sed[on[0]] = 1
+    morph = np.zeros(shape[1:])
+    morph[on[1:]] = 1
+    box = scarlet.Box(shape, origin=origin)
+    comp = scarlet.FactorizedComponent(
+        frame, scarlet.TabulatedSpectrum(frame, sed, bbox=box[0]),
+        scarlet.ImageMorphology(frame, morph, bbox=box[1:]))
+    model = comp.get_model(frame=frame)
+    loc = tuple(np.array(on) + np.array(origin))
+    mask = np.zeros(model.shape, dtype=bool)
+    mask[loc] = True
+    assert_array_equal(model[~mask], 0)
+    assert model[loc] == 1
+    assert [p.name for p in comp.parameters] == ["spectrum", "image", "shift"]
+    cube = np.zeros(shape)
+    cube[on] = 1
+    cc = scarlet.CubeComponent(frame, scarlet.Parameter(cube, name="cube"), bbox=box)
+    assert cc.get_model(frame=frame)[loc] == 1
+    combined = scarlet.CombinedComponent([comp, comp])
+    assert combined.get_model(frame=frame)[loc] == 2
+    blend = scarlet.Blend([comp, combined],
+                          scarlet.Observation(np.zeros(frame.shape, np.float32), channels=np.arange(10)))
+    assert blend.get_model()[loc] == 3 and blend.get_model().dtype == np.float32
+    assert len(blend.parameters) == 9
+
+
+def test_parameter_pickles_with_state():
+    p = scarlet.Parameter(np.arange(4.0), name="x", step=0.5, m=np.ones(4), fixed=True)
+    q = pickle.loads(pickle.dumps(p))
+    assert_array_equal(q, p)
+    assert q.name == "x" and q.step == 0.5 and q.fixed and np.all(q.m == 1)
+    assert scarlet.relative_step(np.array([1.0, 3.0]), 0, factor=0.5, minimum=0.2) == 1.0
+    bad = scarlet.Parameter(np.array([np.nan]), name="bad")
+    assert not bad.is_finite
+
+
+def test_shard_ranges_cover_everything():
+    from scarlet_amd import dist
+
+    for n, world in ((1024, 8), (10, 3), (7, 8), (0, 2)):
+        ranges = [dist.shard_range(n, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+            assert a1 == b0 and a0 <= a1
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
