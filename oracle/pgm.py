@@ -73,6 +73,59 @@ class Component:
         )
 
 
+def get_minimal_boxsize(size, min_size=21, increment=10):
+    """initialization.py:173-177."""
+    boxsize = min_size
+    while boxsize < size:
+        boxsize += increment
+    return boxsize
+
+
+def resize_component(c):
+    """``ImageMorphology.update`` (morphology.py:132-207) on an oracle Component:
+    shrink the (square) box when all four edges are empty, otherwise grow it when
+    the next Adam step pulls flux over an edge.  Moments are sliced / zero-padded,
+    the step is halved.  Returns True if the box changed (``UpdateException``)."""
+    import numpy.ma as ma
+
+    image = c.morph
+    size = max(image.shape)
+    # shrink_box (morphology.py:50-67)
+    dist = 0
+    while (
+        np.all(image[dist, :] <= 0)
+        and np.all(image[-dist - 1, :] <= 0)
+        and np.all(image[:, dist] <= 0)
+        and np.all(image[:, -dist - 1] <= 0)
+    ):
+        dist += 1
+    newsize = get_minimal_boxsize(size - 2 * dist)
+    if newsize < size:
+        d = (size - newsize) // 2
+        sl = (slice(d, d + newsize), slice(d, d + newsize))
+        c.origin = (c.origin[0] + d, c.origin[1] + d)
+        c.morph = image[sl]
+        c.m_morph, c.v_morph, c.vhat_morph = c.m_morph[sl], c.v_morph[sl], c.vhat_morph[sl]
+        c.morph_step = c.morph_step / 2
+        return True
+    gu = -c.m_morph / np.sqrt(np.sqrt(ma.masked_equal(c.v_morph, 0))) * c.morph_step
+    pull = gu * (image > 0)
+    edge_pull = np.array(
+        (pull[:, 0].mean(), pull[:, -1].mean(), pull[0, :].mean(), pull[-1, :].mean())
+    )
+    if np.any(edge_pull > 0.1):
+        newsize = get_minimal_boxsize(size + 1)
+        pad = (newsize - size) // 2
+        c.morph = np.pad(image, pad, mode="linear_ramp")
+        c.m_morph = np.pad(c.m_morph, pad, mode="constant")
+        c.v_morph = np.pad(c.v_morph, pad, mode="constant")
+        c.vhat_morph = np.pad(c.vhat_morph, pad, mode="constant")
+        c.morph_step = c.morph_step / 2
+        c.origin = (c.origin[0] - pad, c.origin[1] - pad)
+        return True
+    return False
+
+
 class Scene:
     def __init__(self, frame_shape, data, weights, kernel, components, dtype=np.float32):
         self.frame_shape = tuple(frame_shape)
@@ -219,26 +272,46 @@ class Scene:
             if not (np.isfinite(c.sed).all() and np.isfinite(c.morph).all()):
                 raise ArithmeticError("component {} is not finite".format(k))
 
-    def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, prox_max_iter=10):
-        """``Blend.fit`` (blend.py:85-198) without box resizing.
+    def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, prox_max_iter=10, resizing=False):
+        """``Blend.fit`` (blend.py:85-198).
 
         Iteration order follows the reference authors' own loop
         (lite/models.py:589-624): gradient (loss appended) -> parameter updates
-        -> convergence test ``it > min_iter and |dL| < e_rel |L|``.  The
-        position of proxmin's callback inside ``adaprox`` is third-party code
-        (parity unpinned, see oracle/__init__.py).
+        -> [every 10 iterations the resize hook, blend.py:284-292] -> convergence
+        test ``it > min_iter and |dL| < e_rel |L|``.  A resize restarts the
+        optimizer counter (``UpdateException``, blend.py:196-198): the next
+        iteration is again a tenth of a step with ``vhat = v``.  The position of
+        proxmin's callback inside ``adaprox`` is third-party code (parity
+        unpinned, see oracle/__init__.py).
 
         Returns ``(len(loss), logL[-1])`` like blend.py:194.
         """
         it = 0
         while it < max_iter:
-            self.step(it, e_rel, prox_max_iter)
-            self.check_parameters()
-            if it > min_iter and abs(self.loss[-1] - self.loss[-2]) < e_rel * abs(
-                self.loss[-1]
-            ):
+            local = 0
+            restart = False
+            while it + local < max_iter:
+                self.step(local, e_rel, prox_max_iter)
+                self.check_parameters()
+                if resizing and local > 0 and local % 10 == 0:
+                    # Blend._callback calls src.update() per source (blend.py:284-292);
+                    # a combined source stops at its first child that resizes
+                    # (component.py:280-290 re-raises out of the loop)
+                    for group in self._groups():
+                        for c in group:
+                            if resize_component(c):
+                                restart = True
+                                break
+                    if restart:
+                        break
+                if local > min_iter and abs(self.loss[-1] - self.loss[-2]) < e_rel * abs(
+                    self.loss[-1]
+                ):
+                    return len(self.loss), -self.loss[-1]
+                local += 1
+            if not restart:
                 break
-            it += 1
+            it = len(self.loss)
         return len(self.loss), -self.loss[-1]
 
 

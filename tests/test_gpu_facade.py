@@ -1,0 +1,98 @@
+"""The reference-style Python API end to end on the GPU: Frame / Observation.match /
+FactorizedComponent / Blend.fit, against the oracle on the quickstart scene
+(initial sources taken from the golden fixture, since source initialisation is
+set-up code outside the loop)."""
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from conftest import hsc_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def build_blend(hsc, resizing):
+    import scarlet_amd as scarlet
+
+    filters = list("grizy")
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5)
+    frame = scarlet.Frame(hsc["images"].shape, psf=model_psf, channels=filters)
+    obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                              weights=hsc["weights"], channels=filters).match(frame)
+    groups = {}
+    for k in range(int(hsc["n_comp"])):
+        h, w = hsc["morph_%d" % k].shape
+        oy, ox = hsc["origin_%d" % k]
+        box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+        spectrum = scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                             min_step=hsc["min_step_%d" % k])
+        center = (oy + h // 2, ox + w // 2)
+        morphology = scarlet.ExtendedSourceMorphology(
+            frame, center, hsc["morph_%d" % k].copy(), bbox=box[1:], monotonic="angle",
+            resizing=resizing)
+        comp = scarlet.FactorizedComponent(frame, spectrum, morphology)
+        groups.setdefault(int(hsc["source_of"][k]), []).append(comp)
+    sources = [g[0] if len(g) == 1 else scarlet.CombinedComponent(g) for g in groups.values()]
+    return scarlet.Blend(sources, obs), obs
+
+
+def components_of(blend):
+    import scarlet_amd as scarlet
+
+    out = []
+    for src in blend.sources:
+        out += [src] if isinstance(src, scarlet.FactorizedComponent) else list(src.children)
+    return out
+
+
+def test_render_and_loglikelihood_api(hsc):
+    blend, obs = build_blend(hsc, resizing=False)
+    model = blend.get_model()
+    np.testing.assert_array_equal(model, hsc["model"])
+    rendered = obs.render(model)
+    assert np.abs(rendered - hsc["rendered"]).max() < 1e-5 * np.abs(hsc["rendered"]).max()
+    assert_allclose(obs.get_log_likelihood(model), float(hsc["logL"]), rtol=1e-6)
+
+
+def test_blend_fit_matches_oracle(hsc):
+    blend, obs = build_blend(hsc, resizing=False)
+    n, logL = blend.fit(40, e_rel=1e-4)
+    sc = hsc_scene(hsc)
+    n_ref, logL_ref = sc.fit(40, e_rel=1e-4)
+    assert n == len(blend.loss) and abs(n - n_ref) <= 2
+    m = min(n, n_ref, 12)
+    chi = np.array(blend.loss[:m]) - sc.log_norm
+    chi_ref = np.array(sc.loss[:m]) - sc.log_norm
+    assert_allclose(chi, chi_ref, rtol=2e-4)
+    assert abs((logL + sc.log_norm) - (logL_ref + sc.log_norm)) < 2e-3 * abs(logL_ref + sc.log_norm)
+    assert_allclose(blend.log_likelihood[-1], logL)
+    # side effects the reference promises (blend.py:153-163, 189-192)
+    for p in blend.parameters:
+        if p.name == "shift":
+            continue
+        assert p.m is not None and p.v.shape == p.shape and p.std.shape == p.shape
+    for comp in components_of(blend):
+        image = comp.children[1].parameters[0]
+        assert image.max() == 1.0 and image.min() >= 0
+    # warm start: a second call continues from the stored moments
+    n2, logL2 = blend.fit(5, e_rel=1e-9)
+    assert n2 == n + 5 and logL2 >= logL - 1e-3 * abs(logL)
+
+
+def test_blend_fit_with_resizing_matches_oracle(hsc):
+    blend, obs = build_blend(hsc, resizing=True)
+    n, logL = blend.fit(45, e_rel=1e-5)
+    sc = hsc_scene(hsc)
+    n_ref, logL_ref = sc.fit(45, e_rel=1e-5, resizing=True)
+    assert n == n_ref == 45
+    comps = components_of(blend)
+    # the same boxes were resized to the same shapes / origins
+    for comp, c in zip(comps, sc.components):
+        assert comp.children[1].parameters[0].shape == c.morph.shape
+        assert tuple(comp.children[1].bbox.origin) == tuple(c.origin)
+    assert any(c.morph.shape != hsc["morph_%d" % k].shape for k, c in enumerate(sc.components))
+    chi = np.array(blend.loss) - sc.log_norm
+    chi_ref = np.array(sc.loss) - sc.log_norm
+    assert_allclose(chi[:25], chi_ref[:25], rtol=5e-4)
+    assert abs(chi[-1] - chi_ref[-1]) < 5e-3 * abs(chi_ref[-1])
