@@ -157,7 +157,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get(k_name)
+                rec = json.load(fh).get(k_name)
+            if rec:  # measured with rocprofv3 --pmc (profiles/), bytes per launch
+                traffic = rec["bytes_per_blend"] * nb
         roofline = {
             "bound": "hbm",
             "achieved": round(achieved, 2),
