@@ -37,7 +37,13 @@ from .component import (  # noqa: F401
     CombinedComponent,
 )
 from .blend import Blend  # noqa: F401
+from .source import (  # noqa: F401
+    ExtendedSource,
+    SingleExtendedSource,
+    MultiExtendedSource,
+    CompactExtendedSource,
+)
 from .model import Model, UpdateException  # noqa: F401
-from . import fft, operator, synthetic  # noqa: F401
+from . import fft, initialization, operator, synthetic  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,244 @@
+"""Source initialisation (reference scarlet/initialization.py): runs once per
+blend on the host before the fit.  The monotonicity sweep used here goes through
+the C ABI (seam 1) to the GPU; rendering for the spectrum solve uses the device
+renderer."""
+
+import logging
+
+import numpy as np
+
+from .bbox import Box
+from .morphology import get_minimal_boxsize  # noqa: F401  (reference exports it here)
+from .renderer import ConvolutionRenderer, NullRenderer
+
+logger = logging.getLogger("scarlet_amd.initialization")
+
+
+def _as_tuple(observations):
+    return observations if hasattr(observations, "__iter__") else (observations,)
+
+
+def _warn_nonpositive(spectrum, sky_coord):
+    if np.any(spectrum <= 0):
+        msg = f"Zero or negative spectrum {spectrum} at {sky_coord}"
+        (logger.warning if np.all(spectrum <= 0) else logger.info)(msg)
+
+
+def get_pixel_spectrum(sky_coord, observations, correct_psf=False, models=None, concat=True):
+    """Data values at the pixel of ``sky_coord`` in every channel; divided by
+    the PSF peak (``correct_psf``) or by a model's value there (``models``)."""
+    if models is not None:
+        assert correct_psf is False
+    if not hasattr(observations, "__iter__"):
+        observations, models = (observations,), (models,)
+    elif models is None:
+        models = (None,) * len(observations)
+    else:
+        assert len(models) == len(observations)
+    spectra = []
+    for obs, model in zip(observations, models):
+        iy, ix = np.round(obs.get_pixel(sky_coord)).astype("int")
+        spectrum = obs.data[:, iy, ix].copy()
+        if correct_psf and obs.psf is not None:
+            spectrum /= obs.psf.get_model().max(axis=(1, 2))
+        elif model is not None:
+            spectrum /= model[:, iy, ix].copy()
+        spectra.append(spectrum)
+        _warn_nonpositive(spectrum, sky_coord)
+    return np.concatenate(spectra).reshape(-1) if concat else spectra
+
+
+def get_psf_spectrum(sky_coord, observations, compute_snr=False, concat=True):
+    """PSF-weighted (matched-filter) flux per channel at ``sky_coord`` and,
+    optionally, the signal-to-noise ratio of a point source there."""
+    observations = _as_tuple(observations)
+    spectra, num, den = [], [], []
+    for obs in observations:
+        index = np.round(obs.get_pixel(sky_coord)).astype("int")
+        psf = obs.psf.get_model()
+        bbox = obs.psf.bbox + (0, *index)
+        img = bbox.extract_from(obs.data)
+        noise = bbox.extract_from(obs.noise_rms)
+        masked = bbox.extract_from(obs.noise_rms.mask)
+        spec = []
+        for c in range(obs.C):
+            ok = ~masked[c]
+            p, d = psf[c, ok], img[c, ok]
+            flux = d @ p
+            spec.append(flux / (p @ p))
+            if compute_snr:
+                num.append(flux)
+                den.append((p * noise[c, ok] ** 2) @ p)
+        spec = np.array(spec)
+        spectra.append(spec)
+        _warn_nonpositive(spec, sky_coord)
+    if concat:
+        spectra = np.concatenate(spectra).reshape(-1)
+    if compute_snr:
+        return spectra, np.sum(num) / np.sqrt(np.sum(den))
+    return spectra
+
+
+def trim_morphology(center_index, morph, bg_thresh=0, boxsize=None):
+    """Zero the pixels at or below ``bg_thresh`` and cut a square box of
+    standard size around ``center_index`` that holds what is left."""
+    morph[~(morph > bg_thresh)] = 0
+    bbox = Box.from_data(morph, min_value=0)
+    if bbox.contains(center_index):
+        size = 2 * max(
+            center_index[0] - bbox.start[-2], bbox.stop[0] - center_index[-2],
+            center_index[1] - bbox.start[-1], bbox.stop[1] - center_index[-1],
+        )
+    else:
+        size = 0
+    if boxsize is None:
+        boxsize = get_minimal_boxsize(size)
+    half = boxsize // 2
+    bbox = Box.from_bounds(
+        (center_index[0] - half, center_index[0] + half + 1),
+        (center_index[1] - half, center_index[1] + half + 1),
+    )
+    return bbox.extract_from(morph), bbox
+
+
+def build_initialization_image(observations, spectra=None):
+    """Inverse-variance, spectrum-weighted coadd of all channels and its noise
+    level: the detection image morphologies are initialised from."""
+    if not hasattr(observations, "__iter__"):
+        observations, spectra = (observations,), (spectra,)
+    assert len(observations) == len(spectra)
+    frame = observations[0].model_frame
+    usable = [isinstance(o.renderer, (NullRenderer, ConvolutionRenderer)) for o in observations]
+    if not hasattr(observations[0], "_detect"):
+        detect, var = [], []
+        for obs, ok in zip(observations, usable):
+            if not ok:
+                continue
+            d = np.zeros(frame.shape, dtype=frame.dtype)
+            v = np.zeros(frame.shape, dtype=frame.dtype)
+            data_sl, model_sl = obs.renderer.slices
+            obs.renderer.map_channels(d)[model_sl] += obs.data[data_sl]
+            obs.renderer.map_channels(v)[model_sl] += obs.noise_rms[data_sl] ** 2
+            detect.append(d)
+            var.append(v)
+        observations[0]._detect = (np.array(detect), np.array(var))
+    detect, var = observations[0]._detect
+    weights_c = []
+    for obs, ok, spec in zip(observations, usable, spectra):
+        if not ok:
+            continue
+        s = np.zeros(frame.C)
+        obs.renderer.map_channels(s)[:] = 1 if spec is None else spec
+        weights_c.append(s)
+    spectrum = np.stack(weights_c, axis=0)[:, :, None, None]
+    weight = np.zeros(var.shape)
+    positive = var > 0
+    weight[positive] = 1 / var[positive]
+    weight *= spectrum
+    return (weight * detect).sum(axis=(0, 1)), np.sqrt((spectrum * weight).sum(axis=(0, 1)))
+
+
+def init_source(frame, center, observations, thresh=1, max_components=1, min_components=1,
+                min_snr=50, shifting=False, resizing=True, boxsize=None, fallback=True):
+    """One source at ``center`` with up to ``max_components`` components; with
+    ``fallback`` the count is limited by the point-source SNR and reduced (down
+    to a compact source) while initialisation yields non-finite parameters."""
+    from .source import ExtendedSource
+
+    observations = _as_tuple(observations)
+    if fallback:
+        _, snr = get_psf_spectrum(center, observations, compute_snr=True)
+        by_snr = np.floor(snr / min_snr).astype("int")
+        max_components = np.min([max_components, np.max([min_components, by_snr])])
+    while max_components >= 0:
+        try:
+            if max_components > 0:
+                source = ExtendedSource(frame, center, observations, thresh=thresh,
+                                        shifting=shifting, resizing=resizing, boxsize=boxsize,
+                                        K=max_components)
+            else:
+                source = ExtendedSource(frame, center, observations, shifting=shifting,
+                                        resizing=resizing, boxsize=boxsize, compact=True)
+            source.check_parameters()
+        except ArithmeticError as exc:
+            if not fallback:
+                raise exc
+            logger.info(f"Could not initialize source at {center} with {max_components} "
+                        f"components: {exc}")
+            max_components -= 1
+            continue
+        return source
+
+
+def init_all_sources(frame, centers, observations, thresh=1, max_components=1,
+                     min_components=1, min_snr=50, shifting=False, resizing=True, boxsize=None,
+                     fallback=True, silent=False, set_spectra=True):
+    """Initialise a source at every centre; returns ``(sources, skipped)``."""
+    observations = _as_tuple(observations)
+    sources, skipped = [], []
+    for k, center in enumerate(centers):
+        try:
+            sources.append(
+                init_source(frame, center, observations, thresh=thresh,
+                            max_components=max_components, min_components=min_components,
+                            min_snr=min_snr, shifting=shifting, resizing=resizing,
+                            boxsize=boxsize, fallback=fallback)
+            )
+        except Exception as exc:
+            logger.warning(f"Failed to initialize source {k}")
+            if not silent:
+                raise exc
+            skipped.append(k)
+    if set_spectra:
+        set_spectra_to_match(sources, observations)
+    return sources, skipped
+
+
+def set_spectra_to_match(sources, observations):
+    """Best-fit amplitude of every component in every channel: weighted linear
+    least squares of the rendered unit-spectrum component models against the data."""
+    from .component import CombinedComponent
+
+    observations = _as_tuple(observations)
+    frame = observations[0].model_frame
+    parameters, update_of, models = [], [], []
+    for i, src in enumerate(sources):
+        comps = src.children if isinstance(src, CombinedComponent) else (src,)
+        for j, comp in enumerate(comps):
+            p = comp.get_parameter("spectrum")
+            parameters.append(p)
+            if p is not None and not p.fixed:
+                p[:] = 1
+            model = comp.get_model(frame=frame)
+            target = len(models)
+            for prev, other in enumerate(models):
+                if np.allclose(model, other):
+                    target = prev
+                    logger.warning(
+                        f"Source {i}, Component {j} has a model identical to another component.\n"
+                        "This is likely not intended, and the source/component should be deleted. "
+                        "Spectra will be identical.")
+            update_of.append(target)
+            if target == len(models):
+                models.append(model)
+    models = np.array(models)
+    n_models = len(models)
+    for obs in observations:
+        rendered = np.stack([obs.render(m) for m in models], axis=0)
+        spectra = np.zeros((n_models, obs.C))
+        for c in range(obs.C):
+            im = obs.data[c].reshape(-1)
+            w = obs.weights[c].reshape(-1)
+            m = rendered[:, c].reshape(n_models, -1)
+            mw = m * w[None, :]
+            seen = np.flatnonzero(np.sum(mw, axis=1) / np.sum(m, axis=1) / np.mean(w) > 0.1)
+            if len(seen) == n_models:
+                spectra[:, c] = np.linalg.inv(mw @ m.T) @ m @ (im * w)
+            else:
+                spectra[seen, c] = np.linalg.inv(mw[seen] @ m[seen].T) @ m[seen] @ (im * w)
+        for k, p in enumerate(parameters):
+            if p is not None and not p.fixed:
+                obs.renderer.map_channels(p)[:] = spectra[update_of[k]]
+    for p in parameters:
+        if p is not None and p.constraint is not None:
+            p[:] = p.constraint(p, 0)

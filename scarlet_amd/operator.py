@@ -214,8 +214,14 @@ def uncentered_operator(X, func, center=None, fill=None, **kwargs):
     return X
 
 
-def prox_uncentered_symmetry(X, step, center=None, algorithm="sdss", fill=None, strength=0.5):
-    """Symmetry about an off-centre peak (reference operator.py:328-400)."""
+def prox_uncentered_symmetry(X, step, center=None, algorithm="kspace", fill=None, shift=None,
+                             strength=0.5):
+    """Symmetry about an off-centre peak (reference operator.py:328-400); the
+    k-space variant for fractional shifts is not supported."""
+    if algorithm == "kspace":
+        if shift is not None and not np.all(np.asarray(shift) == 0):
+            raise NotImplementedError("k-space symmetry with a fractional shift")
+        algorithm, strength = "soft", 1
     if algorithm == "sdss":
         return uncentered_operator(X, prox_sdss_symmetry, center, step=step, fill=fill)
     if algorithm == "soft":
