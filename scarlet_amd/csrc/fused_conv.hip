@@ -29,7 +29,7 @@ using fftk::csub;
 
 namespace {
 
-constexpr int kThreads = 512;
+constexpr int kThreads = 1024;
 constexpr int kF2 = 16;      // second radix of every 1-D transform
 constexpr int kPairs = 32;   // row pairs per chunk (64 rows)
 
