@@ -39,8 +39,11 @@ struct Cfg {
     static constexpr int NKX = FX / 2 + 1;
     static constexpr int SY = FY + 1;  // column stride of T (complex), odd
     static constexpr int SX = FX + 1;  // row-pair stride of the scratch (complex), odd
+    // + twiddle tables tw[k1 * 16 + n2] = exp(-2 pi i n2 k1 / F) for both axes and the
+    //   digit-swapped positions of +kx and -kx for the Hermitian row separation
     static constexpr size_t lds_bytes =
-        sizeof(float2) * ((size_t)NKX * SY + (size_t)kPairs * SX + FY + FX);
+        sizeof(float2) * ((size_t)NKX * SY + (size_t)kPairs * SX + FY + FX) +
+        sizeof(uint32_t) * (size_t)((NKX + 3) & ~3);
 };
 
 // ---- one radix-F1 pass over elements a[16 n1 + n2] -----------------------------
@@ -57,7 +60,7 @@ __device__ __forceinline__ void pass_stride(float2 *a, int n2, const float2 *tw,
     fftk::Dft<F1, INV>::run(v);
 #pragma unroll
     for (int k1 = 0; k1 < F1; ++k1) {
-        if (!INV && k1 > 0) v[k1] = cmul(v[k1], tw[n2 * k1]);
+        if (!INV && k1 > 0) v[k1] = cmul(v[k1], tw[kF2 * k1 + n2]);
         a[kF2 * k1 + n2] = v[k1];
     }
 }
@@ -71,7 +74,7 @@ __device__ __forceinline__ void pass_block(float2 *a, int k1, const float2 *tw) 
     fftk::Dft<kF2, INV>::run(v);
 #pragma unroll
     for (int j = 0; j < kF2; ++j) {
-        if (INV && j > 0) v[j] = cmulc(v[j], tw[j * k1]);
+        if (INV && j > 0) v[j] = cmulc(v[j], tw[kF2 * k1 + j]);
         a[kF2 * k1 + j] = v[j];
     }
 }
@@ -95,6 +98,7 @@ template <int FY1, int FX1>
 struct Conv {
     using C = Cfg<FY1, FX1>;
     float2 *T, *Z, *twy, *twx;
+    uint32_t *posx;  // pos(kx) | pos(-kx) << 16
     int tid;
 
     // column transforms fused with the spectral product:
@@ -128,7 +132,7 @@ struct Conv {
             fftk::Dft<kF2, true>::run(v);
 #pragma unroll
             for (int j = 0; j < kF2; ++j) {
-                if (j > 0) v[j] = cmulc(v[j], twy[j * k1]);
+                if (j > 0) v[j] = cmulc(v[j], twy[kF2 * k1 + j]);
                 a[j] = v[j];
             }
             kx += dr;
@@ -165,8 +169,9 @@ struct Conv {
             const int y = y0 + 2 * j;
             if (y + 1 < C::FY) {
                 const float2 *z = Z + j * C::SX;
-                const float2 za = z[pos<FX1>(kx)];
-                const float2 zb = z[pos<FX1>((C::FX - kx) % C::FX)];
+                const uint32_t pp = posx[kx];
+                const float2 za = z[pp & 0xffff];
+                const float2 zb = z[pp >> 16];
                 // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^)
                 float2 *t = T + kx * C::SY + y;
                 t[0] = make_float2(za.x + zb.x, za.y - zb.y);
@@ -188,9 +193,10 @@ struct Conv {
                 xb = t[1];
             }
             float2 *z = Z + j * C::SX;
-            z[pos<FX1>(kx)] = make_float2(xa.x - xb.y, xa.y + xb.x);  // Xa + i Xb
-            if (kx != 0 && 2 * kx != C::FX)                           // conj(Xa) + i conj(Xb)
-                z[pos<FX1>(C::FX - kx)] = make_float2(xa.x + xb.y, xb.x - xa.y);
+            const uint32_t pp = posx[kx];
+            z[pp & 0xffff] = make_float2(xa.x - xb.y, xa.y + xb.x);  // Xa + i Xb
+            if (kx != 0 && 2 * kx != C::FX)                          // conj(Xa) + i conj(Xb)
+                z[pp >> 16] = make_float2(xa.x + xb.y, xb.x - xa.y);
         }
         __syncthreads();
         for (int b = tid; b < kPairs * FX1; b += kThreads)
@@ -237,16 +243,19 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     cv.twy = cv.Z + kPairs * C::SX;
     cv.twx = cv.twy + C::FY;
     cv.tid = tid;
-    for (int j = tid; j < C::FY; j += kThreads) {
+    for (int j = tid; j < C::FY; j += kThreads) {  // j = 16 k1 + n2
         float s, co;
-        sincospif(2.0f * (float)j / (float)C::FY, &s, &co);
+        sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FY, &s, &co);
         cv.twy[j] = make_float2(co, -s);
     }
     for (int j = tid; j < C::FX; j += kThreads) {
         float s, co;
-        sincospif(2.0f * (float)j / (float)C::FX, &s, &co);
+        sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FX, &s, &co);
         cv.twx[j] = make_float2(co, -s);
     }
+    cv.posx = reinterpret_cast<uint32_t *>(cv.twx + C::FX);
+    for (int kx = tid; kx < C::NKX; kx += kThreads)
+        cv.posx[kx] = (uint32_t)pos<FX1>(kx) | ((uint32_t)pos<FX1>((C::FX - kx) % C::FX) << 16);
     const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
                                C::FY * C::NKX;
     const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
@@ -411,7 +420,8 @@ bool fused_conv_supported(int Fy, int Fx) {
     auto ok = [](int f) { return f == 64 || f == 80 || f == 96 || f == 128 || f == 160; };
     if (!ok(Fy) || !ok(Fx)) return false;
     const size_t lds = sizeof(float2) * ((size_t)(Fx / 2 + 1) * (Fy + 1) +
-                                         (size_t)kPairs * (Fx + 1) + Fy + Fx);
+                                         (size_t)kPairs * (Fx + 1) + Fy + Fx) +
+                       sizeof(uint32_t) * (size_t)((Fx / 2 + 1 + 3) & ~3);
     return lds <= 160 * 1024;
 }
 
