@@ -249,13 +249,16 @@ __device__ __forceinline__ CompCtx comp_ctx(const BatchView &v) {
 __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompCtx &c,
                                                  const float *G, float *us) {
     float g_sed = 0.f;
+    const float inv_w = 1.0f / (float)c.w;
     for (int c0 = 0; c0 < c.C; c0 += kBandChunk) {
         const int nc = min(kBandChunk, c.C - c0);
         float acc[kBandChunk];
 #pragma unroll
         for (int j = 0; j < kBandChunk; ++j) acc[j] = 0.f;
         for (int i = c.lane; i < c.N; i += 64) {
-            const int y = i / c.w, x = i - y * c.w;
+            // exact for i < 2^20: the float quotient is off by < 1e-6 relative
+            int y = (int)(((float)i + 0.5f) * inv_w);
+            const int x = i - y * c.w;
             const int fy = y + c.oy, fx = x + c.ox;
             float gm = c0 == 0 ? 0.f : us[i];
             if ((unsigned)fy < (unsigned)v.H && (unsigned)fx < (unsigned)v.W) {
@@ -541,8 +544,9 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
         }
     }
     pmax = wave_max(pmax);
+    const float rpmax = 1.f / pmax;
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) rs[j] = rs[j] / pmax;
+    for (int j = 0; j < NPL; ++j) rs[j] = rs[j] * rpmax;
 
     const bool monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
     const SweepSlotEntry *slots = nullptr;
@@ -580,6 +584,10 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
         float div = 1.f;
         if (flags & SMI_PROX_NORM_MAX) div = wave_max(mx);
         if (flags & SMI_PROX_NORM_SUM) div = wave_sum(sm);
+        // one correctly rounded reciprocal per sub-iteration instead of N divisions; the
+        // maximum itself still maps to exactly 1 (x / x), everything else is within
+        // 1 ulp of the quotient
+        const float rdiv = 1.f / div;
         float d2 = 0.f, z2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
@@ -588,7 +596,8 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
                 float u = us[i];  // second read instead of NPL more registers
                 if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
                 if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, 1e-6f);
-                if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM)) u = u / div;
+                if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
+                    u = (u == div && (flags & SMI_PROX_NORM_MAX)) ? 1.f : u * rdiv;
                 d2 += (u - zs[j]) * (u - zs[j]);
                 z2 += zs[j] * zs[j];
                 zs[j] = u;
