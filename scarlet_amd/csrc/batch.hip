@@ -448,32 +448,40 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
     if ((rc = upload(&dp.cnt, hp.cnt.data(), hp.cnt.size()))) return rc;
     if ((rc = upload(&dp.nbr, hp.nbr.data(), hp.nbr.size()))) return rc;
     if ((rc = upload(&dp.wt, wt.data(), wt.size()))) return rc;
-    if (hp.max_terms <= 4 && h * w < 65536) {
-        // slot layout of the fast update kernel: every level padded to 64-lane steps
+    if (hp.max_terms <= 4 && h * w <= 16380) {
+        // slot layout of the fast update kernel: every level padded to 64-lane steps,
+        // an even number of steps in total
+        const uint32_t spare = (uint32_t)(((h * w + 3) & ~3) * 4);
+        SweepSlotEntry idle{};
+        idle.p_n0 = spare | (spare << 16);
+        idle.n1_n2 = spare | (spare << 16);
+        idle.n3 = spare;
         std::vector<SweepSlotEntry> slots;
         for (int l = 0; l < dp.n_levels; ++l) {
             const int s0 = hp.level_start[l], s1 = hp.level_start[l + 1];
             for (int base = s0; base < s1; base += 64) {
                 for (int lane = 0; lane < 64; ++lane) {
-                    SweepSlotEntry e{};
+                    SweepSlotEntry e = idle;
                     const int q = base + lane;
                     if (q < s1) {
-                        const int p = hp.pix[q], n = hp.cnt[q];
-                        uint32_t nb4[4] = {(uint32_t)p, (uint32_t)p, (uint32_t)p, (uint32_t)p};
+                        const uint32_t p = (uint32_t)hp.pix[q] * 4;
+                        const int n = hp.cnt[q];
+                        uint32_t nb4[4] = {p, p, p, p};
+                        for (int j = 0; j < 4; ++j) e.w[j] = 0.f;
                         for (int j = 0; j < n; ++j) {
-                            nb4[j] = (uint32_t)hp.nbr[(size_t)j * hp.n_entries + q];
+                            nb4[j] = (uint32_t)hp.nbr[(size_t)j * hp.n_entries + q] * 4;
                             e.w[j] = (float)hp.wt[(size_t)j * hp.n_entries + q];
                         }
-                        e.pc = p | (n << 16);
-                        e.n01 = nb4[0] | (nb4[1] << 16);
-                        e.n23 = nb4[2] | (nb4[3] << 16);
-                    } else {
-                        e.pc = -1;
+                        e.p_n0 = p | (nb4[0] << 16);
+                        e.n1_n2 = nb4[1] | (nb4[2] << 16);
+                        e.n3 = nb4[3];
                     }
                     slots.push_back(e);
                 }
             }
         }
+        if ((slots.size() / 64) % 2)
+            for (int lane = 0; lane < 64; ++lane) slots.push_back(idle);
         dp.n_slots = (int32_t)(slots.size() / 64);
         if ((rc = upload(&dp.slots, slots.data(), slots.size()))) return rc;
     }

@@ -60,13 +60,12 @@ bool build_sweep_plan(int32_t n_pix, const double *weights, const int32_t *offse
                       int32_t n_off, const int32_t *dist_idx, int32_t n_idx,
                       SweepPlanHost *out);
 
-// One lane's work in one 64-wide step of the sweep (fast path, <= 4 terms,
-// < 65536 pixels): pc = pixel | n_terms << 16 (or -1: idle lane), n01 / n23 =
-// neighbour pixel indices packed two per word, w = weights.
+// One lane's work in one 64-wide step of the sweep (fast path: <= 4 terms, images of
+// at most 16380 pixels): LDS byte addresses, two per word -- p | n0 << 16, n1 | n2 << 16,
+// n3 -- and the four weights.  Missing terms: own address, weight 0.  Idle lanes:
+// all five addresses = the spare zero cell behind the image, weights 0.
 struct alignas(16) SweepSlotEntry {
-    int32_t pc;
-    uint32_t n01, n23;
-    int32_t pad;
+    uint32_t p_n0, n1_n2, n3, pad;
     float w[4];
 };
 
