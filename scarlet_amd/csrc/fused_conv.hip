@@ -48,7 +48,9 @@ struct Cfg {
 
 // ---- one radix-F1 pass over elements a[16 n1 + n2] -----------------------------
 // forward: A[k1] = w_F^(n2 k1) DFT_F1(x)[k1] written to a[16 k1 + n2]; inputs with
-// index >= valid are taken as zero.  inverse: plain inverse DFT_F1.
+// index >= valid are taken as zero.  inverse: the inputs B[k1] are first multiplied by
+// w_F^(-n2 k1) (both directions carry their twiddles in this pass, which has the most
+// work items, so the radix-16 pass stays short), then inverse DFT_F1.
 template <int F1, bool INV>
 __device__ __forceinline__ void pass_stride(float2 *a, int n2, const float2 *tw, int valid) {
     float2 v[F1];
@@ -56,6 +58,7 @@ __device__ __forceinline__ void pass_stride(float2 *a, int n2, const float2 *tw,
     for (int n1 = 0; n1 < F1; ++n1) {
         const int idx = kF2 * n1 + n2;
         v[n1] = (INV || idx < valid) ? a[idx] : make_float2(0.f, 0.f);
+        if (INV && n1 > 0) v[n1] = cmulc(v[n1], tw[kF2 * n1 + n2]);
     }
     fftk::Dft<F1, INV>::run(v);
 #pragma unroll
@@ -67,16 +70,13 @@ __device__ __forceinline__ void pass_stride(float2 *a, int n2, const float2 *tw,
 
 // ---- radix-16 pass over the contiguous block a[16 k1 .. 16 k1 + 15] ---------------
 template <bool INV>
-__device__ __forceinline__ void pass_block(float2 *a, int k1, const float2 *tw) {
+__device__ __forceinline__ void pass_block(float2 *a, int k1) {
     float2 v[kF2];
 #pragma unroll
     for (int j = 0; j < kF2; ++j) v[j] = a[kF2 * k1 + j];
     fftk::Dft<kF2, INV>::run(v);
 #pragma unroll
-    for (int j = 0; j < kF2; ++j) {
-        if (INV && j > 0) v[j] = cmulc(v[j], tw[kF2 * k1 + j]);
-        a[kF2 * k1 + j] = v[j];
-    }
+    for (int j = 0; j < kF2; ++j) a[kF2 * k1 + j] = v[j];
 }
 
 // position of natural frequency k in the digit-swapped order of a length F1*16 transform
@@ -131,10 +131,7 @@ struct Conv {
             for (int j = 0; j < kF2; ++j) v[j] = conj ? cmulc(v[j], kv[j]) : cmul(v[j], kv[j]);
             fftk::Dft<kF2, true>::run(v);
 #pragma unroll
-            for (int j = 0; j < kF2; ++j) {
-                if (j > 0) v[j] = cmulc(v[j], twy[kF2 * k1 + j]);
-                a[j] = v[j];
-            }
+            for (int j = 0; j < kF2; ++j) a[j] = v[j];
             kx += dr;
             k1 += dq;
             if (kx >= C::NKX) {
@@ -162,7 +159,7 @@ struct Conv {
             pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
         __syncthreads();
         for (int b = tid; b < kPairs * FX1; b += kThreads)
-            pass_block<false>(Z + (b % kPairs) * C::SX, b / kPairs, twx);
+            pass_block<false>(Z + (b % kPairs) * C::SX, b / kPairs);
         __syncthreads();
         for (int b = tid; b < C::NKX * kPairs; b += kThreads) {
             const int j = b % kPairs, kx = b / kPairs;
@@ -200,7 +197,7 @@ struct Conv {
         }
         __syncthreads();
         for (int b = tid; b < kPairs * FX1; b += kThreads)
-            pass_block<true>(Z + (b % kPairs) * C::SX, b / kPairs, twx);
+            pass_block<true>(Z + (b % kPairs) * C::SX, b / kPairs);
         __syncthreads();
         for (int b = tid; b < kPairs * kF2; b += kThreads)
             pass_stride<FX1, true>(Z + (b % kPairs) * C::SX, b / kPairs, twx, C::FX);
