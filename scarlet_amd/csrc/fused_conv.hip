@@ -311,12 +311,13 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         // data / weights of the chunk are fetched before the inverse row transforms so
         // that their HBM latency hides behind them
         constexpr int kRows = 2 * kPairs / (kThreads / 64);
-        float dpre[kRows][kXIter], wpre[kRows][kXIter];
+        constexpr int kXPre = kXIter > 2 ? 2 : kXIter;  // columns >= 128 are loaded late
+        float dpre[kRows][kXPre], wpre[kRows][kXPre];
 #pragma unroll
         for (int j = 0; j < kRows; ++j) {
             const int y = y0 + wave + j * (kThreads / 64);
 #pragma unroll
-            for (int q = 0; q < kXIter; ++q) {
+            for (int q = 0; q < kXPre; ++q) {
                 const int x = lane + 64 * q;
                 dpre[j][q] = 0.f;
                 wpre[j][q] = 0.f;
@@ -340,9 +341,12 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                 float res = 0.f;
                 if (x < W && y < H) {
                     const float m = slot;
-                    if (mode == 1) out[(((int64_t)b * v.C + c) * H + y) * W + x] = m;
-                    const float diff = m - dpre[j][q];
-                    res = wpre[j][q] * diff;
+                    const int64_t iD = (((int64_t)b * v.C + c) * H + y) * W + x;
+                    if (mode == 1) out[iD] = m;
+                    const float dv = q < kXPre ? dpre[j][q < kXPre ? q : 0] : v.data[iD];
+                    const float wv = q < kXPre ? wpre[j][q < kXPre ? q : 0] : v.weights[iD];
+                    const float diff = m - dv;
+                    res = wv * diff;
                     loss += (double)(res * diff);
                 }
                 slot = res;
