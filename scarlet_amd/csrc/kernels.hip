@@ -17,10 +17,23 @@ constexpr int kBandChunk = 8;
 constexpr int kPixBlock = 256;
 constexpr float kB1 = 0.9f, kB2 = 0.999f, kEps = 1e-8f;  // lite/parameters.py:194
 
+// float reductions over the wavefront without LDS traffic: four DPP steps reduce each
+// row of 16 lanes (quad swaps, half-row mirror, row mirror), v_readlane combines the
+// four rows.  The result is wave-uniform and deterministic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -28,9 +41,15 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 // np.maximum semantics: a NaN in the data propagates (fmaxf would drop it)
 __device__ __forceinline__ float max_nan(float a, float b) { return a != a ? a : fmaxf(a, b); }
