@@ -274,24 +274,41 @@ __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompC
         float acc[kBandChunk];
 #pragma unroll
         for (int j = 0; j < kBandChunk; ++j) acc[j] = 0.f;
-        for (int i = c.lane; i < c.N; i += 64) {
-            // exact for i < 2^20: the float quotient is off by < 1e-6 relative
-            int y = (int)(((float)i + 0.5f) * inv_w);
-            const int x = i - y * c.w;
-            const int fy = y + c.oy, fx = x + c.ox;
-            float gm = c0 == 0 ? 0.f : us[i];
-            if ((unsigned)fy < (unsigned)v.H && (unsigned)fx < (unsigned)v.W) {
-                const float mv = c.morph[i];
+        // kGU pixels per lane in flight: all loads of a group are issued before the first
+        // one is consumed (the gather is bound by memory latency, not by bandwidth)
+        constexpr int kGU = 3;
+        for (int i0 = c.lane; i0 < c.N; i0 += 64 * kGU) {
+            float gv[kGU][kBandChunk], mv[kGU];
+            bool in_box[kGU];
+#pragma unroll
+            for (int u = 0; u < kGU; ++u) {
+                const int i = i0 + 64 * u;
+                // exact for i < 2^20: the float quotient is off by < 1e-6 relative
+                const int y = (int)(((float)i + 0.5f) * inv_w);
+                const int x = i - y * c.w;
+                const int fy = y + c.oy, fx = x + c.ox;
+                in_box[u] = i < c.N;
+                const bool ok =
+                    in_box[u] && (unsigned)fy < (unsigned)v.H && (unsigned)fx < (unsigned)v.W;
+                mv[u] = ok ? c.morph[i] : 0.f;
                 const float *g = G + (((int64_t)c.b * c.C + c0) * v.Fy + fy) * v.Fx + fx;
 #pragma unroll
                 for (int j = 0; j < kBandChunk; ++j)
-                    if (j < nc) {
-                        const float gv = g[(int64_t)j * v.Fy * v.Fx];
-                        gm = fmaf(c.sed[c0 + j], gv, gm);
-                        acc[j] = fmaf(gv, mv, acc[j]);
-                    }
+                    gv[u][j] = (ok && j < nc) ? g[(int64_t)j * v.Fy * v.Fx] : 0.f;
             }
-            us[i] = gm;
+#pragma unroll
+            for (int u = 0; u < kGU; ++u) {
+                const int i = i0 + 64 * u;
+                if (!in_box[u]) continue;
+                float gm = c0 == 0 ? 0.f : us[i];
+#pragma unroll
+                for (int j = 0; j < kBandChunk; ++j)
+                    if (j < nc) {
+                        gm = fmaf(c.sed[c0 + j], gv[u][j], gm);
+                        acc[j] = fmaf(gv[u][j], mv[u], acc[j]);
+                    }
+                us[i] = gm;
+            }
         }
 #pragma unroll
         for (int j = 0; j < kBandChunk; ++j)
