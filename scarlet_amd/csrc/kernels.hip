@@ -276,7 +276,10 @@ __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompC
         for (int j = 0; j < kBandChunk; ++j) acc[j] = 0.f;
         // kGU pixels per lane in flight: all loads of a group are issued before the first
         // one is consumed (the gather is bound by memory latency, not by bandwidth)
-        constexpr int kGU = 3;
+#ifndef SMI_GU
+#define SMI_GU 3
+#endif
+        constexpr int kGU = SMI_GU;
         for (int i0 = c.lane; i0 < c.N; i0 += 64 * kGU) {
             float gv[kGU][kBandChunk], mv[kGU];
             bool in_box[kGU];
