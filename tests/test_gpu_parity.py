@@ -399,3 +399,119 @@ def test_make_batch_matches_host_generator(amd):
         assert_array_equal(s["seds"], host["seds"])
         assert_array_equal(np.array(s["morphs"]), np.array(host["morphs"]))
         assert_array_equal(s["origins"], host["origins"])
+
+
+# ------------------------------------------------------------------ edge cases
+def _random_scene(rng, C, H, W, boxes, kernel_shape=None, **comp_kw):
+    from oracle import pgm
+
+    specs, ocomps = [], []
+    import scarlet_amd as amd
+
+    for (h, w), (oy, ox) in boxes:
+        yy, xx = np.mgrid[:h, :w]
+        morph = np.exp(-0.5 * (((yy - h // 2) / (0.2 * h)) ** 2 + ((xx - w // 2) / (0.25 * w)) ** 2))
+        morph = (morph * rng.uniform(0.7, 1.3, morph.shape)).astype(np.float32)
+        morph /= morph.max()
+        sed = rng.uniform(0.5, 3, C).astype(np.float32)
+        specs.append((sed, morph, (oy, ox)))
+    kernel = None
+    if kernel_shape is not None:
+        from scarlet_amd import fft
+        from scarlet_amd.psf import GaussianPSF
+
+        obs = GaussianPSF(1.8, boxsize=kernel_shape).get_model().astype(np.float32)
+        mod = GaussianPSF(0.8).get_model().astype(np.float32)
+        kernel = fft.match_psf(fft.Fourier(obs), fft.Fourier(mod), padding=10).image.astype(np.float32)
+    truth = pgm.Scene((C, H, W), None, None, kernel,
+                      [pgm.Component(s.copy(), m.copy(), o) for s, m, o in specs])
+    data = truth.render(truth.get_model()) + rng.normal(0, 0.05, (C, H, W)).astype(np.float32)
+    data = data.astype(np.float32)
+    weights = np.full((C, H, W), 400.0, dtype=np.float32)
+    return specs, kernel, data, weights
+
+
+def _compare_steps(amd, specs, kernel, data, weights, n_it, comp_kw, ocomp_kw, flags=None, **batch_kw):
+    from oracle import pgm
+
+    comps = [amd.ComponentSpec(s * 0.8, m, o, sed_min_step=0.05, **({"prox_flags": flags} if flags is not None else {}), **comp_kw)
+             for s, m, o in specs]
+    batch = amd.BlendBatch(data[None], weights[None], [comps], kernel=kernel, max_iter=n_it + 1, **batch_kw)
+    sc = pgm.Scene(data.shape, data, weights, kernel,
+                   [pgm.Component((s * 0.8).astype(np.float32), m.copy(), o, sed_min_step=0.05, **ocomp_kw)
+                    for s, m, o in specs])
+    batch.step(0, n_it, e_rel=1e-3)
+    for it in range(n_it):
+        sc.step(it, 1e-3)
+    sed, morphs = batch.parameters()
+    assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm, rtol=3e-5)
+    for k, c in enumerate(sc.components):
+        assert rel_err(sed[k], c.sed) < 2e-4, k
+        assert np.abs(morphs[k] - c.morph).max() < 2e-4, k
+    return batch, sc
+
+
+@pytest.mark.parametrize("mode,g,symmetric", [("flat", 0.1, False), ("nearest", 0.0, False),
+                                              ("angle", 0.25, True)])
+def test_weightings_symmetry_and_gradient(amd, mode, g, symmetric):
+    from scarlet_amd import _lib
+
+    rng = np.random.default_rng(21)
+    boxes = [((21, 21), (3, 5)), ((31, 31), (20, 25)), ((25, 35), (30, -4)), ((22, 30), (-5, 40))]
+    specs, kernel, data, weights = _random_scene(rng, 3, 64, 72, boxes, kernel_shape=21)
+    flags = _lib.PROX_EXTENDED_SOURCE | (_lib.PROX_SYMMETRY if symmetric else 0)
+    _compare_steps(amd, specs, kernel, data, weights, 3,
+                   dict(neighbor_weight=mode, min_gradient=g),
+                   dict(monotonic=mode, min_gradient=g, symmetric=symmetric), flags=flags)
+
+
+def test_many_bands_big_boxes_null_renderer(amd):
+    """C = 10 (> one band chunk), boxes 61^2 (register path NPL=59) and 81^2 (generic
+    LDS kernel), NullRenderer"""
+    rng = np.random.default_rng(22)
+    specs, kernel, data, weights = _random_scene(
+        rng, 10, 96, 100, [((61, 61), (10, 20)), ((41, 41), (50, 50))])
+    _compare_steps(amd, specs, None, data, weights, 2, {}, {})
+    specs, kernel, data, weights = _random_scene(
+        rng, 2, 120, 120, [((81, 81), (10, 20)), ((21, 21), (90, 90))])
+    _compare_steps(amd, specs, None, data, weights, 2, {}, {})
+
+
+def test_large_frame_uses_rocfft(amd):
+    """200x180 frame + 25^2 kernel: the padded band does not fit the LDS, so the batch
+    falls back to the rocFFT pipeline with the reference's FFT shape"""
+    rng = np.random.default_rng(23)
+    specs, kernel, data, weights = _random_scene(
+        rng, 2, 200, 180, [((41, 41), (30, 40)), ((31, 31), (150, 120))], kernel_shape=25)
+    batch, sc = _compare_steps(amd, specs, kernel, data, weights, 2, {}, {})
+    from oracle import fftconv
+
+    assert list(batch.fft_shape) == fftconv.fft_shape((2, 200, 180), kernel.shape, 3, (1, 2))
+    with pytest.raises(Exception):
+        amd.BlendBatch(data[None], weights[None], [[]], kernel=kernel, conv_path="fused")
+
+
+def test_blend_without_components_and_mixed_batch(amd):
+    """a batch where one blend has no components at all"""
+    from oracle import pgm
+    from scarlet_amd import synthetic
+
+    kern = synthetic.psfs()
+    s = synthetic.make_blend(5, kernel=kern)
+    comps = [amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                               sed_min_step=s["noise_rms"]) for k in range(10)]
+    data = np.stack([s["data"], s["data"]])
+    weights = np.stack([s["weights"], s["weights"]])
+    batch = amd.BlendBatch(data, weights, [[], comps], kernel=kern[2], max_iter=4)
+    model, rendered, logL = batch.forward()
+    assert not model[0].any() and not rendered[0].any()
+    sc = pgm.Scene(s["data"].shape, s["data"], s["weights"], kern[2], [])
+    assert abs(logL[0] - sc.log_likelihood(np.zeros_like(s["data"]))) < 1e-5 * abs(logL[0])
+    batch.step(0, 2)
+    assert batch.status() == (2, -1)
+    sc1 = pgm.Scene(s["data"].shape, s["data"], s["weights"], kern[2],
+                    [pgm.Component(s["seds"][k].copy(), s["morphs"][k].copy(), s["origins"][k],
+                                   sed_min_step=s["noise_rms"]) for k in range(10)])
+    for it in range(2):
+        sc1.step(it, 1e-3)
+    assert_loss_close(batch.loss_history()[1], sc1.loss, sc1.log_norm)
