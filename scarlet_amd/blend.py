@@ -70,21 +70,54 @@ class Blend(CombinedComponent):
 
     # ------------------------------------------------------------------ device
     def _observation(self):
-        if len(self.observations) != 1:
-            raise NotImplementedError("fitting several observations at once is not supported yet")
-        obs = self.observations[0]
-        r = obs.renderer
-        if type(r) not in (NullRenderer, ConvolutionRenderer):
-            raise NotImplementedError(
-                "renderer {} cannot run on the device".format(type(r).__name__)
-            )
-        if r.channel_map is not None or tuple(obs.shape) != tuple(self.frame.shape):
-            raise NotImplementedError(
-                "observations must cover the model frame with identical channels"
-            )
-        if obs.parameters:
-            raise NotImplementedError("parameterised renderers are not supported")
-        return obs
+        """(data, weights, kernel) of the scene as ONE cube over the model channels.
+
+        Several observations on the model's pixel grid (e.g. different instruments
+        covering different channels) are merged: every model channel must be
+        observed exactly once; per-channel difference kernels are zero-padded to a
+        common stamp, a NullRenderer observation contributes a delta kernel.  The
+        summed log-likelihood of the reference's loop over observations
+        (blend.py:265-271) is the log-likelihood of the merged cube."""
+        C = self.frame.C
+        spatial = tuple(self.frame.shape[1:])
+        channels = list(self.frame.channels)
+        data = np.zeros(self.frame.shape, dtype=np.float32)
+        weights = np.zeros(self.frame.shape, dtype=np.float32)
+        kernels, covered = [None] * C, np.zeros(C, dtype=int)
+        for obs in self.observations:
+            r = obs.renderer
+            if type(r) not in (NullRenderer, ConvolutionRenderer):
+                raise NotImplementedError(
+                    "renderer {} cannot run on the device".format(type(r).__name__))
+            if tuple(obs.shape[1:]) != spatial:
+                raise NotImplementedError("observations must cover the model frame spatially")
+            if obs.parameters:
+                raise NotImplementedError("parameterised renderers are not supported")
+            idx = [channels.index(c) for c in obs.channels]
+            covered[idx] += 1
+            data[idx] = obs.data
+            weights[idx] = obs.weights
+            if isinstance(r, ConvolutionRenderer):
+                k = np.asarray(r.diff_kernel.image, dtype=np.float32)
+                for j, c in enumerate(idx):
+                    kernels[c] = k[j if k.shape[0] > 1 else 0]
+        if np.any(covered != 1):
+            raise NotImplementedError("every model channel must be observed exactly once")
+        if all(k is None for k in kernels):
+            return data, weights, None
+        ph = max(k.shape[0] for k in kernels if k is not None)
+        pw = max(k.shape[1] for k in kernels if k is not None)
+        ph, pw = ph | 1, pw | 1  # odd, so that the stamps share their centre
+        kernel = np.zeros((C, ph, pw), dtype=np.float32)
+        for c, k in enumerate(kernels):
+            if k is None:
+                kernel[c, ph // 2, pw // 2] = 1
+            else:
+                oy, ox = ph // 2 - k.shape[0] // 2, pw // 2 - k.shape[1] // 2
+                kernel[c, oy:oy + k.shape[0], ox:ox + k.shape[1]] = k
+        if all(np.array_equal(kernel[0], kernel[c]) for c in range(1, C)):
+            kernel = kernel[:1]
+        return data, weights, kernel
 
     def _specs(self, comps):
         specs = []
@@ -121,15 +154,9 @@ class Blend(CombinedComponent):
         return specs
 
     def _build_batch(self, comps, capacity):
-        obs = self._observation()
-        kernel = None
-        if isinstance(obs.renderer, ConvolutionRenderer):
-            kernel = np.ascontiguousarray(obs.renderer.diff_kernel.image, dtype=np.float32)
-        batch = BlendBatch(
-            np.asarray(obs.data, dtype=np.float32)[None],
-            np.asarray(obs.weights, dtype=np.float32)[None],
-            [self._specs(comps)], kernel=kernel, max_iter=max(capacity, 1),
-        )
+        data, weights, kernel = self._observation()
+        batch = BlendBatch(data[None], weights[None], [self._specs(comps)], kernel=kernel,
+                           max_iter=max(capacity, 1))
         params = [(c.children[0].parameters[0], c.children[1].parameters[0]) for c in comps]
         if all(p.m is not None and p.v is not None and p.vhat is not None
                for pair in params for p in pair):

@@ -129,3 +129,28 @@ def test_quickstart_initialisation_matches_reference(hsc):
     assert abs(logL0 - float(hsc["logL"])) < 1e-3 * abs(float(hsc["logL"]))
     n, logL = blend.fit(100, e_rel=1e-4)
     assert logL > logL0 and n <= 100
+
+
+def test_two_observations_equal_one(hsc):
+    """the same scene observed as (g,r,i) and (z,y) by two Observations gives the same
+    fit as the single 5-band Observation (loss summed over observations, blend.py:265-271)"""
+    import scarlet_amd as scarlet
+
+    blend1, _ = build_blend(hsc, resizing=False)
+    n1, logL1 = blend1.fit(12, e_rel=1e-6)
+
+    filters = list("grizy")
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5)
+    frame = scarlet.Frame(hsc["images"].shape, psf=model_psf, channels=filters)
+    obs_a = scarlet.Observation(hsc["images"][:3], psf=scarlet.ImagePSF(hsc["psfs"][:3].copy()),
+                                weights=hsc["weights"][:3], channels=filters[:3]).match(frame)
+    obs_b = scarlet.Observation(hsc["images"][3:], psf=scarlet.ImagePSF(hsc["psfs"][3:].copy()),
+                                weights=hsc["weights"][3:], channels=filters[3:]).match(frame)
+    assert obs_a.renderer.channel_map == slice(0, 3) and obs_b.renderer.channel_map == slice(3, 5)
+    blend2, _ = build_blend(hsc, resizing=False)
+    blend2.observations = (obs_a, obs_b)
+    n2, logL2 = blend2.fit(12, e_rel=1e-6)
+    assert n1 == n2 == 12
+    assert_allclose(np.array(blend2.loss), np.array(blend1.loss), rtol=1e-6)
+    for p1, p2 in zip(blend1.parameters, blend2.parameters):
+        assert_allclose(np.asarray(p2), np.asarray(p1), rtol=1e-5, atol=1e-7)
