@@ -934,13 +934,13 @@ int smi_debug_fused_stamps(smi_batch *b, long long *out6) {
     SMI_REQUIRE(b && out6, "null argument");
     SMI_HIP(hipSetDevice(b->device));
     if (!b->dbg) {
-        SMI_HIP(dev_alloc(&b->dbg, 8));
-        SMI_HIP(hipMemset(b->dbg, 0, 8 * sizeof(long long)));
-        std::memset(out6, 0, 6 * sizeof(long long));
+        SMI_HIP(dev_alloc(&b->dbg, 16));
+        SMI_HIP(hipMemset(b->dbg, 0, 16 * sizeof(long long)));
+        std::memset(out6, 0, 16 * sizeof(long long));
         return SMI_OK;
     }
     SMI_HIP(hipStreamSynchronize(b->stream));
-    SMI_HIP(hipMemcpy(out6, b->dbg, 6 * sizeof(long long), hipMemcpyDeviceToHost));
+    SMI_HIP(hipMemcpy(out6, b->dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     return SMI_OK;
 }
 

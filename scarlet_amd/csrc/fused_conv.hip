@@ -205,6 +205,11 @@ struct Conv {
     }
 };
 
+// workgroup barrier that orders LDS traffic only (no vector-memory drain)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // element (row r of the chunk, column x) of the pair-packed scratch
 __device__ __forceinline__ float &zref(float2 *Z, int SX, int r, int x) {
     float2 &e = Z[(r >> 1) * SX + x];
@@ -257,6 +262,19 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                                C::FY * C::NKX;
     const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
     const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
+    // component metadata of the blend, one component per lane (groups of 64), fetched
+    // once with vector loads and broadcast later with v_readlane: the per-component
+    // scalar loads were the latency chain of the render stage
+    auto lane_meta = [&](int k0, int &oy, int &ox, int &hh, int &ww, int &mo, float &sd) {
+        const int k = k0 + lane;
+        const bool ok = k < ce;
+        oy = ok ? v.c_oy[k] : 0;
+        ox = ok ? v.c_ox[k] : 0;
+        hh = ok ? v.c_h[k] : 0;
+        ww = ok ? v.c_w[k] : 0;
+        mo = ok ? (int)v.c_moff[k] : 0;  // packed morphology offsets fit 31 bits
+        sd = ok ? v.sed[(int64_t)k * v.C + c] : 0.f;
+    };
     __syncthreads();
 #define SMI_STAMP(i) if (dbg && tid == 0 && blockIdx.x == 0) dbg[i] = clock64()
     SMI_STAMP(0);
@@ -269,36 +287,88 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         // pixel still accumulates its components in ascending order
         for (int i = tid; i < kPairs * C::SX; i += kThreads) cv.Z[i] = make_float2(0.f, 0.f);
         __syncthreads();
-        for (int k = cs; k < ce; ++k) {
-            const int oy = v.c_oy[k], ox = v.c_ox[k], w = v.c_w[k];
-            const int r_lo = max(y0, oy), r_hi = min(min(y0 + 2 * kPairs, H), oy + v.c_h[k]);
-            const int x_lo = max(0, ox), x_hi = min(W, ox + w);
-            const int ncols = x_hi - x_lo, npx = (r_hi - r_lo) * ncols;
-            if (r_hi <= r_lo || ncols <= 0) continue;  // wave-uniform
-            const float sed = v.sed[(int64_t)k * v.C + c];
-            const float *mbase = v.morph + v.c_moff[k];
-            for (int p0 = tid; p0 < npx; p0 += 4 * kThreads) {
-                float mv[4];
-                int rr[4], xx[4];
+        // Components in groups of kGroup.  Phase 1 issues every morphology load of the
+        // group (<= kPer pixels per thread and component) before any is consumed: one
+        // memory latency per group instead of one per component.  Phase 2 adds the
+        // components one after the other (read-modify-write in LDS, LDS-only barrier in
+        // between), so every pixel still sums its components in ascending order.
+        constexpr int kGroup = 12, kPer = 2;
+        if (ch == 0) SMI_STAMP(6);
+        for (int kb = cs; kb < ce; kb += 64) {
+            int l_oy, l_ox, l_h, l_w, l_mo;
+            float l_sed;
+            lane_meta(kb, l_oy, l_ox, l_h, l_w, l_mo, l_sed);
+            const int kend = min(ce, kb + 64);
+            for (int k0 = kb; k0 < kend; k0 += kGroup) {
+                float mv[kGroup][kPer];
+                int cell[kGroup][kPer];  // float index into Z, -1: nothing to add
+                unsigned big = 0;        // components with a tail beyond kPer * kThreads pixels
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int p = p0 + u * kThreads;
-                    const int ry = p / ncols;
-                    rr[u] = r_lo + ry;
-                    xx[u] = x_lo + (p - ry * ncols);
-                    mv[u] = p < npx ? mbase[(int64_t)(rr[u] - oy) * w + (xx[u] - ox)] : 0.f;
-                }
+                for (int g = 0; g < kGroup; ++g) {
+                    const int kl = min(k0 + g, kend - 1) - kb;  // lane that holds component k
+                    const int oy = __builtin_amdgcn_readlane(l_oy, kl);
+                    const int ox = __builtin_amdgcn_readlane(l_ox, kl);
+                    const int w = __builtin_amdgcn_readlane(l_w, kl);
+                    const int hh = __builtin_amdgcn_readlane(l_h, kl);
+                    const int mo = __builtin_amdgcn_readlane(l_mo, kl);
+                    const int r_lo = max(y0, oy), r_hi = min(min(y0 + 2 * kPairs, H), oy + hh);
+                    const int x_lo = max(0, ox), ncols = min(W, ox + w) - x_lo;
+                    const int npx =
+                        (k0 + g < kend && r_hi > r_lo && ncols > 0) ? (r_hi - r_lo) * ncols : 0;
+                    if (npx > kPer * kThreads) big |= 1u << g;
+                    const float inv = 1.0f / (float)max(ncols, 1);
+                    const float *mbase = v.morph + mo;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (p0 + u * kThreads < npx) {
-                        float &slot = zref(cv.Z, C::SX, rr[u] - y0, xx[u]);
-                        slot = fmaf(sed, mv[u], slot);
+                    for (int u = 0; u < kPer; ++u) {
+                        const int p = tid + u * kThreads;
+                        cell[g][u] = -1;
+                        mv[g][u] = 0.f;
+                        if (p < npx) {
+                            const int ry = (int)(((float)p + 0.5f) * inv);  // exact: p < 2^16
+                            const int rr = r_lo + ry, xx = x_lo + p - ry * ncols;
+                            mv[g][u] = mbase[(rr - oy) * w + (xx - ox)];
+                            cell[g][u] = 2 * (((rr - y0) >> 1) * C::SX + xx) + ((rr - y0) & 1);
+                        }
                     }
+                }
+                float *zf = reinterpret_cast<float *>(cv.Z);
+                if (ch == 0) SMI_STAMP(7);
+                // phase 2 is kept to a dozen instructions per component: every wave of the
+                // block has to issue them before the barrier releases
+#pragma unroll
+                for (int g = 0; g < kGroup; ++g) {
+                    if (k0 + g >= kend) break;
+                    const int kl = k0 + g - kb;
+                    const float sed = __int_as_float(
+                        __builtin_amdgcn_readlane(__float_as_int(l_sed), kl));
+#pragma unroll
+                    for (int u = 0; u < kPer; ++u)
+                        if (cell[g][u] >= 0)
+                            zf[cell[g][u]] = fmaf(sed, mv[g][u], zf[cell[g][u]]);
+                    if (big & (1u << g)) {  // box with more than kPer * kThreads pixels here
+                        const int oy = __builtin_amdgcn_readlane(l_oy, kl);
+                        const int ox = __builtin_amdgcn_readlane(l_ox, kl);
+                        const int w = __builtin_amdgcn_readlane(l_w, kl);
+                        const int hh = __builtin_amdgcn_readlane(l_h, kl);
+                        const int r_lo = max(y0, oy), r_hi = min(min(y0 + 2 * kPairs, H), oy + hh);
+                        const int x_lo = max(0, ox), ncols = min(W, ox + w) - x_lo;
+                        const int npx = (r_hi - r_lo) * ncols;
+                        const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
+                        for (int p = tid + kPer * kThreads; p < npx; p += kThreads) {
+                            const int ry = p / ncols;
+                            const int rr = r_lo + ry, xx = x_lo + p - ry * ncols;
+                            float &slot = zref(cv.Z, C::SX, rr - y0, xx);
+                            slot = fmaf(sed, mbase[(rr - oy) * w + (xx - ox)], slot);
+                        }
+                    }
+                    lds_barrier();
+                }
             }
-            __syncthreads();
         }
         __syncthreads();
+        if (ch == 0) SMI_STAMP(8);
         cv.rows_forward(y0, W);
+        if (ch == 0) SMI_STAMP(9);
     }
     SMI_STAMP(1);
     // ---- B: columns, x K^ --------------------------------------------------------

@@ -8,7 +8,7 @@ scenes = synthetic.make_batch(range(1234, 1234 + nb), kernel=kern)
 comps = [[ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k], sed_min_step=s["noise_rms"]) for k in range(10)] for s in scenes]
 b = BlendBatch(np.stack([s["data"] for s in scenes]), np.stack([s["weights"] for s in scenes]), comps, kernel=kern[2], max_iter=64)
 lib = _lib.load()
-out = (ctypes.c_longlong * 6)()
+out = (ctypes.c_longlong * 16)()
 lib.smi_debug_fused_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.smi_debug_fused_stamps(b._h, out)
 b.step(0, 5)
@@ -19,3 +19,4 @@ names = ["A rows fwd+render", "B columns", "C inv+resid+fwd", "B' columns", "D r
 for i, n in enumerate(names):
     print("%-22s %8d cycles" % (n, t[i + 1] - t[i]))
 print("total", t[5] - t[0])
+print("chunk0 A: zero", t[6]-t[0], "phase1 loads", t[7]-t[6], "phase2 rmw", t[8]-t[7], "rows_fwd", t[9]-t[8])
