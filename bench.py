@@ -87,10 +87,19 @@ def main():
     import torch
     from scarlet_amd import BlendBatch, ComponentSpec, dist as sdist
 
-    rank, local_rank, world = sdist.init_process_group()
-    assert world == args.gpus, "launch with torchrun --nproc-per-node == --gpus"
+    # SCARLET_AMD_DIST_BACKEND=gloo + SCARLET_AMD_SHARE_GPU=1 let several ranks share one GPU
+    # (used only to exercise the multi-rank code path on a single-GPU box)
+    backend = os.environ.get("SCARLET_AMD_DIST_BACKEND")
+    share = os.environ.get("SCARLET_AMD_SHARE_GPU") == "1"
+    if share:
+        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+    rank, local_rank, world = sdist.env_rank()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    sdist.init_process_group(backend=backend, device_index=local_rank)
+    assert world == args.gpus, "launch with torchrun --nproc-per-node == --gpus"
     e_rel = 1e-3  # Blend.fit default; tolerance of the prox sub-iterations
 
     nb = args.blends

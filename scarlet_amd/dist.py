@@ -26,19 +26,21 @@ def shard_range(n_total, rank, world_size):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, device_index=None):
     """Initialise ``torch.distributed`` from the environment if WORLD_SIZE > 1."""
     import torch
     import torch.distributed as dist
 
     rank, local_rank, world = env_rank()
+    if device_index is None:
+        device_index = local_rank
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(device_index)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
