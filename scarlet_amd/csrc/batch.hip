@@ -358,9 +358,9 @@ int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
     } else {
         SMI_HIP(dev_alloc(&b->Q, n_real));
         SMI_HIP(hipMemset(b->Q, 0, n_real * sizeof(float)));
-        SMI_FFT(rocfft_setup());
     }
     if (padded) {
+        SMI_FFT(rocfft_setup());
         const size_t n_cplx = (size_t)nb * C * b->Fy * b->Fxh;
         SMI_HIP(dev_alloc(&b->S, n_cplx));
         const size_t lengths[2] = {(size_t)b->Fx, (size_t)b->Fy};
@@ -535,6 +535,23 @@ int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
     float *d_kern = nullptr, *d_pad = nullptr;
     int rc;
     if ((rc = upload(&d_kern, kernel, (size_t)n_img * ph * pw))) return rc;
+    if (b->fused) {
+        // direct DFT of the stamp (no rocFFT plan): 0.5 = the 1/2 of the fused kernel's
+        // Hermitian row separation, 1/(Fy Fx) = normalisation of its inverse transforms
+        double2 *d_tmp = nullptr;
+        SMI_HIP(dev_alloc(&d_tmp, (size_t)n_img * ph * b->Fxh));
+        if (!b->Kt) SMI_HIP(dev_alloc(&b->Kt, n_cplx));
+        const double sc = 0.5 / ((double)b->Fy * (double)b->Fx);
+        if ((rc = launch_stamp_spectrum(d_kern, d_tmp, b->Kt, n_img, ph, pw, b->Fy, b->Fx, sc,
+                                        b->stream)))
+            return rc;
+        SMI_HIP(hipStreamSynchronize(b->stream));
+        SMI_HIP(hipGetLastError());
+        (void)hipFree(d_tmp);
+        (void)hipFree(d_kern);
+        b->have_kernel = true;
+        return SMI_OK;
+    }
     SMI_HIP(dev_alloc(&d_pad, n_real));
     SMI_HIP(hipMemsetAsync(d_pad, 0, n_real * sizeof(float), b->stream));
     const float scale = 1.0f / ((float)b->Fy * (float)b->Fx);

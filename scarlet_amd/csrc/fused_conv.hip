@@ -467,6 +467,51 @@ __global__ void permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int NKX,
     Kt[((int64_t)img * FY + pos<FY1>(ky)) * NKX + kx] = make_float2(k.x * scale, k.y * scale);
 }
 
+// Kernel spectrum for the fused path without rocFFT (whose plan creation costs ~0.6 s of
+// run-time compilation per batch): a separable direct DFT of the small stamp,
+//   A[dy][kx]  = sum_dx K[dy][dx] exp(-2 pi i kx (dx - pw/2) / Fx)
+//   K^[ky][kx] = sum_dy A[dy][kx] exp(-2 pi i ky (dy - ph/2) / Fy)
+// i.e. the stamp centre sits on index 0 (the layout the reference reaches with _pad +
+// ifftshift, fft.py:255-273); written in the digit-swapped ky order, scaled.
+__global__ void stamp_dft_x(const float *kern, double2 *A, int ph, int pw, int Fx, int NKX) {
+    const int img = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ph * NKX) return;
+    const int dy = i / NKX, kx = i - dy * NKX;
+    double re = 0.0, im = 0.0;  // set-up code: double accumulation, exact angle reduction
+    for (int dx = 0; dx < pw; ++dx) {
+        int t = (kx * (dx - pw / 2)) % Fx;
+        if (t < 0) t += Fx;
+        double s, c;
+        sincospi(2.0 * (double)t / (double)Fx, &s, &c);
+        const double k = (double)kern[((int64_t)img * ph + dy) * pw + dx];
+        re += k * c;
+        im -= k * s;
+    }
+    A[(int64_t)img * ph * NKX + i] = make_double2(re, im);
+}
+
+template <int FY1>
+__global__ void stamp_dft_y(const double2 *A, float2 *Kt, int ph, int NKX, double scale) {
+    constexpr int FY = FY1 * kF2;
+    const int img = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= FY * NKX) return;
+    const int ky = i / NKX, kx = i - ky * NKX;
+    double re = 0.0, im = 0.0;
+    for (int dy = 0; dy < ph; ++dy) {
+        int t = (ky * (dy - ph / 2)) % FY;
+        if (t < 0) t += FY;
+        double s, c;
+        sincospi(2.0 * (double)t / (double)FY, &s, &c);
+        const double2 a = A[((int64_t)img * ph + dy) * NKX + kx];
+        re += a.x * c + a.y * s;   // a * (c - i s)
+        im += a.y * c - a.x * s;
+    }
+    Kt[((int64_t)img * FY + pos<FY1>(ky)) * NKX + kx] =
+        make_float2((float)(re * scale), (float)(im * scale));
+}
+
 template <int FY1, int FX1>
 int launch_impl(const BatchView &v, const float2 *Kt, int k_bands, int k_per_blend, float *out,
                 int mode, long long *dbg, hipStream_t s) {
@@ -534,6 +579,26 @@ int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float2 *Kt, int 
     SMI_FUSED_DISPATCH(launch_impl, v, Kt, k_bands, k_per_blend, out, mode, dbg, s)
     set_error("fused convolution: FFT shape not instantiated");
     return SMI_ERR_INVALID;
+}
+
+// d_kern: [n_img][ph][pw] on the device; Kt: [n_img][Fy][Fx/2+1]
+int launch_stamp_spectrum(const float *d_kern, double2 *d_tmp, float2 *Kt, int n_img, int ph,
+                          int pw, int Fy, int Fx, double scale, hipStream_t s) {
+    const int NKX = Fx / 2 + 1;
+    hipLaunchKernelGGL(stamp_dft_x, dim3((ph * NKX + 255) / 256, n_img), dim3(256), 0, s, d_kern,
+                       d_tmp, ph, pw, Fx, NKX);
+    const dim3 grid((Fy * NKX + 255) / 256, n_img);
+    switch (Fy / 16) {
+        case 4: hipLaunchKernelGGL(stamp_dft_y<4>, grid, dim3(256), 0, s, d_tmp, Kt, ph, NKX, scale); break;
+        case 5: hipLaunchKernelGGL(stamp_dft_y<5>, grid, dim3(256), 0, s, d_tmp, Kt, ph, NKX, scale); break;
+        case 6: hipLaunchKernelGGL(stamp_dft_y<6>, grid, dim3(256), 0, s, d_tmp, Kt, ph, NKX, scale); break;
+        case 8: hipLaunchKernelGGL(stamp_dft_y<8>, grid, dim3(256), 0, s, d_tmp, Kt, ph, NKX, scale); break;
+        case 10: hipLaunchKernelGGL(stamp_dft_y<10>, grid, dim3(256), 0, s, d_tmp, Kt, ph, NKX, scale); break;
+        default:
+            set_error("stamp spectrum: unsupported FFT height");
+            return SMI_ERR_INVALID;
+    }
+    return SMI_OK;
 }
 
 int launch_permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int n_img, int Fy, int Fx,
