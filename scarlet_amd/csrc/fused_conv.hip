@@ -303,6 +303,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                 float mv[kGroup][kPer];
                 int cell[kGroup][kPer];  // float index into Z, -1: nothing to add
                 unsigned big = 0;        // components with a tail beyond kPer * kThreads pixels
+                unsigned live = 0;       // components that touch this chunk at all
 #pragma unroll
                 for (int g = 0; g < kGroup; ++g) {
                     const int kl = min(k0 + g, kend - 1) - kb;  // lane that holds component k
@@ -316,13 +317,18 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                     const int npx =
                         (k0 + g < kend && r_hi > r_lo && ncols > 0) ? (r_hi - r_lo) * ncols : 0;
                     if (npx > kPer * kThreads) big |= 1u << g;
+                    if (npx > 0) live |= 1u << g;
+#pragma unroll
+                    for (int u = 0; u < kPer; ++u) {
+                        cell[g][u] = -1;
+                        mv[g][u] = 0.f;
+                    }
+                    if (npx <= 0) continue;  // block-uniform: box does not touch this chunk
                     const float inv = 1.0f / (float)max(ncols, 1);
                     const float *mbase = v.morph + mo;
 #pragma unroll
                     for (int u = 0; u < kPer; ++u) {
                         const int p = tid + u * kThreads;
-                        cell[g][u] = -1;
-                        mv[g][u] = 0.f;
                         if (p < npx) {
                             const int ry = (int)(((float)p + 0.5f) * inv);  // exact: p < 2^16
                             const int rr = r_lo + ry, xx = x_lo + p - ry * ncols;
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
 #pragma unroll
                 for (int g = 0; g < kGroup; ++g) {
                     if (k0 + g >= kend) break;
+                    if (!(live & (1u << g))) continue;  // block-uniform
                     const int kl = k0 + g - kb;
                     const float sed = __int_as_float(
                         __builtin_amdgcn_readlane(__float_as_int(l_sed), kl));
