@@ -515,3 +515,39 @@ def test_blend_without_components_and_mixed_batch(amd):
     for it in range(2):
         sc1.step(it, 1e-3)
     assert_loss_close(batch.loss_history()[1], sc1.loss, sc1.log_norm)
+
+
+def test_batch_fit_to_convergence_mixed_states(amd):
+    """64 blends fitted together until each one converges on its own: blends freeze at
+    different iterations; two of them are compared with the oracle run alone"""
+    from oracle import pgm
+    from scarlet_amd import synthetic
+
+    kern = synthetic.psfs()
+    scenes = synthetic.make_batch(range(500, 564), kernel=kern)
+    comps = [[amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                                sed_min_step=s["noise_rms"]) for k in range(10)] for s in scenes]
+    batch = amd.BlendBatch(np.stack([s["data"] for s in scenes]),
+                           np.stack([s["weights"] for s in scenes]), comps, kernel=kern[2],
+                           max_iter=200)
+    n_iter, logL = batch.fit(max_iter=200, e_rel=1e-3)
+    assert batch.status() == (0, -1)
+    assert n_iter.min() >= 3 and n_iter.max() < 200 and len(set(n_iter.tolist())) > 3
+    losses = batch.loss_history()
+    for b in range(64):
+        assert len(losses[b]) == n_iter[b]
+        assert -losses[b][-1] > -losses[b][0]
+        # the stopping rule held exactly at the last iteration and not before (blend.py:294-299)
+        d = np.abs(np.diff(losses[b]))
+        rel = d / np.abs(losses[b][1:])
+        assert rel[-1] < 1e-3
+        assert np.all(rel[1:-1] >= 1e-3)
+    for b in (0, 37):
+        s = scenes[b]
+        sc = pgm.Scene(s["data"].shape, s["data"], s["weights"], kern[2],
+                       [pgm.Component(s["seds"][k].copy(), s["morphs"][k].copy(), s["origins"][k],
+                                      sed_min_step=s["noise_rms"]) for k in range(10)])
+        n_ref, logL_ref = sc.fit(max_iter=200, e_rel=1e-3)
+        assert abs(int(n_iter[b]) - n_ref) <= max(2, n_ref // 10)
+        chi, chi_ref = -logL[b] - sc.log_norm, -logL_ref - sc.log_norm
+        assert abs(chi - chi_ref) < 3e-3 * abs(chi_ref)
