@@ -166,6 +166,10 @@ int smi_batch_get_moments(smi_batch *b, float *m_sed, float *v_sed, float *vhat_
 int smi_batch_get_parameters(smi_batch *b, float *sed, float *morph);
 int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph);
 
+/* AMSGrad constants forwarded by Blend.fit(**alg_kwargs) to adaprox (blend.py:165-180);
+ * defaults b1 = 0.9, b2 = 0.999, eps = 1e-8 (lite/parameters.py:194) */
+int smi_batch_set_optimizer(smi_batch *b, float b1, float b2, float eps);
+
 /* HIP stream the batch launches on (hipStream_t as void*); NULL = default stream */
 int smi_batch_set_stream(smi_batch *b, void *stream);
 

@@ -272,7 +272,8 @@ class Scene:
             if not (np.isfinite(c.sed).all() and np.isfinite(c.morph).all()):
                 raise ArithmeticError("component {} is not finite".format(k))
 
-    def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, prox_max_iter=10, resizing=False):
+    def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, prox_max_iter=10, resizing=False,
+            b1=0.9, b2=0.999, eps=1e-8):
         """``Blend.fit`` (blend.py:85-198).
 
         Iteration order follows the reference authors' own loop
@@ -291,7 +292,7 @@ class Scene:
             local = 0
             restart = False
             while it + local < max_iter:
-                self.step(local, e_rel, prox_max_iter)
+                self.step(local, e_rel, prox_max_iter, b1, b2, eps)
                 self.check_parameters()
                 if resizing and local > 0 and local % 10 == 0:
                     # Blend._callback calls src.update() per source (blend.py:284-292);

@@ -97,6 +97,9 @@ SYMBOLS = {
     "smi_batch_get_moments": (ctypes.c_int, [ctypes.c_void_p] + [c_f32p] * 6),
     "smi_batch_get_parameters": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
     "smi_batch_set_parameters": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
+    "smi_batch_set_optimizer": (
+        ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float]
+    ),
     "smi_batch_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "smi_batch_forward": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f64p]),
     "smi_batch_gradient": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),

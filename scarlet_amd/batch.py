@@ -169,6 +169,10 @@ class BlendBatch:
         _lib.check(self._lib.smi_batch_fft_shape(self._h, ctypes.byref(fy), ctypes.byref(fx)))
         return fy.value, fx.value
 
+    def set_optimizer(self, b1=0.9, b2=0.999, eps=1e-8):
+        """AMSGrad constants (``proxmin.adaprox`` keywords b1, b2, eps)."""
+        _lib.check(self._lib.smi_batch_set_optimizer(self._h, b1, b2, eps))
+
     def set_stream(self, stream_handle):
         """Launch on the given HIP stream (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
         _lib.check(self._lib.smi_batch_set_stream(self._h, ctypes.c_void_p(stream_handle)))

@@ -200,6 +200,8 @@ class Blend(CombinedComponent):
         prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
         if scheme != "amsgrad":
             raise NotImplementedError("only scheme='amsgrad' runs on the device")
+        opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
+                   eps=alg_kwargs.pop("eps", 1e-8))
         if alg_kwargs:
             raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
 
@@ -207,6 +209,7 @@ class Blend(CombinedComponent):
         while it < max_iter:
             comps = _flatten(self.sources)
             batch = self._build_batch(comps, max_iter - it)
+            batch.set_optimizer(**opt)
             restart = False
             try:
                 local = 0  # adaprox's own counter, restarts after every resize

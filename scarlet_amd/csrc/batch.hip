@@ -107,6 +107,7 @@ struct smi_batch {
     SweepPlanDev *d_plans = nullptr;
     int max_levels = 0;
     BatchView view{};
+    float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> events;
@@ -161,6 +162,9 @@ void refresh_view(smi_batch *b) {
     v.plans = b->d_plans;
     v.max_levels = b->max_levels;
     v.fast_plans = 1;
+    v.b1 = b->b1;
+    v.b2 = b->b2;
+    v.eps = b->eps;
     for (const auto &pl : b->plans)
         if (!pl.slots) v.fast_plans = 0;
 }
@@ -713,6 +717,18 @@ int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph)
     if (morph)
         SMI_HIP(hipMemcpy(b->morph, morph, (size_t)b->n_morph * sizeof(float),
                           hipMemcpyHostToDevice));
+    return SMI_OK;
+}
+
+int smi_batch_set_optimizer(smi_batch *b, float b1, float b2, float eps) {
+    SMI_REQUIRE(b, "null batch");
+    SMI_REQUIRE(b1 >= 0.f && b1 < 1.f && b2 >= 0.f && b2 < 1.f && eps >= 0.f, "bad AMSGrad constants");
+    b->b1 = b1;
+    b->b2 = b2;
+    b->eps = eps;
+    const int keep = b->view.max_box_pixels;
+    refresh_view(b);
+    b->view.max_box_pixels = keep;
     return SMI_OK;
 }
 

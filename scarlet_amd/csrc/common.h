@@ -111,6 +111,7 @@ struct BatchView {
     int32_t max_box_pixels;
     int32_t max_levels;  // over all plans
     int32_t fast_plans;  // every plan has the slot layout
+    float b1, b2, eps;   // AMSGrad constants (defaults 0.9, 0.999, 1e-8: lite/parameters.py:194)
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);

@@ -15,7 +15,6 @@ namespace {
 
 constexpr int kBandChunk = 8;
 constexpr int kPixBlock = 256;
-constexpr float kB1 = 0.9f, kB2 = 0.999f, kEps = 1e-8f;  // lite/parameters.py:194
 
 // float reductions over the wavefront without LDS traffic: four DPP steps reduce each
 // row of 16 lanes (quad swaps, half-row mirror, row mirror), v_readlane combines the
@@ -334,13 +333,13 @@ __device__ __forceinline__ int update_spectrum(const BatchView &v, const CompCtx
     float psi = 0.f, x = s;
     if (on) {
         const float alpha = fmaxf(v.c_sed_min_step[idx], v.c_sed_rel[c.k] * mean);
-        const float m = (1.f - kB1) * g_sed + kB1 * v.m_sed[idx];
-        const float vv = (1.f - kB2) * g_sed * g_sed + kB2 * v.v_sed[idx];
+        const float m = (1.f - v.b1) * g_sed + v.b1 * v.m_sed[idx];
+        const float vv = (1.f - v.b2) * g_sed * g_sed + v.b2 * v.v_sed[idx];
         const float vh = it == 0 ? vv : fmaxf(v.vh_sed[idx], vv);
         v.m_sed[idx] = m;
         v.v_sed[idx] = vv;
         v.vh_sed[idx] = vh;
-        psi = sqrtf(fmaxf(vh, kEps));
+        psi = sqrtf(fmaxf(vh, v.eps));
         float upd = alpha * m / psi;
         if (it == 0) upd /= 10.f;  // lite/parameters.py:288-291
         x = s - upd;
@@ -427,13 +426,13 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     float pmax = 0.f;
     for (int i = lane; i < N; i += 64) {
         const float g = us[i];
-        const float m = (1.f - kB1) * g + kB1 * v.m_morph[c.moff + i];
-        const float vv = (1.f - kB2) * g * g + kB2 * v.v_morph[c.moff + i];
+        const float m = (1.f - v.b1) * g + v.b1 * v.m_morph[c.moff + i];
+        const float vv = (1.f - v.b2) * g * g + v.b2 * v.v_morph[c.moff + i];
         const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
         v.m_morph[c.moff + i] = m;
         v.v_morph[c.moff + i] = vv;
         v.vh_morph[c.moff + i] = vh;
-        const float psi = sqrtf(fmaxf(vh, kEps));
+        const float psi = sqrtf(fmaxf(vh, v.eps));
         float upd = alpha * m / psi;
         if (it == 0) upd /= 10.f;
         const float x = c.morph[i] - upd;
@@ -579,13 +578,13 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
         rs[j] = 0.f;
         if (i < N) {
             const float g = us[i];
-            const float m = (1.f - kB1) * g + kB1 * v.m_morph[c.moff + i];
-            const float vv = (1.f - kB2) * g * g + kB2 * v.v_morph[c.moff + i];
+            const float m = (1.f - v.b1) * g + v.b1 * v.m_morph[c.moff + i];
+            const float vv = (1.f - v.b2) * g * g + v.b2 * v.v_morph[c.moff + i];
             const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
             v.m_morph[c.moff + i] = m;
             v.v_morph[c.moff + i] = vv;
             v.vh_morph[c.moff + i] = vh;
-            const float psi = sqrtf(fmaxf(vh, kEps));
+            const float psi = sqrtf(fmaxf(vh, v.eps));
             float upd = alpha * m / psi;
             if (it == 0) upd /= 10.f;
             xs[j] = zs[j] - upd;

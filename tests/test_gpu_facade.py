@@ -154,3 +154,20 @@ def test_two_observations_equal_one(hsc):
     assert_allclose(np.array(blend2.loss), np.array(blend1.loss), rtol=1e-6)
     for p1, p2 in zip(blend1.parameters, blend2.parameters):
         assert_allclose(np.asarray(p2), np.asarray(p1), rtol=1e-5, atol=1e-7)
+
+
+def test_fit_forwards_adam_constants(hsc):
+    """Blend.fit(**alg_kwargs): b1, b2, eps reach the device optimizer (blend.py:165-180)"""
+    blend, obs = build_blend(hsc, resizing=False)
+    n, logL = blend.fit(8, e_rel=1e-9, b1=0.8, b2=0.99, eps=1e-6)
+    sc = hsc_scene(hsc)
+    n_ref, logL_ref = sc.fit(8, e_rel=1e-9, b1=0.8, b2=0.99, eps=1e-6)
+    assert n == n_ref == 8
+    assert_allclose(np.array(blend.loss) - sc.log_norm, np.array(sc.loss) - sc.log_norm, rtol=2e-4)
+    default, _ = build_blend(hsc, resizing=False)
+    default.fit(8, e_rel=1e-9)
+    assert abs(default.loss[-1] - blend.loss[-1]) > 1e-3 * abs(blend.loss[-1] - sc.log_norm)
+    with pytest.raises(NotImplementedError):
+        blend.fit(2, scheme="adam")
+    with pytest.raises(NotImplementedError):
+        blend.fit(2, callback=lambda *a, **k: None)
