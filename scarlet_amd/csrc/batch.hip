@@ -302,7 +302,8 @@ int smi_apply_filter_f64(const double *image, int32_t H, int32_t W, const double
                                 result);
 }
 
-int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
+static int batch_create_impl(const smi_batch_desc *desc, int device, smi_batch **out,
+                             smi_batch **partial) {
     SMI_REQUIRE(desc && out, "null argument");
     SMI_REQUIRE(desc->n_blends > 0 && desc->n_blends <= 65535, "n_blends must be in [1, 65535]");
     SMI_REQUIRE(desc->C > 0 && desc->C <= 64, "C must be in [1, 64]");
@@ -319,6 +320,7 @@ int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
     SMI_HIP(hipSetDevice(device));
 
     smi_batch *b = new smi_batch();
+    *partial = b;  // released by the caller if anything below fails
     b->d = *desc;
     b->device = device;
     b->null_renderer = desc->kernel_h == 0;
@@ -398,7 +400,19 @@ int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
     SMI_HIP(hipMemset(b->last_loss, 0, nb * sizeof(double)));
     refresh_view(b);
     *out = b;
+    *partial = nullptr;
     return SMI_OK;
+}
+
+int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
+    smi_batch *partial = nullptr;
+    const int rc = batch_create_impl(desc, device, out, &partial);
+    if (rc != SMI_OK && partial) {
+        const std::string msg = g_error;  // destroy() must not clobber the reason
+        smi_batch_destroy(partial);
+        g_error = msg;
+    }
+    return rc;
 }
 
 int smi_batch_destroy(smi_batch *b) {
@@ -623,6 +637,7 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     }
     for (int i = 0; i < nb; ++i) start[i + 1] += start[i];
     b->n_morph = moff[n];
+    SMI_REQUIRE(b->n_morph < ((int64_t)1 << 31), "more than 2^31 morphology pixels in one batch");
     b->view.max_box_pixels = max_pix;
 
     std::vector<float> zeros_n(n, 0.f), rel(n, 1e-2f);
