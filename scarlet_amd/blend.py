@@ -193,11 +193,17 @@ class Blend(CombinedComponent):
         (blend.py:194).  Iteration order: gradient at the current parameters
         (loss appended), AMSGrad + proximal update of every parameter, every 10
         iterations the resize hook, then the convergence test
-        ``it > min_iter and |dL| < e_rel |L|``."""
+        ``it > min_iter and |dL| < e_rel |L|``.
+
+        ``callback(*parameters, it=it)`` (an ``alg_kwargs`` entry like in the
+        reference, blend.py:168,301-302) switches to host-stepped mode: one
+        iteration per device call, parameters downloaded before every call of the
+        callback; ``StopIteration`` raised by it ends the fit cleanly."""
         if noise_factor:
             raise NotImplementedError("noise_factor > 0 is not supported")
         scheme = alg_kwargs.pop("scheme", "amsgrad")
         prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
+        callback = alg_kwargs.pop("callback", None)
         if scheme != "amsgrad":
             raise NotImplementedError("only scheme='amsgrad' runs on the device")
         opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
@@ -218,6 +224,8 @@ class Blend(CombinedComponent):
                     # i.e. once 11, 21, ... iterations of this batch are done
                     next_hook = 11 if local == 0 else ((local - 1) // 10 + 1) * 10 + 1
                     n = min(next_hook - local, max_iter - it - local)
+                    if callback is not None:
+                        n = 1
                     batch.step(local, n, e_rel=e_rel, min_iter=min_iter,
                                prox_max_iter=prox_max_iter, check_convergence=True)
                     active, err = batch.status()
@@ -237,6 +245,13 @@ class Blend(CombinedComponent):
                                 restart = True
                     if active == 0 and not restart:
                         break
+                    if callback is not None and not restart:
+                        if not hook:
+                            self._download(batch, comps)
+                        try:
+                            callback(*self.parameters, it=local - 1)
+                        except StopIteration:
+                            break
                 self.loss.extend(batch.loss_history()[0])
                 if not restart:
                     self._download(batch, comps)

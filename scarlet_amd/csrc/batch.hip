@@ -340,9 +340,9 @@ static int batch_create_impl(const smi_batch_desc *desc, int device, smi_batch *
             b->Fx = desc->fft_w;
             b->fused = desc->conv_path != 1 && fused_conv_instantiated(b->Fy, b->Fx);
         } else {
-            const int fy = fused_conv_length(H + desc->kernel_h / 2);
-            const int fx = fused_conv_length(W + desc->kernel_w / 2);
-            if (desc->conv_path != 1 && fy && fx && fused_conv_instantiated(fy, fx)) {
+            int fy = 0, fx = 0;
+            if (desc->conv_path != 1 &&
+                fused_conv_choose(H + desc->kernel_h / 2, W + desc->kernel_w / 2, &fy, &fx)) {
                 b->fused = true;
                 b->Fy = fy;
                 b->Fx = fx;

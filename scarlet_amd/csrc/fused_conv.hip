@@ -557,28 +557,50 @@ int fused_conv_length(int n) {
 
 #define SMI_FUSED_DISPATCH(FN, ...)                                             \
     switch (Fy / 16 * 100 + Fx / 16) {                                          \
-        case 404: return FN<4, 4>(__VA_ARGS__);                                 \
-        case 405: return FN<4, 5>(__VA_ARGS__);                                 \
-        case 505: return FN<5, 5>(__VA_ARGS__);                                 \
-        case 504: return FN<5, 4>(__VA_ARGS__);                                 \
-        case 506: return FN<5, 6>(__VA_ARGS__);                                 \
-        case 605: return FN<6, 5>(__VA_ARGS__);                                 \
-        case 606: return FN<6, 6>(__VA_ARGS__);                                 \
-        case 808: return FN<8, 8>(__VA_ARGS__);                                 \
-        case 810: return FN<8, 10>(__VA_ARGS__);                                \
-        case 1008: return FN<10, 8>(__VA_ARGS__);                               \
-        case 1010: return FN<10, 10>(__VA_ARGS__);                              \
+        case 404: return FN<4, 4>(__VA_ARGS__);                  \
+        case 405: return FN<4, 5>(__VA_ARGS__);                  \
+        case 406: return FN<4, 6>(__VA_ARGS__);                  \
+        case 408: return FN<4, 8>(__VA_ARGS__);                  \
+        case 410: return FN<4, 10>(__VA_ARGS__);                 \
+        case 504: return FN<5, 4>(__VA_ARGS__);                  \
+        case 505: return FN<5, 5>(__VA_ARGS__);                  \
+        case 506: return FN<5, 6>(__VA_ARGS__);                  \
+        case 508: return FN<5, 8>(__VA_ARGS__);                  \
+        case 510: return FN<5, 10>(__VA_ARGS__);                 \
+        case 604: return FN<6, 4>(__VA_ARGS__);                  \
+        case 605: return FN<6, 5>(__VA_ARGS__);                  \
+        case 606: return FN<6, 6>(__VA_ARGS__);                  \
+        case 608: return FN<6, 8>(__VA_ARGS__);                  \
+        case 610: return FN<6, 10>(__VA_ARGS__);                 \
+        case 804: return FN<8, 4>(__VA_ARGS__);                  \
+        case 805: return FN<8, 5>(__VA_ARGS__);                  \
+        case 806: return FN<8, 6>(__VA_ARGS__);                  \
+        case 808: return FN<8, 8>(__VA_ARGS__);                  \
+        case 810: return FN<8, 10>(__VA_ARGS__);                 \
+        case 1004: return FN<10, 4>(__VA_ARGS__);                \
+        case 1005: return FN<10, 5>(__VA_ARGS__);                \
+        case 1006: return FN<10, 6>(__VA_ARGS__);                \
+        case 1008: return FN<10, 8>(__VA_ARGS__);                \
+        case 1010: return FN<10, 10>(__VA_ARGS__);               \
         default: break;                                                         \
     }
 
-bool fused_conv_instantiated(int Fy, int Fx) {
-    switch (Fy / 16 * 100 + Fx / 16) {
-        case 404: case 405: case 505: case 504: case 506: case 605: case 606:
-        case 808: case 810: case 1008: case 1010:
-            return fused_conv_supported(Fy, Fx);
-        default:
-            return false;
-    }
+// every (Fy, Fx) in {64,80,96,128,160}^2 is instantiated; the LDS bound decides
+bool fused_conv_instantiated(int Fy, int Fx) { return fused_conv_supported(Fy, Fx); }
+
+// smallest-area supported shape with Fy >= ny and Fx >= nx
+bool fused_conv_choose(int ny, int nx, int *Fy, int *Fx) {
+    long best = 0;
+    for (int fy : {64, 80, 96, 128, 160})
+        for (int fx : {64, 80, 96, 128, 160}) {
+            if (fy < ny || fx < nx || !fused_conv_supported(fy, fx)) continue;
+            if (!best || (long)fy * fx < best) {
+                best = (long)fy * fx;
+                *Fy = fy;
+                *Fx = fx;
+            }
+        }
+    return best != 0;
 }
 
 int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float2 *Kt, int k_bands,

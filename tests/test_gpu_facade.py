@@ -98,6 +98,38 @@ def test_blend_fit_with_resizing_matches_oracle(hsc):
     assert abs(chi[-1] - chi_ref[-1]) < 5e-3 * abs(chi_ref[-1])
 
 
+def test_blend_fit_callback_host_stepped(hsc):
+    """``callback=`` (reference blend.py:168,301-302): same trajectory as the device
+    loop, called once per non-terminal iteration with the live parameters;
+    StopIteration from the callback ends the fit cleanly."""
+    blend, _ = build_blend(hsc, resizing=True)
+    n_ref, logL_ref = blend.fit(25, e_rel=1e-5)
+    loss_ref = list(blend.loss)
+
+    blend2, _ = build_blend(hsc, resizing=True)
+    seen = []
+
+    def cb(*params, it=None):
+        assert len(params) == len(blend2.parameters)
+        seen.append((it, float(np.asarray(params[0]).sum())))
+
+    n, logL = blend2.fit(25, e_rel=1e-5, callback=cb)
+    assert n == n_ref and logL == logL_ref
+    assert_allclose(blend2.loss, loss_ref, rtol=0, atol=0)
+    # adaprox's counter restarts after every resize; one call per iteration otherwise
+    assert seen[0][0] == 0 and len(seen) >= n - 3
+    assert len({v for _, v in seen}) > 1  # parameters are live, not the initial ones
+
+    blend3, _ = build_blend(hsc, resizing=False)
+
+    def stop(*params, it=None):
+        if it == 4:
+            raise StopIteration
+
+    n3, _ = blend3.fit(25, e_rel=1e-5, callback=stop)
+    assert n3 == 5
+
+
 def test_quickstart_initialisation_matches_reference(hsc):
     """docs/0-quickstart.ipynb / testing/deblend.py sequence: init_all_sources on the
     bundled HSC scene reproduces the reference's initial sources (golden), then fits."""
@@ -170,4 +202,4 @@ def test_fit_forwards_adam_constants(hsc):
     with pytest.raises(NotImplementedError):
         blend.fit(2, scheme="adam")
     with pytest.raises(NotImplementedError):
-        blend.fit(2, callback=lambda *a, **k: None)
+        blend.fit(2, no_such_option=1)

@@ -477,6 +477,21 @@ def test_many_bands_big_boxes_null_renderer(amd):
     _compare_steps(amd, specs, None, data, weights, 2, {}, {})
 
 
+@pytest.mark.parametrize("H,W,F", [
+    (50, 85, (64, 96)), (85, 50, (96, 64)), (70, 110, (80, 128)), (110, 70, (128, 80)),
+    (88, 150, (96, 160)), (150, 88, (160, 96)), (120, 120, (128, 128)), (57, 153, (64, 160)),
+    (153, 57, (160, 64)), (89, 73, (96, 80)), (60, 121, (80, 128)), (40, 40, (64, 64))])
+def test_fused_path_every_fft_length(amd, H, W, F):
+    """every LDS-resident FFT length (64, 80, 96, 128, 160 = 16 x {4,5,6,8,10}) on both
+    axes: forward, gradient and two full steps against the oracle, 15^2 kernel"""
+    rng = np.random.default_rng(H * 1000 + W)
+    boxes = [((21, 21), (3, 5)), ((31, 31), (H - 35, W - 36)), ((15, 25), (H // 2, -6)),
+             ((25, 15), (-7, W // 2))]
+    specs, kernel, data, weights = _random_scene(rng, 3, H, W, boxes, kernel_shape=15)
+    batch, sc = _compare_steps(amd, specs, kernel, data, weights, 2, {}, {}, conv_path="fused")
+    assert tuple(batch.fft_shape) == F
+
+
 def test_large_frame_uses_rocfft(amd):
     """200x180 frame + 25^2 kernel: the padded band does not fit the LDS, so the batch
     falls back to the rocFFT pipeline with the reference's FFT shape"""
