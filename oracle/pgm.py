@@ -73,6 +73,88 @@ class Component:
         )
 
 
+def integrated_gaussian(X, sigma):
+    """Pixel-integrated 1-D Gaussian ``GaussianPSF._f`` (psf.py:128-142)."""
+    from scipy.special import erfc
+
+    sqrt2 = np.sqrt(2)
+    return (
+        np.sqrt(np.pi / 2)
+        * sigma
+        * (1 - erfc((0.5 - X) / (sqrt2 * sigma)) + 1 - erfc((2 * X + 1) / (2 * sqrt2 * sigma)))
+    )
+
+
+def integrated_gaussian_deriv(X, sigma):
+    """d/dX of :func:`integrated_gaussian`: the difference of the Gaussian at the
+    two pixel edges."""
+    return np.exp(-((X + 0.5) ** 2) / (2 * sigma**2)) - np.exp(-((X - 0.5) ** 2) / (2 * sigma**2))
+
+
+class PointComponent:
+    """``PointSource`` (source.py:92-128): spectrum x model PSF evaluated at a
+    free sub-pixel ``center``.  The box is the PSF box (psf.py:60-66) moved to
+    the rounded initial centre (morphology.py:494-497) and never changes; the
+    offset handed to the PSF is ``center - mean(box bounds)``
+    (morphology.py:503-507).  ``morph`` is derived from ``center``."""
+
+    source = None
+    symmetric = False
+
+    def __init__(self, sed, center, sigma, boxsize=None, sed_min_step=0.0, center_step=3e-2,
+                 sed_zero=1e-20):
+        self.sed = sed
+        self.center = np.array(center, dtype=np.float64)
+        self.sigma = float(sigma)
+        if boxsize is None:
+            boxsize = int(np.ceil(10 * self.sigma))  # psf.py:94-95
+        if boxsize % 2 == 0:
+            boxsize += 1  # psf.py:57-58
+        self.size = boxsize
+        pixel_center = np.round(self.center).astype(int)
+        self.origin = (int(pixel_center[0]) - boxsize // 2, int(pixel_center[1]) - boxsize // 2)
+        self.sed_min_step = sed_min_step
+        self.center_step = center_step  # source.py:115
+        self.sed_zero = sed_zero
+        self.m_sed = np.zeros(sed.shape)
+        self.v_sed = np.zeros(sed.shape)
+        self.vhat_sed = np.zeros(sed.shape)
+        self.m_center = np.zeros(2)
+        self.v_center = np.zeros(2)
+        self.vhat_center = np.zeros(2)
+
+    def _axes(self):
+        offset = self.center - (np.array(self.origin) + self.size / 2)
+        grid = np.arange(self.size) - self.size // 2
+        return grid - offset[0], grid - offset[1]
+
+    @property
+    def morph(self):
+        """``GaussianPSF.get_model(offset=)`` for a band-independent sigma
+        (psf.py:97-126): separable profile, normalised to unit sum."""
+        Y, X = self._axes()
+        image = integrated_gaussian(Y, self.sigma)[:, None] * integrated_gaussian(X, self.sigma)[None, :]
+        return image / image.sum()
+
+    def center_gradient(self, g_morph):
+        """Chain rule d(-logL)/d(center) = sum_yx g_morph * d(morph)/d(center)."""
+        Y, X = self._axes()
+        fy, fx = integrated_gaussian(Y, self.sigma), integrated_gaussian(X, self.sigma)
+        # d f(Y_j - offset)/d center = -f'(Y_j - offset)
+        dfy, dfx = -integrated_gaussian_deriv(Y, self.sigma), -integrated_gaussian_deriv(X, self.sigma)
+        S = fy.sum() * fx.sum()
+        A = fy[:, None] * fx[None, :]
+        d_y = dfy[:, None] * fx[None, :] / S - A * (dfy.sum() * fx.sum()) / S**2
+        d_x = fy[:, None] * dfx[None, :] / S - A * (fy.sum() * dfx.sum()) / S**2
+        return np.array([(g_morph * d_y).sum(), (g_morph * d_x).sum()])
+
+    def sed_step(self, it=0):
+        return np.maximum(self.sed_min_step, 1e-2 * self.sed.mean())
+
+    def sed_prox(self, x, step):
+        return proxops.prox_positivity(x, step, self.sed_zero)
+
+
 def get_minimal_boxsize(size, min_size=21, increment=10):
     """initialization.py:173-177."""
     boxsize = min_size
@@ -235,6 +317,9 @@ class Scene:
             boxed[bs] = G[fs]
             g_sed = np.einsum("cyx,yx->c", boxed, c.morph)
             g_morph = np.einsum("c,cyx->yx", c.sed, boxed)
+            if isinstance(c, PointComponent):
+                # second entry is d/d(center) for a point source
+                g_morph = c.center_gradient(g_morph)
             out.append((g_sed, g_morph))
         return out
 
@@ -255,12 +340,20 @@ class Scene:
         blend.py:165-180 (amsgrad, prox_max_iter=10)."""
         _, grads = self.loss_and_gradients()
         # all steps are evaluated on the pre-update parameters (blend.py:135-138)
-        alphas = [(c.sed_step(it), c.morph_step) for c in self.components]
+        alphas = [(c.sed_step(it), c.center_step if isinstance(c, PointComponent) else c.morph_step)
+                  for c in self.components]
         for c, (g_sed, g_morph), (a_sed, a_morph) in zip(self.components, grads, alphas):
             adaprox_update(
                 it, c.sed, g_sed, c.m_sed, c.v_sed, c.vhat_sed, a_sed, c.sed_prox,
                 e_rel, prox_max_iter, b1, b2, eps,
             )
+            if isinstance(c, PointComponent):
+                # the centre has no constraint (source.py:115): plain AMSGrad step
+                adaprox_update(
+                    it, c.center, g_morph, c.m_center, c.v_center, c.vhat_center, a_morph,
+                    None, e_rel, prox_max_iter, b1, b2, eps,
+                )
+                continue
             adaprox_update(
                 it, c.morph, g_morph, c.m_morph, c.v_morph, c.vhat_morph, a_morph,
                 c.morph_prox, e_rel, prox_max_iter, b1, b2, eps,
@@ -269,7 +362,8 @@ class Scene:
     def check_parameters(self):
         """``Model.check_parameters`` (model.py:153-165)."""
         for k, c in enumerate(self.components):
-            if not (np.isfinite(c.sed).all() and np.isfinite(c.morph).all()):
+            free = c.center if isinstance(c, PointComponent) else c.morph
+            if not (np.isfinite(c.sed).all() and np.isfinite(free).all()):
                 raise ArithmeticError("component {} is not finite".format(k))
 
     def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, prox_max_iter=10, resizing=False,
@@ -300,7 +394,7 @@ class Scene:
                     # (component.py:280-290 re-raises out of the loop)
                     for group in self._groups():
                         for c in group:
-                            if resize_component(c):
+                            if not isinstance(c, PointComponent) and resize_component(c):
                                 restart = True
                                 break
                     if restart:

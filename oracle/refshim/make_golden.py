@@ -240,6 +240,87 @@ def psf_unmatched(scarlet):
     )
 
 
+def point_source(scarlet):
+    """docs/tutorials/point_source.ipynb: psf_unmatched_sim scene, stars as
+    PointSource, galaxies as ExtendedSource; state up to the first gradient."""
+    d = np.load("/root/reference/data/psf_unmatched_sim.npz")
+    images, psfs, catalog = d["images"], d["psfs"], d["catalog"]
+    filters = [str(f) for f in d["filters"]]
+    weights = np.ones_like(images) / 2**2
+
+    def build(dtype):
+        model_psf = scarlet.GaussianPSF(sigma=0.9)
+        frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters, dtype=dtype)
+        obs = scarlet.Observation(
+            images, psf=scarlet.ImagePSF(psfs), weights=weights, channels=filters
+        ).match(frame)
+        sources = []
+        for idx in np.unique(catalog["index"]):
+            src = catalog[catalog["index"] == idx][0]
+            if src["is_star"]:
+                sources.append(scarlet.PointSource(frame, (src["y"], src["x"]), obs))
+            else:
+                sources.append(scarlet.ExtendedSource(frame, (src["y"], src["x"]), obs))
+        return model_psf, frame, obs, sources
+
+    model_psf, frame, obs, sources = build(np.float32)
+    blend = scarlet.Blend(sources, obs)
+    model = blend.get_model()
+    out = dict(
+        images=images, psfs=psfs, model_psf=model_psf.get_model(),
+        diff_kernel=obs.renderer.diff_kernel.image, model=model, rendered=obs.render(model),
+        logL=obs.get_log_likelihood(model), log_norm=obs.log_norm, n_src=len(sources),
+        is_star=np.array([isinstance(s, scarlet.PointSource) for s in sources]),
+        sky=np.array([(c["y"], c["x"]) for c in
+                      (catalog[catalog["index"] == i][0] for i in np.unique(catalog["index"]))]),
+    )
+
+    def arrays(srcs, tag):
+        for k, src in enumerate(srcs):
+            spectrum, morphology = src.children
+            out["%ssed_%d" % (tag, k)] = np.array(spectrum.parameters[0])
+            out["%sorigin_%d" % (tag, k)] = np.array(morphology.bbox.origin[-2:])
+            if not tag:
+                out["min_step_%d" % k] = np.asarray(spectrum.parameters[0].step.keywords["minimum"])
+            if isinstance(src, scarlet.PointSource):
+                out["%scenter_%d" % (tag, k)] = np.array(morphology.parameters[0])
+                out["%smorph_%d" % (tag, k)] = np.array(morphology.get_model()[0])
+            else:
+                out["%smorph_%d" % (tag, k)] = np.array(morphology.parameters[0])
+
+    arrays(sources, "")
+
+    # finite differences of the reference's forward in float64, centres included
+    _, frame64, obs64, sources64 = build(np.float64)
+    blend64 = scarlet.Blend(sources64, obs64)
+    params = [np.array(p, dtype=np.float64) for p in blend64.parameters]
+    names = [p.name for p in blend64.parameters]
+    rng = np.random.default_rng(4)
+    n_dir = 6
+    fd = np.zeros(n_dir)
+    for j in range(n_dir):
+        direction = []
+        for p, name in zip(params, names):
+            if name == "shift":  # the unused shift of every ImageMorphology
+                direction.append(np.zeros_like(p))
+            else:
+                direction.append(rng.standard_normal(p.shape))
+        eps = 1e-6
+        lp = _forward(blend64, obs64, [p + eps * t for p, t in zip(params, direction)])[1]
+        lm = _forward(blend64, obs64, [p - eps * t for p, t in zip(params, direction)])[1]
+        fd[j] = (lp - lm) / (2 * eps)
+        i = 0
+        for t, name in zip(direction, names):
+            if name != "shift":
+                # order: (sed_0, morph_0 | center_0, sed_1, ...)
+                out["dir%d_%d" % (j, i)] = t
+                i += 1
+    out["fd_dlogL"] = fd
+    arrays(sources64, "f64_")
+    np.savez_compressed(os.path.join(OUT, "point_source.npz"), **out)
+    print("point_source: %d sources, logL=%.3f" % (len(sources), out["logL"]))
+
+
 def synthetic_cfg2(scarlet):
     sys.path.insert(0, REPO)
     from scarlet_amd import synthetic
@@ -277,7 +358,7 @@ def main(which=None):
     os.makedirs(OUT, exist_ok=True)
     jobs = dict(
         operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
-        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched,
+        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source,
         synthetic_cfg2=synthetic_cfg2,
     )
     for name, fn in jobs.items():

@@ -42,3 +42,24 @@ def hsc_scene(g, dtype64=False):
     weights = g["weights"].astype(dt)
     kernel = g["diff_kernel"].astype(dt)
     return pgm.Scene(images.shape, images, weights, kernel, comps, dtype=dt)
+
+
+def point_scene(g, dtype64=False):
+    """oracle.pgm.Scene of the point-source tutorial blend (stars = PointComponent)."""
+    from oracle import pgm
+
+    tag = "f64_" if dtype64 else ""
+    comps = []
+    for k in range(int(g["n_src"])):
+        sed = g["%ssed_%d" % (tag, k)].copy()
+        if g["is_star"][k]:
+            comps.append(pgm.PointComponent(sed, g["%scenter_%d" % (tag, k)], 0.9,
+                                            sed_min_step=g["min_step_%d" % k]))
+        else:
+            comps.append(pgm.Component(sed, g["%smorph_%d" % (tag, k)].copy(),
+                                       g["%sorigin_%d" % (tag, k)],
+                                       sed_min_step=g["min_step_%d" % k]))
+    dt = np.float64 if dtype64 else np.float32
+    images = g["images"].astype(dt)
+    weights = np.full(images.shape, 0.25, dtype=dt)
+    return pgm.Scene(images.shape, images, weights, g["diff_kernel"].astype(dt), comps, dtype=dt)
