@@ -94,7 +94,11 @@ enum {
     SMI_PROX_NORM_MAX = 16,  /* NormalizationConstraint("max") (95-114)         */
     SMI_PROX_NORM_SUM = 32,  /* NormalizationConstraint("sum")                  */
     SMI_PROX_L1 = 64,        /* L1Constraint -> proxmin prox_soft (134-145)     */
-    SMI_PROX_L0 = 128        /* L0Constraint -> proxmin prox_hard (117-130)     */
+    SMI_PROX_L0 = 128,       /* L0Constraint -> proxmin prox_hard (117-130)     */
+    /* not a constraint: the component is a PointSource (source.py:92-128) whose
+     * morphology is the model PSF evaluated at a free sub-pixel centre
+     * (PointSourceMorphology, morphology.py:476-513; GaussianPSF, psf.py:80-142) */
+    SMI_COMPONENT_POINT_SOURCE = 1 << 16
 };
 #define SMI_PROX_EXTENDED_SOURCE \
     (SMI_PROX_MONOTONIC | SMI_PROX_POSITIVE | SMI_PROX_CENTER_ON | SMI_PROX_NORM_MAX)
@@ -135,6 +139,13 @@ typedef struct smi_components {
     const float *l_thresh;      /* threshold for SMI_PROX_L1/L0 (absolute)          */
     const float *morph_rel_step;/* step = max(morph_step, rel * mean(morph)); NULL=0 */
                                 /* (relative_step, parameter.py:126-129)            */
+    /* point sources (SMI_COMPONENT_POINT_SOURCE in prox_flags); both NULL if none.
+     * For such a component the box is the PSF box at the rounded initial centre
+     * (morphology.py:494-497), its `morph` input is ignored (the library evaluates
+     * the pixel-integrated Gaussian), and `morph_step` is the step of the centre
+     * (3e-2, source.py:115). */
+    const double *center;       /* [n_components][2] (y, x) in frame pixels          */
+    const float *psf_sigma;     /* [n_components] model PSF sigma (all bands alike)  */
 } smi_components;
 
 int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out);
@@ -164,6 +175,13 @@ int smi_batch_set_moments(smi_batch *b, const float *m_sed, const float *v_sed,
 int smi_batch_get_moments(smi_batch *b, float *m_sed, float *v_sed, float *vhat_sed,
                           float *m_morph, float *v_morph, float *vhat_morph);
 int smi_batch_get_parameters(smi_batch *b, float *sed, float *morph);
+/* point-source centres [n_components][2] (entries of other components: 0) and their
+ * AMSGrad moments; the gradient is valid after smi_batch_gradient.  Any pointer may
+ * be NULL. */
+int smi_batch_get_centers(smi_batch *b, double *center, double *m, double *v, double *vhat,
+                          double *gradient);
+int smi_batch_set_center_moments(smi_batch *b, const double *m, const double *v,
+                                 const double *vhat);
 int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph);
 
 /* AMSGrad constants forwarded by Blend.fit(**alg_kwargs) to adaprox (blend.py:165-180);

@@ -24,7 +24,7 @@ from .constraint import (  # noqa: F401
 from .parameter import Parameter, relative_step  # noqa: F401
 from .prior import Prior  # noqa: F401
 from .psf import PSF, ImagePSF, FunctionPSF, GaussianPSF, MoffatPSF  # noqa: F401
-from .batch import BlendBatch, ComponentSpec  # noqa: F401
+from .batch import BlendBatch, ComponentSpec, PointSourceSpec  # noqa: F401
 from .frame import Frame  # noqa: F401
 from .observation import Observation  # noqa: F401
 from .renderer import Renderer, NullRenderer, ConvolutionRenderer  # noqa: F401

@@ -34,6 +34,28 @@ class ComponentSpec:
         self.l_thresh = float(l_thresh)
 
 
+class PointSourceSpec(ComponentSpec):
+    """A ``PointSource`` (source.py:92-128): spectrum x the model PSF -- a
+    pixel-integrated Gaussian of width ``psf_sigma`` in every band -- evaluated at
+    the free sub-pixel ``center`` (frame pixels).  The box is the PSF box
+    (psf.py:55-66, 93-95) moved to the rounded initial centre
+    (morphology.py:494-497) and stays fixed."""
+
+    def __init__(self, sed, center, psf_sigma, boxsize=None, sed_min_step=0.0,
+                 sed_rel_step=1e-2, center_step=3e-2):
+        self.center = np.array(center, dtype=np.float64).reshape(2)
+        self.psf_sigma = float(psf_sigma)
+        if boxsize is None:
+            boxsize = int(np.ceil(10 * self.psf_sigma))
+        if boxsize % 2 == 0:
+            boxsize += 1
+        pixel = np.round(self.center).astype(int)
+        origin = (int(pixel[0]) - boxsize // 2, int(pixel[1]) - boxsize // 2)
+        super().__init__(sed, np.zeros((boxsize, boxsize), dtype=np.float32), origin,
+                         sed_min_step=sed_min_step, sed_rel_step=sed_rel_step,
+                         morph_step=center_step, prox_flags=_lib.COMPONENT_POINT_SOURCE)
+
+
 class BlendBatch:
     """A batch of blends sharing the frame shape ``(C, H, W)``.
 
@@ -131,6 +153,10 @@ class BlendBatch:
             min_gradient=_lib.f32([c.min_gradient for c in flat]),
             l_thresh=_lib.f32([c.l_thresh for c in flat]),
             morph_rel_step=_lib.f32([c.morph_rel_step for c in flat]),
+            center=np.ascontiguousarray(
+                [getattr(c, "center", (0.0, 0.0)) for c in flat], dtype=np.float64
+            ).reshape(-1, 2),
+            psf_sigma=_lib.f32([getattr(c, "psf_sigma", 0.0) for c in flat]),
         )
         comps = _lib.Components()
         for name, ctype in _lib.Components._fields_:
@@ -274,6 +300,28 @@ class BlendBatch:
             )
         )
         return sed, self._split_morphs(morph)
+
+    def centers(self):
+        """Point-source state: dict of (n_components, 2) float64 arrays ``center``
+        (frame pixels; zeros for other components), ``m``, ``v``, ``vhat`` and, after
+        ``gradient()``, ``gradient``."""
+        out = {k: np.zeros((self.n_components, 2)) for k in ("center", "m", "v", "vhat", "gradient")}
+        _lib.check(
+            self._lib.smi_batch_get_centers(
+                self._h, *[_lib.ptr(out[k], ctypes.c_double)
+                           for k in ("center", "m", "v", "vhat", "gradient")]
+            )
+        )
+        return out
+
+    def set_center_moments(self, m=None, v=None, vhat=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 2)
+                for a in (m, v, vhat)]
+        _lib.check(
+            self._lib.smi_batch_set_center_moments(
+                self._h, *[_lib.ptr(a, ctypes.c_double) for a in arrs]
+            )
+        )
 
     def set_parameters(self, seds=None, morphs=None):
         sed = None if seds is None else _lib.f32(seds)

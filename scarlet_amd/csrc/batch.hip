@@ -97,6 +97,12 @@ struct smi_batch {
     float *sed = nullptr, *morph = nullptr;
     float *mom[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float *g_sed = nullptr, *g_morph = nullptr;
+    // point sources: {offset, m, v, vhat} x (y, x) per component, gradient, PSF sigma
+    double *pt = nullptr, *g_center = nullptr;
+    float *c_sigma = nullptr;
+    int n_point = 0;
+    std::vector<double> box_center;  // mean of the box bounds per component (y, x)
+    std::vector<char> is_point;
     int64_t n_morph = 0;
     bool have_components = false, have_obs = false, have_kernel = false;
     // per blend
@@ -165,6 +171,9 @@ void refresh_view(smi_batch *b) {
     v.b1 = b->b1;
     v.b2 = b->b2;
     v.eps = b->eps;
+    v.n_point = b->n_point;
+    v.pt = b->pt;
+    v.c_sigma = b->c_sigma;
     for (const auto &pl : b->plans)
         if (!pl.slots) v.fast_plans = 0;
 }
@@ -436,7 +445,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->c_flags, b->c_plan, b->c_moff, b->c_sed_min_step, b->c_sed_rel,
                     b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
-                    b->g_sed, b->g_morph, b->state, b->zero_state, b->n_loss, b->status_out,
+                    b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->state, b->zero_state, b->n_loss, b->status_out,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -628,6 +637,12 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         const int64_t np = (int64_t)c->box_h[k] * c->box_w[k];
         moff[k + 1] = moff[k] + np;
         if (np > max_pix) max_pix = (int)np;
+        if (c->prox_flags[k] & SMI_COMPONENT_POINT_SOURCE) {
+            SMI_REQUIRE(c->center && c->psf_sigma, "point source without center / psf_sigma");
+            SMI_REQUIRE(c->box_h[k] < 64 && c->box_w[k] < 64, "point-source box larger than 63 pixels");
+            SMI_REQUIRE(c->psf_sigma[k] > 0.f, "point source with psf_sigma <= 0");
+            SMI_REQUIRE(!(c->prox_flags[k] & SMI_PROX_MONOTONIC), "point source with a morphology constraint");
+        }
         if (c->prox_flags[k] & SMI_PROX_MONOTONIC) {
             const int pid = c->sweep_plan ? c->sweep_plan[k] : -1;
             SMI_REQUIRE(pid >= 0 && pid < (int)b->plans.size(), "monotonic component without sweep plan");
@@ -673,10 +688,78 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     if (b->g_morph) SMI_HIP(hipFree(b->g_morph));
     SMI_HIP(dev_alloc(&b->g_sed, (size_t)n * C));
     SMI_HIP(dev_alloc(&b->g_morph, (size_t)b->n_morph));
+    // point sources: offset of the centre from the mean of the box bounds
+    // (morphology.py:503-507), moments zero
+    std::vector<double> pt((size_t)n * 8, 0.0);
+    std::vector<float> sigma(n, 0.f);
+    b->box_center.assign((size_t)n * 2, 0.0);
+    b->is_point.assign((size_t)n, 0);
+    b->n_point = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!(c->prox_flags[k] & SMI_COMPONENT_POINT_SOURCE)) continue;
+        b->n_point++;
+        b->is_point[k] = 1;
+        b->box_center[2 * k] = c->origin_y[k] + 0.5 * c->box_h[k];
+        b->box_center[2 * k + 1] = c->origin_x[k] + 0.5 * c->box_w[k];
+        pt[8 * k] = c->center[2 * k] - b->box_center[2 * k];
+        pt[8 * k + 1] = c->center[2 * k + 1] - b->box_center[2 * k + 1];
+        sigma[k] = c->psf_sigma[k];
+    }
+    if ((rc = upload(&b->pt, pt.data(), pt.size()))) return rc;
+    if ((rc = upload(&b->c_sigma, sigma.data(), (size_t)n))) return rc;
+    if (b->g_center) SMI_HIP(hipFree(b->g_center));
+    SMI_HIP(dev_alloc(&b->g_center, (size_t)n * 2));
+    SMI_HIP(hipMemset(b->g_center, 0, (size_t)(n ? n : 1) * 2 * sizeof(double)));
     b->have_components = true;
     const int keep = b->view.max_box_pixels;
     refresh_view(b);
     b->view.max_box_pixels = keep;
+    // the morphology of a point source is derived from its centre
+    const BatchView v = unmasked_view(b);
+    if ((rc = launch_point_sources(v, nullptr, 0, 0.f, 0, nullptr, nullptr, 2, b->stream))) return rc;
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_batch_get_centers(smi_batch *b, double *center, double *m, double *v, double *vhat,
+                          double *gradient) {
+    SMI_REQUIRE(b && b->have_components, "components not set");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int n = b->d.n_components;
+    std::vector<double> pt((size_t)n * 8);
+    if (n) SMI_HIP(hipMemcpy(pt.data(), b->pt, pt.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double *dst[4] = {center, m, v, vhat};
+    for (int f = 0; f < 4; ++f) {
+        if (!dst[f]) continue;
+        for (int k = 0; k < n; ++k)
+            for (int a = 0; a < 2; ++a) {
+                double val = pt[8 * k + 2 * f + a];
+                if (f == 0 && b->is_point[k]) val += b->box_center[2 * k + a];
+                dst[f][2 * k + a] = val;
+            }
+    }
+    if (gradient && n)
+        SMI_HIP(hipMemcpy(gradient, b->g_center, (size_t)n * 2 * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+
+int smi_batch_set_center_moments(smi_batch *b, const double *m, const double *v,
+                                 const double *vhat) {
+    SMI_REQUIRE(b && b->have_components, "components not set");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int n = b->d.n_components;
+    if (!n) return SMI_OK;
+    std::vector<double> pt((size_t)n * 8);
+    SMI_HIP(hipMemcpy(pt.data(), b->pt, pt.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const double *src[3] = {m, v, vhat};
+    for (int f = 0; f < 3; ++f)
+        for (int k = 0; k < n; ++k)
+            for (int a = 0; a < 2; ++a) pt[8 * k + 2 * (f + 1) + a] = src[f] ? src[f][2 * k + a] : 0.0;
+    SMI_HIP(hipMemcpy(b->pt, pt.data(), pt.size() * sizeof(double), hipMemcpyHostToDevice));
     return SMI_OK;
 }
 
@@ -815,6 +898,8 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
         if ((rc = convolve(b, v, 1))) return rc;
     }
     if ((rc = launch_update(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_morph, 1, b->stream))) return rc;
+    if ((rc = launch_point_sources(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_center, 1, b->stream)))
+        return rc;
     SMI_HIP(hipStreamSynchronize(b->stream));
     if (g_sed)
         SMI_HIP(hipMemcpy(g_sed, b->g_sed, (size_t)v.n_comp * v.C * sizeof(float),
@@ -868,6 +953,9 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
             if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
         }
         if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, b->stream)))
+            return rc;
+        if ((rc = launch_point_sources(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0,
+                                       b->stream)))
             return rc;
         if (check) launch_advance(v, b->stream);
         if (ev) SMI_HIP(hipEventRecord(ev[5], b->stream));

@@ -112,6 +112,11 @@ struct BatchView {
     int32_t max_levels;  // over all plans
     int32_t fast_plans;  // every plan has the slot layout
     float b1, b2, eps;   // AMSGrad constants (defaults 0.9, 0.999, 1e-8: lite/parameters.py:194)
+    // point sources: per component {offset y, x, m y, x, v y, x, vhat y, x} with
+    // offset = centre - mean(box bounds) (morphology.py:503-507), and the PSF sigma
+    int32_t n_point;
+    double *pt;
+    const float *c_sigma;
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);
@@ -125,6 +130,11 @@ void launch_cmul(float2 *S, const float2 *K, int32_t nb, int32_t C, int64_t plan
 int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
                   int32_t prox_max_iter, float *g_sed_out, float *g_morph_out,
                   int32_t grad_only, hipStream_t s);
+// mode 0: one optimizer step of every point source (spectrum + centre), 1: gradients only
+// (g_sed_out, g_center_out[n_comp][2]), 2: evaluate the morphologies from the centres
+int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e_rel,
+                         int32_t prox_max_iter, float *g_sed_out, double *g_center_out,
+                         int32_t mode, hipStream_t s);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);
 void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,

@@ -400,6 +400,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
                                                     int grad_only) {
     const CompCtx c = comp_ctx(v);
     if (!grad_only && v.state[c.b] >= 2) return;
+    if (!grad_only && v.n_point && (v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
     const int lane = c.lane, N = c.N;
     const int npad = (v.max_box_pixels + 3) & ~3;
     float *xs = lds_dyn;       // x after the gradient step
@@ -495,6 +496,127 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
 }
 
+// -- point sources ---------------------------------------------------------------
+// PointSource (source.py:92-128): spectrum x model PSF at a free sub-pixel centre.
+// The PSF is the separable pixel-integrated Gaussian of GaussianPSF._f
+// (psf.py:128-142), normalised to unit sum over the box (psf.py:126); its
+// derivative w.r.t. the centre is the difference of the Gaussian at the two pixel
+// edges.  The centre has no constraint, so its update is the bare AMSGrad step of
+// lite/parameters.py:274-291.  All of this is evaluated in double like the
+// reference's float64 centre parameter; the box has at most 63 x 63 pixels.
+__device__ __forceinline__ double integrated_gaussian(double X, double sigma) {
+    const double sqrt2 = 1.4142135623730951;
+    return 1.2533141373155001 * sigma *
+           (1.0 - erfc((0.5 - X) / (sqrt2 * sigma)) + 1.0 -
+            erfc((2.0 * X + 1.0) / (2.0 * sqrt2 * sigma)));
+}
+
+__device__ __forceinline__ double integrated_gaussian_deriv(double X, double sigma) {
+    const double s2 = 2.0 * sigma * sigma;
+    return exp(-(X + 0.5) * (X + 0.5) / s2) - exp(-(X - 0.5) * (X - 0.5) / s2);
+}
+
+__global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const float *G, int it,
+                                                          float e_rel, int prox_max_iter,
+                                                          float *g_sed_out, double *g_ctr_out,
+                                                          int mode) {
+    const CompCtx c = comp_ctx(v);
+    if (!(v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
+    if (mode == 0 && v.state[c.b] >= 2) return;
+    const int lane = c.lane, N = c.N;
+    __shared__ double fy[64], fx[64], dfy[64], dfx[64];
+    float *us = lds_dyn;
+    double *pt = v.pt + (int64_t)c.k * 8;
+    const double sigma = (double)v.c_sigma[c.k];
+    double off_y = pt[0], off_x = pt[1];
+    const float inv_w = 1.0f / (float)c.w;
+    int bad = 0;
+
+    auto profiles = [&](bool with_deriv) {
+        // FunctionPSF grid (psf.py:60-66): pixel j sits at j - size // 2
+        const double Y = (double)(lane - c.h / 2) - off_y;
+        const double X = (double)(lane - c.w / 2) - off_x;
+        fy[lane] = lane < c.h ? integrated_gaussian(Y, sigma) : 0.0;
+        fx[lane] = lane < c.w ? integrated_gaussian(X, sigma) : 0.0;
+        if (with_deriv) {
+            // d f(Y_j - offset) / d centre = -f'(Y_j - offset)
+            dfy[lane] = lane < c.h ? -integrated_gaussian_deriv(Y, sigma) : 0.0;
+            dfx[lane] = lane < c.w ? -integrated_gaussian_deriv(X, sigma) : 0.0;
+        }
+        __syncthreads();
+    };
+
+    if (mode != 2) {
+        const float g_sed = gather_gradient(v, c, G, us);
+        __syncthreads();
+        profiles(true);
+        const double Sy = wave_sum(fy[lane]), Sx = wave_sum(fx[lane]);
+        const double dSy = wave_sum(dfy[lane]), dSx = wave_sum(dfx[lane]);
+        const double S = Sy * Sx;
+        double gy = 0.0, gx = 0.0;
+        for (int i = lane; i < N; i += 64) {
+            const int y = (int)(((float)i + 0.5f) * inv_w);
+            const int x = i - y * c.w;
+            const double A = fy[y] * fx[x];
+            const double d_y = dfy[y] * fx[x] / S - A * (dSy * Sx) / (S * S);
+            const double d_x = fy[y] * dfx[x] / S - A * (Sy * dSx) / (S * S);
+            gy += (double)us[i] * d_y;
+            gx += (double)us[i] * d_x;
+        }
+        gy = wave_sum(gy);
+        gx = wave_sum(gx);
+        if (mode == 1) {
+            if (lane < c.C) g_sed_out[(int64_t)c.k * c.C + lane] = g_sed;
+            if (lane == 0) {
+                g_ctr_out[2 * c.k] = gy;
+                g_ctr_out[2 * c.k + 1] = gx;
+            }
+            return;
+        }
+        bad = update_spectrum(v, c, g_sed, it, e_rel * e_rel, prox_max_iter);
+        const double b1 = v.b1, b2 = v.b2, eps = v.eps, alpha = v.c_morph_step[c.k];
+        double upd[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const double g = a ? gx : gy;
+            const double m = (1.0 - b1) * g + b1 * pt[2 + a];
+            const double vv = (1.0 - b2) * g * g + b2 * pt[4 + a];
+            const double vh = it == 0 ? vv : fmax(pt[6 + a], vv);
+            upd[a] = alpha * m / sqrt(fmax(vh, eps));
+            if (it == 0) upd[a] /= 10.0;
+            __syncthreads();
+            if (lane == 0) {
+                pt[2 + a] = m;
+                pt[4 + a] = vv;
+                pt[6 + a] = vh;
+            }
+        }
+        off_y -= upd[0];
+        off_x -= upd[1];
+        __syncthreads();
+        if (lane == 0) {
+            pt[0] = off_y;
+            pt[1] = off_x;
+        }
+        bad |= !isfinite(off_y) || !isfinite(off_x);
+    }
+    // morphology at the (new) centre: outer product / its sum (psf.py:104-126)
+    profiles(false);
+    double part = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        const int y = (int)(((float)i + 0.5f) * inv_w);
+        part += fy[y] * fx[i - y * c.w];
+    }
+    const double total = wave_sum(part);
+    for (int i = lane; i < N; i += 64) {
+        const int y = (int)(((float)i + 0.5f) * inv_w);
+        const float z = (float)(fy[y] * fx[i - y * c.w] / total);
+        v.morph[c.moff + i] = z;
+        bad |= !isfinite(z);
+    }
+    if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);
+}
+
 // -- fast variant --------------------------------------------------------------
 // Boxes of at most 64*NPL pixels and plans with at most 4 terms per pixel (the
 // reference's 'flat' / 'angle' / 'nearest' tables): x, psi/max(psi) and the
@@ -551,6 +673,7 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
                                                         float e_rel, int prox_max_iter) {
     const CompCtx c = comp_ctx(v);
     if (v.state[c.b] >= 2) return;
+    if (v.n_point && (v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
     const int lane = c.lane, N = c.N;
     float *us = lds_dyn;
 
@@ -832,6 +955,17 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
     }
     hipLaunchKernelGGL(update_kernel, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
                        prox_max_iter, g_sed_out, g_morph_out, grad_only);
+    return SMI_OK;
+}
+
+int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e_rel,
+                         int32_t prox_max_iter, float *g_sed_out, double *g_center_out,
+                         int32_t mode, hipStream_t s) {
+    if (v.n_point == 0 || v.n_comp == 0) return SMI_OK;
+    const size_t lds = (size_t)(((v.max_box_pixels + 3) & ~3) + 4) * sizeof(float);
+    SMI_REQUIRE(lds <= 64 * 1024, "component box too large for the point-source kernel");
+    hipLaunchKernelGGL(point_source_kernel, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
+                       prox_max_iter, g_sed_out, g_center_out, mode);
     return SMI_OK;
 }
 

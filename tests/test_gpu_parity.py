@@ -566,3 +566,77 @@ def test_batch_fit_to_convergence_mixed_states(amd):
         assert abs(int(n_iter[b]) - n_ref) <= max(2, n_ref // 10)
         chi, chi_ref = -logL[b] - sc.log_norm, -logL_ref - sc.log_norm
         assert abs(chi - chi_ref) < 3e-3 * abs(chi_ref)
+
+
+# ---------------------------------------------------------------- point sources
+def _point_batch(amd, g, **kw):
+    specs = []
+    for k in range(int(g["n_src"])):
+        if g["is_star"][k]:
+            specs.append(amd.PointSourceSpec(g["sed_%d" % k], g["center_%d" % k], 0.9,
+                                             sed_min_step=g["min_step_%d" % k]))
+        else:
+            specs.append(amd.ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
+                                           sed_min_step=g["min_step_%d" % k]))
+    w = np.full(g["images"].shape, 0.25, dtype=np.float32)
+    return amd.BlendBatch(g["images"][None], w[None], [specs], kernel=g["diff_kernel"], **kw)
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_point_source_scene_forward_and_gradient(amd, path):
+    """docs/tutorials/point_source.ipynb scene (3 PointSources + 2 ExtendedSources):
+    PSF morphologies, model, rendered image and logL against the reference's golden
+    values; gradients (centres included) against the oracle"""
+    from conftest import point_scene
+
+    g = golden("point_source")
+    batch = _point_batch(amd, g, max_iter=4, conv_path=path)
+    sc = point_scene(g)
+    _, morphs = batch.parameters()
+    for k in range(int(g["n_src"])):
+        if g["is_star"][k]:
+            assert morphs[k].shape == g["morph_%d" % k].shape
+            assert np.abs(morphs[k] - g["morph_%d" % k]).max() < 1e-7
+    assert_allclose(batch.centers()["center"][g["is_star"]],
+                    [g["center_%d" % k] for k in np.flatnonzero(g["is_star"])], rtol=0, atol=1e-12)
+    model, rendered, logL = batch.forward()
+    assert rel_err(model[0], g["model"]) < RTOL
+    assert rel_err(rendered[0], g["rendered"]) < RTOL
+    assert abs(logL[0] - float(g["logL"])) < RTOL * abs(float(g["logL"]))
+    g_sed, g_morph = batch.gradient()
+    g_center = batch.centers()["gradient"]
+    _, grads = sc.loss_and_gradients()
+    for k, c in enumerate(sc.components):
+        s_sed = np.abs(grads[k][0]).max()
+        assert np.abs(g_sed[k] - grads[k][0]).max() < 2e-5 * max(s_sed, 1.0), k
+        if g["is_star"][k]:
+            assert np.abs(g_center[k] - grads[k][1]).max() < 2e-5 * np.abs(grads[k][1]).max() + 1e-3, k
+        else:
+            assert np.abs(g_morph[k] - grads[k][1]).max() < 2e-5 * np.abs(grads[k][1]).max() + 1e-3, k
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_point_source_scene_steps(amd, path):
+    """12 full iterations of the mixed scene: losses, spectra, centres, morphologies"""
+    from conftest import point_scene
+
+    g = golden("point_source")
+    n_it = 12
+    batch = _point_batch(amd, g, max_iter=n_it + 1, conv_path=path)
+    sc = point_scene(g)
+    batch.step(0, n_it, e_rel=1e-4)
+    for it in range(n_it):
+        sc.step(it, 1e-4)
+    assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm, rtol=1e-4)
+    sed, morphs = batch.parameters()
+    ctr = batch.centers()
+    for k, c in enumerate(sc.components):
+        assert rel_err(sed[k], c.sed) < 5e-4, k
+        assert np.abs(morphs[k] - c.morph).max() < 5e-4, k
+        if g["is_star"][k]:
+            assert np.abs(ctr["center"][k] - c.center).max() < 1e-4, k
+            assert_allclose(ctr["m"][k], c.m_center, rtol=1e-3, atol=1e-3 * np.abs(c.m_center).max())
+            assert_allclose(ctr["vhat"][k], c.vhat_center, rtol=2e-3)
+    # the centres did move
+    assert max(np.abs(c.center - g["center_%d" % k]).max()
+               for k, c in enumerate(sc.components) if g["is_star"][k]) > 1e-3
