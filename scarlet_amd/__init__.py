@@ -29,7 +29,12 @@ from .frame import Frame  # noqa: F401
 from .observation import Observation  # noqa: F401
 from .renderer import Renderer, NullRenderer, ConvolutionRenderer  # noqa: F401
 from .spectrum import Spectrum, TabulatedSpectrum  # noqa: F401
-from .morphology import Morphology, ImageMorphology, ExtendedSourceMorphology  # noqa: F401
+from .morphology import (  # noqa: F401
+    Morphology,
+    ImageMorphology,
+    ExtendedSourceMorphology,
+    PointSourceMorphology,
+)
 from .component import (  # noqa: F401
     Component,
     FactorizedComponent,
@@ -42,6 +47,7 @@ from .source import (  # noqa: F401
     SingleExtendedSource,
     MultiExtendedSource,
     CompactExtendedSource,
+    PointSource,
 )
 from .model import Model, UpdateException  # noqa: F401
 from . import fft, initialization, operator, synthetic  # noqa: F401

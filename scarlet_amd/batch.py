@@ -42,15 +42,17 @@ class PointSourceSpec(ComponentSpec):
     (morphology.py:494-497) and stays fixed."""
 
     def __init__(self, sed, center, psf_sigma, boxsize=None, sed_min_step=0.0,
-                 sed_rel_step=1e-2, center_step=3e-2):
+                 sed_rel_step=1e-2, center_step=3e-2, origin=None):
         self.center = np.array(center, dtype=np.float64).reshape(2)
         self.psf_sigma = float(psf_sigma)
         if boxsize is None:
             boxsize = int(np.ceil(10 * self.psf_sigma))
         if boxsize % 2 == 0:
             boxsize += 1
-        pixel = np.round(self.center).astype(int)
-        origin = (int(pixel[0]) - boxsize // 2, int(pixel[1]) - boxsize // 2)
+        if origin is None:
+            pixel = np.round(self.center).astype(int)
+            origin = (int(pixel[0]) - boxsize // 2, int(pixel[1]) - boxsize // 2)
+        # else: the box of a source whose centre has already moved stays where it was
         super().__init__(sed, np.zeros((boxsize, boxsize), dtype=np.float32), origin,
                          sed_min_step=sed_min_step, sed_rel_step=sed_rel_step,
                          morph_step=center_step, prox_flags=_lib.COMPONENT_POINT_SOURCE)

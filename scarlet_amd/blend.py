@@ -15,11 +15,13 @@ import numpy as np
 import numpy.ma as ma
 
 from . import _lib
-from .batch import BlendBatch, ComponentSpec
+from .batch import BlendBatch, ComponentSpec, PointSourceSpec
 from .bbox import overlapped_slices
 from .component import CombinedComponent, FactorizedComponent
 from .constraint import PositivityConstraint, device_flags
 from .model import UpdateException
+from .morphology import PointSourceMorphology
+from .psf import GaussianPSF
 from .parameter import relative_step
 from .renderer import ConvolutionRenderer, NullRenderer
 
@@ -125,6 +127,9 @@ class Blend(CombinedComponent):
             spectrum, morphology = comp.children
             sed = spectrum.parameters[0]
             image = morphology.parameters[0]
+            if isinstance(morphology, PointSourceMorphology):
+                specs.append(self._point_spec(sed, image, morphology))
+                continue
             if getattr(morphology, "shifting", False):
                 raise NotImplementedError("shifting morphologies are not supported yet")
             if sed.prior is not None or image.prior is not None:
@@ -153,21 +158,54 @@ class Blend(CombinedComponent):
             )
         return specs
 
+    @staticmethod
+    def _point_spec(sed, center, morphology):
+        """PointSource -> device description; the model PSF must be a pixel-integrated
+        Gaussian with one width for all bands (what the device kernel evaluates)."""
+        psf = morphology.psf
+        if not (isinstance(psf, GaussianPSF) and psf.integrate and psf.is_same):
+            raise NotImplementedError(
+                "point sources need a pixel-integrated GaussianPSF model PSF with one sigma")
+        if sed.prior is not None or center.prior is not None or sed.fixed or center.fixed:
+            raise NotImplementedError("priors / fixed parameters are not supported on the device")
+        if center.constraint is not None:
+            raise NotImplementedError("constraints on a point-source centre are not supported")
+        if not (isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20):
+            raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
+        s_const, s_rel, s_min = _step_rule(sed.step, "spectrum")
+        c_const, c_rel, _ = _step_rule(center.step, "center")
+        if c_rel:
+            raise NotImplementedError("relative steps for a point-source centre")
+        spec = PointSourceSpec(
+            np.asarray(sed), np.asarray(center), float(psf.get_parameter(0)[0]),
+            boxsize=morphology.bbox.shape[-1],
+            sed_min_step=np.maximum(np.asarray(s_min, dtype=np.float64), s_const),
+            sed_rel_step=s_rel, center_step=c_const, origin=morphology.bbox.origin[-2:])
+        return spec
+
     def _build_batch(self, comps, capacity):
         data, weights, kernel = self._observation()
         batch = BlendBatch(data[None], weights[None], [self._specs(comps)], kernel=kernel,
                            max_iter=max(capacity, 1))
         params = [(c.children[0].parameters[0], c.children[1].parameters[0]) for c in comps]
+        point = [isinstance(c.children[1], PointSourceMorphology) for c in comps]
         if all(p.m is not None and p.v is not None and p.vhat is not None
                for pair in params for p in pair):
+            # a point source has no image on the device side: zeros of its box shape
+            def image_state(name):
+                return [np.zeros(batch._shapes[k]) if point[k] else getattr(i, name)
+                        for k, (_, i) in enumerate(params)]
+
             batch.set_moments(
                 m_sed=np.stack([s.m for s, _ in params]),
                 v_sed=np.stack([s.v for s, _ in params]),
                 vhat_sed=np.stack([s.vhat for s, _ in params]),
-                m_morph=[i.m for _, i in params],
-                v_morph=[i.v for _, i in params],
-                vhat_morph=[i.vhat for _, i in params],
+                m_morph=image_state("m"), v_morph=image_state("v"), vhat_morph=image_state("vhat"),
             )
+            if any(point):
+                batch.set_center_moments(
+                    *[[getattr(i, name) if point[k] else (0.0, 0.0)
+                       for k, (_, i) in enumerate(params)] for name in ("m", "v", "vhat")])
         return batch
 
     @staticmethod
@@ -175,12 +213,19 @@ class Blend(CombinedComponent):
         """Device -> the Parameters (values in place, moments as float64 arrays)."""
         seds, morphs = batch.parameters()
         mom = batch.moments()
+        centers = None
         for k, comp in enumerate(comps):
             sed = comp.children[0].parameters[0]
             image = comp.children[1].parameters[0]
             sed[...] = seds[k]
-            image[...] = morphs[k]
             sed.m, sed.v, sed.vhat = (mom[n][k].astype(np.float64) for n in ("m_sed", "v_sed", "vhat_sed"))
+            if isinstance(comp.children[1], PointSourceMorphology):
+                if centers is None:
+                    centers = batch.centers()
+                image[...] = centers["center"][k]
+                image.m, image.v, image.vhat = (centers[n][k].copy() for n in ("m", "v", "vhat"))
+                continue
+            image[...] = morphs[k]
             image.m, image.v, image.vhat = (
                 mom[n][k].astype(np.float64) for n in ("m_morph", "v_morph", "vhat_morph")
             )

@@ -1,6 +1,6 @@
 """Image morphologies of factorized components (reference
-scarlet/morphology.py:26-207, 607-688).  Parametric profiles (Gaussian, Spergel,
-point source, starlet) are outside the scope of this package."""
+scarlet/morphology.py:26-207, 476-513, 607-688).  Parametric profiles (Gaussian,
+Spergel, starlet) are outside the scope of this package."""
 
 import numpy as np
 import numpy.ma as ma
@@ -16,7 +16,7 @@ from .constraint import (
 )
 from .frame import Frame
 from .model import Model, UpdateException
-from .parameter import Parameter, relative_step
+from .parameter import prepare_param, Parameter, relative_step
 
 
 def get_minimal_boxsize(size, min_size=21, increment=10):
@@ -160,3 +160,28 @@ class ExtendedSourceMorphology(ImageMorphology):
     @property
     def center(self):
         return self.pixel_center
+
+
+class PointSourceMorphology(Morphology):
+    """The model PSF (``frame.psf``) evaluated at a free sub-pixel ``center``
+    (reference morphology.py:476-513).  The box is the PSF box moved to the rounded
+    initial centre and never changes; the only parameter is the centre."""
+
+    def __init__(self, frame, center):
+        from .psf import PSF
+
+        assert frame.psf is not None and isinstance(frame.psf, PSF)
+        self.psf = frame.psf
+        pixel_center = tuple(np.round(center).astype("int"))
+        bbox = self.psf.bbox + (0, *pixel_center)
+        self.center = prepare_param(center, name="center")
+        super().__init__(frame, self.center, bbox=bbox)
+
+    def get_model(self, *parameters):
+        center = self.get_parameter(0, *parameters)
+        box_center = np.mean(self.bbox.bounds[1:], axis=1)
+        return self.psf.get_model(offset=np.asarray(center) - box_center)
+
+    @property
+    def integral(self):
+        return self.psf.get_model().sum()

@@ -1,7 +1,7 @@
 """Extended-source models (reference scarlet/source.py:249-522, 615-807):
 ``ExtendedSource`` factory -> ``SingleExtendedSource`` / ``MultiExtendedSource`` /
-``CompactExtendedSource``.  Point, Gaussian, Spergel, starlet and random sources
-are outside the scope of this package."""
+``CompactExtendedSource``, and ``PointSource`` (source.py:92-128).  Gaussian,
+Spergel, starlet and random sources are outside the scope of this package."""
 
 import logging
 
@@ -12,7 +12,8 @@ from . import operator
 from .bbox import Box, overlapped_slices
 from .component import CombinedComponent, FactorizedComponent
 from .constraint import CenterOnConstraint
-from .morphology import ExtendedSourceMorphology
+from .morphology import ExtendedSourceMorphology, PointSourceMorphology
+from .parameter import Parameter
 from .spectrum import TabulatedSpectrum
 
 logger = logging.getLogger("scarlet_amd.source")
@@ -22,6 +23,22 @@ def _noise_rms(observations):
     return np.concatenate(
         [np.array(np.mean(obs.noise_rms, axis=(1, 2))) for obs in observations]
     ).reshape(-1)
+
+
+class PointSource(FactorizedComponent):
+    """Point source: the model PSF at a free centre times a spectrum taken from the
+    peak pixel of the observations, corrected for the PSF (source.py:92-128)."""
+
+    def __init__(self, model_frame, sky_coord, observations):
+        if not hasattr(observations, "__iter__"):
+            observations = (observations,)
+        center = Parameter(np.array(model_frame.get_pixel(sky_coord), dtype=float),
+                           name="center", step=3e-2)
+        morphology = PointSourceMorphology(model_frame, center)
+        spectrum = init.get_pixel_spectrum(sky_coord, observations, correct_psf=True)
+        spectrum = TabulatedSpectrum(model_frame, spectrum, min_step=_noise_rms(observations))
+        super().__init__(model_frame, spectrum, morphology)
+        self.center = morphology.center
 
 
 class CompactExtendedSource(FactorizedComponent):

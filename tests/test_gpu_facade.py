@@ -203,3 +203,54 @@ def test_fit_forwards_adam_constants(hsc):
         blend.fit(2, scheme="adam")
     with pytest.raises(NotImplementedError):
         blend.fit(2, no_such_option=1)
+
+
+def test_point_source_tutorial_scene():
+    """docs/tutorials/point_source.ipynb through the facade: PointSource /
+    ExtendedSource initialisation reproduces the reference's sources (golden), the
+    fit follows the oracle (centres of the stars are free parameters)."""
+    import scarlet_amd as scarlet
+    from conftest import golden, point_scene
+
+    g = golden("point_source")
+    images = g["images"]
+    filters = list("ugrizy")
+    model_psf = scarlet.GaussianPSF(sigma=0.9)
+    frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters)
+    obs = scarlet.Observation(images, psf=scarlet.ImagePSF(g["psfs"].copy()),
+                              weights=np.ones_like(images) / 4, channels=filters).match(frame)
+    sources = []
+    for k in range(int(g["n_src"])):
+        cls = scarlet.PointSource if g["is_star"][k] else scarlet.ExtendedSource
+        sources.append(cls(frame, tuple(g["sky"][k]), obs))
+    for k, src in enumerate(sources):
+        spectrum, morphology = src.children
+        assert tuple(morphology.bbox.origin[-2:]) == tuple(g["origin_%d" % k])
+        assert_allclose(np.asarray(spectrum.parameters[0]), g["sed_%d" % k], rtol=2e-5)
+        if g["is_star"][k]:
+            assert_allclose(np.asarray(morphology.parameters[0]), g["center_%d" % k], rtol=0, atol=0)
+            assert_allclose(morphology.get_model()[0], g["morph_%d" % k], rtol=0, atol=1e-15)
+        else:
+            assert np.abs(np.asarray(morphology.parameters[0]) - g["morph_%d" % k]).max() < 1e-5
+    blend = scarlet.Blend(sources, obs)
+    model = blend.get_model()
+    assert np.abs(model - g["model"]).max() < 2e-5 * np.abs(g["model"]).max()
+    assert abs(obs.get_log_likelihood(model) - float(g["logL"])) < 1e-4 * abs(float(g["logL"]))
+
+    n, logL = blend.fit(35, e_rel=1e-6)
+    sc = point_scene(g)
+    n_ref, logL_ref = sc.fit(35, e_rel=1e-6, resizing=True)
+    assert n == n_ref == 35
+    chi = np.array(blend.loss) - sc.log_norm
+    chi_ref = np.array(sc.loss) - sc.log_norm
+    assert_allclose(chi[:20], chi_ref[:20], rtol=1e-3)
+    assert abs(chi[-1] - chi_ref[-1]) < 1e-2 * abs(chi_ref[-1])
+    for src, c in zip(sources, sc.components):
+        if isinstance(src, scarlet.PointSource):
+            center = src.children[1].parameters[0]
+            assert np.abs(np.asarray(center) - c.center).max() < 5e-3
+            assert center.m is not None and center.std.shape == (2,)
+            assert src.center is center
+        else:
+            assert src.children[1].parameters[0].shape == c.morph.shape
+    assert logL > float(g["logL"])
