@@ -50,6 +50,6 @@ from .source import (  # noqa: F401
     PointSource,
 )
 from .model import Model, UpdateException  # noqa: F401
-from . import fft, initialization, operator, synthetic  # noqa: F401
+from . import fft, initialization, measure, operator, synthetic  # noqa: F401
 
 __version__ = "0.1.0"

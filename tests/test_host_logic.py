@@ -223,3 +223,21 @@ def test_shard_ranges_cover_everything():
             assert a1 == b0 and a0 <= a1
         sizes = [b - a for a, b in ranges]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_measure_functions():
+    """scarlet.measure names (reference measure.py): known answers on a small cube"""
+    from scarlet_amd import measure
+
+    cube = np.zeros((2, 5, 7))
+    cube[0, 1, 2] = 3.0
+    cube[1, 3, 4] = 1.0
+    assert measure.max_pixel(cube) == (0, 1, 2)
+    assert_allclose(measure.flux(cube), [3.0, 1.0])
+    assert_allclose(measure.centroid(cube), [0.25, 1.5, 2.5])
+    M = measure.moments(cube, N=2, centroid=(0, 0))
+    assert set(M) == {(0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)}
+    assert_allclose(M[0, 0], [3.0, 1.0])
+    # first index = power of the second-axis offset (the reference's convention)
+    assert_allclose(M[1, 0], [3.0 * 2, 1.0 * 4])
+    assert_allclose(M[0, 1], [3.0 * 1, 1.0 * 3])
