@@ -131,7 +131,13 @@ class Blend(CombinedComponent):
                 specs.append(self._point_spec(sed, image, morphology))
                 continue
             if getattr(morphology, "shifting", False):
-                raise NotImplementedError("shifting morphologies are not supported yet")
+                # the reference's default shift of a shifting morphology is a FIXED zero
+                # vector (morphology.py:113): the Fourier shift is then the identity
+                shift = morphology.parameters[1]
+                if not shift.fixed or np.any(np.asarray(shift) != 0):
+                    raise NotImplementedError(
+                        "a free or non-zero Fourier shift of an image morphology is not "
+                        "supported on the device")
             if sed.prior is not None or image.prior is not None:
                 raise NotImplementedError("priors are not supported on the device")
             if sed.fixed or image.fixed:

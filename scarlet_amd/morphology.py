@@ -70,8 +70,6 @@ class ImageMorphology(Morphology):
             bbox = Box(image.shape)
         else:
             assert bbox.shape == image.shape
-        if shifting:
-            raise NotImplementedError("shifting=True (Fourier sub-pixel shifts) is not supported yet")
         self.resizing = resizing
         self.shifting = shifting
         if shift is None:
@@ -85,7 +83,16 @@ class ImageMorphology(Morphology):
         super().__init__(frame, image, shift, bbox=bbox)
 
     def get_model(self, *parameters):
-        return self.get_parameter(0, *parameters)
+        image = self.get_parameter(0, *parameters)
+        if self.shifting:
+            # Fourier sub-pixel shift (morphology.py:124-130).  The reference creates
+            # the shift with ``fixed=self.shifting`` (morphology.py:113), so with
+            # shifting=True and no explicit ``shift`` it stays at zero and this is the
+            # identity up to FFT round-off.
+            from . import fft
+
+            image = fft.shift(image, self.get_parameter(1, *parameters), return_Fourier=False)
+        return image
 
     def update(self):
         """Every 10 iterations: shrink the box when all edges are empty, grow it
@@ -153,12 +160,18 @@ class ExtendedSourceMorphology(ImageMorphology):
                         NormalizationConstraint("max")]
         image = Parameter(image, name="image", step=1e-2, constraint=ConstraintChain(*constraints))
         self.pixel_center = np.round(center).astype("int")
-        self.shift = None
-        super().__init__(frame, image, bbox=bbox, shifting=shifting, shift=None,
+        # with shifting the sub-pixel offset of the centre becomes a free parameter
+        # (morphology.py:673-676); Blend.fit refuses it: free Fourier shifts do not run
+        # on the device yet
+        self.shift = (Parameter(np.asarray(center, dtype=float) - self.pixel_center,
+                                name="shift", step=1e-1) if shifting else None)
+        super().__init__(frame, image, bbox=bbox, shifting=shifting, shift=self.shift,
                          resizing=resizing)
 
     @property
     def center(self):
+        if self.shift is not None:
+            return self.pixel_center + self.shift
         return self.pixel_center
 
 

@@ -12,7 +12,7 @@ from conftest import hsc_scene
 pytestmark = pytest.mark.gpu
 
 
-def build_blend(hsc, resizing):
+def build_blend(hsc, resizing, shifting=False):
     import scarlet_amd as scarlet
 
     filters = list("grizy")
@@ -30,7 +30,7 @@ def build_blend(hsc, resizing):
         center = (oy + h // 2, ox + w // 2)
         morphology = scarlet.ExtendedSourceMorphology(
             frame, center, hsc["morph_%d" % k].copy(), bbox=box[1:], monotonic="angle",
-            resizing=resizing)
+            resizing=resizing, shifting=shifting)
         comp = scarlet.FactorizedComponent(frame, spectrum, morphology)
         groups.setdefault(int(hsc["source_of"][k]), []).append(comp)
     sources = [g[0] if len(g) == 1 else scarlet.CombinedComponent(g) for g in groups.values()]
@@ -254,3 +254,36 @@ def test_point_source_tutorial_scene():
         else:
             assert src.children[1].parameters[0].shape == c.morph.shape
     assert logL > float(g["logL"])
+
+
+def test_shifting_image_morphology(hsc):
+    """A bare ``ImageMorphology(shifting=True)`` gets a FIXED zero shift in the
+    reference (``fixed=self.shifting``, morphology.py:113): the Fourier shift never
+    moves, so the fit equals the one without shifting.  ``ExtendedSource(shifting=True)``
+    makes the shift a free parameter (morphology.py:673-676): refused loudly."""
+    import scarlet_amd as scarlet
+
+    def blend_of(shifting):
+        blend, obs = build_blend(hsc, resizing=False)
+        comps = []
+        for comp in components_of(blend)[:4]:
+            spectrum, morphology = comp.children
+            image = np.asarray(morphology.parameters[0]).copy()
+            comps.append(scarlet.FactorizedComponent(
+                blend.frame, spectrum,
+                scarlet.ImageMorphology(blend.frame, image, bbox=morphology.bbox.copy(),
+                                        shifting=shifting, resizing=False)))
+        return scarlet.Blend(comps, obs)
+
+    a, b = blend_of(False), blend_of(True)
+    assert all(p.fixed for p in b.parameters if p.name == "shift")
+    na, la = a.fit(8, e_rel=1e-9)
+    nb, lb = b.fit(8, e_rel=1e-9)
+    assert na == nb == 8 and la == lb
+    morphology = b.sources[0].children[1]
+    assert np.abs(morphology.get_model() - np.asarray(morphology.parameters[0])).max() < 1e-12
+
+    free, _ = build_blend(hsc, resizing=False, shifting=True)
+    assert any(p.name == "shift" and not p.fixed for p in free.parameters)
+    with pytest.raises(NotImplementedError):
+        free.fit(2)
