@@ -208,3 +208,57 @@ def fourier_shift(image, shift, axes=(-2, -1)):
     if image.ndim > 2:
         ramp = ramp.reshape((1,) * (image.ndim - 2) + ramp.shape)
     return inverse_fft(forward_fft(image, shape, axes) * ramp, shape, image.shape, axes)
+
+
+class ShiftOperator:
+    """:func:`fourier_shift` of an (h, w) image written out as the linear map it is:
+
+        shifted = Dr @ x @ Tx.T - Di @ x @ Hx.T
+
+    with Toeplitz matrices ``M[n, n'] = v(n - n')`` built from the phase ramps of
+    fft.py:399-428 / interpolation.py:341-375 (``fftfreq`` along y, ``rfftfreq`` along x
+    whose Nyquist column keeps only its real part in the C2R transform).  ``Di`` is the
+    imaginary part the y-Nyquist frequency (f = -1/2, even FFT length) leaves behind.
+    Gives the adjoint and the derivative w.r.t. the shift that the reference gets from
+    autograd; the forward is checked against the FFT implementation in the tests."""
+
+    def __init__(self, shape, shift):
+        h, w = shape
+        Fy, Fx = fft_shape(shape, shape, padding=10, axes=(-2, -1))
+        self.fft_shape = (Fy, Fx)
+        sy, sx = float(shift[0]), float(shift[1])
+        dy = np.arange(-(h - 1), h)
+        k = np.fft.fftfreq(Fy) * Fy  # integer frequencies, -Fy/2 at Nyquist
+        ang = 2 * np.pi * k[None, :] * (dy[:, None] - sy) / Fy
+        wk = 2 * np.pi * k / Fy
+        dx = np.arange(-(w - 1), w)
+        l = np.arange(Fx // 2 + 1)
+        c = np.where((l == 0) | (l == Fx // 2), 1.0, 2.0)
+        bng = 2 * np.pi * l[None, :] * (dx[:, None] - sx) / Fx
+        wl = 2 * np.pi * l / Fx
+
+        def toep(v, n):
+            return v[np.arange(n)[:, None] - np.arange(n)[None, :] + (n - 1)]
+
+        self.Dr = toep(np.cos(ang).sum(1) / Fy, h)
+        self.Di = toep(np.sin(ang).sum(1) / Fy, h)
+        self.dDr = toep((wk * np.sin(ang)).sum(1) / Fy, h)    # d/d sy
+        self.dDi = toep(-(wk * np.cos(ang)).sum(1) / Fy, h)
+        self.Tx = toep((c * np.cos(bng)).sum(1) / Fx, w)
+        self.Hx = toep((c * np.sin(bng)).sum(1) / Fx, w)
+        self.dTx = toep((c * wl * np.sin(bng)).sum(1) / Fx, w)  # d/d sx
+        self.dHx = toep(-(c * wl * np.cos(bng)).sum(1) / Fx, w)
+
+    def forward(self, x):
+        return self.Dr @ x @ self.Tx.T - self.Di @ x @ self.Hx.T
+
+    def adjoint(self, g):
+        """Gradient w.r.t. the unshifted image given the gradient ``g`` w.r.t. the
+        shifted one."""
+        return self.Dr.T @ g @ self.Tx - self.Di.T @ g @ self.Hx
+
+    def shift_gradient(self, x, g):
+        """(d/d sy, d/d sx) of ``sum(g * forward(x))``."""
+        d_y = self.dDr @ x @ self.Tx.T - self.dDi @ x @ self.Hx.T
+        d_x = self.Dr @ x @ self.dTx.T - self.Di @ x @ self.dHx.T
+        return np.array([(g * d_y).sum(), (g * d_x).sum()])

@@ -35,7 +35,15 @@ class Component:
         symmetric=False,
         sed_zero=1e-20,
         source=None,
+        shift=None,
+        shift_step=1e-1,
     ):
+        # ExtendedSourceMorphology(shifting=True): the sub-pixel offset of the centre
+        # is a free 2-vector, step 1e-1, no constraint (morphology.py:673-676); the
+        # model uses the Fourier-shifted image (morphology.py:124-130)
+        self.shift = None if shift is None else np.array(shift, dtype=np.float64)
+        self.shift_step = shift_step
+        self.m_shift, self.v_shift, self.vhat_shift = np.zeros(2), np.zeros(2), np.zeros(2)
         self.sed = sed
         self.morph = morph
         self.origin = (int(origin[0]), int(origin[1]))
@@ -57,6 +65,12 @@ class Component:
         self.m_morph = np.zeros(morph.shape)
         self.v_morph = np.zeros(morph.shape)
         self.vhat_morph = np.zeros(morph.shape)
+
+    def model_morph(self):
+        """What enters the model: the image, Fourier-shifted if ``shift`` is free."""
+        if self.shift is None:
+            return self.morph
+        return fftconv.fourier_shift(self.morph, self.shift)
 
     def sed_step(self, it=0):
         """``relative_step`` (parameter.py:126-129) with axis=None."""
@@ -135,6 +149,9 @@ class PointComponent:
         Y, X = self._axes()
         image = integrated_gaussian(Y, self.sigma)[:, None] * integrated_gaussian(X, self.sigma)[None, :]
         return image / image.sum()
+
+    def model_morph(self):
+        return self.morph
 
     def center_gradient(self, g_morph):
         """Chain rule d(-logL)/d(center) = sum_yx g_morph * d(morph)/d(center)."""
@@ -252,7 +269,7 @@ class Scene:
         for group in self._groups():
             if len(group) == 1:
                 c = group[0]
-                boxed = c.sed[:, None, None] * c.morph[None, :, :]
+                boxed = c.sed[:, None, None] * c.model_morph()[None, :, :]
                 fs, bs = self.box_slices(c)
                 full[fs] += boxed[bs]
                 continue
@@ -264,7 +281,7 @@ class Scene:
             for c in group:
                 oy, ox = c.origin[0] - y0, c.origin[1] - x0
                 h, w = c.morph.shape
-                summed[:, oy : oy + h, ox : ox + w] += c.sed[:, None, None] * c.morph[None]
+                summed[:, oy : oy + h, ox : ox + w] += c.sed[:, None, None] * c.model_morph()[None]
             ylo, yhi = max(y0, 0), min(y1, H)
             xlo, xhi = max(x0, 0), min(x1, W)
             if yhi > ylo and xhi > xlo:
@@ -315,11 +332,16 @@ class Scene:
             boxed = np.zeros((self.frame_shape[0], h, w), dtype=np.float64)
             fs, bs = self.box_slices(c)
             boxed[bs] = G[fs]
-            g_sed = np.einsum("cyx,yx->c", boxed, c.morph)
+            g_sed = np.einsum("cyx,yx->c", boxed, c.model_morph())
             g_morph = np.einsum("c,cyx->yx", c.sed, boxed)
             if isinstance(c, PointComponent):
                 # second entry is d/d(center) for a point source
                 g_morph = c.center_gradient(g_morph)
+            elif c.shift is not None:
+                # pull the gradient back through the Fourier shift; third entry d/d(shift)
+                op = fftconv.ShiftOperator(c.morph.shape, c.shift)
+                out.append((g_sed, op.adjoint(g_morph), op.shift_gradient(c.morph, g_morph)))
+                continue
             out.append((g_sed, g_morph))
         return out
 
@@ -342,7 +364,7 @@ class Scene:
         # all steps are evaluated on the pre-update parameters (blend.py:135-138)
         alphas = [(c.sed_step(it), c.center_step if isinstance(c, PointComponent) else c.morph_step)
                   for c in self.components]
-        for c, (g_sed, g_morph), (a_sed, a_morph) in zip(self.components, grads, alphas):
+        for c, (g_sed, g_morph, *g_shift), (a_sed, a_morph) in zip(self.components, grads, alphas):
             adaprox_update(
                 it, c.sed, g_sed, c.m_sed, c.v_sed, c.vhat_sed, a_sed, c.sed_prox,
                 e_rel, prox_max_iter, b1, b2, eps,
@@ -358,6 +380,11 @@ class Scene:
                 it, c.morph, g_morph, c.m_morph, c.v_morph, c.vhat_morph, a_morph,
                 c.morph_prox, e_rel, prox_max_iter, b1, b2, eps,
             )
+            if g_shift:
+                adaprox_update(
+                    it, c.shift, g_shift[0], c.m_shift, c.v_shift, c.vhat_shift, c.shift_step,
+                    None, e_rel, prox_max_iter, b1, b2, eps,
+                )
 
     def check_parameters(self):
         """``Model.check_parameters`` (model.py:153-165)."""

@@ -240,6 +240,78 @@ def psf_unmatched(scarlet):
     )
 
 
+def hsc_shifting(scarlet):
+    """Quickstart scene with ``shifting=True``: every ExtendedSource carries a free
+    sub-pixel shift (morphology.py:673-676) applied by ``fft.shift``.  Images /
+    weights / PSFs are those of hsc_cosmos_35.npz and are not repeated."""
+    from scarlet.initialization import init_all_sources
+
+    d = np.load("/root/reference/data/hsc_cosmos_35.npz")
+    images = d["images"]
+    filters = [str(f) for f in d["filters"]]
+    weights = 1 / d["variance"]
+    # the catalogue positions are whole pixels; move them off the grid so that the
+    # initial shifts (centre - rounded centre) are not zero
+    off = np.random.default_rng(11).uniform(-0.4, 0.4, (len(d["catalog"]), 2))
+    centers = [(s["y"] + o[0], s["x"] + o[1]) for s, o in zip(d["catalog"], off)]
+
+    def build(dtype):
+        model_psf = scarlet.GaussianPSF(sigma=(0.8,) * len(filters))
+        frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters, dtype=dtype)
+        obs = scarlet.Observation(
+            images, psf=scarlet.ImagePSF(d["psfs"]), weights=weights, channels=filters
+        ).match(frame)
+        sources, _ = init_all_sources(
+            frame, centers, obs, max_components=2, min_snr=50, thresh=1,
+            fallback=True, silent=True, set_spectra=True, shifting=True,
+        )
+        return obs, sources
+
+    def flat(sources):
+        out = []
+        for i, src in enumerate(sources):
+            comps = [src] if isinstance(src, scarlet.FactorizedComponent) else list(src.children)
+            out += [(i, c) for c in comps]
+        return out
+
+    obs, sources = build(np.float32)
+    blend = scarlet.Blend(sources, obs)
+    model = blend.get_model()
+    out = dict(model=model, rendered=obs.render(model), logL=obs.get_log_likelihood(model),
+               centers=np.array(centers), n_comp=len(flat(sources)),
+               source_of=np.array([i for i, _ in flat(sources)]))
+    for k, (_, comp) in enumerate(flat(sources)):
+        spectrum, morphology = comp.children
+        out["sed_%d" % k] = np.array(spectrum.parameters[0])
+        out["morph_%d" % k] = np.array(morphology.parameters[0])
+        out["shift_%d" % k] = np.array(morphology.parameters[1])
+        out["origin_%d" % k] = np.array(morphology.bbox.origin[-2:])
+        out["min_step_%d" % k] = np.asarray(spectrum.parameters[0].step.keywords["minimum"])
+        out["shifted_%d" % k] = np.array(morphology.get_model())
+        assert not morphology.parameters[1].fixed and morphology.parameters[1].step == 1e-1
+
+    obs64, sources64 = build(np.float64)
+    blend64 = scarlet.Blend(sources64, obs64)
+    params = [np.array(p, dtype=np.float64) for p in blend64.parameters]
+    rng = np.random.default_rng(6)
+    fd = np.zeros(6)
+    for j in range(6):
+        direction = [rng.standard_normal(p.shape) for p in params]
+        eps = 1e-6
+        lp = _forward(blend64, obs64, [p + eps * t for p, t in zip(params, direction)])[1]
+        lm = _forward(blend64, obs64, [p - eps * t for p, t in zip(params, direction)])[1]
+        fd[j] = (lp - lm) / (2 * eps)
+        for i, t in enumerate(direction):
+            # order: (sed_0, morph_0, shift_0, sed_1, ...)
+            out["dir%d_%d" % (j, i)] = t.astype(np.float32) if t.size > 8 else t
+    out["fd_dlogL"] = fd
+    for k, (_, comp) in enumerate(flat(sources64)):
+        out["sed64_%d" % k] = np.array(comp.children[0].parameters[0])
+        out["morph64_%d" % k] = np.array(comp.children[1].parameters[0])
+    np.savez_compressed(os.path.join(OUT, "hsc_shifting.npz"), **out)
+    print("hsc_shifting: %d components, logL=%.3f" % (out["n_comp"], out["logL"]))
+
+
 def point_source(scarlet):
     """docs/tutorials/point_source.ipynb: psf_unmatched_sim scene, stars as
     PointSource, galaxies as ExtendedSource; state up to the first gradient."""
@@ -358,7 +430,7 @@ def main(which=None):
     os.makedirs(OUT, exist_ok=True)
     jobs = dict(
         operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
-        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source,
+        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, hsc_shifting=hsc_shifting,
         synthetic_cfg2=synthetic_cfg2,
     )
     for name, fn in jobs.items():

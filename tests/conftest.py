@@ -63,3 +63,21 @@ def point_scene(g, dtype64=False):
     images = g["images"].astype(dt)
     weights = np.full(images.shape, 0.25, dtype=dt)
     return pgm.Scene(images.shape, images, weights, g["diff_kernel"].astype(dt), comps, dtype=dt)
+
+
+def shifting_scene(g, hsc, dtype64=False):
+    """oracle.pgm.Scene of the quickstart blend with free Fourier shifts
+    (ExtendedSource(shifting=True)); observation from the hsc_cosmos_35 fixture."""
+    from oracle import pgm
+
+    comps = []
+    for k in range(int(g["n_comp"])):
+        sed = g["sed64_%d" % k] if dtype64 else g["sed_%d" % k]
+        morph = g["morph64_%d" % k] if dtype64 else g["morph_%d" % k]
+        comps.append(pgm.Component(sed.copy(), morph.copy(), g["origin_%d" % k],
+                                   sed_min_step=g["min_step_%d" % k],
+                                   source=int(g["source_of"][k]), shift=g["shift_%d" % k]))
+    dt = np.float64 if dtype64 else np.float32
+    images = hsc["images"].astype(dt)
+    return pgm.Scene(images.shape, images, hsc["weights"].astype(dt),
+                     hsc["diff_kernel"].astype(dt), comps, dtype=dt)

@@ -267,6 +267,36 @@ def test_point_source_scene_golden():
         assert_allclose(-dot, g["fd_dlogL"][j], rtol=2e-6)
 
 
+def test_shifting_scene_golden(hsc):
+    """ExtendedSource(shifting=True) built by the reference: Fourier-shifted
+    morphologies, model, logL; the separable shift operator equals the FFT
+    implementation; gradient (shifts included) against finite differences of the
+    reference's forward."""
+    from conftest import shifting_scene
+
+    g = golden("hsc_shifting")
+    sc = shifting_scene(g, hsc)
+    for k, c in enumerate(sc.components):
+        assert np.abs(c.shift).max() > 0
+        shifted = c.model_morph()
+        assert_allclose(shifted, g["shifted_%d" % k], rtol=0, atol=1e-14)
+        op = fftconv.ShiftOperator(c.morph.shape, c.shift)
+        assert_allclose(op.forward(c.morph), shifted, rtol=0, atol=1e-13)
+    model = sc.get_model()
+    assert_allclose(model, g["model"], rtol=0, atol=1e-6 * np.abs(g["model"]).max())
+    rendered = sc.render(model)
+    assert_allclose(sc.log_likelihood(rendered), g["logL"], rtol=1e-6)
+
+    sc64 = shifting_scene(g, hsc, dtype64=True)
+    _, grads = sc64.loss_and_gradients()
+    for j in range(len(g["fd_dlogL"])):
+        dot = 0.0
+        for k in range(int(g["n_comp"])):
+            for i in range(3):
+                dot += np.sum(grads[k][i] * g["dir%d_%d" % (j, 3 * k + i)].astype(np.float64))
+        assert_allclose(-dot, g["fd_dlogL"][j], rtol=2e-6)
+
+
 def test_synthetic_cfg2_golden():
     from scarlet_amd import synthetic
 
