@@ -98,7 +98,11 @@ enum {
     /* not a constraint: the component is a PointSource (source.py:92-128) whose
      * morphology is the model PSF evaluated at a free sub-pixel centre
      * (PointSourceMorphology, morphology.py:476-513; GaussianPSF, psf.py:80-142) */
-    SMI_COMPONENT_POINT_SOURCE = 1 << 16
+    SMI_COMPONENT_POINT_SOURCE = 1 << 16,
+    /* the image morphology is moved by a free sub-pixel Fourier shift
+     * (ExtendedSource(shifting=True): morphology.py:124-130, 673-676; fft.shift,
+     * fft.py:399-428): `center` holds the initial shift (y, x), `shift_step` its step */
+    SMI_COMPONENT_SHIFTING = 1 << 17
 };
 #define SMI_PROX_EXTENDED_SOURCE \
     (SMI_PROX_MONOTONIC | SMI_PROX_POSITIVE | SMI_PROX_CENTER_ON | SMI_PROX_NORM_MAX)
@@ -144,8 +148,11 @@ typedef struct smi_components {
      * (morphology.py:494-497), its `morph` input is ignored (the library evaluates
      * the pixel-integrated Gaussian), and `morph_step` is the step of the centre
      * (3e-2, source.py:115). */
-    const double *center;       /* [n_components][2] (y, x) in frame pixels          */
+    const double *center;       /* [n_components][2] (y, x) in frame pixels; for     */
+                                /* SMI_COMPONENT_SHIFTING entries: the shift (y, x)  */
     const float *psf_sigma;     /* [n_components] model PSF sigma (all bands alike)  */
+    const float *shift_step;    /* [n_components] step of a free shift (1e-1,        */
+                                /* morphology.py:675); NULL = 1e-1                   */
 } smi_components;
 
 int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out);
@@ -175,13 +182,16 @@ int smi_batch_set_moments(smi_batch *b, const float *m_sed, const float *v_sed,
 int smi_batch_get_moments(smi_batch *b, float *m_sed, float *v_sed, float *vhat_sed,
                           float *m_morph, float *v_morph, float *vhat_morph);
 int smi_batch_get_parameters(smi_batch *b, float *sed, float *morph);
-/* point-source centres [n_components][2] (entries of other components: 0) and their
- * AMSGrad moments; the gradient is valid after smi_batch_gradient.  Any pointer may
- * be NULL. */
+/* point-source centres / free shifts [n_components][2] (entries of other components:
+ * 0) and their AMSGrad moments; the gradient is valid after smi_batch_gradient.  Any
+ * pointer may be NULL.  For a shifting component smi_batch_get_parameters returns the
+ * image parameter; smi_batch_get_model_morphology returns what enters the model (the
+ * shifted image; equal to the parameter for every other component). */
 int smi_batch_get_centers(smi_batch *b, double *center, double *m, double *v, double *vhat,
                           double *gradient);
 int smi_batch_set_center_moments(smi_batch *b, const double *m, const double *v,
                                  const double *vhat);
+int smi_batch_get_model_morphology(smi_batch *b, float *morph);
 int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph);
 
 /* AMSGrad constants forwarded by Blend.fit(**alg_kwargs) to adaprox (blend.py:165-180);

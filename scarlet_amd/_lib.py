@@ -24,6 +24,7 @@ PROX_NORM_SUM = 32
 PROX_L1 = 64
 PROX_L0 = 128
 COMPONENT_POINT_SOURCE = 1 << 16  # PointSource: morphology = model PSF at a free centre
+COMPONENT_SHIFTING = 1 << 17  # image morphology moved by a free Fourier shift
 PROX_EXTENDED_SOURCE = PROX_MONOTONIC | PROX_POSITIVE | PROX_CENTER_ON | PROX_NORM_MAX
 
 ERR_ARITHMETIC = -4
@@ -50,7 +51,7 @@ class Components(ctypes.Structure):
         ("sed_min_step", c_f32p), ("sed_rel_step", c_f32p), ("morph_step", c_f32p),
         ("prox_flags", c_i32p), ("sweep_plan", c_i32p), ("min_gradient", c_f32p),
         ("l_thresh", c_f32p), ("morph_rel_step", c_f32p),
-        ("center", c_f64p), ("psf_sigma", c_f32p),
+        ("center", c_f64p), ("psf_sigma", c_f32p), ("shift_step", c_f32p),
     ]
 
 
@@ -101,6 +102,7 @@ SYMBOLS = {
     "smi_batch_set_parameters": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
     "smi_batch_get_centers": (ctypes.c_int, [ctypes.c_void_p] + [c_f64p] * 5),
     "smi_batch_set_center_moments": (ctypes.c_int, [ctypes.c_void_p] + [c_f64p] * 3),
+    "smi_batch_get_model_morphology": (ctypes.c_int, [ctypes.c_void_p, c_f32p]),
     "smi_batch_set_optimizer": (
         ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float]
     ),

@@ -18,7 +18,8 @@ class ComponentSpec:
 
     def __init__(self, sed, morph, origin, sed_min_step=0.0, sed_rel_step=1e-2,
                  morph_step=1e-2, morph_rel_step=0.0, prox_flags=_lib.PROX_EXTENDED_SOURCE,
-                 neighbor_weight="angle", min_gradient=0.0, l_thresh=0.0):
+                 neighbor_weight="angle", min_gradient=0.0, l_thresh=0.0, shift=None,
+                 shift_step=1e-1):
         self.sed = np.asarray(sed, dtype=np.float32)
         self.morph = np.ascontiguousarray(morph, dtype=np.float32)
         self.origin = (int(origin[0]), int(origin[1]))
@@ -32,6 +33,12 @@ class ComponentSpec:
         self.neighbor_weight = neighbor_weight
         self.min_gradient = float(min_gradient)
         self.l_thresh = float(l_thresh)
+        # ExtendedSource(shifting=True): free sub-pixel Fourier shift of the image
+        # (morphology.py:124-130, 673-676); the device keeps it in the `center` slot
+        self.shift_step = float(shift_step)
+        if shift is not None:
+            self.center = np.array(shift, dtype=np.float64).reshape(2)
+            self.prox_flags |= _lib.COMPONENT_SHIFTING
 
 
 class PointSourceSpec(ComponentSpec):
@@ -159,6 +166,7 @@ class BlendBatch:
                 [getattr(c, "center", (0.0, 0.0)) for c in flat], dtype=np.float64
             ).reshape(-1, 2),
             psf_sigma=_lib.f32([getattr(c, "psf_sigma", 0.0) for c in flat]),
+            shift_step=_lib.f32([c.shift_step for c in flat]),
         )
         comps = _lib.Components()
         for name, ctype in _lib.Components._fields_:
@@ -303,10 +311,18 @@ class BlendBatch:
         )
         return sed, self._split_morphs(morph)
 
+    def model_morphologies(self):
+        """The morphologies as they enter the model: the Fourier-shifted image of a
+        shifting component, the PSF image of a point source, else the parameter."""
+        morph = np.empty(int(self._morph_offsets[-1]), dtype=np.float32)
+        _lib.check(self._lib.smi_batch_get_model_morphology(self._h, _lib.ptr(morph, ctypes.c_float)))
+        return self._split_morphs(morph)
+
     def centers(self):
-        """Point-source state: dict of (n_components, 2) float64 arrays ``center``
-        (frame pixels; zeros for other components), ``m``, ``v``, ``vhat`` and, after
-        ``gradient()``, ``gradient``."""
+        """State of the free 2-vectors: dict of (n_components, 2) float64 arrays
+        ``center`` (point sources: centre in frame pixels; shifting components: the
+        shift; zeros otherwise), ``m``, ``v``, ``vhat`` and, after ``gradient()``,
+        ``gradient``."""
         out = {k: np.zeros((self.n_components, 2)) for k in ("center", "m", "v", "vhat", "gradient")}
         _lib.check(
             self._lib.smi_batch_get_centers(

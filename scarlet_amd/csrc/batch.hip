@@ -103,6 +103,12 @@ struct smi_batch {
     int n_point = 0;
     std::vector<double> box_center;  // mean of the box bounds per component (y, x)
     std::vector<char> is_point;
+    // free Fourier shifts
+    int n_shift = 0, max_box_side = 1;
+    float *morph_param = nullptr, *c_shift_step = nullptr;
+    int32_t *c_shift_fft = nullptr;
+    std::vector<char> is_shift;
+    std::vector<int64_t> h_moff;
     int64_t n_morph = 0;
     bool have_components = false, have_obs = false, have_kernel = false;
     // per blend
@@ -174,6 +180,13 @@ void refresh_view(smi_batch *b) {
     v.n_point = b->n_point;
     v.pt = b->pt;
     v.c_sigma = b->c_sigma;
+    v.n_shift = b->n_shift;
+    v.max_box_side = b->max_box_side;
+    v.morph_param = b->morph_param;
+    v.g_sed_buf = b->g_sed;
+    v.g_morph_buf = b->g_morph;
+    v.c_shift_step = b->c_shift_step;
+    v.c_shift_fft = b->c_shift_fft;
     for (const auto &pl : b->plans)
         if (!pl.slots) v.fast_plans = 0;
 }
@@ -445,7 +458,8 @@ int smi_batch_destroy(smi_batch *b) {
                     b->c_flags, b->c_plan, b->c_moff, b->c_sed_min_step, b->c_sed_rel,
                     b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
-                    b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->state, b->zero_state, b->n_loss, b->status_out,
+                    b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
+                    b->c_shift_step, b->c_shift_fft, b->state, b->zero_state, b->n_loss, b->status_out,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -637,6 +651,13 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         const int64_t np = (int64_t)c->box_h[k] * c->box_w[k];
         moff[k + 1] = moff[k] + np;
         if (np > max_pix) max_pix = (int)np;
+        if (c->prox_flags[k] & SMI_COMPONENT_SHIFTING) {
+            SMI_REQUIRE(c->center, "shifting component without its shift (center)");
+            SMI_REQUIRE(!(c->prox_flags[k] & SMI_COMPONENT_POINT_SOURCE),
+                        "a point source cannot carry a Fourier shift");
+            SMI_REQUIRE(c->box_h[k] <= 100 && c->box_w[k] <= 100,
+                        "shifting component box larger than 100 pixels");
+        }
         if (c->prox_flags[k] & SMI_COMPONENT_POINT_SOURCE) {
             SMI_REQUIRE(c->center && c->psf_sigma, "point source without center / psf_sigma");
             SMI_REQUIRE(c->box_h[k] < 64 && c->box_w[k] < 64, "point-source box larger than 63 pixels");
@@ -695,6 +716,37 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     b->box_center.assign((size_t)n * 2, 0.0);
     b->is_point.assign((size_t)n, 0);
     b->n_point = 0;
+    b->n_shift = 0;
+    b->max_box_side = 1;
+    b->is_shift.assign((size_t)n, 0);
+    b->h_moff = moff;
+    std::vector<float> shift_step(n, 1e-1f);
+    std::vector<int32_t> shift_fft((size_t)n * 2, 0);
+    for (int k = 0; k < n; ++k) {
+        b->max_box_side = std::max(b->max_box_side, std::max(c->box_h[k], c->box_w[k]));
+        if (!(c->prox_flags[k] & SMI_COMPONENT_SHIFTING)) continue;
+        b->n_shift++;
+        b->is_shift[k] = 1;
+        pt[8 * k] = c->center[2 * k];
+        pt[8 * k + 1] = c->center[2 * k + 1];
+        if (c->shift_step) shift_step[k] = c->shift_step[k];
+        // fft.shift: _get_fft_shape(image, image, padding=10) (fft.py:116-167, 401-403)
+        int fy = next_fast_len(2 * c->box_h[k] + 10), fx = next_fast_len(2 * c->box_w[k] + 10);
+        while (fx % 2) fx = next_fast_len(fx + 1);
+        if (c->box_h[k] % 2 == 0)
+            while (fy % 2) fy = next_fast_len(fy + 1);
+        shift_fft[2 * k] = fy;
+        shift_fft[2 * k + 1] = fx;
+    }
+    if ((rc = upload(&b->c_shift_step, shift_step.data(), (size_t)n))) return rc;
+    if ((rc = upload(&b->c_shift_fft, shift_fft.data(), (size_t)n * 2))) return rc;
+    if (b->n_shift) {
+        // the uploaded images are the parameters; `morph` becomes the shifted image
+        if ((rc = upload(&b->morph_param, c->morph, (size_t)b->n_morph))) return rc;
+    } else if (b->morph_param) {
+        SMI_HIP(hipFree(b->morph_param));
+        b->morph_param = nullptr;
+    }
     for (int k = 0; k < n; ++k) {
         if (!(c->prox_flags[k] & SMI_COMPONENT_POINT_SOURCE)) continue;
         b->n_point++;
@@ -717,8 +769,17 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     // the morphology of a point source is derived from its centre
     const BatchView v = unmasked_view(b);
     if ((rc = launch_point_sources(v, nullptr, 0, 0.f, 0, nullptr, nullptr, 2, b->stream))) return rc;
+    if ((rc = launch_shift_forward(v, 0, b->stream))) return rc;
     SMI_HIP(hipStreamSynchronize(b->stream));
     SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_batch_get_model_morphology(smi_batch *b, float *morph) {
+    SMI_REQUIRE(b && b->have_components && morph, "components not set / null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipMemcpy(morph, b->morph, (size_t)b->n_morph * sizeof(float), hipMemcpyDeviceToHost));
     return SMI_OK;
 }
 
@@ -799,9 +860,16 @@ int smi_batch_get_parameters(smi_batch *b, float *sed, float *morph) {
     if (sed)
         SMI_HIP(hipMemcpy(sed, b->sed, (size_t)b->d.n_components * b->d.C * sizeof(float),
                           hipMemcpyDeviceToHost));
-    if (morph)
+    if (morph) {
         SMI_HIP(hipMemcpy(morph, b->morph, (size_t)b->n_morph * sizeof(float),
                           hipMemcpyDeviceToHost));
+        // the parameter of a shifting component is its unshifted image
+        for (int k = 0; k < b->d.n_components && b->n_shift; ++k)
+            if (b->is_shift[k])
+                SMI_HIP(hipMemcpy(morph + b->h_moff[k], b->morph_param + b->h_moff[k],
+                                  (size_t)(b->h_moff[k + 1] - b->h_moff[k]) * sizeof(float),
+                                  hipMemcpyDeviceToHost));
+    }
     return SMI_OK;
 }
 
@@ -812,9 +880,17 @@ int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph)
     if (sed)
         SMI_HIP(hipMemcpy(b->sed, sed, (size_t)b->d.n_components * b->d.C * sizeof(float),
                           hipMemcpyHostToDevice));
-    if (morph)
+    if (morph) {
         SMI_HIP(hipMemcpy(b->morph, morph, (size_t)b->n_morph * sizeof(float),
                           hipMemcpyHostToDevice));
+        if (b->n_shift) {
+            SMI_HIP(hipMemcpy(b->morph_param, morph, (size_t)b->n_morph * sizeof(float),
+                              hipMemcpyHostToDevice));
+            int rc = launch_shift_forward(unmasked_view(b), 0, b->stream);
+            if (rc) return rc;
+            SMI_HIP(hipStreamSynchronize(b->stream));
+        }
+    }
     return SMI_OK;
 }
 
@@ -900,6 +976,7 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     if ((rc = launch_update(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_morph, 1, b->stream))) return rc;
     if ((rc = launch_point_sources(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_center, 1, b->stream)))
         return rc;
+    if ((rc = launch_shift_backward(v, b->Q, 0, b->g_center, 1, b->stream))) return rc;
     SMI_HIP(hipStreamSynchronize(b->stream));
     if (g_sed)
         SMI_HIP(hipMemcpy(g_sed, b->g_sed, (size_t)v.n_comp * v.C * sizeof(float),
@@ -952,11 +1029,13 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
             if ((rc = convolve(b, v, 1))) return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
         }
+        if ((rc = launch_shift_backward(v, b->Q, it, nullptr, 0, b->stream))) return rc;
         if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, b->stream)))
             return rc;
         if ((rc = launch_point_sources(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0,
                                        b->stream)))
             return rc;
+        if ((rc = launch_shift_forward(v, 1, b->stream))) return rc;
         if (check) launch_advance(v, b->stream);
         if (ev) SMI_HIP(hipEventRecord(ev[5], b->stream));
     }

@@ -117,6 +117,14 @@ struct BatchView {
     int32_t n_point;
     double *pt;
     const float *c_sigma;
+    // free Fourier shifts (shift.hip): pt holds {shift y, x, m, v, vhat}; `morph` is the
+    // shifted image the model uses, `morph_param` the image parameter; the update
+    // kernels read the pulled-back gradient from g_morph_buf / g_sed_buf
+    int32_t n_shift, max_box_side;
+    float *morph_param;
+    float *g_sed_buf, *g_morph_buf;
+    const float *c_shift_step;
+    const int32_t *c_shift_fft;  // (Fy, Fx) per component, fft.py:116-167 with padding 10
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);
@@ -135,6 +143,9 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
 int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e_rel,
                          int32_t prox_max_iter, float *g_sed_out, double *g_center_out,
                          int32_t mode, hipStream_t s);
+int launch_shift_backward(const BatchView &v, const float *G, int32_t it, double *g_shift_out,
+                          int32_t grad_only, hipStream_t s);
+int launch_shift_forward(const BatchView &v, int32_t respect_state, hipStream_t s);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);
 void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,

@@ -243,6 +243,8 @@ struct CompCtx {
     int k, b, C, h, w, N, oy, ox, lane;
     int64_t moff;
     const float *morph, *sed;
+    float *morph_out;
+    bool pre;  // gradient already gathered and pulled back through a Fourier shift
 };
 
 __device__ __forceinline__ CompCtx comp_ctx(const BatchView &v) {
@@ -257,7 +259,11 @@ __device__ __forceinline__ CompCtx comp_ctx(const BatchView &v) {
     c.oy = v.c_oy[c.k];
     c.ox = v.c_ox[c.k];
     c.moff = v.c_moff[c.k];
-    c.morph = v.morph + c.moff;
+    c.pre = v.n_shift && (v.c_flags[c.k] & SMI_COMPONENT_SHIFTING);
+    // a shifting component is updated on its image parameter; `morph` (what the model
+    // uses) is rebuilt from it by shift_forward_kernel afterwards
+    c.morph_out = (c.pre ? v.morph_param : v.morph) + c.moff;
+    c.morph = c.morph_out;
     c.sed = v.sed + (int64_t)c.k * c.C;
     return c;
 }
@@ -267,6 +273,10 @@ __device__ __forceinline__ CompCtx comp_ctx(const BatchView &v) {
 __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompCtx &c,
                                                  const float *G, float *us) {
     float g_sed = 0.f;
+    if (c.pre) {
+        for (int i = c.lane; i < c.N; i += 64) us[i] = v.g_morph_buf[c.moff + i];
+        return c.lane < c.C ? v.g_sed_buf[(int64_t)c.k * c.C + c.lane] : 0.f;
+    }
     const float inv_w = 1.0f / (float)c.w;
     for (int c0 = 0; c0 < c.C; c0 += kBandChunk) {
         const int nc = min(kBandChunk, c.C - c0);
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     }
     for (int i = lane; i < N; i += 64) {
         const float z = zs[i];
-        v.morph[c.moff + i] = z;
+        c.morph_out[i] = z;
         bad |= !isfinite(z);
     }
     if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
     for (int j = 0; j < NPL; ++j) {
         const int i = lane + 64 * j;
         if (i < N) {
-            v.morph[c.moff + i] = zs[j];
+            c.morph_out[i] = zs[j];
             bad |= !isfinite(zs[j]);
         }
     }

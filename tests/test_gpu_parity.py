@@ -640,3 +640,68 @@ def test_point_source_scene_steps(amd, path):
     # the centres did move
     assert max(np.abs(c.center - g["center_%d" % k]).max()
                for k, c in enumerate(sc.components) if g["is_star"][k]) > 1e-3
+
+
+# ---------------------------------------------------------------- free Fourier shifts
+def _shifting_batch(amd, g, hsc, **kw):
+    specs = [amd.ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
+                               sed_min_step=g["min_step_%d" % k], shift=g["shift_%d" % k])
+             for k in range(int(g["n_comp"]))]
+    return amd.BlendBatch(hsc["images"][None], hsc["weights"][None], [specs],
+                          kernel=hsc["diff_kernel"], **kw)
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_shifting_scene_forward_and_gradient(amd, hsc, path):
+    """ExtendedSource(shifting=True) scene built by the reference (golden): shifted
+    morphologies, model, logL against the reference's values; gradients w.r.t.
+    spectra, images (pulled back through the shift) and shifts against the oracle"""
+    from conftest import shifting_scene
+
+    g = golden("hsc_shifting")
+    batch = _shifting_batch(amd, g, hsc, max_iter=4, conv_path=path)
+    sc = shifting_scene(g, hsc)
+    shifted = batch.model_morphologies()
+    _, params = batch.parameters()
+    for k in range(int(g["n_comp"])):
+        assert np.abs(shifted[k] - g["shifted_%d" % k]).max() < 2e-6, k
+        assert_array_equal(params[k], g["morph_%d" % k].astype(np.float32))
+    assert_allclose(batch.centers()["center"], [g["shift_%d" % k] for k in range(int(g["n_comp"]))])
+    model, rendered, logL = batch.forward()
+    assert rel_err(model[0], g["model"]) < RTOL
+    assert rel_err(rendered[0], g["rendered"]) < RTOL
+    assert abs(logL[0] - float(g["logL"])) < RTOL * abs(float(g["logL"]))
+    g_sed, g_morph = batch.gradient()
+    g_shift = batch.centers()["gradient"]
+    _, grads = sc.loss_and_gradients()
+    # tolerances relative to the magnitudes the float32 sums run over (sum |G||morph|;
+    # the shift derivative sums |g| |d shifted / d s| ~ the image-gradient scale x pixels)
+    # (2e-5: the Fourier-shifted images ring over the whole box, so every box pixel of
+    # the float32 gradient image contributes its rounding to the sums)
+    for k, (s_sed, s_morph) in enumerate(grad_scales(sc)):
+        assert np.abs(g_sed[k] - grads[k][0]).max() < 2 * RTOL * s_sed, k
+        assert np.abs(g_morph[k] - grads[k][1]).max() < 2 * RTOL * s_morph, k
+        n_pix = grads[k][1].size
+        assert np.abs(g_shift[k] - grads[k][2]).max() < 2 * RTOL * s_morph * np.sqrt(n_pix), k
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_shifting_scene_steps(amd, hsc, path):
+    """10 full iterations with free shifts: losses, spectra, images, shifts, moments"""
+    from conftest import shifting_scene
+
+    g = golden("hsc_shifting")
+    n_it = 10
+    batch = _shifting_batch(amd, g, hsc, max_iter=n_it + 1, conv_path=path)
+    sc = shifting_scene(g, hsc)
+    batch.step(0, n_it, e_rel=1e-4)
+    for it in range(n_it):
+        sc.step(it, 1e-4)
+    assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm, rtol=2e-4)
+    sed, morphs = batch.parameters()
+    st = batch.centers()
+    for k, c in enumerate(sc.components):
+        assert rel_err(sed[k], c.sed) < 1e-3, k
+        assert np.abs(morphs[k] - c.morph).max() < 2e-3, k
+        assert np.abs(st["center"][k] - c.shift).max() < 2e-3, k
+    assert max(np.abs(c.shift - g["shift_%d" % k]).max() for k, c in enumerate(sc.components)) > 1e-2
