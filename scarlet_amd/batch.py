@@ -132,6 +132,7 @@ class BlendBatch:
                         )
                     )
         self._shapes = [c.morph.shape for c in flat]
+        self._flags = [c.prox_flags for c in flat]
         self._morph_offsets = np.concatenate(
             [[0], np.cumsum([s[0] * s[1] for s in self._shapes])]
         ).astype(np.int64)
@@ -310,6 +311,10 @@ class BlendBatch:
             )
         )
         return sed, self._split_morphs(morph)
+
+    def has_shift(self, k):
+        """True if component ``k`` carries a Fourier shift on the device."""
+        return bool(self._flags[k] & _lib.COMPONENT_SHIFTING)
 
     def model_morphologies(self):
         """The morphologies as they enter the model: the Fourier-shifted image of a

@@ -130,14 +130,19 @@ class Blend(CombinedComponent):
             if isinstance(morphology, PointSourceMorphology):
                 specs.append(self._point_spec(sed, image, morphology))
                 continue
+            shift_kw = {}
             if getattr(morphology, "shifting", False):
-                # the reference's default shift of a shifting morphology is a FIXED zero
-                # vector (morphology.py:113): the Fourier shift is then the identity
+                # Fourier sub-pixel shift (morphology.py:124-130).  A fixed zero shift --
+                # the reference's default for a bare ImageMorphology, morphology.py:113 --
+                # is the identity; a fixed non-zero one is applied with step 0
                 shift = morphology.parameters[1]
+                if shift.prior is not None or shift.constraint is not None:
+                    raise NotImplementedError("priors / constraints on a shift parameter")
                 if not shift.fixed or np.any(np.asarray(shift) != 0):
-                    raise NotImplementedError(
-                        "a free or non-zero Fourier shift of an image morphology is not "
-                        "supported on the device")
+                    const, rel, _ = _step_rule(shift.step, "shift")
+                    if rel:
+                        raise NotImplementedError("relative steps for a shift parameter")
+                    shift_kw = dict(shift=np.asarray(shift), shift_step=0.0 if shift.fixed else const)
             if sed.prior is not None or image.prior is not None:
                 raise NotImplementedError("priors are not supported on the device")
             if sed.fixed or image.fixed:
@@ -160,6 +165,7 @@ class Blend(CombinedComponent):
                     neighbor_weight=flags["neighbor_weight"] or "angle",
                     min_gradient=flags["min_gradient"],
                     l_thresh=flags["l_thresh"],
+                    **shift_kw,
                 )
             )
         return specs
@@ -208,10 +214,17 @@ class Blend(CombinedComponent):
                 vhat_sed=np.stack([s.vhat for s, _ in params]),
                 m_morph=image_state("m"), v_morph=image_state("v"), vhat_morph=image_state("vhat"),
             )
-            if any(point):
-                batch.set_center_moments(
-                    *[[getattr(i, name) if point[k] else (0.0, 0.0)
-                       for k, (_, i) in enumerate(params)] for name in ("m", "v", "vhat")])
+        vec = [None] * len(comps)  # the free 2-vector of a component, if it has one
+        for k, c in enumerate(comps):
+            if point[k]:
+                vec[k] = params[k][1]
+            elif batch.has_shift(k):
+                vec[k] = c.children[1].parameters[1]
+        if any(p is not None and p.m is not None and p.v is not None and p.vhat is not None
+               for p in vec):
+            batch.set_center_moments(
+                *[[getattr(p, name) if p is not None and getattr(p, name) is not None
+                   else (0.0, 0.0) for p in vec] for name in ("m", "v", "vhat")])
         return batch
 
     @staticmethod
@@ -231,6 +244,12 @@ class Blend(CombinedComponent):
                 image[...] = centers["center"][k]
                 image.m, image.v, image.vhat = (centers[n][k].copy() for n in ("m", "v", "vhat"))
                 continue
+            if batch.has_shift(k):
+                if centers is None:
+                    centers = batch.centers()
+                shift = comp.children[1].parameters[1]
+                shift[...] = centers["center"][k]
+                shift.m, shift.v, shift.vhat = (centers[n][k].copy() for n in ("m", "v", "vhat"))
             image[...] = morphs[k]
             image.m, image.v, image.vhat = (
                 mom[n][k].astype(np.float64) for n in ("m_morph", "v_morph", "vhat_morph")

@@ -259,8 +259,7 @@ def test_point_source_tutorial_scene():
 def test_shifting_image_morphology(hsc):
     """A bare ``ImageMorphology(shifting=True)`` gets a FIXED zero shift in the
     reference (``fixed=self.shifting``, morphology.py:113): the Fourier shift never
-    moves, so the fit equals the one without shifting.  ``ExtendedSource(shifting=True)``
-    makes the shift a free parameter (morphology.py:673-676): refused loudly."""
+    moves, so the fit equals the one without shifting."""
     import scarlet_amd as scarlet
 
     def blend_of(shifting):
@@ -283,7 +282,52 @@ def test_shifting_image_morphology(hsc):
     morphology = b.sources[0].children[1]
     assert np.abs(morphology.get_model() - np.asarray(morphology.parameters[0])).max() < 1e-12
 
-    free, _ = build_blend(hsc, resizing=False, shifting=True)
-    assert any(p.name == "shift" and not p.fixed for p in free.parameters)
-    with pytest.raises(NotImplementedError):
-        free.fit(2)
+
+def test_extended_sources_with_free_shifts(hsc):
+    """``init_all_sources(..., shifting=True)``: every ExtendedSource carries a free
+    Fourier shift (morphology.py:673-676).  Initialisation equals the reference's
+    (golden), the fit with box resizing follows the oracle, shifts and their optimizer
+    state land on the ``shift`` Parameters."""
+    import scarlet_amd as scarlet
+    from scarlet_amd.initialization import init_all_sources
+    from conftest import golden, shifting_scene
+
+    g = golden("hsc_shifting")
+    filters = list("grizy")
+    frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5),
+                          channels=filters)
+    obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                              weights=hsc["weights"], channels=filters).match(frame)
+    centers = [tuple(c) for c in g["centers"]]
+    sources, skipped = init_all_sources(frame, centers, obs, max_components=2, min_snr=50,
+                                        thresh=1, fallback=True, silent=True, set_spectra=True,
+                                        shifting=True)
+    blend = scarlet.Blend(sources, obs)
+    comps = components_of(blend)
+    assert len(comps) == int(g["n_comp"])
+    for k, comp in enumerate(comps):
+        morphology = comp.children[1]
+        image, shift = morphology.parameters
+        assert not shift.fixed and shift.step == 1e-1
+        assert_allclose(np.asarray(shift), g["shift_%d" % k], atol=1e-12)
+        assert np.abs(np.asarray(image) - g["morph_%d" % k]).max() < 1e-5
+        assert np.abs(morphology.get_model() - g["shifted_%d" % k]).max() < 1e-5
+    model = blend.get_model()
+    assert np.abs(model - g["model"]).max() < 2e-4 * np.abs(g["model"]).max()
+
+    n, logL = blend.fit(32, e_rel=1e-6)
+    sc = shifting_scene(g, hsc)
+    n_ref, logL_ref = sc.fit(32, e_rel=1e-6, resizing=True)
+    assert n == n_ref == 32
+    chi = np.array(blend.loss) - sc.log_norm
+    chi_ref = np.array(sc.loss) - sc.log_norm
+    assert_allclose(chi[:15], chi_ref[:15], rtol=2e-3)
+    assert abs(chi[-1] - chi_ref[-1]) < 2e-2 * abs(chi_ref[-1])
+    moved = 0.0
+    for k, (comp, c) in enumerate(zip(comps, sc.components)):
+        image, shift = comp.children[1].parameters
+        assert image.shape == c.morph.shape
+        assert np.abs(np.asarray(shift) - c.shift).max() < 2e-2
+        assert shift.m is not None and shift.std.shape == (2,)
+        moved = max(moved, np.abs(np.asarray(shift) - g["shift_%d" % k]).max())
+    assert moved > 1e-2 and logL > float(g["logL"])
