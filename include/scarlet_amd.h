@@ -95,6 +95,14 @@ enum {
     SMI_PROX_NORM_SUM = 32,  /* NormalizationConstraint("sum")                  */
     SMI_PROX_L1 = 64,        /* L1Constraint -> proxmin prox_soft (134-145)     */
     SMI_PROX_L0 = 128,       /* L0Constraint -> proxmin prox_hard (117-130)     */
+    /* MonotonicityConstraint(fit_center_radius=1) (constraint.py:203-208,
+     * operator.py:99-129): the sweep starts at the brightest pixel of the 3x3 block
+     * around the box centre; `sweep_plan` is the first of 9 consecutive plans built
+     * for the centres (cy-1..cy+1) x (cx-1..cx+1), row major */
+    SMI_PROX_FIT_CENTER = 256,
+    /* scarlet.lite background threshold (lite/models.py:222-228): a pixel is set to 0
+     * when sed[c] * morph < bg_level[c] in every band (new sed); replaces positivity */
+    SMI_PROX_BG_THRESH = 512,
     /* not a constraint: the component is a PointSource (source.py:92-128) whose
      * morphology is the model PSF evaluated at a free sub-pixel centre
      * (PointSourceMorphology, morphology.py:476-513; GaussianPSF, psf.py:80-142) */
@@ -153,6 +161,15 @@ typedef struct smi_components {
     const float *psf_sigma;     /* [n_components] model PSF sigma (all bands alike)  */
     const float *shift_step;    /* [n_components] step of a free shift (1e-1,        */
                                 /* morphology.py:675); NULL = 1e-1                   */
+    const float *center_floor;  /* [n_components] floor of the centre pixel for      */
+                                /* SMI_PROX_CENTER_ON: 1e-6 (CenterOnConstraint,     */
+                                /* constraint.py:276-287) or the `floor` of a lite   */
+                                /* component (lite/models.py:233-236); NULL = 1e-6   */
+    const float *bg_level;      /* [n_components][C] bg_rms * bg_thresh for          */
+                                /* SMI_PROX_BG_THRESH; NULL if unused                */
+    const float *fista_step;    /* [n_components] FistaParameter.step                */
+                                /* (lite/initialization.py:308-312); NULL unless the */
+                                /* batch runs SMI_SCHEME_FISTA                       */
 } smi_components;
 
 int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out);
@@ -194,9 +211,27 @@ int smi_batch_set_center_moments(smi_batch *b, const double *m, const double *v,
 int smi_batch_get_model_morphology(smi_batch *b, float *morph);
 int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph);
 
+/* Update rule of the parameters.  SMI_SCHEME_AMSGRAD (default): proxmin.adaprox as used
+ * by Blend.fit and lite's AdaproxParameter.  SMI_SCHEME_FISTA: lite's FistaParameter
+ * (lite/parameters.py:92-165, Beck & Teboulle 2009): y = z - step/sum(other^2) * grad,
+ * x' = prox(y), t' = (1 + sqrt(1 + 4 t^2))/2, z = x + (1 + (t-1)/t')(x' - x); the
+ * proximal operator is applied once.  Call before smi_batch_set_components; the
+ * state is z (same layout as sed / morph, initialised to x) and t per parameter. */
+enum { SMI_SCHEME_AMSGRAD = 0, SMI_SCHEME_FISTA = 1 };
+int smi_batch_set_scheme(smi_batch *b, int32_t scheme);
+/* t: [n_components][2] (spectrum, morphology); any pointer may be NULL */
+int smi_batch_get_fista_state(smi_batch *b, float *z_sed, float *z_morph, double *t);
+int smi_batch_set_fista_state(smi_batch *b, const float *z_sed, const float *z_morph,
+                              const double *t);
+
 /* AMSGrad constants forwarded by Blend.fit(**alg_kwargs) to adaprox (blend.py:165-180);
  * defaults b1 = 0.9, b2 = 0.999, eps = 1e-8 (lite/parameters.py:194) */
 int smi_batch_set_optimizer(smi_batch *b, float b1, float b2, float eps);
+
+/* scarlet.lite's loss has no normalisation term (lite/models.py:541): with
+ * include = 0 the recorded loss is 1/2 sum w (m - d)^2 only (default 1: + log_norm,
+ * observation.py:147-186).  Call before smi_batch_set_observation. */
+int smi_batch_set_log_norm(smi_batch *b, int32_t include);
 
 /* HIP stream the batch launches on (hipStream_t as void*); NULL = default stream */
 int smi_batch_set_stream(smi_batch *b, void *stream);

@@ -312,6 +312,61 @@ def hsc_shifting(scarlet):
     print("hsc_shifting: %d components, logL=%.3f" % (out["n_comp"], out["logL"]))
 
 
+def lite(scarlet):
+    """``scarlet.lite``: LiteBlend.fit on the quickstart scene, run by the reference
+    itself.  Components start from the hsc_cosmos_35 fixture's initial sources (the lite
+    initialisation needs the compiled mask operators, which cannot be built here).
+    ``lite_fista.npz``: FistaParameter -- every line of the loop is reference code.
+    ``lite_adaprox.npz``: AdaproxParameter around the shim's AMSGrad moments."""
+    from scarlet.bbox import Box
+    from scarlet.lite import models as lm
+    import importlib
+
+    li = importlib.import_module("scarlet.lite.initialization")
+
+    d = np.load("/root/reference/data/hsc_cosmos_35.npz")
+    g = np.load(os.path.join(OUT, "hsc_cosmos_35.npz"))
+    images = d["images"].astype(np.float32)
+    variance = d["variance"].astype(np.float32)
+    weights = (1 / d["variance"]).astype(np.float32)
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5).get_model().astype(np.float32)
+
+    for kind in ("fista", "adaprox"):
+        obs = lm.LiteObservation(images, variance, weights, d["psfs"].astype(np.float32),
+                                 model_psf=model_psf[0][None], convolution_mode="fft")
+        comps = []
+        for k in range(int(g["n_comp"])):
+            morph = g["morph_%d" % k].astype(np.float32)
+            sed = g["sed_%d" % k].astype(np.float32)
+            oy, ox = (int(v) for v in g["origin_%d" % k])
+            h, w = morph.shape
+            bbox = Box((5, h, w), origin=(0, oy, ox))
+            center = (oy + h // 2, ox + w // 2)
+            if kind == "fista":
+                comps.append(li.init_fista_component(center, bbox, sed.copy(), morph.copy(), obs,
+                                                     bg_thresh=0.25))
+            else:
+                comps.append(li.init_adaprox_component(center, bbox, sed.copy(), morph.copy(), obs,
+                                                       bg_thresh=0.25))
+        blend = lm.LiteBlend([lm.LiteSource([c], images.dtype) for c in comps], obs)
+        out = dict(diff_kernel=obs.diff_kernel.image, noise_rms=np.asarray(obs.noise_rms),
+                   n_comp=len(comps))
+        if kind == "fista":
+            out["fista_step"] = np.array([c._sed.step for c in comps])
+        # checkpoints: state after 3 iterations, then the run to 25 with resizing at 10, 20
+        for tag, n in (("a", 3), ("b", 25)):
+            it, loss = blend.fit(n, e_rel=1e-9, min_iter=1, resize=10, reweight=False)
+            out["it_" + tag] = it
+            for k, c in enumerate(comps):
+                out["%s_sed_%d" % (tag, k)] = np.array(c.sed)
+                out["%s_morph_%d" % (tag, k)] = np.array(c.morph)
+                out["%s_origin_%d" % (tag, k)] = np.array(c.bbox.origin[1:])
+        out["loss"] = np.array(blend.loss)
+        np.savez_compressed(os.path.join(OUT, "lite_%s.npz" % kind), **out)
+        print("lite", kind, "it", it, "loss", blend.loss[0], "->", blend.loss[-1],
+              [c.morph.shape[0] for c in comps])
+
+
 def point_source(scarlet):
     """docs/tutorials/point_source.ipynb: psf_unmatched_sim scene, stars as
     PointSource, galaxies as ExtendedSource; state up to the first gradient."""
@@ -430,7 +485,7 @@ def main(which=None):
     os.makedirs(OUT, exist_ok=True)
     jobs = dict(
         operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
-        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, hsc_shifting=hsc_shifting,
+        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, hsc_shifting=hsc_shifting, lite=lite,
         synthetic_cfg2=synthetic_cfg2,
     )
     for name, fn in jobs.items():

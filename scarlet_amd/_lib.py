@@ -23,6 +23,9 @@ PROX_NORM_MAX = 16
 PROX_NORM_SUM = 32
 PROX_L1 = 64
 PROX_L0 = 128
+PROX_FIT_CENTER = 256  # MonotonicityConstraint(fit_center_radius=1): 9 consecutive plans
+PROX_BG_THRESH = 512   # scarlet.lite background threshold (replaces positivity)
+SCHEME_AMSGRAD, SCHEME_FISTA = 0, 1
 COMPONENT_POINT_SOURCE = 1 << 16  # PointSource: morphology = model PSF at a free centre
 COMPONENT_SHIFTING = 1 << 17  # image morphology moved by a free Fourier shift
 PROX_EXTENDED_SOURCE = PROX_MONOTONIC | PROX_POSITIVE | PROX_CENTER_ON | PROX_NORM_MAX
@@ -52,6 +55,7 @@ class Components(ctypes.Structure):
         ("prox_flags", c_i32p), ("sweep_plan", c_i32p), ("min_gradient", c_f32p),
         ("l_thresh", c_f32p), ("morph_rel_step", c_f32p),
         ("center", c_f64p), ("psf_sigma", c_f32p), ("shift_step", c_f32p),
+        ("center_floor", c_f32p), ("bg_level", c_f32p), ("fista_step", c_f32p),
     ]
 
 
@@ -103,6 +107,10 @@ SYMBOLS = {
     "smi_batch_get_centers": (ctypes.c_int, [ctypes.c_void_p] + [c_f64p] * 5),
     "smi_batch_set_center_moments": (ctypes.c_int, [ctypes.c_void_p] + [c_f64p] * 3),
     "smi_batch_get_model_morphology": (ctypes.c_int, [ctypes.c_void_p, c_f32p]),
+    "smi_batch_set_scheme": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "smi_batch_get_fista_state": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f64p]),
+    "smi_batch_set_fista_state": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f64p]),
+    "smi_batch_set_log_norm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "smi_batch_set_optimizer": (
         ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float]
     ),

@@ -19,7 +19,7 @@ class ComponentSpec:
     def __init__(self, sed, morph, origin, sed_min_step=0.0, sed_rel_step=1e-2,
                  morph_step=1e-2, morph_rel_step=0.0, prox_flags=_lib.PROX_EXTENDED_SOURCE,
                  neighbor_weight="angle", min_gradient=0.0, l_thresh=0.0, shift=None,
-                 shift_step=1e-1):
+                 shift_step=1e-1, center_floor=1e-6, bg_level=None, fista_step=0.0):
         self.sed = np.asarray(sed, dtype=np.float32)
         self.morph = np.ascontiguousarray(morph, dtype=np.float32)
         self.origin = (int(origin[0]), int(origin[1]))
@@ -36,6 +36,14 @@ class ComponentSpec:
         # ExtendedSource(shifting=True): free sub-pixel Fourier shift of the image
         # (morphology.py:124-130, 673-676); the device keeps it in the `center` slot
         self.shift_step = float(shift_step)
+        # scarlet.lite: floor of the centre pixel, background threshold per band
+        # (bg_rms * bg_thresh; sets PROX_BG_THRESH), FistaParameter.step
+        self.center_floor = float(center_floor)
+        self.bg_level = None
+        if bg_level is not None:
+            self.bg_level = np.broadcast_to(np.asarray(bg_level, dtype=np.float32), self.sed.shape)
+            self.prox_flags |= _lib.PROX_BG_THRESH
+        self.fista_step = float(fista_step)
         if shift is not None:
             self.center = np.array(shift, dtype=np.float64).reshape(2)
             self.prox_flags |= _lib.COMPONENT_SHIFTING
@@ -81,10 +89,15 @@ class BlendBatch:
         fits the LDS, otherwise rocFFT), "rocfft" (rocFFT pipeline with the
         reference's FFT shape by default) or "fused"
     device: GPU index
+    scheme: "amsgrad" (``proxmin.adaprox`` as used by ``Blend.fit`` and lite's
+        ``AdaproxParameter``) or "fista" (lite's ``FistaParameter``; every component
+        needs ``fista_step``)
+    log_norm: include the normalisation term of ``Observation.log_norm`` in the loss
+        (False = scarlet.lite's loss, lite/models.py:541)
     """
 
     def __init__(self, data, weights, components, kernel=None, max_iter=200,
-                 fft_shape=None, device=0, conv_path="auto"):
+                 fft_shape=None, device=0, conv_path="auto", scheme="amsgrad", log_norm=True):
         lib = _lib.load()
         self._lib = lib
         self._h = ctypes.c_void_p()
@@ -116,21 +129,40 @@ class BlendBatch:
             desc.fft_h, desc.fft_w = int(fft_shape[0]), int(fft_shape[1])
         desc.conv_path = {"auto": 0, "rocfft": 1, "fused": 2}[conv_path]
         _lib.check(lib.smi_batch_create(ctypes.byref(desc), int(device), ctypes.byref(self._h)))
+        self.scheme = scheme
+        _lib.check(lib.smi_batch_set_scheme(
+            self._h, {"amsgrad": _lib.SCHEME_AMSGRAD, "fista": _lib.SCHEME_FISTA}[scheme]))
+        _lib.check(lib.smi_batch_set_log_norm(self._h, int(bool(log_norm))))
 
-        # monotonicity plans, one per (box shape, weighting)
+        # monotonicity plans, one per (box shape, weighting); with centre fitting
+        # (PROX_FIT_CENTER) nine consecutive ones for the centres around the box centre
         plan_ids = {}
+
+        def add_plan(shape, weighting, center):
+            wts, off, didx = operator.monotonic_tables(shape, weighting, center)
+            return _lib.check(
+                lib.smi_batch_add_sweep_plan(
+                    self._h, shape[0], shape[1], _lib.ptr(wts, ctypes.c_double),
+                    _lib.ptr(off, ctypes.c_int32), _lib.ptr(didx, ctypes.c_int32), didx.size,
+                )
+            )
+
         for c in flat:
             if c.prox_flags & _lib.PROX_MONOTONIC:
-                key = (c.morph.shape, c.neighbor_weight)
-                if key not in plan_ids:
-                    wts, off, didx = operator.monotonic_tables(c.morph.shape, c.neighbor_weight)
-                    plan_ids[key] = _lib.check(
-                        lib.smi_batch_add_sweep_plan(
-                            self._h, c.morph.shape[0], c.morph.shape[1],
-                            _lib.ptr(wts, ctypes.c_double), _lib.ptr(off, ctypes.c_int32),
-                            _lib.ptr(didx, ctypes.c_int32), didx.size,
-                        )
-                    )
+                fit = bool(c.prox_flags & _lib.PROX_FIT_CENTER)
+                key = (c.morph.shape, c.neighbor_weight, fit)
+                if key in plan_ids:
+                    continue
+                h, w = c.morph.shape
+                if not fit:
+                    plan_ids[key] = add_plan(c.morph.shape, c.neighbor_weight, None)
+                    continue
+                if h < 3 or w < 3:
+                    raise ValueError("centre fitting needs boxes of at least 3x3 pixels")
+                ids = [add_plan(c.morph.shape, c.neighbor_weight, (h // 2 + dy, w // 2 + dx))
+                       for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+                assert ids == list(range(ids[0], ids[0] + 9))
+                plan_ids[key] = ids[0]
         self._shapes = [c.morph.shape for c in flat]
         self._flags = [c.prox_flags for c in flat]
         self._morph_offsets = np.concatenate(
@@ -155,7 +187,8 @@ class BlendBatch:
             prox_flags=_lib.i32([c.prox_flags for c in flat]),
             sweep_plan=_lib.i32(
                 [
-                    plan_ids.get((c.morph.shape, c.neighbor_weight), -1)
+                    plan_ids.get((c.morph.shape, c.neighbor_weight,
+                                  bool(c.prox_flags & _lib.PROX_FIT_CENTER)), -1)
                     if c.prox_flags & _lib.PROX_MONOTONIC else -1
                     for c in flat
                 ]
@@ -168,6 +201,12 @@ class BlendBatch:
             ).reshape(-1, 2),
             psf_sigma=_lib.f32([getattr(c, "psf_sigma", 0.0) for c in flat]),
             shift_step=_lib.f32([c.shift_step for c in flat]),
+            center_floor=_lib.f32([c.center_floor for c in flat]),
+            bg_level=_lib.f32(
+                np.stack([c.bg_level if c.bg_level is not None else np.zeros(C, np.float32)
+                          for c in flat]) if flat else np.zeros((0, C))
+            ),
+            fista_step=_lib.f32([c.fista_step for c in flat]),
         )
         comps = _lib.Components()
         for name, ctype in _lib.Components._fields_:
@@ -345,6 +384,26 @@ class BlendBatch:
                 self._h, *[_lib.ptr(a, ctypes.c_double) for a in arrs]
             )
         )
+
+    def fista_state(self):
+        """FISTA state: dict with ``z_sed`` (n_components, C), ``z_morph`` (list) and
+        ``t`` (n_components, 2) for (spectrum, morphology)."""
+        z_sed = np.empty((self.n_components, self.C), dtype=np.float32)
+        z_morph = np.empty(int(self._morph_offsets[-1]), dtype=np.float32)
+        t = np.empty((self.n_components, 2), dtype=np.float64)
+        _lib.check(self._lib.smi_batch_get_fista_state(
+            self._h, _lib.ptr(z_sed, ctypes.c_float), _lib.ptr(z_morph, ctypes.c_float),
+            _lib.ptr(t, ctypes.c_double)))
+        return dict(z_sed=z_sed, z_morph=self._split_morphs(z_morph), t=t)
+
+    def set_fista_state(self, z_sed=None, z_morph=None, t=None):
+        zs = None if z_sed is None else _lib.f32(z_sed)
+        zm = None if z_morph is None else _lib.f32(
+            np.concatenate([np.asarray(m).reshape(-1) for m in z_morph]))
+        tt = None if t is None else np.ascontiguousarray(t, dtype=np.float64).reshape(-1, 2)
+        _lib.check(self._lib.smi_batch_set_fista_state(
+            self._h, _lib.ptr(zs, ctypes.c_float), _lib.ptr(zm, ctypes.c_float),
+            _lib.ptr(tt, ctypes.c_double)))
 
     def set_parameters(self, seds=None, morphs=None):
         sed = None if seds is None else _lib.f32(seds)

@@ -109,6 +109,12 @@ struct smi_batch {
     int32_t *c_shift_fft = nullptr;
     std::vector<char> is_shift;
     std::vector<int64_t> h_moff;
+    // scarlet.lite
+    float *c_center_floor = nullptr, *c_bg_level = nullptr, *c_fista_step = nullptr;
+    double *fista_t = nullptr;
+    int scheme = SMI_SCHEME_AMSGRAD;
+    bool include_log_norm = true;
+    bool lite_flags = false;  // some component uses FIT_CENTER / BG_THRESH
     int64_t n_morph = 0;
     bool have_components = false, have_obs = false, have_kernel = false;
     // per blend
@@ -187,6 +193,12 @@ void refresh_view(smi_batch *b) {
     v.g_morph_buf = b->g_morph;
     v.c_shift_step = b->c_shift_step;
     v.c_shift_fft = b->c_shift_fft;
+    v.c_center_floor = b->c_center_floor;
+    v.c_bg_level = b->c_bg_level;
+    v.scheme = b->scheme;
+    v.lite = b->scheme == SMI_SCHEME_FISTA || b->lite_flags;
+    v.c_fista_step = b->c_fista_step;
+    v.fista_t = b->fista_t;
     for (const auto &pl : b->plans)
         if (!pl.slots) v.fast_plans = 0;
 }
@@ -459,7 +471,8 @@ int smi_batch_destroy(smi_batch *b) {
                     b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
                     b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
-                    b->c_shift_step, b->c_shift_fft, b->state, b->zero_state, b->n_loss, b->status_out,
+                    b->c_shift_step, b->c_shift_fft, b->c_center_floor, b->c_bg_level,
+                    b->c_fista_step, b->fista_t, b->state, b->zero_state, b->n_loss, b->status_out,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -543,8 +556,51 @@ int smi_batch_set_observation(smi_batch *b, const float *data, const float *weig
     b->own_obs = true;
     launch_log_norm(b->weights, b->log_norm, b->d.n_blends, (int64_t)b->d.C * b->d.H * b->d.W,
                     b->stream);
+    if (!b->include_log_norm)
+        SMI_HIP(hipMemsetAsync(b->log_norm, 0, b->d.n_blends * sizeof(double), b->stream));
     b->have_obs = true;
     refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_set_log_norm(smi_batch *b, int32_t include) {
+    SMI_REQUIRE(b, "null batch");
+    SMI_REQUIRE(!b->have_obs, "smi_batch_set_log_norm must precede smi_batch_set_observation");
+    b->include_log_norm = include != 0;
+    return SMI_OK;
+}
+
+int smi_batch_set_scheme(smi_batch *b, int32_t scheme) {
+    SMI_REQUIRE(b, "null batch");
+    SMI_REQUIRE(scheme == SMI_SCHEME_AMSGRAD || scheme == SMI_SCHEME_FISTA, "unknown scheme");
+    SMI_REQUIRE(!b->have_components, "smi_batch_set_scheme must precede smi_batch_set_components");
+    b->scheme = scheme;
+    refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_get_fista_state(smi_batch *b, float *z_sed, float *z_morph, double *t) {
+    SMI_REQUIRE(b && b->have_components && b->scheme == SMI_SCHEME_FISTA, "not a FISTA batch");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const size_t n = b->d.n_components;
+    if (z_sed && n) SMI_HIP(hipMemcpy(z_sed, b->mom[0], n * b->d.C * sizeof(float), hipMemcpyDeviceToHost));
+    if (z_morph && b->n_morph)
+        SMI_HIP(hipMemcpy(z_morph, b->mom[3], (size_t)b->n_morph * sizeof(float), hipMemcpyDeviceToHost));
+    if (t && n) SMI_HIP(hipMemcpy(t, b->fista_t, n * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+
+int smi_batch_set_fista_state(smi_batch *b, const float *z_sed, const float *z_morph,
+                              const double *t) {
+    SMI_REQUIRE(b && b->have_components && b->scheme == SMI_SCHEME_FISTA, "not a FISTA batch");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const size_t n = b->d.n_components;
+    if (z_sed && n) SMI_HIP(hipMemcpy(b->mom[0], z_sed, n * b->d.C * sizeof(float), hipMemcpyHostToDevice));
+    if (z_morph && b->n_morph)
+        SMI_HIP(hipMemcpy(b->mom[3], z_morph, (size_t)b->n_morph * sizeof(float), hipMemcpyHostToDevice));
+    if (t && n) SMI_HIP(hipMemcpy(b->fista_t, t, n * 2 * sizeof(double), hipMemcpyHostToDevice));
     return SMI_OK;
 }
 
@@ -560,6 +616,8 @@ int smi_batch_set_observation_device(smi_batch *b, const float *d_data, const fl
     b->weights = const_cast<float *>(d_weights);
     launch_log_norm(b->weights, b->log_norm, b->d.n_blends, (int64_t)b->d.C * b->d.H * b->d.W,
                     b->stream);
+    if (!b->include_log_norm)
+        SMI_HIP(hipMemsetAsync(b->log_norm, 0, b->d.n_blends * sizeof(double), b->stream));
     b->have_obs = true;
     refresh_view(b);
     return SMI_OK;
@@ -666,12 +724,20 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         }
         if (c->prox_flags[k] & SMI_PROX_MONOTONIC) {
             const int pid = c->sweep_plan ? c->sweep_plan[k] : -1;
-            SMI_REQUIRE(pid >= 0 && pid < (int)b->plans.size(), "monotonic component without sweep plan");
-            SMI_REQUIRE(b->plans[pid].h == c->box_h[k] && b->plans[pid].w == c->box_w[k],
-                        "sweep plan shape does not match the component box");
+            const int last = pid + ((c->prox_flags[k] & SMI_PROX_FIT_CENTER) ? 8 : 0);
+            SMI_REQUIRE(pid >= 0 && last < (int)b->plans.size(), "monotonic component without sweep plan");
+            for (int q = pid; q <= last; ++q)
+                SMI_REQUIRE(b->plans[q].h == c->box_h[k] && b->plans[q].w == c->box_w[k],
+                            "sweep plan shape does not match the component box");
         }
+        if (c->prox_flags[k] & SMI_PROX_BG_THRESH)
+            SMI_REQUIRE(c->bg_level, "SMI_PROX_BG_THRESH without bg_level");
+        SMI_REQUIRE(C <= 64, "more than 64 bands");
     }
     for (int i = 0; i < nb; ++i) start[i + 1] += start[i];
+    b->lite_flags = false;
+    for (int k = 0; k < n; ++k)
+        if (c->prox_flags[k] & (SMI_PROX_FIT_CENTER | SMI_PROX_BG_THRESH)) b->lite_flags = true;
     b->n_morph = moff[n];
     SMI_REQUIRE(b->n_morph < ((int64_t)1 << 31), "more than 2^31 morphology pixels in one batch");
     b->view.max_box_pixels = max_pix;
@@ -698,12 +764,33 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     UP(c_lthresh, c->l_thresh ? c->l_thresh : zeros_n.data(), n);
     UP(sed, c->sed, (size_t)n * C);
     UP(morph, c->morph, (size_t)b->n_morph);
+    std::vector<float> cfloor(n, 1e-6f);
+    UP(c_center_floor, c->center_floor ? c->center_floor : cfloor.data(), n);
+    if (c->bg_level) {
+        UP(c_bg_level, c->bg_level, (size_t)n * C);
+    } else if (b->c_bg_level) {
+        SMI_HIP(hipFree(b->c_bg_level));
+        b->c_bg_level = nullptr;
+    }
+    if (b->scheme == SMI_SCHEME_FISTA) {
+        SMI_REQUIRE(c->fista_step, "SMI_SCHEME_FISTA needs fista_step");
+        UP(c_fista_step, c->fista_step, n);
+        std::vector<double> ones((size_t)n * 2, 1.0);
+        UP(fista_t, ones.data(), (size_t)n * 2);
+    }
 #undef UP
     for (int i = 0; i < 6; ++i) {
         const size_t cnt = i < 3 ? (size_t)n * C : (size_t)b->n_morph;
         if (b->mom[i]) SMI_HIP(hipFree(b->mom[i]));
         SMI_HIP(dev_alloc(&b->mom[i], cnt));
         SMI_HIP(hipMemset(b->mom[i], 0, (cnt ? cnt : 1) * sizeof(float)));
+    }
+    if (b->scheme == SMI_SCHEME_FISTA) {
+        // FistaParameter: z0 = x (lite/parameters.py:126-131)
+        if (n) SMI_HIP(hipMemcpy(b->mom[0], b->sed, (size_t)n * C * sizeof(float), hipMemcpyDeviceToDevice));
+        if (b->n_morph)
+            SMI_HIP(hipMemcpy(b->mom[3], b->morph, (size_t)b->n_morph * sizeof(float),
+                              hipMemcpyDeviceToDevice));
     }
     if (b->g_sed) SMI_HIP(hipFree(b->g_sed));
     if (b->g_morph) SMI_HIP(hipFree(b->g_morph));

@@ -125,6 +125,13 @@ struct BatchView {
     float *g_sed_buf, *g_morph_buf;
     const float *c_shift_step;
     const int32_t *c_shift_fft;  // (Fy, Fx) per component, fft.py:116-167 with padding 10
+    // scarlet.lite: centre floor, background threshold levels [n_comp][C], FISTA
+    const float *c_center_floor;
+    const float *c_bg_level;
+    int32_t lite;                // FISTA, or a component with FIT_CENTER / BG_THRESH
+    int32_t scheme;              // SMI_SCHEME_*; FISTA keeps z in m_sed / m_morph
+    const float *c_fista_step;
+    double *fista_t;             // [n_comp][2]
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);

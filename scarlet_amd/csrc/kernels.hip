@@ -333,13 +333,33 @@ __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompC
 }
 
 // spectrum (spectrum.py:54-56): relative step, AMSGrad, positivity at 1e-20.
+// FISTA (lite/parameters.py:134-150): y = z - step / sum(morph^2) g, x' = max(y, 1e-20),
+// z' = x + (1 + (t - 1) / t') (x' - x).  The new spectrum is also left in
+// `sed_new[lane]` for the background threshold of the morphology.
 // Returns non-zero if the new value is not finite.
 __device__ __forceinline__ int update_spectrum(const BatchView &v, const CompCtx &c, float g_sed,
-                                               int it, float e2, int prox_max_iter) {
+                                               int it, float e2, int prox_max_iter,
+                                               float sum_morph2, float *sed_new) {
     const bool on = c.lane < c.C;
     const float s = on ? c.sed[c.lane] : 0.f;
-    const float mean = wave_sum(s) / (float)c.C;
     const int64_t idx = (int64_t)c.k * c.C + c.lane;
+    if (v.scheme == SMI_SCHEME_FISTA) {
+        double *tp = v.fista_t + 2 * (int64_t)c.k;
+        const float t = (float)tp[0];
+        const float tn = 0.5f * (1.f + sqrtf(1.f + 4.f * t * t));
+        const float omega = 1.f + (t - 1.f) / tn;
+        float xn = 0.f;
+        if (on) {
+            const float step = v.c_fista_step[c.k] / sum_morph2;
+            xn = max_nan(v.m_sed[idx] - step * g_sed, 1e-20f);
+            v.m_sed[idx] = s + omega * (xn - s);
+            v.sed[idx] = xn;
+            sed_new[c.lane] = xn;
+        }
+        if (c.lane == 0) tp[0] = (double)tn;
+        return on && !isfinite(xn);
+    }
+    const float mean = wave_sum(s) / (float)c.C;
     float psi = 0.f, x = s;
     if (on) {
         const float alpha = fmaxf(v.c_sed_min_step[idx], v.c_sed_rel[c.k] * mean);
@@ -364,15 +384,51 @@ __device__ __forceinline__ int update_spectrum(const BatchView &v, const CompCtx
         z = zn;
         if (d2 <= e2 * z2) break;
     }
-    if (on) v.sed[idx] = z;
+    if (on) {
+        v.sed[idx] = z;
+        sed_new[c.lane] = z;
+    }
     return on && !isfinite(z);
+}
+
+// MonotonicityConstraint(fit_center_radius=1): index (0..8, row major) of the brightest
+// pixel of the 3x3 block around the box centre, first maximum like np.argmax
+// (operator.py:99-129); the block is clipped at index 0 only, like the slices there
+__device__ __forceinline__ int fit_center_index(const float *us, const CompCtx &c) {
+    const int cy = c.h / 2, cx = c.w / 2;
+    int best = 4;
+    float bv = -INFINITY;
+    bool first = true;
+    for (int j = 0; j < 9; ++j) {
+        const int yy = cy + j / 3 - 1, xx = cx + j % 3 - 1;
+        if (yy < 0 || xx < 0 || yy >= c.h || xx >= c.w) continue;
+        const float val = us[yy * c.w + xx];
+        if (first || val > bv) {
+            bv = val;
+            best = j;
+            first = false;
+        }
+    }
+    return best;
 }
 
 // the element-wise members of the chain that act on the LDS image `us` before the
 // final positivity / centre / normalisation pass (constraint.py:262-273, 117-145)
 __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCtx &c, int flags,
-                                                         float lthresh) {
+                                                         float lthresh, const float *sed_new,
+                                                         const float *bg_level) {
     const int h = c.h, w = c.w, N = c.N, lane = c.lane;
+    if (flags & SMI_PROX_BG_THRESH) {
+        // lite/models.py:222-228: zero where the model stays below the background
+        // level in every band (spectrum already updated)
+        for (int i = lane; i < N; i += 64) {
+            const float u = us[i];
+            bool below = true;
+            for (int b = 0; b < c.C; ++b) below = below && (sed_new[b] * u < bg_level[b]);
+            if (below) us[i] = 0.f;
+        }
+        __syncthreads();
+    }
     if (flags & SMI_PROX_SYMMETRY) {
         // prox_soft_symmetry, strength 1 (operator.py:274-293): even axes are
         // padded by one trailing zero before the 180-degree rotation
@@ -427,41 +483,68 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         return;
     }
     const float e2 = e_rel * e_rel;
-    int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter);
+    __shared__ float sed_new[64];
+    const bool fista = v.scheme == SMI_SCHEME_FISTA;
+    if (fista) prox_max_iter = 1;  // FistaParameter applies the prox once
+    float msum = 0.f, msum2 = 0.f;
+    for (int i = lane; i < N; i += 64) {
+        const float mval = c.morph[i];
+        msum += mval;
+        msum2 += mval * mval;
+    }
+    msum = wave_sum(msum);
+    msum2 = wave_sum(msum2);
+    // sum of the squared *old* spectrum: FISTA step of the morphology (lite/models.py:249-254)
+    const float so = lane < c.C ? c.sed[lane] : 0.f;
+    const float ssum2 = wave_sum(so * so);
+    const float t_old = fista ? (float)v.fista_t[2 * (int64_t)c.k + 1] : 1.f;
+    int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, sed_new);
 
     const int flags = v.c_flags[c.k];
     const int plan_id = v.c_plan[c.k];
-    float msum = 0.f;
-    for (int i = lane; i < N; i += 64) msum += c.morph[i];
-    const float alpha = fmaxf(v.c_morph_step[c.k], v.c_morph_rel[c.k] * (wave_sum(msum) / (float)N));
+    const float alpha = fmaxf(v.c_morph_step[c.k], v.c_morph_rel[c.k] * (msum / (float)N));
     float pmax = 0.f;
-    for (int i = lane; i < N; i += 64) {
-        const float g = us[i];
-        const float m = (1.f - v.b1) * g + v.b1 * v.m_morph[c.moff + i];
-        const float vv = (1.f - v.b2) * g * g + v.b2 * v.v_morph[c.moff + i];
-        const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
-        v.m_morph[c.moff + i] = m;
-        v.v_morph[c.moff + i] = vv;
-        v.vh_morph[c.moff + i] = vh;
-        const float psi = sqrtf(fmaxf(vh, v.eps));
-        float upd = alpha * m / psi;
-        if (it == 0) upd /= 10.f;
-        const float x = c.morph[i] - upd;
-        xs[i] = x;
-        zs[i] = x;
-        rs[i] = psi;
-        pmax = fmaxf(pmax, psi);
+    if (fista) {
+        const float step = v.c_fista_step[c.k] / ssum2;
+        for (int i = lane; i < N; i += 64) {
+            const float y = v.m_morph[c.moff + i] - step * us[i];
+            xs[i] = y;
+            zs[i] = y;
+            rs[i] = 0.f;
+        }
+        pmax = 1.f;
+    } else {
+        for (int i = lane; i < N; i += 64) {
+            const float g = us[i];
+            const float m = (1.f - v.b1) * g + v.b1 * v.m_morph[c.moff + i];
+            const float vv = (1.f - v.b2) * g * g + v.b2 * v.v_morph[c.moff + i];
+            const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
+            v.m_morph[c.moff + i] = m;
+            v.v_morph[c.moff + i] = vv;
+            v.vh_morph[c.moff + i] = vh;
+            const float psi = sqrtf(fmaxf(vh, v.eps));
+            float upd = alpha * m / psi;
+            if (it == 0) upd /= 10.f;
+            const float x = c.morph[i] - upd;
+            xs[i] = x;
+            zs[i] = x;
+            rs[i] = psi;
+            pmax = fmaxf(pmax, psi);
+        }
+        pmax = wave_max(pmax);
     }
-    pmax = wave_max(pmax);
 
     const bool monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
+    const bool fit_center = monotonic && (flags & SMI_PROX_FIT_CENTER);
     SweepPlanDev pl;
-    if (monotonic) {
+    if (monotonic && !fit_center) {
         pl = v.plans[plan_id];
         for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
     }
     const float one_minus_g = 1.f - v.c_min_grad[c.k];
     const int ctr = (c.h / 2) * c.w + (c.w / 2);
+    const float cfloor = v.c_center_floor[c.k];
+    const float *bg_level = v.c_bg_level ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;
     __syncthreads();
     for (int i = lane; i < N; i += 64) rs[i] = rs[i] / pmax;
 
@@ -469,15 +552,20 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         for (int i = lane; i < N; i += 64) us[i] = zs[i] - rs[i] * (zs[i] - xs[i]);
         __syncthreads();
         // ConstraintChain (constraint.py:76-80) in the order of morphology.py:644-670
+        if (fit_center) {
+            pl = v.plans[plan_id + fit_center_index(us, c)];
+            for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
+            __syncthreads();
+        }
         if (monotonic)
             sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
                                        pl.nbr, pl.wt, one_minus_g, lane);
-        chain_symmetry_threshold(us, c, flags, v.c_lthresh[c.k]);
+        chain_symmetry_threshold(us, c, flags, v.c_lthresh[c.k], sed_new, bg_level);
         float mx = -INFINITY, sm = 0.f;
         for (int i = lane; i < N; i += 64) {
             float u = us[i];
             if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
-            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, 1e-6f);
+            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
             us[i] = u;
             mx = fmaxf(mx, u);
             sm += u;
@@ -498,8 +586,18 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         __syncthreads();
         if (d2 <= e2 * z2) break;
     }
+    float omega = 0.f;
+    if (fista) {
+        const float tn = 0.5f * (1.f + sqrtf(1.f + 4.f * t_old * t_old));
+        omega = 1.f + (t_old - 1.f) / tn;
+        if (lane == 0) v.fista_t[2 * (int64_t)c.k + 1] = (double)tn;
+    }
     for (int i = lane; i < N; i += 64) {
         const float z = zs[i];
+        if (fista) {
+            const float xo = c.morph[i];
+            v.m_morph[c.moff + i] = xo + omega * (z - xo);
+        }
         c.morph_out[i] = z;
         bad |= !isfinite(z);
     }
@@ -583,7 +681,8 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
             }
             return;
         }
-        bad = update_spectrum(v, c, g_sed, it, e_rel * e_rel, prox_max_iter);
+        __shared__ float sed_new[64];
+        bad = update_spectrum(v, c, g_sed, it, e_rel * e_rel, prox_max_iter, 1.f, sed_new);
         const double b1 = v.b1, b2 = v.b2, eps = v.eps, alpha = v.c_morph_step[c.k];
         double upd[2];
 #pragma unroll
@@ -678,9 +777,14 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
     }
 }
 
-template <int NPL>
+// LITE = false is the ExtendedSource / AMSGrad path of Blend.fit; the scarlet.lite
+// variants (FISTA, centre fitting of the monotonic sweep, background threshold) are
+// compiled into a second instantiation so that they cost the main path no registers.
+// MODE 0: Blend.fit, 1: lite with AdaproxParameter, 2: lite with FistaParameter
+template <int NPL, int MODE>
 __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float *G, int it,
                                                         float e_rel, int prox_max_iter) {
+    constexpr bool LITE = MODE != 0;
     const CompCtx c = comp_ctx(v);
     if (v.state[c.b] >= 2) return;
     if (v.n_point && (v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
@@ -690,57 +794,86 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
     const float g_sed = gather_gradient(v, c, G, us);
     __syncthreads();
     const float e2 = e_rel * e_rel;
-    int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter);
+    __shared__ float sed_new[64];
+    constexpr bool fista = MODE == 2;
+    if (fista) prox_max_iter = 1;  // FistaParameter applies the prox once
 
     const int flags = v.c_flags[c.k];
     const int plan_id = v.c_plan[c.k];
     float xs[NPL], rs[NPL], zs[NPL];
-    float msum = 0.f;
+    float msum = 0.f, msum2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
         const int i = lane + 64 * j;
         zs[j] = i < N ? c.morph[i] : 0.f;
         msum += zs[j];
+        msum2 = fmaf(zs[j], zs[j], msum2);
     }
+    float ssum2 = 1.f, t_old = 1.f;
+    if (fista) {
+        // sums over the *old* parameters: FISTA steps (lite/parameters.py:138)
+        msum2 = wave_sum(msum2);
+        const float so = lane < c.C ? c.sed[lane] : 0.f;
+        ssum2 = wave_sum(so * so);
+        t_old = (float)v.fista_t[2 * (int64_t)c.k + 1];
+    }
+    int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, sed_new);
     const float alpha = fmaxf(v.c_morph_step[c.k], v.c_morph_rel[c.k] * (wave_sum(msum) / (float)N));
     float pmax = 0.f;
+    if (fista) {
+        const float step = v.c_fista_step[c.k] / ssum2;
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        const int i = lane + 64 * j;
-        xs[j] = 0.f;
-        rs[j] = 0.f;
-        if (i < N) {
-            const float g = us[i];
-            const float m = (1.f - v.b1) * g + v.b1 * v.m_morph[c.moff + i];
-            const float vv = (1.f - v.b2) * g * g + v.b2 * v.v_morph[c.moff + i];
-            const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
-            v.m_morph[c.moff + i] = m;
-            v.v_morph[c.moff + i] = vv;
-            v.vh_morph[c.moff + i] = vh;
-            const float psi = sqrtf(fmaxf(vh, v.eps));
-            float upd = alpha * m / psi;
-            if (it == 0) upd /= 10.f;
-            xs[j] = zs[j] - upd;
+        for (int j = 0; j < NPL; ++j) {
+            const int i = lane + 64 * j;
+            xs[j] = 0.f;
+            rs[j] = 0.f;
+            if (i < N) xs[j] = v.m_morph[c.moff + i] - step * us[i];
             zs[j] = xs[j];
-            rs[j] = psi;
-            pmax = fmaxf(pmax, psi);
         }
+        pmax = 1.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int i = lane + 64 * j;
+            xs[j] = 0.f;
+            rs[j] = 0.f;
+            if (i < N) {
+                const float g = us[i];
+                const float m = (1.f - v.b1) * g + v.b1 * v.m_morph[c.moff + i];
+                const float vv = (1.f - v.b2) * g * g + v.b2 * v.v_morph[c.moff + i];
+                const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
+                v.m_morph[c.moff + i] = m;
+                v.v_morph[c.moff + i] = vv;
+                v.vh_morph[c.moff + i] = vh;
+                const float psi = sqrtf(fmaxf(vh, v.eps));
+                float upd = alpha * m / psi;
+                if (it == 0) upd /= 10.f;
+                xs[j] = zs[j] - upd;
+                zs[j] = xs[j];
+                rs[j] = psi;
+                pmax = fmaxf(pmax, psi);
+            }
+        }
+        pmax = wave_max(pmax);
     }
-    pmax = wave_max(pmax);
     const float rpmax = 1.f / pmax;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) rs[j] = rs[j] * rpmax;
 
     const bool monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
+    const bool fit_center = LITE && monotonic && (flags & SMI_PROX_FIT_CENTER);
     const SweepSlotEntry *slots = nullptr;
     int n_slots = 0;
-    if (monotonic) {
+    if (monotonic && !fit_center) {
         slots = v.plans[plan_id].slots;
         n_slots = v.plans[plan_id].n_slots;
     }
     const float one_minus_g = 1.f - v.c_min_grad[c.k];
     const int ctr = (c.h / 2) * c.w + (c.w / 2);
     const float lthresh = v.c_lthresh[c.k];
+    const float cfloor = v.c_center_floor[c.k];
+    const float *bg_level =
+        (LITE && v.c_bg_level) ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;
     if (lane == 0) us[(v.max_box_pixels + 3) & ~3] = 0.f;  // spare cell for idle sweep lanes
     __syncthreads();
 
@@ -751,8 +884,14 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
             if (i < N) us[i] = zs[j] - rs[j] * (zs[j] - xs[j]);
         }
         __syncthreads();
+        if (fit_center) {
+            const SweepPlanDev &pl = v.plans[plan_id + fit_center_index(us, c)];
+            slots = pl.slots;
+            n_slots = pl.n_slots;
+        }
         if (monotonic) sweep_slots(us, slots, n_slots, one_minus_g, lane);
-        chain_symmetry_threshold(us, c, flags, lthresh);
+        chain_symmetry_threshold(us, c, LITE ? flags : (flags & ~SMI_PROX_BG_THRESH), lthresh,
+                                 sed_new, bg_level);
         float mx = -INFINITY, sm = 0.f;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
@@ -760,7 +899,7 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
             if (i < N) {
                 float u = us[i];
                 if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
-                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, 1e-6f);
+                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
                 mx = fmaxf(mx, u);
                 sm += u;
             }
@@ -779,7 +918,7 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
             if (i < N) {
                 float u = us[i];  // second read instead of NPL more registers
                 if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
-                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, 1e-6f);
+                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
                 if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
                     u = (u == div && (flags & SMI_PROX_NORM_MAX)) ? 1.f : u * rdiv;
                 d2 += (u - zs[j]) * (u - zs[j]);
@@ -792,10 +931,20 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
         __syncthreads();
         if (d2 <= e2 * z2) break;
     }
+    float omega = 0.f;
+    if (fista) {
+        const float tn = 0.5f * (1.f + sqrtf(1.f + 4.f * t_old * t_old));
+        omega = 1.f + (t_old - 1.f) / tn;
+        if (lane == 0) v.fista_t[2 * (int64_t)c.k + 1] = (double)tn;
+    }
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
         const int i = lane + 64 * j;
         if (i < N) {
+            if (fista) {
+                const float xo = c.morph[i];
+                v.m_morph[c.moff + i] = xo + omega * (zs[j] - xo);
+            }
             c.morph_out[i] = zs[j];
             bad |= !isfinite(zs[j]);
         }
@@ -933,8 +1082,15 @@ template <int NPL>
 static void launch_update_reg(const BatchView &v, const float *G, int32_t it, float e_rel,
                               int32_t prox_max_iter, hipStream_t s) {
     const size_t lds = (size_t)(((v.max_box_pixels + 3) & ~3) + 4) * sizeof(float);
-    hipLaunchKernelGGL(update_kernel_reg<NPL>, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
-                       prox_max_iter);
+    if (v.scheme == SMI_SCHEME_FISTA)
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 2>), dim3(v.n_comp), dim3(64), lds, s, v, G,
+                           it, e_rel, prox_max_iter);
+    else if (v.lite)
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 1>), dim3(v.n_comp), dim3(64), lds, s, v, G,
+                           it, e_rel, prox_max_iter);
+    else
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 0>), dim3(v.n_comp), dim3(64), lds, s, v, G,
+                           it, e_rel, prox_max_iter);
 }
 
 int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,

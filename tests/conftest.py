@@ -81,3 +81,21 @@ def shifting_scene(g, hsc, dtype64=False):
     images = hsc["images"].astype(dt)
     return pgm.Scene(images.shape, images, hsc["weights"].astype(dt),
                      hsc["diff_kernel"].astype(dt), comps, dtype=dt)
+
+
+def lite_scene(g, hsc, kind):
+    """oracle.lite.LiteScene of the quickstart blend, components as the lite goldens
+    were started (hsc_cosmos_35 initial sources, bg_thresh 0.25)."""
+    from oracle import lite
+
+    images = hsc["images"].astype(np.float32)
+    weights = hsc["weights"].astype(np.float32)
+    comps = []
+    for k in range(int(g["n_comp"])):
+        sed = hsc["sed_%d" % k].astype(np.float32).copy()
+        morph = hsc["morph_%d" % k].astype(np.float32).copy()
+        kw = dict(fista_step=float(g["fista_step"][k])) if kind == "fista" else dict(
+            sed_min_step=g["noise_rms"] / 10)
+        comps.append(lite.LiteComponent(sed, morph, hsc["origin_%d" % k], g["noise_rms"],
+                                        bg_thresh=0.25, kind=kind, **kw))
+    return lite.LiteScene(images, weights, g["diff_kernel"], comps)

@@ -297,6 +297,32 @@ def test_shifting_scene_golden(hsc):
         assert_allclose(-dot, g["fd_dlogL"][j], rtol=2e-6)
 
 
+@pytest.mark.parametrize("kind", ["fista", "adaprox"])
+def test_lite_fit_matches_the_reference_run(hsc, kind):
+    """LiteBlend.fit run by the reference in the build container (FISTA: every line of
+    the loop is reference code; adaprox: the reference's loop around the shim's AMSGrad
+    moments): losses of all 26 evaluations, state after 3 iterations, boxes and state
+    after 25 iterations with two resize rounds."""
+    from conftest import lite_scene
+
+    g = golden("lite_" + kind)
+    sc = lite_scene(g, hsc, kind)
+    assert_allclose(sc.kernel, g["diff_kernel"])
+    it, _ = sc.fit(3, e_rel=1e-9, resize=10)
+    assert it == int(g["it_a"])
+    for k, c in enumerate(sc.components):
+        assert_allclose(c.sed, g["a_sed_%d" % k], rtol=2e-5)
+        assert_allclose(c.morph, g["a_morph_%d" % k], rtol=0, atol=2e-5)
+    it, _ = sc.fit(25, e_rel=1e-9, resize=10)
+    assert it == int(g["it_b"]) and len(sc.loss) == len(g["loss"])
+    assert_allclose(sc.loss, g["loss"], rtol=2e-4)
+    for k, c in enumerate(sc.components):
+        assert c.morph.shape == g["b_morph_%d" % k].shape, k
+        assert tuple(c.origin) == tuple(g["b_origin_%d" % k]), k
+        assert_allclose(c.sed, g["b_sed_%d" % k], rtol=2e-3)
+        assert_allclose(c.morph, g["b_morph_%d" % k], rtol=0, atol=2e-3)
+
+
 def test_synthetic_cfg2_golden():
     from scarlet_amd import synthetic
 
