@@ -705,3 +705,42 @@ def test_shifting_scene_steps(amd, hsc, path):
         assert np.abs(morphs[k] - c.morph).max() < 2e-3, k
         assert np.abs(st["center"][k] - c.shift).max() < 2e-3, k
     assert max(np.abs(c.shift - g["shift_%d" % k]).max() for k, c in enumerate(sc.components)) > 1e-2
+
+
+# ---------------------------------------------------------------- scarlet.lite
+def _lite_batch(amd, g, hsc, kind, **kw):
+    from scarlet_amd import _lib
+
+    flags = (_lib.PROX_MONOTONIC | _lib.PROX_FIT_CENTER | _lib.PROX_CENTER_ON | _lib.PROX_NORM_MAX)
+    specs = []
+    for k in range(int(g["n_comp"])):
+        extra = dict(fista_step=float(g["fista_step"][k])) if kind == "fista" else dict(
+            sed_min_step=g["noise_rms"] / 10)
+        specs.append(amd.ComponentSpec(
+            hsc["sed_%d" % k], hsc["morph_%d" % k], hsc["origin_%d" % k], prox_flags=flags,
+            neighbor_weight="angle", min_gradient=0.0, center_floor=1e-20,
+            bg_level=g["noise_rms"] * 0.25, morph_step=1e-2, **extra))
+    return amd.BlendBatch(hsc["images"][None], hsc["weights"][None], [specs],
+                          kernel=g["diff_kernel"], log_norm=False,
+                          scheme="fista" if kind == "fista" else "amsgrad", **kw)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("kind", ["fista", "adaprox"])
+def test_lite_loop_vs_the_reference_run(amd, hsc, kind, path):
+    """scarlet.lite loop (LiteBlend.fit: lite loss, FISTA / adaprox parameters with one
+    prox application, centre-fitted monotonicity, background threshold, floor 1e-20)
+    against what the reference itself produced (golden): losses of the first 10
+    evaluations and the state after 3 iterations"""
+    g = golden("lite_" + kind)
+    batch = _lite_batch(amd, g, hsc, kind, max_iter=12, conv_path=path)
+    batch.step(0, 3, e_rel=1e-6, prox_max_iter=1)
+    sed, morphs = batch.parameters()
+    for k in range(int(g["n_comp"])):
+        assert rel_err(sed[k], g["a_sed_%d" % k]) < 1e-4, k
+        assert np.abs(morphs[k] - g["a_morph_%d" % k]).max() < 1e-4, k
+    batch.step(3, 7, e_rel=1e-6, prox_max_iter=1)
+    # lite's loss is -1/2 sum w (d - m)^2 (lite/models.py:541)
+    loss = -np.array(batch.loss_history()[0])
+    assert_allclose(loss, g["loss"][:10], rtol=3e-4)
+    assert_allclose(loss[:4], g["loss"][:4], rtol=3e-5)
