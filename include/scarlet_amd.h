@@ -233,6 +233,12 @@ int smi_batch_set_optimizer(smi_batch *b, float b1, float b2, float eps);
  * observation.py:147-186).  Call before smi_batch_set_observation. */
 int smi_batch_set_log_norm(smi_batch *b, int32_t include);
 
+/* Seed the "previous loss" of the stopping rule |L - L_prev| < e_rel |L| (same sign
+ * convention as smi_batch_get_loss) for a batch that continues an earlier one, e.g.
+ * after scarlet.lite resized a box: LiteBlend.fit keeps counting and compares the first
+ * new loss with the last old one (lite/models.py:617-619). */
+int smi_batch_set_previous_loss(smi_batch *b, const double *loss /* [n_blends] */);
+
 /* HIP stream the batch launches on (hipStream_t as void*); NULL = default stream */
 int smi_batch_set_stream(smi_batch *b, void *stream);
 

@@ -30,6 +30,13 @@ Parity pinning ("Oracle"):
   dependency that is neither vendored in the reference checkout nor installed
   here; the update is restated from the reference's in-repo mirror
   ``scarlet/lite/parameters.py:274-305`` and from Reddi, Kale & Kumar (2018).
+* ``scarlet.lite`` loop (``oracle/lite.py``): PINNED, bit for bit, against a
+  25-iteration ``LiteBlend.fit`` trajectory with ``FistaParameter`` that the reference
+  itself ran in the build container (every line of that loop is in-repo reference code;
+  ``tests/golden/lite_fista.npz``).  The same convolution / gradient / proximal code
+  serves the main path, so this also pins those pieces end to end.  The
+  ``AdaproxParameter`` golden ran the reference's loop around the shim's AMSGrad
+  moments (ours): it pins everything but those five lines.
 """
 
-from . import fftconv, proxops, pgm  # noqa: F401
+from . import fftconv, proxops, pgm, lite  # noqa: F401

@@ -362,6 +362,17 @@ def lite(scarlet):
                 out["%s_morph_%d" % (tag, k)] = np.array(c.morph)
                 out["%s_origin_%d" % (tag, k)] = np.array(c.bbox.origin[1:])
         out["loss"] = np.array(blend.loss)
+        if kind == "fista":
+            # post-processing on the fitted state: flux re-weighting and the joint
+            # least-squares spectra for the fitted morphologies
+            from scarlet.lite.measure import weight_sources
+
+            weight_sources(blend)
+            for i, src in enumerate(blend.sources):
+                out["flux_%d" % i] = np.array(src.flux)
+                out["flux_origin_%d" % i] = np.array(src.flux_box.origin)
+            out["multifit_seds"] = li.multifit_seds(
+                obs, [c.morph for c in comps], [c.bbox[1:] for c in comps])
         np.savez_compressed(os.path.join(OUT, "lite_%s.npz" % kind), **out)
         print("lite", kind, "it", it, "loss", blend.loss[0], "->", blend.loss[-1],
               [c.morph.shape[0] for c in comps])

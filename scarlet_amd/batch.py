@@ -336,6 +336,11 @@ class BlendBatch:
         )
         return [out[b, : min(n[b], self.max_iter)].copy() for b in range(self.n_blends)]
 
+    def set_previous_loss(self, loss):
+        """Seed the stopping rule's previous loss (a batch that continues another)."""
+        loss = np.ascontiguousarray(np.broadcast_to(loss, (self.n_blends,)), dtype=np.float64)
+        _lib.check(self._lib.smi_batch_set_previous_loss(self._h, _lib.ptr(loss, ctypes.c_double)))
+
     def reset(self):
         _lib.check(self._lib.smi_batch_reset(self._h))
 

@@ -115,6 +115,7 @@ struct smi_batch {
     int scheme = SMI_SCHEME_AMSGRAD;
     bool include_log_norm = true;
     bool lite_flags = false;  // some component uses FIT_CENTER / BG_THRESH
+    int32_t *have_prev = nullptr;
     int64_t n_morph = 0;
     bool have_components = false, have_obs = false, have_kernel = false;
     // per blend
@@ -175,6 +176,7 @@ void refresh_view(smi_batch *b) {
     v.loss_hist = b->loss_hist;
     v.hist_cap = b->d.max_iter;
     v.last_loss = b->last_loss;
+    v.have_prev = b->have_prev;
     v.loss_partial = b->loss_partial;
     v.n_partial = b->fused ? b->d.C : (b->d.H * b->d.W + 255) / 256;
     v.plans = b->d_plans;
@@ -426,6 +428,8 @@ static int batch_create_impl(const smi_batch_desc *desc, int device, smi_batch *
     SMI_HIP(dev_alloc(&b->status_out, 2));
     SMI_HIP(dev_alloc(&b->loss_hist, (size_t)nb * desc->max_iter));
     SMI_HIP(dev_alloc(&b->last_loss, nb));
+    SMI_HIP(dev_alloc(&b->have_prev, nb));
+    SMI_HIP(hipMemset(b->have_prev, 0, nb * sizeof(int32_t)));
     SMI_HIP(dev_alloc(&b->log_norm, nb));
     SMI_HIP(dev_alloc(&b->loss_partial, (size_t)nb * std::max(C, (H * W + 255) / 256)));
     SMI_HIP(hipMemset(b->state, 0, nb * sizeof(int32_t)));
@@ -472,7 +476,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
                     b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
                     b->c_shift_step, b->c_shift_fft, b->c_center_floor, b->c_bg_level,
-                    b->c_fista_step, b->fista_t, b->state, b->zero_state, b->n_loss, b->status_out,
+                    b->c_fista_step, b->fista_t, b->have_prev, b->state, b->zero_state, b->n_loss, b->status_out,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -560,6 +564,17 @@ int smi_batch_set_observation(smi_batch *b, const float *data, const float *weig
         SMI_HIP(hipMemsetAsync(b->log_norm, 0, b->d.n_blends * sizeof(double), b->stream));
     b->have_obs = true;
     refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_set_previous_loss(smi_batch *b, const double *loss) {
+    SMI_REQUIRE(b && loss, "null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int nb = b->d.n_blends;
+    SMI_HIP(hipMemcpy(b->last_loss, loss, nb * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int32_t> ones(nb, 1);
+    SMI_HIP(hipMemcpy(b->have_prev, ones.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice));
     return SMI_OK;
 }
 
@@ -1215,6 +1230,7 @@ int smi_batch_reset(smi_batch *b) {
     SMI_HIP(hipMemset(b->state, 0, nb * sizeof(int32_t)));
     SMI_HIP(hipMemset(b->n_loss, 0, nb * sizeof(int32_t)));
     SMI_HIP(hipMemset(b->last_loss, 0, nb * sizeof(double)));
+    SMI_HIP(hipMemset(b->have_prev, 0, nb * sizeof(int32_t)));
     return SMI_OK;
 }
 

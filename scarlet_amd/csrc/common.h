@@ -104,6 +104,7 @@ struct BatchView {
     double *loss_hist;    // nb * hist_cap
     int32_t hist_cap;
     double *last_loss;    // nb
+    const int32_t *have_prev;  // nb: last_loss was seeded by smi_batch_set_previous_loss
     double *loss_partial; // nb * n_partial
     int32_t n_partial;
     // sweep plans

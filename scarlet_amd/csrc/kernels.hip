@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64) void finalize_kernel(BatchView v, int it, float
         if (n < v.hist_cap) v.loss_hist[(int64_t)b * v.hist_cap + n] = loss;
         v.n_loss[b] = n + 1;
         v.last_loss[b] = loss;
-        if (check && n >= 1 && it > min_iter && fabs(loss - prev) < (double)e_rel * fabs(loss))
+        if (check && (n >= 1 || v.have_prev[b]) && it > min_iter &&
+            fabs(loss - prev) < (double)e_rel * fabs(loss))
             v.state[b] = 1;  // this iteration's update is the last one
     }
 }

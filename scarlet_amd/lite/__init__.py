@@ -1,0 +1,24 @@
+"""``scarlet.lite`` on the GPU: same names as the reference's lite package
+(scarlet/lite/__init__.py), the fitting loop of ``LiteBlend.fit`` on the device."""
+
+from .initialization import (  # noqa: F401
+    init_adaprox_component,
+    init_fista_component,
+    multifit_seds,
+    parameterize_sources,
+)
+from .measure import calculate_snr, weight_sources  # noqa: F401
+from .models import (  # noqa: F401
+    LiteBlend,
+    LiteComponent,
+    LiteFactorizedComponent,
+    LiteObservation,
+    LiteSource,
+)
+from .parameters import (  # noqa: F401
+    AdaproxParameter,
+    FistaParameter,
+    LiteParameter,
+    grow_array,
+)
+from .utils import insert_image  # noqa: F401
