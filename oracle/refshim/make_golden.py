@@ -331,6 +331,21 @@ def lite(scarlet):
     weights = (1 / d["variance"]).astype(np.float32)
     model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5).get_model().astype(np.float32)
 
+    # the lite initialisation itself (default use_mask=False: weighted monotonicity)
+    obs = lm.LiteObservation(images, variance, weights, d["psfs"].astype(np.float32),
+                             model_psf=model_psf[0][None], convolution_mode="fft")
+    centers = [(int(s["y"]), int(s["x"])) for s in d["catalog"]]
+    init_sources = li.init_all_sources_main(obs, centers, min_snr=50)
+    init_out = dict(centers=np.array(centers), n_src=len(init_sources),
+                    n_comp_of=np.array([len(s.components) for s in init_sources]))
+    for i, src in enumerate(init_sources):
+        for j, c in enumerate(src.components):
+            init_out["sed_%d_%d" % (i, j)] = np.array(c.sed)
+            init_out["morph_%d_%d" % (i, j)] = np.array(c.morph)
+            init_out["origin_%d_%d" % (i, j)] = np.array(c.bbox.origin[1:])
+    np.savez_compressed(os.path.join(OUT, "lite_init.npz"), **init_out)
+    print("lite init: components per source", init_out["n_comp_of"])
+
     for kind in ("fista", "adaprox"):
         obs = lm.LiteObservation(images, variance, weights, d["psfs"].astype(np.float32),
                                  model_psf=model_psf[0][None], convolution_mode="fft")

@@ -116,6 +116,7 @@ struct smi_batch {
     bool include_log_norm = true;
     bool lite_flags = false;  // some component uses FIT_CENTER / BG_THRESH
     int32_t *have_prev = nullptr;
+    float *scratch = nullptr;  // update-kernel state of boxes too large for the LDS
     int64_t n_morph = 0;
     bool have_components = false, have_obs = false, have_kernel = false;
     // per blend
@@ -177,6 +178,7 @@ void refresh_view(smi_batch *b) {
     v.hist_cap = b->d.max_iter;
     v.last_loss = b->last_loss;
     v.have_prev = b->have_prev;
+    v.scratch = b->scratch;
     v.loss_partial = b->loss_partial;
     v.n_partial = b->fused ? b->d.C : (b->d.H * b->d.W + 255) / 256;
     v.plans = b->d_plans;
@@ -476,7 +478,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
                     b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
                     b->c_shift_step, b->c_shift_fft, b->c_center_floor, b->c_bg_level,
-                    b->c_fista_step, b->fista_t, b->have_prev, b->state, b->zero_state, b->n_loss, b->status_out,
+                    b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -807,6 +809,13 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
             SMI_HIP(hipMemcpy(b->mom[3], b->morph, (size_t)b->n_morph * sizeof(float),
                               hipMemcpyDeviceToDevice));
     }
+    if (b->scratch) {
+        SMI_HIP(hipFree(b->scratch));
+        b->scratch = nullptr;
+    }
+    // x / psi / z of the generic update kernel fit the LDS up to ~100^2 pixels per box
+    if (4 * (size_t)((max_pix + 3) & ~3) * sizeof(float) + 4096 > 160 * 1024)
+        SMI_HIP(dev_alloc(&b->scratch, 3 * (size_t)b->n_morph));
     if (b->g_sed) SMI_HIP(hipFree(b->g_sed));
     if (b->g_morph) SMI_HIP(hipFree(b->g_morph));
     SMI_HIP(dev_alloc(&b->g_sed, (size_t)n * C));

@@ -470,10 +470,13 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     if (!grad_only && v.n_point && (v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
     const int lane = c.lane, N = c.N;
     const int npad = (v.max_box_pixels + 3) & ~3;
-    float *xs = lds_dyn;       // x after the gradient step
-    float *rs = xs + npad;     // psi / max(psi)
-    float *zs = rs + npad;     // current proximal iterate
-    float *us = zs + npad;     // candidate (and g_morph before that)
+    // x after the gradient step, psi / max(psi), current proximal iterate: in LDS, or --
+    // for boxes beyond ~100^2 pixels -- in a global scratch area (every lane only ever
+    // touches its own elements of these three); the image being swept is always in LDS
+    float *xs = v.scratch ? v.scratch + 3 * c.moff : lds_dyn;
+    float *rs = xs + (v.scratch ? c.N : npad);
+    float *zs = rs + (v.scratch ? c.N : npad);
+    float *us = v.scratch ? lds_dyn : zs + npad;  // candidate (and g_morph before that)
     int32_t *lvl = reinterpret_cast<int32_t *>(us + npad);  // level_start of the plan
 
     const float g_sed = gather_gradient(v, c, G, us);
@@ -1076,7 +1079,7 @@ void launch_cmul(float2 *S, const float2 *K, int32_t nb, int32_t C, int64_t plan
 
 static size_t update_lds_bytes(const BatchView &v) {
     const size_t npad = (v.max_box_pixels + 3) & ~3;
-    return 4 * npad * sizeof(float) + (size_t)(v.max_levels + 2) * sizeof(int32_t);
+    return (v.scratch ? 1 : 4) * npad * sizeof(float) + (size_t)(v.max_levels + 2) * sizeof(int32_t);
 }
 
 template <int NPL>

@@ -3,7 +3,10 @@
 
 from .initialization import (  # noqa: F401
     init_adaprox_component,
+    init_all_sources_main,
     init_fista_component,
+    init_main_parameters,
+    init_monotonic_morph,
     multifit_seds,
     parameterize_sources,
 )

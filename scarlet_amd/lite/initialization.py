@@ -1,21 +1,108 @@
 """Parameterisation of ``scarlet.lite`` components and the joint spectrum fit
 (reference scarlet/lite/initialization.py:140-186, 250-318, 608-645).
 
-The detection-image initialisation (``init_all_sources_main`` / ``_wavelets``) relies on
-the monotonic mask operators and the starlet transform and is not part of this package;
-start from spectra / morphologies obtained elsewhere (e.g. ``scarlet_amd.initialization``)
-and wrap them with ``init_adaprox_component`` / ``init_fista_component``.
+``init_all_sources_main`` (lite/initialization.py:321-419) is provided with its default
+``use_mask=False`` (weighted monotonicity); the monotonic-mask variant and the wavelet
+initialisation (``init_all_sources_wavelets``) need the mask operators / the starlet
+transform and are not part of this package.
 """
 
 from functools import partial
 
 import numpy as np
 
-from ..bbox import overlapped_slices
+from ..bbox import Box, overlapped_slices
+from ..initialization import trim_morphology
+from ..operator import prox_uncentered_symmetry, prox_weighted_monotonic
 from ..parameter import relative_step
-from .models import LiteFactorizedComponent, LiteSource
+from .measure import calculate_snr
+from .models import LiteComponent, LiteFactorizedComponent, LiteSource
 from .parameters import AdaproxParameter, FistaParameter
 from .utils import insert_image
+
+
+def init_monotonic_morph(detect, center, full_box, grow=0, normalize=True, use_mask=True,
+                         thresh=0):
+    """Morphology of a monotonic source cut out of the 2-D detection image ``detect``:
+    the radial monotonicity operator ('angle' weights, sweep on the GPU) centred on
+    ``center``, trimmed at ``thresh`` (lite/initialization.py:83-138).  Returns
+    ``(bbox, morph)``; ``morph`` is None when nothing is left."""
+    if use_mask:
+        raise NotImplementedError("init_monotonic_morph(use_mask=True) needs the monotonic "
+                                  "mask operators, which are not part of this package")
+    prox = prox_weighted_monotonic(detect.shape, neighbor_weight="angle", center=center,
+                                   min_gradient=0)
+    morph = prox(detect, 0).reshape(detect.shape)
+    morph, bbox = trim_morphology(center, morph, bg_thresh=thresh)
+    if np.max(morph) == 0:
+        return Box((0, 0, 0)), None
+    if normalize:
+        morph /= np.max(morph)
+    return bbox, morph
+
+
+def init_main_parameters(detect, center, observation, convolved=None, use_mask=False, thresh=0.5):
+    """Box, morphology and spectrum of one source the way scarlet main initialises an
+    ExtendedSource (lite/initialization.py:188-247): symmetrised detection image ->
+    monotonic morphology trimmed at ``thresh * mean(noise_rms)``; spectrum = data over
+    convolved morphology at the centre pixel."""
+    symmetric = prox_uncentered_symmetry(detect.copy(), 0, center, "sdss")
+    bbox, morph = init_monotonic_morph(symmetric, center, observation.bbox[1:], grow=0,
+                                       normalize=False, use_mask=use_mask,
+                                       thresh=np.mean(observation.noise_rms) * thresh)
+    if morph is None:
+        return bbox, None, None
+    images = observation.images
+    at_center = (slice(None), center[0], center[1])
+    if convolved is None:
+        full = insert_image(observation.bbox[1:], bbox, morph)
+        convolved = observation.convolve(np.repeat(full[None], images.shape[0], axis=0), mode="real")
+    sed = images[at_center] / convolved[at_center]
+    sed[sed < 0] = 0
+    peak = np.max(morph)
+    return bbox, morph / peak, sed * peak
+
+
+def init_all_sources_main(observation, centers, detect=None, min_snr=50, use_mask=False,
+                          percentile=25, thresh=0.5):
+    """One ``LiteSource`` of plain ``LiteComponent``s per centre
+    (lite/initialization.py:321-419): PSF-shaped if nothing monotonic is found, two
+    components (bulge above / disk below ``percentile`` % of the peak, spectra by a joint
+    fit) when the PSF-weighted SNR allows ``2 * min_snr``, otherwise one.  Wrap the
+    result with ``parameterize_sources``."""
+    if detect is None:
+        detect = np.sum(observation.images / (observation.noise_rms**2)[:, None, None], axis=0)
+    bands = observation.shape[0]
+    convolved = observation.convolve(np.repeat(detect[None], bands, axis=0), mode="real")
+    model_psf = observation.model_psf[0]
+    py, px = model_psf.shape[0] // 2, model_psf.shape[1] // 2
+    psf_sed = observation.convolve(np.repeat(observation.model_psf, bands, axis=0),
+                                   mode="real")[:, py, px]
+    spec_box = observation.bbox[0]
+    sources = []
+    for center in centers:
+        snr = np.floor(calculate_snr(observation.images, observation.variance, observation.psfs,
+                                     center))
+        bbox, morph, sed = init_main_parameters(detect, center, observation, convolved, use_mask,
+                                                thresh)
+        if morph is None:
+            sed = observation.images[:, center[0], center[1]] / psf_sed
+            sed[sed < 0] = 0
+            bbox = Box(model_psf.shape, origin=(center[0] - py, center[1] - px))
+            comps = [LiteComponent(center, spec_box @ bbox, sed, model_psf / np.max(model_psf))]
+        elif snr / min_snr >= 2:
+            level = percentile / 100
+            bulge = np.maximum(morph - level, 0)
+            disk = np.minimum(morph, level)
+            bulge /= np.max(bulge)
+            disk /= np.max(disk)
+            bulge_sed, disk_sed = multifit_seds(observation, [bulge, disk], [bbox, bbox])
+            comps = [LiteComponent(center, spec_box @ bbox, bulge_sed, bulge),
+                     LiteComponent(center, spec_box @ bbox, disk_sed, disk)]
+        else:
+            comps = [LiteComponent(center, spec_box @ bbox, sed, morph)]
+        sources.append(LiteSource(comps, observation.dtype))
+    return sources
 
 
 def multifit_seds(observation, morphs, boxes):

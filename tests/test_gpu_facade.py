@@ -412,3 +412,29 @@ def test_lite_postprocessing_matches_the_reference(hsc):
     assert np.abs(seds - g["multifit_seds"]).max() < 2e-3 * np.abs(g["multifit_seds"]).max()
     assert blend.fit_spectra() is blend
     assert_allclose(np.stack([c.sed for c in blend.components]), np.maximum(seds, 1e-20), rtol=1e-6)
+
+
+def test_lite_init_all_sources_main_matches_the_reference(hsc):
+    """lite/initialization.py:321-419 on the quickstart scene: number of components per
+    source, boxes, morphologies and spectra equal the reference's (golden), and the
+    initialised blend fits"""
+    from conftest import golden
+    from scarlet_amd import lite
+
+    g = golden("lite_init")
+    blend = _lite_blend(hsc, golden("lite_fista"), "fista")
+    obs = blend.observation
+    sources = lite.init_all_sources_main(obs, [tuple(c) for c in g["centers"]], min_snr=50)
+    assert [len(s.components) for s in sources] == list(g["n_comp_of"])
+    for i, src in enumerate(sources):
+        for j, c in enumerate(src.components):
+            assert tuple(c.bbox.origin[1:]) == tuple(g["origin_%d_%d" % (i, j)])
+            assert c.morph.shape == g["morph_%d_%d" % (i, j)].shape
+            assert np.abs(c.morph - g["morph_%d_%d" % (i, j)]).max() < 1e-5, (i, j)
+            ref = g["sed_%d_%d" % (i, j)]
+            assert np.abs(c.sed - ref).max() <= 2e-3 * np.abs(ref).max(), (i, j)
+    fitted = lite.LiteBlend(
+        lite.parameterize_sources(sources, obs, lite.init_adaprox_component), obs)
+    it, loss = fitted.fit(30, e_rel=1e-4)
+    assert loss > fitted.loss[0] and it <= 30
+    assert all(src.flux.shape[0] == 5 for src in fitted.sources)

@@ -492,6 +492,16 @@ def test_fused_path_every_fft_length(amd, H, W, F):
     assert tuple(batch.fft_shape) == F
 
 
+def test_boxes_beyond_the_lds(amd):
+    """121^2 box (what lite's detection-image initialisation produces on small frames):
+    the generic update kernel keeps x / psi / z in a global scratch area, the swept
+    image in LDS"""
+    rng = np.random.default_rng(24)
+    specs, kernel, data, weights = _random_scene(
+        rng, 2, 100, 110, [((121, 121), (-10, -6)), ((21, 21), (40, 70))])
+    _compare_steps(amd, specs, None, data, weights, 2, {}, {})
+
+
 def test_large_frame_uses_rocfft(amd):
     """200x180 frame + 25^2 kernel: the padded band does not fit the LDS, so the batch
     falls back to the rocFFT pipeline with the reference's FFT shape"""
