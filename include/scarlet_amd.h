@@ -79,6 +79,29 @@ int smi_apply_filter_f64(const double *image, int32_t H, int32_t W,
                          const int32_t *x_start, const int32_t *x_end,
                          double *result);
 
+/* get_valid_monotonic_pixels / linear_interpolate_invalid_pixels
+ * (operators_pybind11.cc:61-232, float32 and float64 overload sets; callers
+ * operator.py:155-176).  Row-major (rows, cols) images; `unchecked` / `orphans` are the
+ * NumPy bool maps as bytes; `bounds` = (min row, max row, min col, max col); all updated
+ * in place like the Eigen::Ref arguments of the reference.  Bit-identical maps and
+ * values to the C++ recursion (tests: test_mask_operators_bit_exact). */
+int smi_get_valid_monotonic_pixels_f32(int32_t i, int32_t j, const float *image, int32_t rows,
+                                       int32_t cols, uint8_t *unchecked, uint8_t *orphans,
+                                       double variance, int32_t *bounds, double thresh);
+int smi_get_valid_monotonic_pixels_f64(int32_t i, int32_t j, const double *image, int32_t rows,
+                                       int32_t cols, uint8_t *unchecked, uint8_t *orphans,
+                                       double variance, int32_t *bounds, double thresh);
+int smi_linear_interpolate_invalid_pixels_f32(const int32_t *row_indices,
+                                              const int32_t *column_indices, int32_t n_indices,
+                                              uint8_t *unchecked, float *model, int32_t rows,
+                                              int32_t cols, uint8_t *orphans, double variance,
+                                              int32_t recursive, int32_t *bounds);
+int smi_linear_interpolate_invalid_pixels_f64(const int32_t *row_indices,
+                                              const int32_t *column_indices, int32_t n_indices,
+                                              uint8_t *unchecked, double *model, int32_t rows,
+                                              int32_t cols, uint8_t *orphans, double variance,
+                                              int32_t recursive, int32_t *bounds);
+
 /* ------------------------------------------------------------------------- *
  * Seam 2: batched proximal-gradient fit.
  * ------------------------------------------------------------------------- */

@@ -323,3 +323,70 @@ def morph_chain(morph, step=0, monotonic="angle", min_gradient=0.0, symmetric=Fa
     x = prox_center_on(x, step)
     x = prox_normalization(x, step, "max")
     return x
+
+
+# ---------------------------------------------------------------------------
+# monotonic mask operators (operators_pybind11.cc:61-232, operator.py:131-176)
+# ---------------------------------------------------------------------------
+def _as_bytes(a):
+    assert a.dtype == bool and a.flags.c_contiguous
+    return a.view(np.uint8)
+
+
+def get_valid_monotonic_pixels(i, j, image, unchecked, orphans, variance, bounds, thresh=0):
+    """In place on ``unchecked`` / ``orphans`` (bool) and ``bounds`` (int32[4])."""
+    assert image.flags.c_contiguous and bounds.dtype == np.int32
+    name = "oracle_get_valid_monotonic_pixels_" + ("f32" if image.dtype == np.float32 else "f64")
+    fn = getattr(_lib(), name)
+    fn.restype = None
+    vp = ctypes.c_void_p
+    fn(ctypes.c_int(int(i)), ctypes.c_int(int(j)), image.ctypes.data_as(vp),
+       ctypes.c_int(image.shape[0]), ctypes.c_int(image.shape[1]),
+       _as_bytes(unchecked).ctypes.data_as(vp), _as_bytes(orphans).ctypes.data_as(vp),
+       ctypes.c_double(variance), bounds.ctypes.data_as(vp), ctypes.c_double(thresh))
+
+
+def linear_interpolate_invalid_pixels(row_indices, column_indices, unchecked, model, orphans,
+                                      variance, recursive, bounds):
+    assert model.flags.c_contiguous and bounds.dtype == np.int32
+    rows = np.ascontiguousarray(row_indices, dtype=np.int32)
+    cols = np.ascontiguousarray(column_indices, dtype=np.int32)
+    name = "oracle_linear_interpolate_invalid_pixels_" + (
+        "f32" if model.dtype == np.float32 else "f64")
+    fn = getattr(_lib(), name)
+    fn.restype = None
+    vp = ctypes.c_void_p
+    fn(rows.ctypes.data_as(vp), cols.ctypes.data_as(vp), ctypes.c_int(rows.size),
+       _as_bytes(unchecked).ctypes.data_as(vp), model.ctypes.data_as(vp),
+       ctypes.c_int(model.shape[0]), ctypes.c_int(model.shape[1]),
+       _as_bytes(orphans).ctypes.data_as(vp), ctypes.c_double(variance),
+       ctypes.c_int(int(bool(recursive))), bounds.ctypes.data_as(vp))
+
+
+def prox_monotonic_mask(X, step, center, center_radius=1, variance=0.0, max_iter=3):
+    """``operator.prox_monotonic_mask`` (operator.py:131-176): pixels reachable from the
+    centre along a non-increasing path are valid; orphans are interpolated from the
+    gradients of their neighbours up to ``max_iter`` times; everything else is cleared.
+    Returns ``(valid, model, bounds)``."""
+    if center_radius > 0:
+        cy, cx = int(center[0]), int(center[1])
+        y0, x0 = max(cy - center_radius, 0), max(cx - center_radius, 0)
+        sub = X[y0 : cy + center_radius + 1, x0 : cx + center_radius + 1]
+        di, dj = np.unravel_index(np.argmax(sub), sub.shape)
+        i, j = di + y0, dj + x0
+    else:
+        i, j = int(np.round(center[0])), int(np.round(center[1]))
+    unchecked = np.ones(X.shape, dtype=bool)
+    unchecked[i, j] = False
+    orphans = np.zeros(X.shape, dtype=bool)
+    bounds = np.array([i, i, j, j], dtype=np.int32)
+    get_valid_monotonic_pixels(i, j, X, unchecked, orphans, variance, bounds, 0)
+    model = X.copy()
+    it = 0
+    while np.sum(orphans & unchecked) > 0 and it < max_iter:
+        it += 1
+        all_i, all_j = np.where(orphans)
+        linear_interpolate_invalid_pixels(all_i, all_j, unchecked, model, orphans, variance, True,
+                                          bounds)
+    valid = ~unchecked & ~orphans
+    return valid, model * valid, bounds

@@ -54,13 +54,13 @@ def _native_stub():
         )
         result[...] = out
 
-    def _absent(*args, **kwargs):
-        raise NotImplementedError("mask operators are out of scope for the oracle")
-
     mod.prox_weighted_monotonic = prox_weighted_monotonic
     mod.apply_filter = apply_filter
-    mod.get_valid_monotonic_pixels = _absent
-    mod.linear_interpolate_invalid_pixels = _absent
+    # the mask operators forward to the oracle's C restatement as well, so that the
+    # reference's own Python around them (operator.prox_monotonic_mask, the lite
+    # initialisation with use_mask=True) can run
+    mod.get_valid_monotonic_pixels = proxops.get_valid_monotonic_pixels
+    mod.linear_interpolate_invalid_pixels = proxops.linear_interpolate_invalid_pixels
     return mod
 
 

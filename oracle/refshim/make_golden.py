@@ -343,6 +343,16 @@ def lite(scarlet):
             init_out["sed_%d_%d" % (i, j)] = np.array(c.sed)
             init_out["morph_%d_%d" % (i, j)] = np.array(c.morph)
             init_out["origin_%d_%d" % (i, j)] = np.array(c.bbox.origin[1:])
+    # the monotonic-mask variant: the reference's Python (operator.prox_monotonic_mask,
+    # init_monotonic_morph, project_morph_to_center) over the oracle's C restatement of the
+    # two compiled mask operators
+    mask_sources = li.init_all_sources_main(obs, centers, min_snr=50, use_mask=True)
+    init_out["mask_n_comp_of"] = np.array([len(s.components) for s in mask_sources])
+    for i, src in enumerate(mask_sources):
+        for j, c in enumerate(src.components):
+            init_out["mask_sed_%d_%d" % (i, j)] = np.array(c.sed)
+            init_out["mask_morph_%d_%d" % (i, j)] = np.array(c.morph)
+            init_out["mask_origin_%d_%d" % (i, j)] = np.array(c.bbox.origin[1:])
     np.savez_compressed(os.path.join(OUT, "lite_init.npz"), **init_out)
     print("lite init: components per source", init_out["n_comp_of"])
 

@@ -35,6 +35,7 @@ ERR_ARITHMETIC = -4
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_f64p = ctypes.POINTER(ctypes.c_double)
 c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
 class BatchDesc(ctypes.Structure):
@@ -83,6 +84,26 @@ SYMBOLS = {
         ctypes.c_int,
         [c_f64p, ctypes.c_int32, ctypes.c_int32, c_f64p, ctypes.c_int32, c_i32p, c_i32p,
          c_i32p, c_i32p, c_f64p],
+    ),
+    "smi_get_valid_monotonic_pixels_f32": (
+        ctypes.c_int,
+        [ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_int32, ctypes.c_int32, c_u8p, c_u8p,
+         ctypes.c_double, c_i32p, ctypes.c_double],
+    ),
+    "smi_get_valid_monotonic_pixels_f64": (
+        ctypes.c_int,
+        [ctypes.c_int32, ctypes.c_int32, c_f64p, ctypes.c_int32, ctypes.c_int32, c_u8p, c_u8p,
+         ctypes.c_double, c_i32p, ctypes.c_double],
+    ),
+    "smi_linear_interpolate_invalid_pixels_f32": (
+        ctypes.c_int,
+        [c_i32p, c_i32p, ctypes.c_int32, c_u8p, c_f32p, ctypes.c_int32, ctypes.c_int32, c_u8p,
+         ctypes.c_double, ctypes.c_int32, c_i32p],
+    ),
+    "smi_linear_interpolate_invalid_pixels_f64": (
+        ctypes.c_int,
+        [c_i32p, c_i32p, ctypes.c_int32, c_u8p, c_f64p, ctypes.c_int32, ctypes.c_int32, c_u8p,
+         ctypes.c_double, ctypes.c_int32, c_i32p],
     ),
     "smi_batch_create": (
         ctypes.c_int,

@@ -125,10 +125,6 @@ class MonotonicityConstraint(Constraint):
 
     def __init__(self, neighbor_weight="flat", min_gradient=0.1, use_mask=False,
                  fit_center_radius=0):
-        if use_mask:
-            raise NotImplementedError(
-                "MonotonicityConstraint(use_mask=True) (monotonic mask operators) is out of scope"
-            )
         self.neighbor_weight = neighbor_weight
         self.min_gradient = min_gradient
         self.use_mask = use_mask
@@ -150,7 +146,15 @@ class MonotonicityConstraint(Constraint):
                 min_gradient=self.min_gradient, center=center,
             )
             Cache.set(name, key, prox)
-        return prox(morph, step)
+        original = morph.copy()
+        result = prox(morph, step)
+        if self.use_mask:
+            # pixels connected to the centre by a monotonic path keep their value
+            # (constraint.py:227-232)
+            valid, masked, _ = operator.prox_monotonic_mask(
+                original, step, center=center, center_radius=0, variance=0, max_iter=0)
+            result[valid] = masked[valid]
+        return result
 
 
 class SymmetryConstraint(Constraint):
@@ -225,9 +229,13 @@ def device_flags(constraint):
             )
         rank = r
         if isinstance(c, MonotonicityConstraint):
-            if c.fit_center:
-                raise NotImplementedError("fit_center_radius > 0 is not supported on the device")
+            if c.use_mask:
+                raise NotImplementedError("use_mask=True is not supported inside the device loop")
+            if c.fit_center_radius > 1:
+                raise NotImplementedError("fit_center_radius > 1 is not supported on the device")
             out["flags"] |= _lib.PROX_MONOTONIC
+            if c.fit_center:
+                out["flags"] |= _lib.PROX_FIT_CENTER
             out["neighbor_weight"] = c.neighbor_weight
             out["min_gradient"] = float(c.min_gradient)
         elif isinstance(c, SymmetryConstraint):

@@ -301,6 +301,41 @@ int seam1_filter(const T *image, int32_t H, int32_t W, const T *values, int32_t 
 
 }  // namespace
 
+namespace {
+template <typename T>
+int seam1_mask_valid(int32_t i, int32_t j, const T *image, int32_t rows, int32_t cols,
+                     uint8_t *unchecked, uint8_t *orphans, double variance, int32_t *bounds,
+                     double thresh) {
+    SMI_REQUIRE(image && unchecked && orphans && bounds, "null argument");
+    SMI_REQUIRE(rows > 0 && cols > 0 && i >= 0 && i < rows && j >= 0 && j < cols, "bad indices");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device available");
+        return SMI_ERR_NO_DEVICE;
+    }
+    return mask_valid_host_buffers<T>(i, j, image, rows, cols, unchecked, orphans, variance,
+                                      bounds, thresh);
+}
+
+template <typename T>
+int seam1_mask_interpolate(const int32_t *ri, const int32_t *ci, int32_t n, uint8_t *unchecked,
+                           T *model, int32_t rows, int32_t cols, uint8_t *orphans,
+                           double variance, int32_t recursive, int32_t *bounds) {
+    SMI_REQUIRE((ri && ci) || n == 0, "null index arrays");
+    SMI_REQUIRE(model && unchecked && orphans && bounds && rows > 0 && cols > 0 && n >= 0,
+                "null argument / bad sizes");
+    for (int32_t k = 0; k < n; ++k)
+        SMI_REQUIRE(ri[k] >= 0 && ri[k] < rows && ci[k] >= 0 && ci[k] < cols, "index out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device available");
+        return SMI_ERR_NO_DEVICE;
+    }
+    return mask_interpolate_host_buffers<T>(ri, ci, n, unchecked, model, rows, cols, orphans,
+                                            variance, recursive, bounds);
+}
+}  // namespace
+
 extern "C" {
 
 const char *smi_last_error(void) { return g_error.c_str(); }
@@ -338,6 +373,31 @@ int smi_apply_filter_f64(const double *image, int32_t H, int32_t W, const double
                          const int32_t *x_start, const int32_t *x_end, double *result) {
     return seam1_filter<double>(image, H, W, values, n_taps, y_start, y_end, x_start, x_end,
                                 result);
+}
+
+int smi_get_valid_monotonic_pixels_f32(int32_t i, int32_t j, const float *image, int32_t rows,
+                                       int32_t cols, uint8_t *unchecked, uint8_t *orphans,
+                                       double variance, int32_t *bounds, double thresh) {
+    return seam1_mask_valid<float>(i, j, image, rows, cols, unchecked, orphans, variance, bounds, thresh);
+}
+int smi_get_valid_monotonic_pixels_f64(int32_t i, int32_t j, const double *image, int32_t rows,
+                                       int32_t cols, uint8_t *unchecked, uint8_t *orphans,
+                                       double variance, int32_t *bounds, double thresh) {
+    return seam1_mask_valid<double>(i, j, image, rows, cols, unchecked, orphans, variance, bounds, thresh);
+}
+int smi_linear_interpolate_invalid_pixels_f32(const int32_t *ri, const int32_t *ci, int32_t n,
+                                              uint8_t *unchecked, float *model, int32_t rows,
+                                              int32_t cols, uint8_t *orphans, double variance,
+                                              int32_t recursive, int32_t *bounds) {
+    return seam1_mask_interpolate<float>(ri, ci, n, unchecked, model, rows, cols, orphans, variance,
+                                         recursive, bounds);
+}
+int smi_linear_interpolate_invalid_pixels_f64(const int32_t *ri, const int32_t *ci, int32_t n,
+                                              uint8_t *unchecked, double *model, int32_t rows,
+                                              int32_t cols, uint8_t *orphans, double variance,
+                                              int32_t recursive, int32_t *bounds) {
+    return seam1_mask_interpolate<double>(ri, ci, n, unchecked, model, rows, cols, orphans,
+                                          variance, recursive, bounds);
 }
 
 static int batch_create_impl(const smi_batch_desc *desc, int device, smi_batch **out,

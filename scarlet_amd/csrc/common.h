@@ -155,6 +155,16 @@ int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e
 int launch_shift_backward(const BatchView &v, const float *G, int32_t it, double *g_shift_out,
                           int32_t grad_only, hipStream_t s);
 int launch_shift_forward(const BatchView &v, int32_t respect_state, hipStream_t s);
+// seam 1, monotonic mask operators (mask.hip)
+template <typename T>
+int mask_valid_host_buffers(int32_t i, int32_t j, const T *image, int32_t rows, int32_t cols,
+                            uint8_t *unchecked, uint8_t *orphans, double variance,
+                            int32_t *bounds, double thresh);
+template <typename T>
+int mask_interpolate_host_buffers(const int32_t *row_idx, const int32_t *col_idx, int32_t n_idx,
+                                  uint8_t *unchecked, T *model, int32_t rows, int32_t cols,
+                                  uint8_t *orphans, double variance, int32_t recursive,
+                                  int32_t *bounds);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);
 void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,

@@ -1,10 +1,10 @@
 """Parameterisation of ``scarlet.lite`` components and the joint spectrum fit
 (reference scarlet/lite/initialization.py:140-186, 250-318, 608-645).
 
-``init_all_sources_main`` (lite/initialization.py:321-419) is provided with its default
-``use_mask=False`` (weighted monotonicity); the monotonic-mask variant and the wavelet
-initialisation (``init_all_sources_wavelets``) need the mask operators / the starlet
-transform and are not part of this package.
+``init_all_sources_main`` (lite/initialization.py:321-419) is provided with both
+monotonicity variants (weighted sweep, or ``use_mask=True``: the monotonic mask operators);
+the wavelet initialisation (``init_all_sources_wavelets``) needs the starlet transform and
+is not part of this package.
 """
 
 from functools import partial
@@ -13,12 +13,12 @@ import numpy as np
 
 from ..bbox import Box, overlapped_slices
 from ..initialization import trim_morphology
-from ..operator import prox_uncentered_symmetry, prox_weighted_monotonic
+from ..operator import prox_monotonic_mask, prox_uncentered_symmetry, prox_weighted_monotonic
 from ..parameter import relative_step
 from .measure import calculate_snr
 from .models import LiteComponent, LiteFactorizedComponent, LiteSource
 from .parameters import AdaproxParameter, FistaParameter
-from .utils import insert_image
+from .utils import bounds_to_bbox, insert_image, project_morph_to_center
 
 
 def init_monotonic_morph(detect, center, full_box, grow=0, normalize=True, use_mask=True,
@@ -28,14 +28,20 @@ def init_monotonic_morph(detect, center, full_box, grow=0, normalize=True, use_m
     ``center``, trimmed at ``thresh`` (lite/initialization.py:83-138).  Returns
     ``(bbox, morph)``; ``morph`` is None when nothing is left."""
     if use_mask:
-        raise NotImplementedError("init_monotonic_morph(use_mask=True) needs the monotonic "
-                                  "mask operators, which are not part of this package")
-    prox = prox_weighted_monotonic(detect.shape, neighbor_weight="angle", center=center,
-                                   min_gradient=0)
-    morph = prox(detect, 0).reshape(detect.shape)
-    morph, bbox = trim_morphology(center, morph, bg_thresh=thresh)
-    if np.max(morph) == 0:
-        return Box((0, 0, 0)), None
+        _, morph, bounds = prox_monotonic_mask(detect, 0, center, max_iter=0)
+        bbox = bounds_to_bbox(bounds)
+        if bbox.shape == (1, 1) and morph[bbox.slices][0, 0] == 0:
+            return bbox, None
+        if grow is not None and grow > 0:
+            bbox = bbox.grow(grow)
+        morph, bbox = project_morph_to_center(morph, center, bbox, full_box)
+    else:
+        prox = prox_weighted_monotonic(detect.shape, neighbor_weight="angle", center=center,
+                                       min_gradient=0)
+        morph = prox(detect, 0).reshape(detect.shape)
+        morph, bbox = trim_morphology(center, morph, bg_thresh=thresh)
+        if np.max(morph) == 0:
+            return Box((0, 0, 0)), None
     if normalize:
         morph /= np.max(morph)
     return bbox, morph

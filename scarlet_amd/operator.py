@@ -172,6 +172,74 @@ def get_center(image, center, radius=1):
     return y0 + dy, x0 + dx
 
 
+def _mask_args(image):
+    if image.dtype == np.float32:
+        return "f32", _lib.ctypes.c_float
+    if image.dtype == np.float64:
+        return "f64", _lib.ctypes.c_double
+    raise TypeError("float32 or float64 array required")
+
+
+def get_valid_monotonic_pixels(i, j, image, unchecked, orphans, variance, bounds, thresh=0):
+    """``operators_pybind11.get_valid_monotonic_pixels`` through the C ABI: flood fill
+    from ``(i, j)`` over pixels that do not rise by more than ``variance`` along the way;
+    ``unchecked`` / ``orphans`` (bool) and ``bounds`` (int32[4]) are updated in place."""
+    lib = _lib.load()
+    tag, ct = _mask_args(image)
+    if not (image.flags.c_contiguous and unchecked.flags.c_contiguous and orphans.flags.c_contiguous):
+        raise ValueError("C-contiguous arrays required")
+    assert unchecked.dtype == bool and orphans.dtype == bool and bounds.dtype == np.int32
+    u8 = _lib.ctypes.c_uint8
+    _lib.check(getattr(lib, "smi_get_valid_monotonic_pixels_" + tag)(
+        int(i), int(j), _lib.ptr(image, ct), image.shape[0], image.shape[1],
+        _lib.ptr(unchecked.view(np.uint8), u8), _lib.ptr(orphans.view(np.uint8), u8),
+        float(variance), _lib.ptr(bounds, _lib.ctypes.c_int32), float(thresh)))
+
+
+def linear_interpolate_invalid_pixels(row_indices, column_indices, unchecked, model, orphans,
+                                      variance, recursive, bounds):
+    """``operators_pybind11.linear_interpolate_invalid_pixels`` through the C ABI: fill the
+    listed orphans from the gradients of their neighbours, in list order, in place."""
+    lib = _lib.load()
+    tag, ct = _mask_args(model)
+    if not (model.flags.c_contiguous and unchecked.flags.c_contiguous and orphans.flags.c_contiguous):
+        raise ValueError("C-contiguous arrays required")
+    assert unchecked.dtype == bool and orphans.dtype == bool and bounds.dtype == np.int32
+    rows, cols = _lib.i32(row_indices), _lib.i32(column_indices)
+    u8, i32 = _lib.ctypes.c_uint8, _lib.ctypes.c_int32
+    _lib.check(getattr(lib, "smi_linear_interpolate_invalid_pixels_" + tag)(
+        _lib.ptr(rows, i32), _lib.ptr(cols, i32), rows.size,
+        _lib.ptr(unchecked.view(np.uint8), u8), _lib.ptr(model, ct), model.shape[0], model.shape[1],
+        _lib.ptr(orphans.view(np.uint8), u8), float(variance), int(bool(recursive)),
+        _lib.ptr(bounds, i32)))
+
+
+def prox_monotonic_mask(X, step, center, center_radius=1, variance=0.0, max_iter=3):
+    """Monotonicity along *any* path from the centre (reference operator.py:131-176):
+    pixels reachable from the (optionally re-fitted) centre without rising by more than
+    ``variance`` are valid; orphans next to them are interpolated up to ``max_iter`` times;
+    the rest is cleared.  Returns ``(valid, model, bounds)``."""
+    if center_radius > 0:
+        i, j = get_center(X, center, center_radius)
+    else:
+        i, j = int(np.round(center[0])), int(np.round(center[1]))
+    X = np.ascontiguousarray(X)
+    unchecked = np.ones(X.shape, dtype=bool)
+    unchecked[i, j] = False
+    orphans = np.zeros(X.shape, dtype=bool)
+    bounds = np.array([i, i, j, j], dtype=np.int32)
+    get_valid_monotonic_pixels(i, j, X, unchecked, orphans, variance, bounds, 0)
+    model = X.copy()
+    it = 0
+    while np.sum(orphans & unchecked) > 0 and it < max_iter:
+        it += 1
+        all_i, all_j = np.where(orphans)
+        linear_interpolate_invalid_pixels(all_i, all_j, unchecked, model, orphans, variance, True,
+                                          bounds)
+    valid = ~unchecked & ~orphans
+    return valid, model * valid, bounds
+
+
 def prox_sdss_symmetry(X, step):
     """Minimum of each pixel and its 180-degree partner, in place."""
     X[:] = np.minimum(X, X[::-1, ::-1])

@@ -433,6 +433,16 @@ def test_lite_init_all_sources_main_matches_the_reference(hsc):
             assert np.abs(c.morph - g["morph_%d_%d" % (i, j)]).max() < 1e-5, (i, j)
             ref = g["sed_%d_%d" % (i, j)]
             assert np.abs(c.sed - ref).max() <= 2e-3 * np.abs(ref).max(), (i, j)
+    # the monotonic-mask variant (use_mask=True) through the GPU mask operators
+    masked = lite.init_all_sources_main(obs, [tuple(c) for c in g["centers"]], min_snr=50,
+                                        use_mask=True)
+    assert [len(s.components) for s in masked] == list(g["mask_n_comp_of"])
+    for i, src in enumerate(masked):
+        for j, c in enumerate(src.components):
+            assert tuple(c.bbox.origin[1:]) == tuple(g["mask_origin_%d_%d" % (i, j)])
+            assert np.abs(c.morph - g["mask_morph_%d_%d" % (i, j)]).max() < 1e-5, (i, j)
+            ref = g["mask_sed_%d_%d" % (i, j)]
+            assert np.abs(c.sed - ref).max() <= 2e-3 * np.abs(ref).max(), (i, j)
     fitted = lite.LiteBlend(
         lite.parameterize_sources(sources, obs, lite.init_adaprox_component), obs)
     it, loss = fitted.fit(30, e_rel=1e-4)

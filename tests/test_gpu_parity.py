@@ -119,6 +119,78 @@ def test_apply_filter_bit_exact(amd, dtype):
     assert_allclose(got, fftconv.apply_filter(img, ker), rtol=1e-4, atol=1e-5)
 
 
+def _bumpy(rng, shape, dtype):
+    yy, xx = np.mgrid[: shape[0], : shape[1]]
+    cy, cx = shape[0] // 2, shape[1] // 2
+    img = np.exp(-0.5 * (((yy - cy) / (0.2 * shape[0])) ** 2 + ((xx - cx) / (0.22 * shape[1])) ** 2))
+    img += 0.5 * np.exp(-0.5 * (((yy - cy // 2) / 2.5) ** 2 + ((xx - 1.6 * cx) / 3.0) ** 2))
+    return (img + rng.normal(0, 0.03, shape)).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(45, 39), (58, 48), (7, 9), (1, 12), (101, 120)])
+def test_mask_operators_bit_exact(amd, dtype, shape):
+    """get_valid_monotonic_pixels / linear_interpolate_invalid_pixels through the C ABI
+    against the C restatement of operators_pybind11.cc:61-232: identical unchecked /
+    orphans maps, bounds and interpolated values (the parallel relaxation on the GPU
+    reaches the same fixed point as the depth-first recursion)"""
+    from oracle import proxops
+    from scarlet_amd import operator
+
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    img = _bumpy(rng, shape, dtype)
+    starts = [(shape[0] // 2, shape[1] // 2), (0, 0), (shape[0] - 1, shape[1] // 3)]
+    for (i, j), variance, thresh in zip(starts, (0.0, 0.02, 0.0), (0.0, 0.0, 0.05)):
+        state = []
+        for mod in (proxops, operator):
+            unchecked = np.ones(shape, dtype=bool)
+            unchecked[i, j] = False
+            if shape[0] > 5:
+                unchecked[2, :3] = False  # pixels some earlier pass already settled
+            orphans = np.zeros(shape, dtype=bool)
+            bounds = np.array([i, i, j, j], dtype=np.int32)
+            mod.get_valid_monotonic_pixels(i, j, img, unchecked, orphans, variance, bounds, thresh)
+            model = img.copy()
+            first = (unchecked.copy(), orphans.copy(), bounds.copy())
+            for recursive in (True, False):
+                oi, oj = np.where(orphans)
+                mod.linear_interpolate_invalid_pixels(oi, oj, unchecked, model, orphans, variance,
+                                                      recursive, bounds)
+            state.append(first + (unchecked, orphans, bounds, model))
+        for a, b in zip(*state):
+            assert_array_equal(a, b)
+        assert state[0][0].sum() < img.size  # something was reached
+
+
+def test_prox_monotonic_mask_and_use_mask_constraint(amd):
+    """operator.prox_monotonic_mask (operator.py:131-176) and
+    MonotonicityConstraint(use_mask=True) (constraint.py:225-232) on the GPU operators
+    against the oracle's restatement"""
+    from oracle import proxops
+    from scarlet_amd import operator
+    import scarlet_amd as scarlet
+
+    rng = np.random.default_rng(5)
+    for dtype in (np.float32, np.float64):
+        img = _bumpy(rng, (51, 47), dtype)
+        for max_iter, radius, variance in ((0, 1, 0.0), (3, 1, 0.0), (2, 0, 0.01)):
+            got = operator.prox_monotonic_mask(img.copy(), 0, (25, 23), center_radius=radius,
+                                               variance=variance, max_iter=max_iter)
+            want = proxops.prox_monotonic_mask(img.copy(), 0, (25, 23), center_radius=radius,
+                                               variance=variance, max_iter=max_iter)
+            for a, b in zip(got, want):
+                assert_array_equal(a, b)
+        morph = img.copy()
+        out = scarlet.MonotonicityConstraint("angle", 0, use_mask=True)(morph, 0)
+        ref = img.copy()
+        w, didx, off = proxops.monotonic_operator(ref.shape, "angle", (25, 23))
+        proxops.sweep(ref, w, off, didx, 0)
+        valid, masked, _ = proxops.prox_monotonic_mask(img.copy(), 0, (25, 23), center_radius=0,
+                                                       variance=0, max_iter=0)
+        ref[valid] = masked[valid]
+        assert_array_equal(out, ref)
+
+
 # ---------------------------------------------------------------- seam 2
 PATHS = ["rocfft", "fused"]
 
