@@ -600,6 +600,7 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
                 }
             }
         }
+
         if ((slots.size() / 64) % 2)
             for (int lane = 0; lane < 64; ++lane) slots.push_back(idle);
         dp.n_slots = (int32_t)(slots.size() / 64);

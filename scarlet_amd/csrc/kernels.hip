@@ -760,30 +760,47 @@ __device__ __forceinline__ void sweep_step(float *us, const int4 a, const float4
     if (lim < cur) *pp = lim;
 }
 
+// Single-wave workgroups: LDS operations of one wave execute in order, so between a
+// step's writes and the next step's reads only the LDS counter has to drain.  Unlike
+// __syncthreads() this leaves the global loads of the plan prefetch in flight.
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slots, int n_slots,
                                             float one_minus_g, int lane) {
     const int4 *meta = reinterpret_cast<const int4 *>(slots) + lane * 2;
     const float4 *wts = reinterpret_cast<const float4 *>(slots) + lane * 2 + 1;
-    // two steps per iteration with ping-pong registers (no register rotation moves);
-    // the plan is padded to an even number of steps
-    int4 a0 = meta[0];
-    float4 w0 = wts[0];
-    for (int s = 0; s < n_slots; s += 2) {
-        const int4 a1 = meta[(int64_t)(s + 1) * 128];
-        const float4 w1 = wts[(int64_t)(s + 1) * 128];
+    // four steps per iteration, each plan entry requested three steps before it is used
+    // (register ping-pong, no rotation moves); the plan is padded to an even number of
+    // steps, reads past the end are clamped to the last step
+    const int last = n_slots - 1;
+    auto at = [&](int s) { return (int64_t)min(s, last) * 128; };
+    int4 a0 = meta[at(0)], a1 = meta[at(1)], a2 = meta[at(2)];
+    float4 w0 = wts[at(0)], w1 = wts[at(1)], w2 = wts[at(2)];
+    for (int s = 0; s < n_slots; s += 4) {
+        const int4 a3 = meta[at(s + 3)];
+        const float4 w3 = wts[at(s + 3)];
         sweep_step(us, a0, w0, one_minus_g);
-        __syncthreads();
-        const int s2 = min(s + 2, n_slots - 1);
-        a0 = meta[(int64_t)s2 * 128];
-        w0 = wts[(int64_t)s2 * 128];
+        wave_lds_fence();
+        if (s + 1 >= n_slots) break;
+        a0 = meta[at(s + 4)];
+        w0 = wts[at(s + 4)];
         sweep_step(us, a1, w1, one_minus_g);
-        __syncthreads();
+        wave_lds_fence();
+        if (s + 2 >= n_slots) break;
+        a1 = meta[at(s + 5)];
+        w1 = wts[at(s + 5)];
+        sweep_step(us, a2, w2, one_minus_g);
+        wave_lds_fence();
+        if (s + 3 >= n_slots) break;
+        a2 = meta[at(s + 6)];
+        w2 = wts[at(s + 6)];
+        sweep_step(us, a3, w3, one_minus_g);
+        wave_lds_fence();
     }
 }
 
-// LITE = false is the ExtendedSource / AMSGrad path of Blend.fit; the scarlet.lite
-// variants (FISTA, centre fitting of the monotonic sweep, background threshold) are
-// compiled into a second instantiation so that they cost the main path no registers.
 // MODE 0: Blend.fit, 1: lite with AdaproxParameter, 2: lite with FistaParameter
 template <int NPL, int MODE>
 __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float *G, int it,

@@ -1,0 +1,26 @@
+"""Development aid: how the update kernel's time splits between the gather / AMSGrad part
+and the proximal sub-iterations (benchmark batch, sub-iterations capped)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401  (loads the HIP runtime first)
+
+from scarlet_amd import BlendBatch, ComponentSpec, synthetic
+
+nb = 1024
+scenes = synthetic.make_batch(range(1234, 1234 + nb))
+kern = synthetic.psfs()
+comps = [[ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k], sed_min_step=s["noise_rms"])
+          for k in range(len(s["morphs"]))] for s in scenes]
+data = np.stack([s["data"] for s in scenes])
+weights = np.stack([s["weights"] for s in scenes])
+for pmi in (0, 1, 2, 3, 10):
+    batch = BlendBatch(data, weights, comps, kernel=kern[2], max_iter=64)
+    batch.step(0, 10, e_rel=1e-3, prox_max_iter=pmi)
+    batch.enable_timing(True)
+    batch.step(10, 40, e_rel=1e-3, prox_max_iter=pmi)
+    t = batch.timing()
+    print("prox_max_iter", pmi, {k: round(v, 3) for k, v in t.items()}, flush=True)
+    batch.close()
