@@ -14,7 +14,6 @@ from functools import partial
 import numpy as np
 import numpy.ma as ma
 
-from . import _lib
 from .batch import BlendBatch, ComponentSpec, PointSourceSpec
 from .bbox import overlapped_slices
 from .component import CombinedComponent, FactorizedComponent

@@ -428,7 +428,6 @@ class LiteBlend:
 
     def _download(self, batch, kind):
         seds, morphs = batch.parameters()
-        dtype = self.observation.images.dtype
         if kind == "fista":
             st = batch.fista_state()
         else:
@@ -443,7 +442,6 @@ class LiteBlend:
                 c._sed.m, c._sed.v, c._sed.vhat = (st[n][k].copy() for n in ("m_sed", "v_sed", "vhat_sed"))
                 c._morph.m, c._morph.v, c._morph.vhat = (
                     st[n][k].copy() for n in ("m_morph", "v_morph", "vhat_morph"))
-        del dtype
 
     def fit(self, max_iter, e_rel=1e-4, min_iter=1, resize=10, reweight=True):
         """Fit all parameters; returns ``(it, loss[-1])`` like the reference

@@ -4,8 +4,6 @@ the fitting path."""
 
 import numpy as np
 
-from .bbox import Box
-
 
 def _model_and_origin(component):
     if hasattr(component, "get_model"):

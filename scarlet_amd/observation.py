@@ -4,7 +4,6 @@
 import numpy as np
 import numpy.ma as ma
 
-from . import _lib
 from .bbox import overlapped_slices
 from .frame import Frame
 from .renderer import ConvolutionRenderer, NullRenderer, Renderer
