@@ -126,6 +126,10 @@ enum {
     /* scarlet.lite background threshold (lite/models.py:222-228): a pixel is set to 0
      * when sed[c] * morph < bg_level[c] in every band (new sed); replaces positivity */
     SMI_PROX_BG_THRESH = 512,
+    /* l_thresh of SMI_PROX_L1 / L0 is relative: multiplied by the step of the proximal
+     * sub-iteration, gamma = alpha / max(psi) (type="relative", the reference's default,
+     * constraint.py:117-145; lite/parameters.py:296-299) */
+    SMI_PROX_L_RELATIVE = 1024,
     /* not a constraint: the component is a PointSource (source.py:92-128) whose
      * morphology is the model PSF evaluated at a free sub-pixel centre
      * (PointSourceMorphology, morphology.py:476-513; GaussianPSF, psf.py:80-142) */
@@ -171,7 +175,8 @@ typedef struct smi_components {
     const int32_t *sweep_plan;  /* index into the plans added with                  */
                                 /* smi_batch_add_sweep_plan, -1 if not monotonic    */
     const float *min_gradient;  /* MonotonicityConstraint.min_gradient              */
-    const float *l_thresh;      /* threshold for SMI_PROX_L1/L0 (absolute)          */
+    const float *l_thresh;      /* threshold for SMI_PROX_L1/L0 (absolute unless     */
+                                /* SMI_PROX_L_RELATIVE)                              */
     const float *morph_rel_step;/* step = max(morph_step, rel * mean(morph)); NULL=0 */
                                 /* (relative_step, parameter.py:126-129)            */
     /* point sources (SMI_COMPONENT_POINT_SOURCE in prox_flags); both NULL if none.

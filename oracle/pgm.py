@@ -37,7 +37,11 @@ class Component:
         source=None,
         shift=None,
         shift_step=1e-1,
+        sparsity=None,
+        tiny=1e-6,
     ):
+        # optional L0 / L1 member of the chain and the CenterOnConstraint floor
+        self.sparsity, self.tiny = sparsity, tiny
         # ExtendedSourceMorphology(shifting=True): the sub-pixel offset of the centre
         # is a free 2-vector, step 1e-1, no constraint (morphology.py:673-676); the
         # model uses the Fourier-shifted image (morphology.py:124-130)
@@ -83,7 +87,7 @@ class Component:
     def morph_prox(self, x, step):
         """ExtendedSourceMorphology chain (morphology.py:644-670)."""
         return proxops.morph_chain(
-            x, step, self.monotonic, self.min_gradient, self.symmetric
+            x, step, self.monotonic, self.min_gradient, self.symmetric, self.sparsity, self.tiny
         )
 
 

@@ -311,16 +311,23 @@ def prox_threshold(x, step=0):
     return prox_hard_plus(x, step, thresh=t, type="absolute")
 
 
-def morph_chain(morph, step=0, monotonic="angle", min_gradient=0.0, symmetric=False):
+def morph_chain(morph, step=0, monotonic="angle", min_gradient=0.0, symmetric=False,
+                sparsity=None, tiny=1e-6):
     """The ``ExtendedSourceMorphology`` constraint chain (morphology.py:644-670):
-    Monotonicity -> [Symmetry] -> Positivity -> CenterOn -> Normalization("max")."""
+    Monotonicity -> [Symmetry] -> Positivity -> CenterOn -> Normalization("max"),
+    optionally with an ``L0Constraint`` / ``L1Constraint`` (``sparsity`` =
+    ("l0" | "l1", thresh, type), constraint.py:117-145) after the symmetry, the order a
+    user chain must have to run on the device."""
     x = morph
     if monotonic is not None:
         x = prox_monotonic(x, step, monotonic, min_gradient)
     if symmetric:
         x = prox_soft_symmetry(x, step)
+    if sparsity is not None:
+        kind, thresh, type = sparsity
+        x = (prox_hard if kind == "l0" else prox_soft)(x, step, thresh, type)
     x = prox_positivity(x, step)
-    x = prox_center_on(x, step)
+    x = prox_center_on(x, step, tiny)
     x = prox_normalization(x, step, "max")
     return x
 

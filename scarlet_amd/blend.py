@@ -164,6 +164,7 @@ class Blend(CombinedComponent):
                     neighbor_weight=flags["neighbor_weight"] or "angle",
                     min_gradient=flags["min_gradient"],
                     l_thresh=flags["l_thresh"],
+                    center_floor=flags["center_floor"],
                     **shift_kw,
                 )
             )

@@ -204,7 +204,8 @@ def device_flags(constraint):
     raises ``NotImplementedError`` for chains the device kernel cannot express
     (user callables, other orders, repeats) -- there is no host fallback.
     """
-    out = dict(flags=0, neighbor_weight=None, min_gradient=0.0, zero=0.0, l_thresh=0.0)
+    out = dict(flags=0, neighbor_weight=None, min_gradient=0.0, zero=0.0, l_thresh=0.0,
+               center_floor=1e-6)
     if constraint is None:
         return out
     if isinstance(constraint, ConstraintChain):
@@ -243,17 +244,18 @@ def device_flags(constraint):
                 raise NotImplementedError("SymmetryConstraint(strength != 1) on the device")
             out["flags"] |= _lib.PROX_SYMMETRY
         elif isinstance(c, (L0Constraint, L1Constraint)):
-            if c.type != "absolute":
-                raise NotImplementedError("relative L0/L1 thresholds on the device")
+            if out["flags"] & (_lib.PROX_L0 | _lib.PROX_L1):
+                raise NotImplementedError("L0 and L1 constraints in one chain")
+            if c.type == "relative":
+                out["flags"] |= _lib.PROX_L_RELATIVE
             out["flags"] |= _lib.PROX_L0 if isinstance(c, L0Constraint) else _lib.PROX_L1
             out["l_thresh"] = float(c.thresh)
         elif isinstance(c, PositivityConstraint):
             out["flags"] |= _lib.PROX_POSITIVE
             out["zero"] = float(c.zero)
         elif isinstance(c, CenterOnConstraint):
-            if c.tiny != 1e-6:
-                raise NotImplementedError("CenterOnConstraint(tiny != 1e-6) on the device")
             out["flags"] |= _lib.PROX_CENTER_ON
+            out["center_floor"] = float(c.tiny)
         elif isinstance(c, NormalizationConstraint):
             out["flags"] |= _lib.PROX_NORM_MAX if c.type == "max" else _lib.PROX_NORM_SUM
     return out

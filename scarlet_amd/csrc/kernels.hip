@@ -548,6 +548,9 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     const float one_minus_g = 1.f - v.c_min_grad[c.k];
     const int ctr = (c.h / 2) * c.w + (c.w / 2);
     const float cfloor = v.c_center_floor[c.k];
+    // relative thresholds scale with the step of the sub-iteration, gamma = alpha / max(psi)
+    const float lthresh =
+        v.c_lthresh[c.k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
     const float *bg_level = v.c_bg_level ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;
     __syncthreads();
     for (int i = lane; i < N; i += 64) rs[i] = rs[i] / pmax;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         if (monotonic)
             sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
                                        pl.nbr, pl.wt, one_minus_g, lane);
-        chain_symmetry_threshold(us, c, flags, v.c_lthresh[c.k], sed_new, bg_level);
+        chain_symmetry_threshold(us, c, flags, lthresh, sed_new, bg_level);
         float mx = -INFINITY, sm = 0.f;
         for (int i = lane; i < N; i += 64) {
             float u = us[i];
@@ -891,7 +894,8 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
     }
     const float one_minus_g = 1.f - v.c_min_grad[c.k];
     const int ctr = (c.h / 2) * c.w + (c.w / 2);
-    const float lthresh = v.c_lthresh[c.k];
+    const float lthresh =
+        v.c_lthresh[c.k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
     const float cfloor = v.c_center_floor[c.k];
     const float *bg_level =
         (LITE && v.c_bg_level) ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;

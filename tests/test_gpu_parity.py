@@ -537,6 +537,24 @@ def test_weightings_symmetry_and_gradient(amd, mode, g, symmetric):
                    dict(monotonic=mode, min_gradient=g, symmetric=symmetric), flags=flags)
 
 
+@pytest.mark.parametrize("kind,thresh,type", [("l1", 0.02, "absolute"), ("l0", 0.05, "absolute"),
+                                              ("l1", 3.0, "relative"), ("l0", 8.0, "relative")])
+def test_sparsity_constraints_and_center_floor(amd, kind, thresh, type):
+    """L0Constraint / L1Constraint in the chain (absolute and relative thresholds; the
+    relative one scales with the step of every proximal sub-iteration) and a
+    CenterOnConstraint floor other than 1e-6"""
+    from scarlet_amd import _lib
+
+    rng = np.random.default_rng(31)
+    boxes = [((21, 21), (3, 5)), ((31, 31), (20, 25)), ((25, 35), (30, -4))]
+    specs, kernel, data, weights = _random_scene(rng, 3, 64, 72, boxes, kernel_shape=15)
+    flags = _lib.PROX_EXTENDED_SOURCE | (_lib.PROX_L1 if kind == "l1" else _lib.PROX_L0)
+    flags |= _lib.PROX_L_RELATIVE if type == "relative" else 0
+    _compare_steps(amd, specs, kernel, data, weights, 3,
+                   dict(l_thresh=thresh, center_floor=1e-3),
+                   dict(sparsity=(kind, thresh, type), tiny=1e-3), flags=flags)
+
+
 def test_many_bands_big_boxes_null_renderer(amd):
     """C = 10 (> one band chunk), boxes 61^2 (register path NPL=59) and 81^2 (generic
     LDS kernel), NullRenderer"""
