@@ -2,6 +2,7 @@
 (scarlet/lite/__init__.py), the fitting loop of ``LiteBlend.fit`` on the device."""
 
 from .initialization import (  # noqa: F401
+    get_min_psf,
     init_adaprox_component,
     init_all_sources_main,
     init_fista_component,
@@ -24,4 +25,11 @@ from .parameters import (  # noqa: F401
     LiteParameter,
     grow_array,
 )
-from .utils import insert_image  # noqa: F401
+from .utils import (  # noqa: F401
+    bounds_to_bbox,
+    get_circle_mask,
+    insert_image,
+    integrated_circular_gaussian,
+    integrated_gaussian,
+    project_morph_to_center,
+)

@@ -21,6 +21,23 @@ from .parameters import AdaproxParameter, FistaParameter
 from .utils import bounds_to_bbox, insert_image, project_morph_to_center
 
 
+def get_min_psf(psfs, thresh=0.01):
+    """Central part of a (bands, h, w) PSF cube outside of which no two bands differ by
+    more than ``thresh`` relative to their overall maximum (lite/initialization.py:19-80)."""
+    py, px = psfs.shape[1] // 2, psfs.shape[2] // 2
+    xx, yy = np.meshgrid(np.arange(psfs.shape[-1]), np.arange(psfs.shape[-2]))
+    R = np.sqrt((xx - px) ** 2 + (yy - py) ** 2)
+    max_radius = 0
+    for p1 in range(len(psfs) - 1):
+        for p2 in range(p1 + 1, len(psfs)):
+            diff = (psfs[p1] - psfs[p2]) / np.max([psfs[p1], psfs[p2]])
+            max_radius = max(max_radius, int(np.max(R * (np.abs(diff) > thresh))))
+    dy, dx = py - max_radius, px - max_radius
+    sy = slice(dy, -dy) if dy > 0 else slice(None)
+    sx = slice(dx, -dx) if dx > 0 else slice(None)
+    return psfs[:, sy, sx].copy()
+
+
 def init_monotonic_morph(detect, center, full_box, grow=0, normalize=True, use_mask=True,
                          thresh=0):
     """Morphology of a monotonic source cut out of the 2-D detection image ``detect``:
