@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--phases", action="store_true", help="print the per-phase device times")
+    ap.add_argument("--loop", default="blend", choices=["blend", "lite-adaprox", "lite-fista"],
+                    help="ablation: run the scarlet.lite loop (LiteBlend.fit semantics) on the "
+                         "same scenes instead of Blend.fit's")
     args = ap.parse_args()
 
     import torch
@@ -105,23 +108,40 @@ def main():
     nb = args.blends
     kern, scenes = build_scenes(nb, 1234 + rank * nb, device=local_rank)
 
-    comps = [
-        [ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k], sed_min_step=s["noise_rms"])
-         for k in range(len(s["morphs"]))]
-        for s in scenes
-    ]
+    lite = args.loop != "blend"
+    if lite:
+        # LiteFactorizedComponent defaults (lite/models.py:143-180, lite/initialization.py:250-318)
+        from scarlet_amd import _lib as slib
+
+        flags = (slib.PROX_MONOTONIC | slib.PROX_FIT_CENTER | slib.PROX_CENTER_ON | slib.PROX_NORM_MAX)
+        extra = (dict(fista_step=1.0 / (2 * 400.0)) if args.loop == "lite-fista" else {})
+        comps = [
+            [ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k], prox_flags=flags,
+                           sed_min_step=s["noise_rms"] / 10, center_floor=1e-20,
+                           bg_level=np.full(5, 0.25 * s["noise_rms"], np.float32), **extra)
+             for k in range(len(s["morphs"]))]
+            for s in scenes
+        ]
+    else:
+        comps = [
+            [ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k], sed_min_step=s["noise_rms"])
+             for k in range(len(s["morphs"]))]
+            for s in scenes
+        ]
     data = np.stack([s["data"] for s in scenes])
     weights = np.stack([s["weights"] for s in scenes])
     total_it = args.warmup + args.steps
     batch = BlendBatch(
         data, weights, comps, kernel=None if args.null_renderer else kern[2],
         max_iter=total_it + 1, fft_shape=args.fft, device=local_rank, conv_path=args.conv_path,
+        scheme="fista" if args.loop == "lite-fista" else "amsgrad", log_norm=not lite,
     )
+    prox_max_iter = 1 if lite else 10  # lite applies the proximal operator once
     stream = torch.cuda.Stream(device=local_rank)
     batch.set_stream(stream.cuda_stream)
 
     # warm-up iterations 0 .. W-1 (untimed), then K timed iterations of the same fit
-    batch.step(0, args.warmup, e_rel=e_rel, check_convergence=False)
+    batch.step(0, args.warmup, e_rel=e_rel, prox_max_iter=prox_max_iter, check_convergence=False)
     torch.cuda.synchronize()
     sdist.barrier()
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -129,7 +149,8 @@ def main():
     t0 = time.perf_counter()
     batch.enable_timing(True)  # HIP events around every phase, on the batch stream
     ev0.record(stream)
-    batch.step(args.warmup, args.steps, e_rel=e_rel, check_convergence=False)
+    batch.step(args.warmup, args.steps, e_rel=e_rel, prox_max_iter=prox_max_iter,
+               check_convergence=False)
     ev1.record(stream)
     torch.cuda.synchronize()
     sdist.barrier()
@@ -205,6 +226,7 @@ def main():
                             "per GPU, 10 ExtendedSource components (41x41) each, %s" % (
                                 nb, "NullRenderer ablation" if args.null_renderer
                                 else "ConvolutionRenderer FFT %dx%d" % batch.fft_shape),
+                "loop": args.loop,
                 "blends_per_gpu": nb,
                 "components_per_blend": 10,
                 "parallelism": "blend-sharded x%d, no data-path collective" % world,
@@ -212,7 +234,7 @@ def main():
             },
             "roofline": roofline,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and not lite:
             v, dt = cpu_baseline(scenes, args.cpu_blends, args.cpu_iters, e_rel)
             line["cpu_baseline"] = {
                 "value": round(v, 2),
