@@ -282,96 +282,77 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     // ---- A: render (blend.py:200-244) and forward row transforms ----------------
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int y0 = ch * 2 * kPairs;
-        // component-major scatter-add into the (zeroed) chunk: each box row is a
-        // contiguous run in memory, so the morphology loads are coalesced, and every
-        // pixel still accumulates its components in ascending order
-        for (int i = tid; i < kPairs * C::SX; i += kThreads) cv.Z[i] = make_float2(0.f, 0.f);
-        __syncthreads();
-        // Components in groups of kGroup.  Phase 1 issues every morphology load of the
-        // group (<= kPer pixels per thread and component) before any is consumed: one
-        // memory latency per group instead of one per component.  Phase 2 adds the
-        // components one after the other (read-modify-write in LDS, LDS-only barrier in
-        // between), so every pixel still sums its components in ascending order.
-        constexpr int kGroup = 12, kPer = 2;
+        // Pixel-owner render: wave `wv` owns kRows consecutive rows of the chunk, lane l
+        // the columns l, l + 64, ...; the pixels accumulate in registers, components in
+        // ascending order (the summation order of blend.py:30-46), and are written to the
+        // row-pair scratch once.  A component whose box misses the wave's rows is skipped
+        // with a wave-uniform test; box rows are contiguous in memory, so the loads of a
+        // wave are coalesced.  No zero fill, no read-modify-write in LDS, no barriers
+        // between components.
+        constexpr int kWaves = kThreads / 64;
+        constexpr int kRows = 2 * kPairs / kWaves;
+        constexpr int kXs = (C::SX + 63) / 64;
+        static_assert(2 * kPairs % kWaves == 0 && kRows % 2 == 0, "rows per wave");
+        const int wv = tid >> 6;
+        const int wr0 = y0 + wv * kRows;
+        float acc[kRows][kXs];
+#pragma unroll
+        for (int j = 0; j < kRows; ++j)
+#pragma unroll
+            for (int q = 0; q < kXs; ++q) acc[j][q] = 0.f;
         if (ch == 0) SMI_STAMP(6);
         for (int kb = cs; kb < ce; kb += 64) {
             int l_oy, l_ox, l_h, l_w, l_mo;
             float l_sed;
             lane_meta(kb, l_oy, l_ox, l_h, l_w, l_mo, l_sed);
             const int kend = min(ce, kb + 64);
-            for (int k0 = kb; k0 < kend; k0 += kGroup) {
-                float mv[kGroup][kPer];
-                int cell[kGroup][kPer];  // float index into Z, -1: nothing to add
-                unsigned big = 0;        // components with a tail beyond kPer * kThreads pixels
-                unsigned live = 0;       // components that touch this chunk at all
+            for (int k = kb; k < kend; ++k) {
+                const int kl = k - kb;
+                const int oy = __builtin_amdgcn_readlane(l_oy, kl);
+                const int hh = __builtin_amdgcn_readlane(l_h, kl);
+                const int r_lo = max(wr0, oy), r_hi = min(min(wr0 + kRows, H), oy + hh);
+                if (r_hi <= r_lo) continue;  // wave-uniform: the box misses these rows
+                const int ox = __builtin_amdgcn_readlane(l_ox, kl);
+                const int w = __builtin_amdgcn_readlane(l_w, kl);
+                const int x_lo = max(0, ox), x_hi = min(W, ox + w);
+                if (x_hi <= x_lo) continue;
+                const float sed =
+                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_sed), kl));
+                const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
+                float mv[kRows][kXs];
 #pragma unroll
-                for (int g = 0; g < kGroup; ++g) {
-                    const int kl = min(k0 + g, kend - 1) - kb;  // lane that holds component k
-                    const int oy = __builtin_amdgcn_readlane(l_oy, kl);
-                    const int ox = __builtin_amdgcn_readlane(l_ox, kl);
-                    const int w = __builtin_amdgcn_readlane(l_w, kl);
-                    const int hh = __builtin_amdgcn_readlane(l_h, kl);
-                    const int mo = __builtin_amdgcn_readlane(l_mo, kl);
-                    const int r_lo = max(y0, oy), r_hi = min(min(y0 + 2 * kPairs, H), oy + hh);
-                    const int x_lo = max(0, ox), ncols = min(W, ox + w) - x_lo;
-                    const int npx =
-                        (k0 + g < kend && r_hi > r_lo && ncols > 0) ? (r_hi - r_lo) * ncols : 0;
-                    if (npx > kPer * kThreads) big |= 1u << g;
-                    if (npx > 0) live |= 1u << g;
+                for (int j = 0; j < kRows; ++j) {
+                    const int rr = wr0 + j;
+                    const bool row_ok = rr >= r_lo && rr < r_hi;
 #pragma unroll
-                    for (int u = 0; u < kPer; ++u) {
-                        cell[g][u] = -1;
-                        mv[g][u] = 0.f;
-                    }
-                    if (npx <= 0) continue;  // block-uniform: box does not touch this chunk
-                    const float inv = 1.0f / (float)max(ncols, 1);
-                    const float *mbase = v.morph + mo;
-#pragma unroll
-                    for (int u = 0; u < kPer; ++u) {
-                        const int p = tid + u * kThreads;
-                        if (p < npx) {
-                            const int ry = (int)(((float)p + 0.5f) * inv);  // exact: p < 2^16
-                            const int rr = r_lo + ry, xx = x_lo + p - ry * ncols;
-                            mv[g][u] = mbase[(rr - oy) * w + (xx - ox)];
-                            cell[g][u] = 2 * (((rr - y0) >> 1) * C::SX + xx) + ((rr - y0) & 1);
-                        }
+                    for (int q = 0; q < kXs; ++q) {
+                        const int x = lane + 64 * q;
+                        const bool ok = row_ok && x >= x_lo && x < x_hi;
+                        mv[j][q] = ok ? mbase[(rr - oy) * w + (x - ox)] : 0.f;
                     }
                 }
-                float *zf = reinterpret_cast<float *>(cv.Z);
-                if (ch == 0) SMI_STAMP(7);
-                // phase 2 is kept to a dozen instructions per component: every wave of the
-                // block has to issue them before the barrier releases
 #pragma unroll
-                for (int g = 0; g < kGroup; ++g) {
-                    if (k0 + g >= kend) break;
-                    if (!(live & (1u << g))) continue;  // block-uniform
-                    const int kl = k0 + g - kb;
-                    const float sed = __int_as_float(
-                        __builtin_amdgcn_readlane(__float_as_int(l_sed), kl));
+                for (int j = 0; j < kRows; ++j) {
+                    const int rr = wr0 + j;
+                    const bool row_ok = rr >= r_lo && rr < r_hi;
 #pragma unroll
-                    for (int u = 0; u < kPer; ++u)
-                        if (cell[g][u] >= 0)
-                            zf[cell[g][u]] = fmaf(sed, mv[g][u], zf[cell[g][u]]);
-                    if (big & (1u << g)) {  // box with more than kPer * kThreads pixels here
-                        const int oy = __builtin_amdgcn_readlane(l_oy, kl);
-                        const int ox = __builtin_amdgcn_readlane(l_ox, kl);
-                        const int w = __builtin_amdgcn_readlane(l_w, kl);
-                        const int hh = __builtin_amdgcn_readlane(l_h, kl);
-                        const int r_lo = max(y0, oy), r_hi = min(min(y0 + 2 * kPairs, H), oy + hh);
-                        const int x_lo = max(0, ox), ncols = min(W, ox + w) - x_lo;
-                        const int npx = (r_hi - r_lo) * ncols;
-                        const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
-                        for (int p = tid + kPer * kThreads; p < npx; p += kThreads) {
-                            const int ry = p / ncols;
-                            const int rr = r_lo + ry, xx = x_lo + p - ry * ncols;
-                            float &slot = zref(cv.Z, C::SX, rr - y0, xx);
-                            slot = fmaf(sed, mbase[(rr - oy) * w + (xx - ox)], slot);
-                        }
+                    for (int q = 0; q < kXs; ++q) {
+                        const int x = lane + 64 * q;
+                        if (row_ok && x >= x_lo && x < x_hi)
+                            acc[j][q] = fmaf(sed, mv[j][q], acc[j][q]);
                     }
-                    lds_barrier();
                 }
             }
         }
+        if (ch == 0) SMI_STAMP(7);
+#pragma unroll
+        for (int j = 0; j < kRows; j += 2)
+#pragma unroll
+            for (int q = 0; q < kXs; ++q) {
+                const int x = lane + 64 * q;
+                if (x < C::SX)
+                    cv.Z[((wr0 - y0 + j) >> 1) * C::SX + x] = make_float2(acc[j][q], acc[j + 1][q]);
+            }
         __syncthreads();
         if (ch == 0) SMI_STAMP(8);
         cv.rows_forward(y0, W);
