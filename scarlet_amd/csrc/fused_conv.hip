@@ -17,6 +17,8 @@
 // so no transposition pass is ever needed; the kernel spectrum K^ is stored in the
 // same order.  Rows are transformed two at a time (row 2j + i row 2j+1) and
 // separated by Hermitian symmetry; zero padding is never stored for the columns.
+#include <type_traits>
+
 #include "common.h"
 #include "fft_regs.h"
 
@@ -291,8 +293,11 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         // between components.
         constexpr int kWaves = kThreads / 64;
         constexpr int kRows = 2 * kPairs / kWaves;
-        constexpr int kXs = (C::SX + 63) / 64;
         static_assert(2 * kPairs % kWaves == 0 && kRows % 2 == 0, "rows per wave");
+        auto render = [&](auto xs_tag) {
+        constexpr int kXs = decltype(xs_tag)::value;
+        // components whose loads are in flight together: 24 values per lane
+        constexpr int kAhead = 24 / (kRows * kXs) > 0 ? 24 / (kRows * kXs) : 1;
         const int wv = tid >> 6;
         const int wr0 = y0 + wv * kRows;
         float acc[kRows][kXs];
@@ -306,42 +311,61 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
             float l_sed;
             lane_meta(kb, l_oy, l_ox, l_h, l_w, l_mo, l_sed);
             const int kend = min(ce, kb + 64);
+            // components of this group whose box touches the wave's rows (wave-uniform)
+            unsigned long long rel = 0;
             for (int k = kb; k < kend; ++k) {
                 const int kl = k - kb;
                 const int oy = __builtin_amdgcn_readlane(l_oy, kl);
                 const int hh = __builtin_amdgcn_readlane(l_h, kl);
-                const int r_lo = max(wr0, oy), r_hi = min(min(wr0 + kRows, H), oy + hh);
-                if (r_hi <= r_lo) continue;  // wave-uniform: the box misses these rows
                 const int ox = __builtin_amdgcn_readlane(l_ox, kl);
                 const int w = __builtin_amdgcn_readlane(l_w, kl);
-                const int x_lo = max(0, ox), x_hi = min(W, ox + w);
-                if (x_hi <= x_lo) continue;
-                const float sed =
-                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_sed), kl));
-                const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
-                float mv[kRows][kXs];
+                const bool hit = min(min(wr0 + kRows, H), oy + hh) > max(wr0, oy) &&
+                                 min(W, ox + w) > max(0, ox);
+                if (hit) rel |= 1ull << kl;
+            }
+            // kAhead components per round: all of their loads are issued before the first
+            // is consumed (one memory latency per round), then they are added in order
+            while (rel) {
+                float mv[kAhead][kRows][kXs];
+                float sd[kAhead];
+                unsigned inside[kAhead];  // bit j * kXs + q: pixel (j, q) lies in the box
+                unsigned long long pend = rel;
 #pragma unroll
-                for (int j = 0; j < kRows; ++j) {
-                    const int rr = wr0 + j;
-                    const bool row_ok = rr >= r_lo && rr < r_hi;
+                for (int g = 0; g < kAhead; ++g) {
+                    const bool have = pend != 0;
+                    const int kl = have ? __builtin_ctzll(pend) : 0;
+                    pend &= pend - 1;
+                    const int oy = __builtin_amdgcn_readlane(l_oy, kl);
+                    const int hh = __builtin_amdgcn_readlane(l_h, kl);
+                    const int ox = __builtin_amdgcn_readlane(l_ox, kl);
+                    const int w = __builtin_amdgcn_readlane(l_w, kl);
+                    const int r_lo = max(wr0, oy), r_hi = min(min(wr0 + kRows, H), oy + hh);
+                    const int x_lo = max(0, ox), x_hi = min(W, ox + w);
+                    sd[g] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_sed), kl));
+                    const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
+                    inside[g] = 0;
 #pragma unroll
-                    for (int q = 0; q < kXs; ++q) {
-                        const int x = lane + 64 * q;
-                        const bool ok = row_ok && x >= x_lo && x < x_hi;
-                        mv[j][q] = ok ? mbase[(rr - oy) * w + (x - ox)] : 0.f;
+                    for (int j = 0; j < kRows; ++j) {
+                        const int rr = wr0 + j;
+                        const bool row_ok = have && rr >= r_lo && rr < r_hi;
+#pragma unroll
+                        for (int q = 0; q < kXs; ++q) {
+                            const int x = lane + 64 * q;
+                            const bool ok = row_ok && x >= x_lo && x < x_hi;
+                            mv[g][j][q] = ok ? mbase[(rr - oy) * w + (x - ox)] : 0.f;
+                            inside[g] |= ok ? 1u << (j * kXs + q) : 0u;
+                        }
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < kRows; ++j) {
-                    const int rr = wr0 + j;
-                    const bool row_ok = rr >= r_lo && rr < r_hi;
+                for (int g = 0; g < kAhead; ++g)
 #pragma unroll
-                    for (int q = 0; q < kXs; ++q) {
-                        const int x = lane + 64 * q;
-                        if (row_ok && x >= x_lo && x < x_hi)
-                            acc[j][q] = fmaf(sed, mv[j][q], acc[j][q]);
-                    }
-                }
+                    for (int j = 0; j < kRows; ++j)
+#pragma unroll
+                        for (int q = 0; q < kXs; ++q)
+                            if (inside[g] & (1u << (j * kXs + q)))  // pixels outside stay untouched
+                                acc[j][q] = fmaf(sd[g], mv[g][j][q], acc[j][q]);
+                rel = pend;
             }
         }
         if (ch == 0) SMI_STAMP(7);
@@ -353,6 +377,14 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                 if (x < C::SX)
                     cv.Z[((wr0 - y0 + j) >> 1) * C::SX + x] = make_float2(acc[j][q], acc[j + 1][q]);
             }
+        };
+        // columns beyond W are never read by the row transform (pass_stride prunes them)
+        if (W <= 64)
+            render(std::integral_constant<int, 1>{});
+        else if (W <= 128)
+            render(std::integral_constant<int, 2>{});
+        else
+            render(std::integral_constant<int, (C::SX + 63) / 64>{});
         __syncthreads();
         if (ch == 0) SMI_STAMP(8);
         cv.rows_forward(y0, W);
