@@ -293,6 +293,9 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
 /* Blocking.  n_active: blends still iterating; error: index of the first blend
  * whose parameters became non-finite, or -1. */
 int smi_batch_status(smi_batch *b, int32_t *n_active, int32_t *first_error);
+/* per-blend state: 0 iterating, 1 in its last iteration, 2 converged (stopping rule),
+ * 3 stopped with non-finite parameters (Model.check_parameters, model.py:153-165) */
+int smi_batch_get_states(smi_batch *b, int32_t *state /* [n_blends] */);
 
 /* Blend.fit for the whole batch: step() in chunks of `sync_every` iterations until
  * max_iter or until every blend has converged.  n_iter[n_blends] receives the

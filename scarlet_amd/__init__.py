@@ -41,7 +41,7 @@ from .component import (  # noqa: F401
     CubeComponent,
     CombinedComponent,
 )
-from .blend import Blend  # noqa: F401
+from .blend import Blend, fit_blends  # noqa: F401
 from .source import (  # noqa: F401
     ExtendedSource,
     SingleExtendedSource,

@@ -146,6 +146,7 @@ SYMBOLS = {
          ctypes.c_int32, ctypes.c_int32],
     ),
     "smi_batch_status": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
+    "smi_batch_get_states": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "smi_batch_fit": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_int32, ctypes.c_int32,

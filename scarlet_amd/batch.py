@@ -307,6 +307,12 @@ class BlendBatch:
         _lib.check(self._lib.smi_batch_status(self._h, ctypes.byref(a), ctypes.byref(e)))
         return a.value, e.value
 
+    def states(self):
+        """Per-blend state: 0 iterating, 1 last iteration, 2 converged, 3 non-finite."""
+        out = np.zeros(self.n_blends, dtype=np.int32)
+        _lib.check(self._lib.smi_batch_get_states(self._h, _lib.ptr(out, ctypes.c_int32)))
+        return out
+
     def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, prox_max_iter=10, sync_every=10):
         """Fit every blend; returns ``(n_iter, logL)`` arrays like the tuple
         ``Blend.fit`` returns (blend.py:194)."""

@@ -1245,6 +1245,14 @@ int smi_batch_status(smi_batch *b, int32_t *n_active, int32_t *first_error) {
     return SMI_OK;
 }
 
+int smi_batch_get_states(smi_batch *b, int32_t *state) {
+    SMI_REQUIRE(b && state, "null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipMemcpy(state, b->state, b->d.n_blends * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+
 int smi_batch_fit(smi_batch *b, int32_t max_iter, float e_rel, int32_t min_iter,
                   int32_t prox_max_iter, int32_t sync_every, int32_t *n_iter) {
     int rc = ready(b);

@@ -448,3 +448,37 @@ def test_lite_init_all_sources_main_matches_the_reference(hsc):
     it, loss = fitted.fit(30, e_rel=1e-4)
     assert loss > fitted.loss[0] and it <= 30
     assert all(src.flux.shape[0] == 5 for src in fitted.sources)
+
+
+def test_fit_blends_equals_individual_fits(hsc):
+    """fit_blends: several Blend objects in one device batch (regrouped after every
+    resize round) give exactly the per-blend results of Blend.fit"""
+    import scarlet_amd as scarlet
+
+    def make(k):
+        full, obs = build_blend(hsc, resizing=True)
+        # different scenes: drop a source and rescale the spectra
+        sources = list(full.sources)
+        blend = scarlet.Blend(sources[:len(sources) - k], obs)
+        for p in blend.parameters:
+            if p.name == "spectrum":
+                p *= 1 + 0.1 * k
+        return blend
+
+    single = [make(k) for k in range(3)]
+    want = [b.fit(35, e_rel=1e-5) for b in single]
+    many = [make(k) for k in range(3)]
+    got = scarlet.fit_blends(many, 35, e_rel=1e-5)
+    for a, b, r1, r2 in zip(single, many, want, got):
+        assert r1 == r2
+        assert_allclose(a.loss, b.loss, rtol=0, atol=0)
+        for p, q in zip(a.parameters, b.parameters):
+            assert p.shape == q.shape
+            assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
+            if p.m is not None:
+                assert_allclose(p.m, q.m, rtol=0, atol=0)
+    # different frame shapes end up in different batches
+    other, _ = build_blend(hsc, resizing=False)
+    small = make(0)
+    res = scarlet.fit_blends([other, small], 5, e_rel=1e-9)
+    assert res[0][0] == res[1][0] == 5
