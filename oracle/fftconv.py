@@ -257,6 +257,11 @@ class ShiftOperator:
         shifted one."""
         return self.Dr.T @ g @ self.Tx - self.Di.T @ g @ self.Hx
 
+    def derivative_images(self, x):
+        """(d/d sy, d/d sx) of ``forward(x)``."""
+        return (self.dDr @ x @ self.Tx.T - self.dDi @ x @ self.Hx.T,
+                self.Dr @ x @ self.dTx.T - self.Di @ x @ self.dHx.T)
+
     def shift_gradient(self, x, g):
         """(d/d sy, d/d sx) of ``sum(g * forward(x))``."""
         d_y = self.dDr @ x @ self.Tx.T - self.dDi @ x @ self.Hx.T

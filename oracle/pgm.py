@@ -230,7 +230,12 @@ def resize_component(c):
 
 
 class Scene:
-    def __init__(self, frame_shape, data, weights, kernel, components, dtype=np.float32):
+    def __init__(self, frame_shape, data, weights, kernel, components, dtype=np.float32,
+                 psf_shift=None):
+        # ConvolutionRenderer(psf_shift=...) (renderer.py:175-177, 215-228): a free
+        # sub-pixel shift of the difference kernel, step 1e-2, no constraint
+        self.psf_shift = None if psf_shift is None else np.array(psf_shift, dtype=np.float64)
+        self.m_psf, self.v_psf, self.vhat_psf = np.zeros(2), np.zeros(2), np.zeros(2)
         self.frame_shape = tuple(frame_shape)
         self.dtype = dtype
         self.data = data
@@ -297,12 +302,28 @@ class Scene:
         identical model and data footprints (renderer.py:86-94, 247-259)."""
         if self.kernel is None:
             return model
-        return fftconv.convolve(model, self.kernel, axes=(1, 2))
+        return fftconv.convolve(model, self.shifted_kernel(), axes=(1, 2))
+
+    def shifted_kernel(self):
+        """The difference kernel, Fourier-shifted by ``psf_shift`` and cropped back to
+        its stamp (renderer.py:220-228 -> fft.py:399-428)."""
+        if self.psf_shift is None:
+            return self.kernel
+        return fftconv.fourier_shift(self.kernel, self.psf_shift).astype(self.kernel.dtype)
 
     def render_adjoint(self, grad):
         if self.kernel is None:
             return grad
-        return fftconv.convolve_adjoint(grad, self.kernel, axes=(1, 2))
+        return fftconv.convolve_adjoint(grad, self.shifted_kernel(), axes=(1, 2))
+
+    def psf_shift_gradient(self, model, rendered):
+        """d(-logL)/d(psf_shift) = sum w (m - d) * (model (*) d kernel / d shift)."""
+        r = self.weights * (rendered - self.data)
+        op = fftconv.ShiftOperator(self.kernel.shape[1:], self.psf_shift)
+        dk = [np.stack([d[a] for d in (op.derivative_images(k.astype(np.float64))
+                                       for k in self.kernel)]) for a in range(2)]
+        return np.array([np.sum(r * fftconv.convolve(model, d.astype(self.kernel.dtype),
+                                                     axes=(1, 2))) for d in dk])
 
     @property
     def log_norm(self):
@@ -357,6 +378,8 @@ class Scene:
         loss = -self.log_likelihood(rendered)
         self.loss.append(loss)
         G = self.model_gradient(rendered)
+        if self.psf_shift is not None:
+            self.g_psf_shift = self.psf_shift_gradient(model, rendered)
         return loss, self.parameter_gradients(G)
 
     # -- optimizer -------------------------------------------------------
@@ -368,6 +391,9 @@ class Scene:
         # all steps are evaluated on the pre-update parameters (blend.py:135-138)
         alphas = [(c.sed_step(it), c.center_step if isinstance(c, PointComponent) else c.morph_step)
                   for c in self.components]
+        if self.psf_shift is not None:
+            # the renderer's parameter comes after the sources' in X (blend.py:103-105)
+            g_psf = self.g_psf_shift
         for c, (g_sed, g_morph, *g_shift), (a_sed, a_morph) in zip(self.components, grads, alphas):
             adaprox_update(
                 it, c.sed, g_sed, c.m_sed, c.v_sed, c.vhat_sed, a_sed, c.sed_prox,
@@ -389,6 +415,9 @@ class Scene:
                     it, c.shift, g_shift[0], c.m_shift, c.v_shift, c.vhat_shift, c.shift_step,
                     None, e_rel, prox_max_iter, b1, b2, eps,
                 )
+        if self.psf_shift is not None:
+            adaprox_update(it, self.psf_shift, g_psf, self.m_psf, self.v_psf, self.vhat_psf, 1e-2,
+                           None, e_rel, prox_max_iter, b1, b2, eps)
 
     def check_parameters(self):
         """``Model.check_parameters`` (model.py:153-165)."""

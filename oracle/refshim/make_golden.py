@@ -403,6 +403,54 @@ def lite(scarlet):
               [c.morph.shape[0] for c in comps])
 
 
+def hsc_psf_shift(scarlet):
+    """ConvolutionRenderer(psf_shift=...): the difference kernel moved by a free sub-pixel
+    shift (renderer.py:175-177, 215-228).  Quickstart scene (sources of hsc_cosmos_35):
+    rendered cube and logL at a non-zero shift, finite differences of the reference's
+    forward w.r.t. the shift."""
+    from scarlet.initialization import init_all_sources
+    from scarlet.renderer import ConvolutionRenderer
+
+    d = np.load("/root/reference/data/hsc_cosmos_35.npz")
+    images = d["images"]
+    filters = [str(f) for f in d["filters"]]
+    weights = 1 / d["variance"]
+    centers = [(s["y"], s["x"]) for s in d["catalog"]]
+    shift0 = np.array([0.21, -0.13])
+
+    def build(dtype, shift):
+        model_psf = scarlet.GaussianPSF(sigma=(0.8,) * len(filters))
+        frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters, dtype=dtype)
+        obs = scarlet.Observation(images, psf=scarlet.ImagePSF(d["psfs"]), weights=weights,
+                                  channels=filters)
+        obs.match(frame, renderer=ConvolutionRenderer(obs, frame, psf_shift=shift.copy()))
+        sources, _ = init_all_sources(frame, centers, obs, max_components=2, min_snr=50, thresh=1,
+                                      fallback=True, silent=True, set_spectra=True)
+        return obs, scarlet.Blend(sources, obs)
+
+    obs, blend = build(np.float32, shift0)
+    assert [p.name for p in obs.parameters] == ["psf_shift"] and obs.parameters[0].step == 1e-2
+    model = blend.get_model()
+    out = dict(psf_shift=shift0, model=model, rendered=obs.render(model),
+               logL=obs.get_log_likelihood(model))
+    obs64, blend64 = build(np.float64, shift0)
+    model64 = blend64.get_model()
+    eps = 1e-6
+    fd = []
+    for a in range(2):
+        vals = []
+        for sgn in (1, -1):
+            s = shift0.copy()
+            s[a] += sgn * eps
+            vals.append(obs64.get_log_likelihood(
+                model64, scarlet.Parameter(s, name="psf_shift", step=1e-2)))
+        fd.append((vals[0] - vals[1]) / (2 * eps))
+    out["fd_dlogL_dshift"] = np.array(fd)
+    out["model64"] = model64
+    np.savez_compressed(os.path.join(OUT, "hsc_psf_shift.npz"), **out)
+    print("hsc_psf_shift: logL=%.3f fd=%s" % (out["logL"], fd))
+
+
 def point_source(scarlet):
     """docs/tutorials/point_source.ipynb: psf_unmatched_sim scene, stars as
     PointSource, galaxies as ExtendedSource; state up to the first gradient."""
@@ -522,6 +570,7 @@ def main(which=None):
     jobs = dict(
         operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
         hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, hsc_shifting=hsc_shifting, lite=lite,
+        hsc_psf_shift=hsc_psf_shift,
         synthetic_cfg2=synthetic_cfg2,
     )
     for name, fn in jobs.items():

@@ -217,6 +217,7 @@ class BlendBatch:
                 self._h, _lib.ptr(data, ctypes.c_float), _lib.ptr(weights, ctypes.c_float)
             )
         )
+        self._kernel_shape = None if kernel is None else kernel.shape
         if kernel is not None:
             _lib.check(lib.smi_batch_set_kernel(self._h, _lib.ptr(kernel, ctypes.c_float)))
 
@@ -244,6 +245,12 @@ class BlendBatch:
         fy, fx = ctypes.c_int32(), ctypes.c_int32()
         _lib.check(self._lib.smi_batch_fft_shape(self._h, ctypes.byref(fy), ctypes.byref(fx)))
         return fy.value, fx.value
+
+    def set_kernel(self, kernel):
+        """Replace the difference kernel (same stamp shape as at construction)."""
+        kernel = _lib.f32(kernel)
+        assert kernel.shape == self._kernel_shape, "kernel shape is fixed at construction"
+        _lib.check(self._lib.smi_batch_set_kernel(self._h, _lib.ptr(kernel, ctypes.c_float)))
 
     def set_optimizer(self, b1=0.9, b2=0.999, eps=1e-8):
         """AMSGrad constants (``proxmin.adaprox`` keywords b1, b2, eps)."""

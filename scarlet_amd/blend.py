@@ -92,14 +92,14 @@ class Blend(CombinedComponent):
                     "renderer {} cannot run on the device".format(type(r).__name__))
             if tuple(obs.shape[1:]) != spatial:
                 raise NotImplementedError("observations must cover the model frame spatially")
-            if obs.parameters:
-                raise NotImplementedError("parameterised renderers are not supported")
+            if any(not p.fixed for p in obs.parameters):
+                raise NotImplementedError("free renderer parameters with several observations")
             idx = [channels.index(c) for c in obs.channels]
             covered[idx] += 1
             data[idx] = obs.data
             weights[idx] = obs.weights
             if isinstance(r, ConvolutionRenderer):
-                k = np.asarray(r.diff_kernel.image, dtype=np.float32)
+                k = np.asarray(r.kernel_image(), dtype=np.float32)
                 for j, c in enumerate(idx):
                     kernels[c] = k[j if k.shape[0] > 1 else 0]
         if np.any(covered != 1):
@@ -291,6 +291,9 @@ class Blend(CombinedComponent):
                    eps=alg_kwargs.pop("eps", 1e-8))
         if alg_kwargs:
             raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
+        free = [p for obs in self.observations for p in obs.parameters if not p.fixed]
+        if free:
+            return self._fit_with_psf_shift(max_iter, e_rel, min_iter, prox_max_iter, opt, callback)
 
         it = 0
         while it < max_iter:
@@ -347,6 +350,108 @@ class Blend(CombinedComponent):
         for p in self.parameters:
             if p.v is not None:
                 p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))  # rough estimate, blend.py:189-192
+        return len(self.loss), -self.loss[-1]
+
+    def _fit_with_psf_shift(self, max_iter, e_rel, min_iter, prox_max_iter, opt, callback):
+        """``ConvolutionRenderer(psf_shift=...)``: the difference kernel carries a free
+        sub-pixel shift (renderer.py:175-177, 215-228).  Host-stepped: per iteration the
+        device runs the usual step with the kernel at the current shift, and two extra
+        forward renders with the kernel's derivatives give
+        ``d(-logL)/d(shift) = sum w (m - d) (model (*) dK/ds)``; the shift then takes its
+        unconstrained AMSGrad step (step 1e-2) on the host."""
+        if len(self.observations) != 1:
+            raise NotImplementedError("psf_shift with several observations")
+        obs = self.observations[0]
+        renderer = obs.renderer
+        shift = renderer.get_parameter("psf_shift")
+        if [id(p) for p in obs.parameters] != [id(shift)] or type(renderer) is not ConvolutionRenderer:
+            raise NotImplementedError("only ConvolutionRenderer(psf_shift=...) has free parameters")
+        if tuple(obs.shape) != tuple(self.frame.shape) or list(obs.channels) != list(self.frame.channels):
+            raise NotImplementedError("psf_shift needs an observation on the model frame")
+        if shift.prior is not None or shift.constraint is not None:
+            raise NotImplementedError("priors / constraints on psf_shift")
+        alpha, rel, _ = _step_rule(shift.step, "psf_shift")
+        if rel:
+            raise NotImplementedError("relative steps for psf_shift")
+        C = self.frame.C
+        data = np.ascontiguousarray(obs.data, dtype=np.float32)
+        weights = np.ascontiguousarray(obs.weights, dtype=np.float32)
+
+        def stamp(k):  # (Ck, p, q) -> (C, odd p, odd q), centres aligned
+            k = np.asarray(k, dtype=np.float32)
+            ph, pw = k.shape[1] | 1, k.shape[2] | 1
+            out = np.zeros((C, ph, pw), dtype=np.float32)
+            oy, ox = ph // 2 - k.shape[1] // 2, pw // 2 - k.shape[2] // 2
+            out[:, oy:oy + k.shape[1], ox:ox + k.shape[2]] = k
+            return out
+
+        for name in ("m", "v", "vhat"):
+            if getattr(shift, name) is None:
+                setattr(shift, name, np.zeros(2))
+        b1, b2, eps = opt["b1"], opt["b2"], opt["eps"]
+        it = 0
+        while it < max_iter:
+            comps = _flatten(self.sources)
+            batch = BlendBatch(data[None], weights[None], [self._specs(comps)],
+                               kernel=stamp(renderer.kernel_image()), max_iter=max(max_iter - it, 1))
+            self._upload_state(batch, comps)
+            batch.set_optimizer(**opt)
+            restart = False
+            try:
+                local = 0
+                while it + local < max_iter and not restart:
+                    # gradient w.r.t. the shift at the parameters of this iteration
+                    _, rendered, _ = batch.forward(model=False)
+                    resid = weights.astype(np.float64) * (rendered[0] - data)
+                    g = np.zeros(2)
+                    for a, dk in enumerate(renderer.kernel_derivatives()):
+                        batch.set_kernel(stamp(dk))
+                        g[a] = np.sum(resid * batch.forward(model=False)[1][0])
+                    batch.set_kernel(stamp(renderer.kernel_image()))
+                    batch.step(local, 1, e_rel=e_rel, min_iter=min_iter,
+                               prox_max_iter=prox_max_iter, check_convergence=True)
+                    # AMSGrad without constraint (lite/parameters.py:274-291)
+                    shift.m = (1 - b1) * g + b1 * shift.m
+                    shift.v = (1 - b2) * g * g + b2 * shift.v
+                    shift.vhat = shift.v.copy() if local == 0 else np.maximum(shift.vhat, shift.v)
+                    upd = alpha * shift.m / np.sqrt(np.maximum(shift.vhat, eps))
+                    shift[...] = np.asarray(shift) - (upd / 10 if local == 0 else upd)
+                    batch.set_kernel(stamp(renderer.kernel_image()))
+                    active, err = batch.status()
+                    done = len(batch.loss_history()[0])
+                    if err >= 0 or not np.all(np.isfinite(np.asarray(shift))):
+                        self.loss.extend(batch.loss_history()[0])
+                        self._download(batch, comps)
+                        raise ArithmeticError("parameters of the blend are not finite")
+                    hook = done == local + 1 and done > 1 and (done - 1) % 10 == 0
+                    local = done
+                    if hook:
+                        self._download(batch, comps)
+                        for src in self.sources:
+                            try:
+                                src.update()
+                            except UpdateException:
+                                restart = True
+                    if active == 0 and not restart:
+                        break
+                    if callback is not None and not restart:
+                        if not hook:
+                            self._download(batch, comps)
+                        try:
+                            callback(*self.parameters, shift, it=local - 1)
+                        except StopIteration:
+                            break
+                self.loss.extend(batch.loss_history()[0])
+                if not restart:
+                    self._download(batch, comps)
+            finally:
+                batch.close()
+            if not restart:
+                break
+            it = len(self.loss)
+        for p in self.parameters + (shift,):
+            if p.v is not None:
+                p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
         return len(self.loss), -self.loss[-1]
 
     # ------------------------------------------------------------------- model

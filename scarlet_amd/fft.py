@@ -209,3 +209,27 @@ def shift(image, shift, fft_shape=None, axes=(-2, -1), return_Fourier=True):
         ramp = np.expand_dims(ramp, axis=lead)
     out = Fourier.from_fft(spectrum * ramp, fft_shape, image.shape, axes)
     return out if return_Fourier else np.real(out.image)
+
+
+def shift_derivatives(image, shift, fft_shape=None, axes=(-2, -1)):
+    """``(d/d shift[0], d/d shift[1])`` of ``shift(image, shift, return_Fourier=False)``:
+    the same pipeline with the spectrum multiplied by the ramp of the differentiated axis
+    (what autograd makes of fft.py:399-428)."""
+    if fft_shape is None:
+        fft_shape = _get_fft_shape(image, image, padding=10, axes=axes)
+    ramp_y, ramp_x = mk_shifter(fft_shape)
+    image = _as_fourier(image)
+    spectrum = image.fft(fft_shape, axes)
+    nd = len(image.shape)
+    lead = tuple(d for d in range(nd) if d not in axes and d - nd not in axes)
+
+    def expand(a):
+        return np.expand_dims(a, axis=lead) if nd > 2 else a
+
+    ramp = expand(np.exp(ramp_y[:, None] * shift[0]) * np.exp(ramp_x[None, :] * shift[1]))
+    out = []
+    for factor in (expand(ramp_y[:, None] * np.ones_like(ramp_x)[None, :]),
+                   expand(np.ones_like(ramp_y)[:, None] * ramp_x[None, :])):
+        out.append(np.real(Fourier.from_fft(spectrum * ramp * factor, fft_shape, image.shape,
+                                            axes).image))
+    return out

@@ -9,7 +9,7 @@ from .frame import Frame
 from .renderer import ConvolutionRenderer, NullRenderer, Renderer
 
 
-def _device_render(renderer, model):
+def _device_render(renderer, model, kernel=None):
     """``model`` (C, H, W) convolved with the renderer's difference kernel on
     the GPU: the cube is presented to the batch as C unit-spectrum components."""
     from .batch import BlendBatch, ComponentSpec
@@ -19,7 +19,8 @@ def _device_render(renderer, model):
     eye = np.eye(C, dtype=np.float32)
     comps = [ComponentSpec(eye[c], model_[c], (0, 0), prox_flags=0) for c in range(C)]
     zeros = np.zeros((1, C, H, W), dtype=np.float32)
-    kernel = np.ascontiguousarray(renderer.diff_kernel.image, dtype=np.float32)
+    kernel = np.ascontiguousarray(
+        renderer.diff_kernel.image if kernel is None else kernel, dtype=np.float32)
     batch = BlendBatch(zeros, zeros + 1, [comps], kernel=kernel, max_iter=1)
     try:
         _, rendered, _ = batch.forward(model=False)

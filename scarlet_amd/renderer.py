@@ -7,6 +7,7 @@ import numpy as np
 from . import fft
 from .bbox import Box, overlapped_slices
 from .model import Model
+from .parameter import Parameter
 
 
 class Renderer(Model):
@@ -54,7 +55,9 @@ class ConvolutionRenderer(Renderer):
     def __init__(self, data_frame, model_frame, *parameters, convolution_type="fft",
                  padding=10, psf_shift=None):
         if psf_shift is not None:
-            raise NotImplementedError("psf_shift parameters are not supported yet")
+            # free sub-pixel shift of the difference kernel (renderer.py:175-177)
+            psf_shift = Parameter(psf_shift, name="psf_shift", step=1.0e-2)
+            parameters = (*parameters, psf_shift)
         super().__init__(data_frame, model_frame, *parameters)
         assert convolution_type in ["real", "fft"], "`convolution` must be either 'real' or 'fft'"
         self._convolution_type = convolution_type
@@ -73,11 +76,26 @@ class ConvolutionRenderer(Renderer):
             padding=padding,
         )
 
+    def kernel_image(self, *parameters):
+        """The difference kernel, moved by ``psf_shift`` if the renderer has one
+        (renderer.py:215-228): Fourier shift of the stamp, cropped back to the stamp."""
+        shift = self.get_parameter("psf_shift", *parameters)
+        image = self.diff_kernel.image
+        if shift is None:
+            return image
+        return fft.shift(image, shift, return_Fourier=False).astype(image.dtype)
+
+    def kernel_derivatives(self, *parameters):
+        """d kernel_image / d psf_shift[0], [1]."""
+        shift = self.get_parameter("psf_shift", *parameters)
+        return [d.astype(self.diff_kernel.image.dtype)
+                for d in fft.shift_derivatives(self.diff_kernel.image, shift)]
+
     def get_model(self, *parameters):
         def transform(model, *parameters):
             from .observation import _device_render
 
-            return _device_render(self, model)
+            return _device_render(self, model, self.kernel_image(*parameters))
 
         return transform
 

@@ -482,3 +482,52 @@ def test_fit_blends_equals_individual_fits(hsc):
     small = make(0)
     res = scarlet.fit_blends([other, small], 5, e_rel=1e-9)
     assert res[0][0] == res[1][0] == 5
+
+
+def test_psf_shift_renderer(hsc):
+    """ConvolutionRenderer(psf_shift=...): rendering with the shifted kernel equals the
+    reference's (golden), and the host-stepped fit (shift = free parameter of the
+    observation) follows the oracle"""
+    import scarlet_amd as scarlet
+    from scarlet_amd.renderer import ConvolutionRenderer
+    from conftest import golden
+
+    gp = golden("hsc_psf_shift")
+    filters = list("grizy")
+    frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5),
+                          channels=filters)
+    obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                              weights=hsc["weights"], channels=filters)
+    obs.match(frame, renderer=ConvolutionRenderer(obs, frame, psf_shift=gp["psf_shift"].copy()))
+    assert [p.name for p in obs.parameters] == ["psf_shift"]
+    rendered = obs.render(gp["model"])
+    assert np.abs(rendered - gp["rendered"]).max() < 1e-5 * np.abs(gp["rendered"]).max()
+    assert_allclose(obs.get_log_likelihood(gp["model"]), float(gp["logL"]), rtol=1e-6)
+
+    comps = []
+    for k in range(int(hsc["n_comp"])):
+        h, w = hsc["morph_%d" % k].shape
+        oy, ox = hsc["origin_%d" % k]
+        box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+        comps.append(scarlet.FactorizedComponent(
+            frame,
+            scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                      min_step=hsc["min_step_%d" % k]),
+            scarlet.ExtendedSourceMorphology(frame, (oy + h // 2, ox + w // 2),
+                                             hsc["morph_%d" % k].copy(), bbox=box[1:],
+                                             resizing=False)))
+    blend = scarlet.Blend(comps, obs)
+    n, logL = blend.fit(12, e_rel=1e-9)
+    sc = hsc_scene(hsc)
+    for c in sc.components:
+        c.source = None
+    sc.psf_shift = gp["psf_shift"].copy()
+    n_ref, logL_ref = sc.fit(12, e_rel=1e-9)
+    assert n == n_ref == 12
+    chi = np.array(blend.loss) - sc.log_norm
+    chi_ref = np.array(sc.loss) - sc.log_norm
+    assert_allclose(chi, chi_ref, rtol=5e-4)
+    shift = obs.parameters[0]
+    assert np.abs(np.asarray(shift) - sc.psf_shift).max() < 1e-4
+    assert np.abs(np.asarray(shift) - gp["psf_shift"]).max() > 1e-3  # it moved
+    assert shift.m is not None and shift.std.shape == (2,)

@@ -324,6 +324,22 @@ def test_lite_fit_matches_the_reference_run(hsc, kind):
         assert_array_equal(c.morph, g["b_morph_%d" % k])
 
 
+def test_psf_shift_golden(hsc):
+    """ConvolutionRenderer(psf_shift=...) run by the reference: rendered cube and logL at
+    a non-zero kernel shift, and the gradient w.r.t. the shift against finite differences
+    of the reference's forward"""
+    gp = golden("hsc_psf_shift")
+    sc = hsc_scene(hsc)
+    sc.psf_shift = gp["psf_shift"].copy()
+    rendered = sc.render(gp["model"])
+    assert_allclose(rendered, gp["rendered"], rtol=0, atol=1e-5 * np.abs(gp["rendered"]).max())
+    assert_allclose(sc.log_likelihood(rendered), gp["logL"], rtol=1e-6)
+    sc64 = hsc_scene(hsc, dtype64=True)
+    sc64.psf_shift = gp["psf_shift"].copy()
+    g = sc64.psf_shift_gradient(gp["model64"], sc64.render(gp["model64"]))
+    assert_allclose(-g, gp["fd_dlogL_dshift"], rtol=1e-6)
+
+
 def test_synthetic_cfg2_golden():
     from scarlet_amd import synthetic
 
