@@ -3,6 +3,8 @@ that include/scarlet_amd.h declares; the ctypes table covers the same set."""
 
 import ctypes
 import os
+
+import pytest
 import re
 
 from conftest import ROOT
@@ -63,3 +65,24 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "oracle/" not in text or f.endswith(".md"), f
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/scarlet_amd.h is a C header (extern "C" ABI, no C++ or torch types): a C99
+    translation unit including it compiles with -pedantic and links against the library"""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text(
+        '#include "scarlet_amd.h"\n'
+        "int main(void) {\n"
+        "    smi_batch_desc d; smi_components c; (void)d; (void)c;\n"
+        "    return smi_version() == 0;\n"
+        "}\n")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                           "-I", os.path.join(root, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "t.o")])
