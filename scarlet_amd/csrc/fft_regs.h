@@ -58,28 +58,52 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// Complex numbers are two-element vectors so that the compiler emits the packed f32
+// instructions of CDNA3/4 (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32: one instruction per
+// complex add, two per multiplication by a constant): the FFT passes are VALU-issue
+// bound.  Swapping the halves of an operand is free (op_sel), so a rotation by +-i is
+// folded into the addition that consumes it (`add_rot` / `sub_rot`) instead of being
+// materialised.
+typedef float cf __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cf ld(const float2 &a) { return cf{a.x, a.y}; }
+__device__ __forceinline__ float2 st(cf a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ cf swp(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cf fma2(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+// a * b = a.xx * b + a.yy * (-b.y, b.x)
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    return fma2(a.yy * cf{-1.f, 1.f}, swp(b), a.xx * b);
 }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+// a * conj(b) = a.xx * (b.x, -b.y) + a.yy * (b.y, b.x)
+__device__ __forceinline__ cf cmulc(cf a, cf b) {
+    return fma2(a.yy, swp(b), (a.xx * cf{1.f, -1.f}) * b);
 }
-// multiply by -i (forward) or +i (inverse)
+// b + w d and b - w d with w = -i (forward) or +i (inverse), scaled by s:
+// -i d = (d.y, -d.x), +i d = (-d.y, d.x)
 template <bool INV>
-__device__ __forceinline__ float2 rot90(float2 a) {
-    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+__device__ __forceinline__ cf add_rot(cf b, cf d, float s = 1.f) {
+    return fma2(swp(d), INV ? cf{-s, s} : cf{s, -s}, b);
+}
+template <bool INV>
+__device__ __forceinline__ cf sub_rot(cf b, cf d, float s = 1.f) {
+    return fma2(swp(d), INV ? cf{s, -s} : cf{-s, s}, b);
 }
 // a * exp(-/+ 2 pi i k / R) with the twiddle as immediate constants
 template <int K, int R, bool INV>
-__device__ __forceinline__ float2 twiddle(float2 a) {
+__device__ __forceinline__ cf twiddle(cf a) {
     constexpr float c = tw_re(K, R);
     constexpr float s = INV ? -tw_im(K, R) : tw_im(K, R);
     if constexpr (((K % R) + R) % R == 0) {
         return a;
+    } else if constexpr (c == 0.f) {
+        return swp(a) * cf{-s, s};  // (-a.y s, a.x s)
+    } else if constexpr (s == 0.f) {
+        return a * c;
     } else {
-        return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
+        return fma2(a.yy, cf{-s, c}, a.xx * cf{c, s});
     }
 }
 
@@ -88,69 +112,69 @@ struct Dft;
 
 template <bool INV>
 struct Dft<2, INV> {
-    static __device__ __forceinline__ void run(float2 *v) {
-        const float2 a = v[0], b = v[1];
-        v[0] = cadd(a, b);
-        v[1] = csub(a, b);
+    static __device__ __forceinline__ void run(cf *v) {
+        const cf a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
     }
 };
 
 template <bool INV>
 struct Dft<3, INV> {
-    static __device__ __forceinline__ void run(float2 *v) {
+    static __device__ __forceinline__ void run(cf *v) {
         constexpr float s = 0.86602540378443864676f;  // sin(pi/3)
-        const float2 t = cadd(v[1], v[2]);
-        const float2 d = rot90<INV>(csub(v[1], v[2]));  // -/+ i (v1 - v2)
-        const float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
-        v[0] = cadd(v[0], t);
-        v[1] = make_float2(m.x + s * d.x, m.y + s * d.y);
-        v[2] = make_float2(m.x - s * d.x, m.y - s * d.y);
+        const cf t = v[1] + v[2];
+        const cf d = v[1] - v[2];
+        const cf m = fma2(t, cf{-0.5f, -0.5f}, v[0]);
+        v[0] = v[0] + t;
+        v[1] = add_rot<INV>(m, d, s);  // m -/+ i s (v1 - v2)
+        v[2] = sub_rot<INV>(m, d, s);
     }
 };
 
 template <bool INV>
 struct Dft<4, INV> {
-    static __device__ __forceinline__ void run(float2 *v) {
-        const float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
-        const float2 c = cadd(v[1], v[3]), d = rot90<INV>(csub(v[1], v[3]));
-        v[0] = cadd(a, c);
-        v[1] = cadd(b, d);
-        v[2] = csub(a, c);
-        v[3] = csub(b, d);
+    static __device__ __forceinline__ void run(cf *v) {
+        const cf a = v[0] + v[2], b = v[0] - v[2];
+        const cf c = v[1] + v[3], d = v[1] - v[3];
+        v[0] = a + c;
+        v[1] = add_rot<INV>(b, d);
+        v[2] = a - c;
+        v[3] = sub_rot<INV>(b, d);
     }
 };
 
 template <bool INV>
 struct Dft<5, INV> {
-    static __device__ __forceinline__ void run(float2 *v) {
+    static __device__ __forceinline__ void run(cf *v) {
         constexpr float c1 = 0.30901699437494742410f;   // cos(2pi/5)
         constexpr float c2 = -0.80901699437494742410f;  // cos(4pi/5)
         constexpr float s1 = 0.95105651629515357212f;   // sin(2pi/5)
         constexpr float s2 = 0.58778525229247312917f;   // sin(4pi/5)
-        const float2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]);
-        const float2 a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
-        const float2 m1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
-        const float2 m2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+        const cf a1 = v[1] + v[4], b1 = v[1] - v[4];
+        const cf a2 = v[2] + v[3], b2 = v[2] - v[3];
+        const cf m1 = fma2(a2, cf{c2, c2}, fma2(a1, cf{c1, c1}, v[0]));
+        const cf m2 = fma2(a2, cf{c1, c1}, fma2(a1, cf{c2, c2}, v[0]));
         // forward: X1 = m1 - i (s1 b1 + s2 b2), X2 = m2 - i (s2 b1 - s1 b2)
-        const float2 n1 = rot90<INV>(make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y));
-        const float2 n2 = rot90<INV>(make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y));
-        v[0] = cadd(v[0], cadd(a1, a2));
-        v[1] = cadd(m1, n1);
-        v[4] = csub(m1, n1);
-        v[2] = cadd(m2, n2);
-        v[3] = csub(m2, n2);
+        const cf q1 = fma2(b2, cf{s2, s2}, b1 * s1);
+        const cf q2 = fma2(b2, cf{-s1, -s1}, b1 * s2);
+        v[0] = v[0] + (a1 + a2);
+        v[1] = add_rot<INV>(m1, q1);
+        v[4] = sub_rot<INV>(m1, q1);
+        v[2] = add_rot<INV>(m2, q2);
+        v[3] = sub_rot<INV>(m2, q2);
     }
 };
 
 // R = RA * RB in registers: n = RB n1 + n2, k = k1 + RA k2
 template <int RA, int RB, bool INV>
 struct DftComposite {
-    static __device__ __forceinline__ void run(float2 *v) {
+    static __device__ __forceinline__ void run(cf *v) {
         constexpr int R = RA * RB;
-        float2 t[RA * RB];  // t[k1 * RB + n2]
+        cf t[RA * RB];  // t[k1 * RB + n2]
         static_for<0, RB>([&](auto n2c) {
             constexpr int n2 = decltype(n2c)::value;
-            float2 c[RA];
+            cf c[RA];
             static_for<0, RA>([&](auto n1c) {
                 constexpr int n1 = decltype(n1c)::value;
                 c[n1] = v[RB * n1 + n2];
@@ -163,7 +187,7 @@ struct DftComposite {
         });
         static_for<0, RA>([&](auto k1c) {
             constexpr int k1 = decltype(k1c)::value;
-            float2 c[RB];
+            cf c[RB];
             static_for<0, RB>([&](auto n2c) {
                 constexpr int n2 = decltype(n2c)::value;
                 c[n2] = t[k1 * RB + n2];

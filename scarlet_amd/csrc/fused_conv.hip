@@ -24,10 +24,11 @@
 
 namespace smi {
 
-using fftk::cadd;
+using fftk::cf;
 using fftk::cmul;
 using fftk::cmulc;
-using fftk::csub;
+using fftk::ld;
+using fftk::st;
 
 namespace {
 
@@ -55,30 +56,30 @@ struct Cfg {
 // work items, so the radix-16 pass stays short), then inverse DFT_F1.
 template <int F1, bool INV>
 __device__ __forceinline__ void pass_stride(float2 *a, int n2, const float2 *tw, int valid) {
-    float2 v[F1];
+    cf v[F1];
 #pragma unroll
     for (int n1 = 0; n1 < F1; ++n1) {
         const int idx = kF2 * n1 + n2;
-        v[n1] = (INV || idx < valid) ? a[idx] : make_float2(0.f, 0.f);
-        if (INV && n1 > 0) v[n1] = cmulc(v[n1], tw[kF2 * n1 + n2]);
+        v[n1] = (INV || idx < valid) ? ld(a[idx]) : cf{0.f, 0.f};
+        if (INV && n1 > 0) v[n1] = cmulc(v[n1], ld(tw[kF2 * n1 + n2]));
     }
     fftk::Dft<F1, INV>::run(v);
 #pragma unroll
     for (int k1 = 0; k1 < F1; ++k1) {
-        if (!INV && k1 > 0) v[k1] = cmul(v[k1], tw[kF2 * k1 + n2]);
-        a[kF2 * k1 + n2] = v[k1];
+        if (!INV && k1 > 0) v[k1] = cmul(v[k1], ld(tw[kF2 * k1 + n2]));
+        a[kF2 * k1 + n2] = st(v[k1]);
     }
 }
 
 // ---- radix-16 pass over the contiguous block a[16 k1 .. 16 k1 + 15] ---------------
 template <bool INV>
 __device__ __forceinline__ void pass_block(float2 *a, int k1) {
-    float2 v[kF2];
+    cf v[kF2];
 #pragma unroll
-    for (int j = 0; j < kF2; ++j) v[j] = a[kF2 * k1 + j];
+    for (int j = 0; j < kF2; ++j) v[j] = ld(a[kF2 * k1 + j]);
     fftk::Dft<kF2, INV>::run(v);
 #pragma unroll
-    for (int j = 0; j < kF2; ++j) a[kF2 * k1 + j] = v[j];
+    for (int j = 0; j < kF2; ++j) a[kF2 * k1 + j] = st(v[j]);
 }
 
 // position of natural frequency k in the digit-swapped order of a length F1*16 transform
@@ -123,17 +124,17 @@ struct Conv {
         for (int kx = kx0, k1 = q0; k1 < FY1;) {
             float2 *a = T + kx * C::SY + kF2 * k1;
             const float2 *kp = Kt + (int64_t)(kF2 * k1) * C::NKX + kx;
-            float2 v[kF2], kv[kF2];
+            cf v[kF2], kv[kF2];
 #pragma unroll
-            for (int j = 0; j < kF2; ++j) kv[j] = kp[j * C::NKX];
+            for (int j = 0; j < kF2; ++j) kv[j] = ld(kp[j * C::NKX]);
 #pragma unroll
-            for (int j = 0; j < kF2; ++j) v[j] = a[j];
+            for (int j = 0; j < kF2; ++j) v[j] = ld(a[j]);
             fftk::Dft<kF2, false>::run(v);
 #pragma unroll
             for (int j = 0; j < kF2; ++j) v[j] = conj ? cmulc(v[j], kv[j]) : cmul(v[j], kv[j]);
             fftk::Dft<kF2, true>::run(v);
 #pragma unroll
-            for (int j = 0; j < kF2; ++j) a[j] = v[j];
+            for (int j = 0; j < kF2; ++j) a[j] = st(v[j]);
             kx += dr;
             k1 += dq;
             if (kx >= C::NKX) {
