@@ -638,6 +638,17 @@ def _lib_flags():
     return _lib.PROX_POSITIVE | _lib.PROX_NORM_MAX
 
 
+def test_more_than_64_components_in_one_blend(amd):
+    """the render stage of the fused kernel walks the components of a blend in groups of
+    64 (one component per lane of metadata): 70 small overlapping boxes"""
+    rng = np.random.default_rng(41)
+    boxes = [((9 + 2 * (k % 3), 9 + 2 * (k % 4)), (int(rng.integers(-3, 50)), int(rng.integers(-3, 60))))
+             for k in range(70)]
+    specs, kernel, data, weights = _random_scene(rng, 2, 56, 66, boxes, kernel_shape=11)
+    for path in PATHS:
+        _compare_steps(amd, specs, kernel, data, weights, 2, {}, {}, conv_path=path)
+
+
 def test_boxes_beyond_the_lds(amd):
     """121^2 box (what lite's detection-image initialisation produces on small frames):
     the generic update kernel keeps x / psi / z in a global scratch area, the swept
