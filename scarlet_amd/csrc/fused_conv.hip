@@ -97,6 +97,11 @@ __device__ __forceinline__ double block_sum(double v, double *part) {
     return t;
 }
 
+// workgroup barrier that orders LDS traffic only (no vector-memory drain)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int FY1, int FX1>
 struct Conv {
     using C = Cfg<FY1, FX1>;
@@ -120,7 +125,7 @@ struct Conv {
                 ++n2;
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int kx = kx0, k1 = q0; k1 < FY1;) {
             float2 *a = T + kx * C::SY + kF2 * k1;
             const float2 *kp = Kt + (int64_t)(kF2 * k1) * C::NKX + kx;
@@ -142,7 +147,7 @@ struct Conv {
                 ++k1;
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int kx = kx0, n2 = q0; n2 < kF2;) {
             pass_stride<FY1, true>(T + kx * C::SY, n2, twy, C::FY);
             kx += dr;
@@ -152,7 +157,7 @@ struct Conv {
                 ++n2;
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // forward row transforms of the chunk in Z (pairs of real rows as re/im) and
@@ -160,10 +165,10 @@ struct Conv {
     __device__ __forceinline__ void rows_forward(int y0, int W) {
         for (int b = tid; b < kPairs * kF2; b += kThreads)
             pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
-        __syncthreads();
+        lds_barrier();
         for (int b = tid; b < kPairs * FX1; b += kThreads)
             pass_block<false>(Z + (b % kPairs) * C::SX, b / kPairs);
-        __syncthreads();
+        lds_barrier();
         for (int b = tid; b < C::NKX * kPairs; b += kThreads) {
             const int j = b % kPairs, kx = b / kPairs;
             const int y = y0 + 2 * j;
@@ -178,7 +183,7 @@ struct Conv {
                 t[1] = make_float2(za.y + zb.y, zb.x - za.x);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
@@ -198,20 +203,16 @@ struct Conv {
             if (kx != 0 && 2 * kx != C::FX)                          // conj(Xa) + i conj(Xb)
                 z[pp >> 16] = make_float2(xa.x + xb.y, xb.x - xa.y);
         }
-        __syncthreads();
+        lds_barrier();
         for (int b = tid; b < kPairs * FX1; b += kThreads)
             pass_block<true>(Z + (b % kPairs) * C::SX, b / kPairs);
-        __syncthreads();
+        lds_barrier();
         for (int b = tid; b < kPairs * kF2; b += kThreads)
             pass_stride<FX1, true>(Z + (b % kPairs) * C::SX, b / kPairs, twx, C::FX);
-        __syncthreads();
+        lds_barrier();
     }
 };
 
-// workgroup barrier that orders LDS traffic only (no vector-memory drain)
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // element (row r of the chunk, column x) of the pair-packed scratch
 __device__ __forceinline__ float &zref(float2 *Z, int SX, int r, int x) {
