@@ -9,8 +9,9 @@
 // only HBM traffic left is data + weights (read once), the morphologies (L2) and the
 // gradient image (written once).
 //
-// Layout: T[kx][y], kx in [0, FX/2], column stride SY = FY + 1 complex (odd, so that
-// 32 lanes working on 32 different columns hit 32 different 8-byte bank pairs).
+// Layout: T[kx][y], kx in [0, FX/2]; element y of a column sits at y + y / 16 and the
+// column stride SY is 16 mod 32 complex, so that the 16 lanes that own a column and the
+// four columns of a wavefront hit different banks in every pass.
 // 1-D transforms of length F = F1 * 16 are two in-place passes (radix F1 over stride
 // 16, radix 16 over contiguous blocks); the forward transform leaves the spectrum in
 // the digit-swapped order pos(k1 + F1 k2) = 16 k1 + k2, the inverse starts from it,
@@ -40,10 +41,15 @@ template <int FY1, int FX1>
 struct Cfg {
     static constexpr int FY = FY1 * kF2, FX = FX1 * kF2;
     static constexpr int NKX = FX / 2 + 1;
-    static constexpr int SY = FY + 1;  // column stride of T (complex), odd
+    // column stride of T (complex).  A column stores element y at y + y / 16 (one pad
+    // per radix-16 block, so that the 10 lanes that each own a block hit different
+    // banks); the stride is 16 mod 32 so that the four columns a wavefront works on
+    // alternate between the two halves of the 64 banks
+    static constexpr int SY = ((FY + FY / kF2 + 15) / 32) * 32 + 16;
     static constexpr int SX = FX + 1;  // row-pair stride of the scratch (complex), odd
     // + twiddle tables tw[k1 * 16 + n2] = exp(-2 pi i n2 k1 / F) for both axes and the
     //   digit-swapped positions of +kx and -kx for the Hermitian row separation
+    static_assert(SY >= FY + FY / kF2 && SY % 32 == 16, "column stride");
     static constexpr size_t lds_bytes =
         sizeof(float2) * ((size_t)NKX * SY + (size_t)kPairs * SX + FY + FX) +
         sizeof(uint32_t) * (size_t)((NKX + 3) & ~3);
@@ -69,6 +75,34 @@ __device__ __forceinline__ void pass_stride(float2 *a, int n2, const float2 *tw,
         if (!INV && k1 > 0) v[k1] = cmul(v[k1], ld(tw[kF2 * k1 + n2]));
         a[kF2 * k1 + n2] = st(v[k1]);
     }
+}
+
+// index of element y of a column of T
+__device__ __forceinline__ int sk(int y) { return y + (y >> 4); }
+
+// the same pass on a column of T (element 16 n1 + n2 lives at 17 n1 + n2)
+template <int F1, bool INV>
+__device__ __forceinline__ void pass_stride_col(float2 *a, int n2, const float2 *tw, int valid) {
+    cf v[F1];
+#pragma unroll
+    for (int n1 = 0; n1 < F1; ++n1) {
+        const int idx = kF2 * n1 + n2;
+        v[n1] = (INV || idx < valid) ? ld(a[(kF2 + 1) * n1 + n2]) : cf{0.f, 0.f};
+        if (INV && n1 > 0) v[n1] = cmulc(v[n1], ld(tw[kF2 * n1 + n2]));
+    }
+    fftk::Dft<F1, INV>::run(v);
+#pragma unroll
+    for (int k1 = 0; k1 < F1; ++k1) {
+        if (!INV && k1 > 0) v[k1] = cmul(v[k1], ld(tw[kF2 * k1 + n2]));
+        a[(kF2 + 1) * k1 + n2] = st(v[k1]);
+    }
+}
+
+// Single wavefront: LDS operations of one wave execute in order, so between passes
+// that exchange data only among the lanes of a wave the LDS counter has to drain, no
+// workgroup barrier is needed.
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // ---- radix-16 pass over the contiguous block a[16 k1 .. 16 k1 + 15] ---------------
@@ -110,52 +144,36 @@ struct Conv {
     int tid;
 
     // column transforms fused with the spectral product:
-    //   T <- IFFT_y( FFT_y(T) * K )   for every column kx, K in digit-swapped order
+    //   T <- IFFT_y( FFT_y(T) * K )   for every column kx, K in digit-swapped order.
+    // A column belongs to 16 lanes of one wavefront from start to end: lane g does the
+    // radix-FY1 butterfly n2 = g of the first pass, the radix-16 block k1 = g of the
+    // second (lanes g < FY1; forward, x K, inverse in registers), and n2 = g of the last.
+    // The three passes of a column only exchange data inside that group, so no
+    // workgroup barrier separates them and the wavefronts drift through the stage
+    // independently (the barriers cost 43 % of this stage before).
     __device__ __forceinline__ void columns(const float2 *Kt, int H, bool conj) {
-        // items (kx, n2) resp. (kx, k1), kx fastest: flat index tid + i * kThreads,
-        // advanced without divisions
-        constexpr int dq = kThreads / C::NKX, dr = kThreads % C::NKX;
-        const int kx0 = tid % C::NKX, q0 = tid / C::NKX;
-        for (int kx = kx0, n2 = q0; n2 < kF2;) {
-            pass_stride<FY1, false>(T + kx * C::SY, n2, twy, H);
-            kx += dr;
-            n2 += dq;
-            if (kx >= C::NKX) {
-                kx -= C::NKX;
-                ++n2;
+        const int g = tid & (kF2 - 1);
+        for (int kx = tid >> 4; kx < C::NKX; kx += kThreads / kF2) {
+            float2 *a = T + kx * C::SY;
+            pass_stride_col<FY1, false>(a, g, twy, H);
+            wave_lds_fence();
+            if (g < FY1) {
+                float2 *blk = a + (kF2 + 1) * g;
+                const float2 *kp = Kt + (int64_t)kx * C::FY + kF2 * g;
+                cf v[kF2], kv[kF2];
+#pragma unroll
+                for (int j = 0; j < kF2; ++j) kv[j] = ld(kp[j]);
+#pragma unroll
+                for (int j = 0; j < kF2; ++j) v[j] = ld(blk[j]);
+                fftk::Dft<kF2, false>::run(v);
+#pragma unroll
+                for (int j = 0; j < kF2; ++j) v[j] = conj ? cmulc(v[j], kv[j]) : cmul(v[j], kv[j]);
+                fftk::Dft<kF2, true>::run(v);
+#pragma unroll
+                for (int j = 0; j < kF2; ++j) blk[j] = st(v[j]);
             }
-        }
-        lds_barrier();
-        for (int kx = kx0, k1 = q0; k1 < FY1;) {
-            float2 *a = T + kx * C::SY + kF2 * k1;
-            const float2 *kp = Kt + (int64_t)(kF2 * k1) * C::NKX + kx;
-            cf v[kF2], kv[kF2];
-#pragma unroll
-            for (int j = 0; j < kF2; ++j) kv[j] = ld(kp[j * C::NKX]);
-#pragma unroll
-            for (int j = 0; j < kF2; ++j) v[j] = ld(a[j]);
-            fftk::Dft<kF2, false>::run(v);
-#pragma unroll
-            for (int j = 0; j < kF2; ++j) v[j] = conj ? cmulc(v[j], kv[j]) : cmul(v[j], kv[j]);
-            fftk::Dft<kF2, true>::run(v);
-#pragma unroll
-            for (int j = 0; j < kF2; ++j) a[j] = st(v[j]);
-            kx += dr;
-            k1 += dq;
-            if (kx >= C::NKX) {
-                kx -= C::NKX;
-                ++k1;
-            }
-        }
-        lds_barrier();
-        for (int kx = kx0, n2 = q0; n2 < kF2;) {
-            pass_stride<FY1, true>(T + kx * C::SY, n2, twy, C::FY);
-            kx += dr;
-            n2 += dq;
-            if (kx >= C::NKX) {
-                kx -= C::NKX;
-                ++n2;
-            }
+            wave_lds_fence();
+            pass_stride_col<FY1, true>(a, g, twy, C::FY);
         }
         lds_barrier();
     }
@@ -178,7 +196,7 @@ struct Conv {
                 const float2 za = z[pp & 0xffff];
                 const float2 zb = z[pp >> 16];
                 // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^)
-                float2 *t = T + kx * C::SY + y;
+                float2 *t = T + kx * C::SY + sk(y);
                 t[0] = make_float2(za.x + zb.x, za.y - zb.y);
                 t[1] = make_float2(za.y + zb.y, zb.x - za.x);
             }
@@ -193,7 +211,7 @@ struct Conv {
             const int y = y0 + 2 * j;
             float2 xa = make_float2(0.f, 0.f), xb = xa;
             if (y + 1 < C::FY) {
-                const float2 *t = T + kx * C::SY + y;
+                const float2 *t = T + kx * C::SY + sk(y);
                 xa = t[0];
                 xb = t[1];
             }
@@ -486,7 +504,7 @@ __global__ void permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int NKX,
     if (i >= FY * NKX) return;
     const int ky = i / NKX, kx = i - ky * NKX;
     const float2 k = Khat[(int64_t)img * FY * NKX + i];
-    Kt[((int64_t)img * FY + pos<FY1>(ky)) * NKX + kx] = make_float2(k.x * scale, k.y * scale);
+    Kt[((int64_t)img * NKX + kx) * FY + pos<FY1>(ky)] = make_float2(k.x * scale, k.y * scale);
 }
 
 // Kernel spectrum for the fused path without rocFFT (whose plan creation costs ~0.6 s of
@@ -530,7 +548,7 @@ __global__ void stamp_dft_y(const double2 *A, float2 *Kt, int ph, int NKX, doubl
         re += a.x * c + a.y * s;   // a * (c - i s)
         im += a.y * c - a.x * s;
     }
-    Kt[((int64_t)img * FY + pos<FY1>(ky)) * NKX + kx] =
+    Kt[((int64_t)img * NKX + kx) * FY + pos<FY1>(ky)] =
         make_float2((float)(re * scale), (float)(im * scale));
 }
 
@@ -557,7 +575,8 @@ int launch_impl(const BatchView &v, const float2 *Kt, int k_bands, int k_per_ble
 bool fused_conv_supported(int Fy, int Fx) {
     auto ok = [](int f) { return f == 64 || f == 80 || f == 96 || f == 128 || f == 160; };
     if (!ok(Fy) || !ok(Fx)) return false;
-    const size_t lds = sizeof(float2) * ((size_t)(Fx / 2 + 1) * (Fy + 1) +
+    const size_t sy = (size_t)((Fy + Fy / kF2 + 15) / 32) * 32 + 16;
+    const size_t lds = sizeof(float2) * ((size_t)(Fx / 2 + 1) * sy +
                                          (size_t)kPairs * (Fx + 1) + Fy + Fx) +
                        sizeof(uint32_t) * (size_t)((Fx / 2 + 1 + 3) & ~3);
     return lds <= 160 * 1024;
