@@ -150,11 +150,22 @@ def prox_weighted_monotonic(shape, neighbor_weight="flat", min_gradient=0.1, cen
     )
 
 
+_TABLES = {}
+
+
 def monotonic_tables(shape, neighbor_weight, center=None):
     """(weights, offsets, didx without the peak) as int32/float64 arrays for the
-    C ABI (``smi_batch_add_sweep_plan``)."""
+    C ABI (``smi_batch_add_sweep_plan``); cached per (shape, weighting, centre) like
+    the reference caches its operators (constraint.py:209-223)."""
     if center is None:
         center = (shape[0] // 2, shape[1] // 2)
+    key = (tuple(shape), neighbor_weight, (int(center[0]), int(center[1])))
+    if key not in _TABLES:
+        _TABLES[key] = _monotonic_tables(shape, neighbor_weight, center)
+    return _TABLES[key]
+
+
+def _monotonic_tables(shape, neighbor_weight, center):
     weights = np.ascontiguousarray(
         getRadialMonotonicWeights(shape, neighbor_weight, center), dtype=np.float64
     )
