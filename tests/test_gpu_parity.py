@@ -638,6 +638,34 @@ def _lib_flags():
     return _lib.PROX_POSITIVE | _lib.PROX_NORM_MAX
 
 
+def test_batch_invariance_at_benchmark_shape(amd):
+    """a blend of the benchmark workload (5 x 128 x 128, 10 components of 41 x 41) gives
+    bit-identical losses and parameters whether it runs alone or inside a batch of 48"""
+    from scarlet_amd import synthetic
+
+    scenes = synthetic.make_batch(range(1234, 1234 + 48))
+    kern = synthetic.psfs()
+
+    def run(sel):
+        comps = [[amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                                    sed_min_step=s["noise_rms"]) for k in range(len(s["morphs"]))]
+                 for s in sel]
+        b = amd.BlendBatch(np.stack([s["data"] for s in sel]), np.stack([s["weights"] for s in sel]),
+                           comps, kernel=kern[2], max_iter=8)
+        b.step(0, 6, e_rel=1e-3)
+        out = b.loss_history(), b.parameters()
+        b.close()
+        return out
+
+    loss_all, (sed_all, morph_all) = run(scenes)
+    for i in (0, 17, 47):
+        loss_one, (sed_one, morph_one) = run([scenes[i]])
+        assert_array_equal(loss_one[0], loss_all[i])
+        assert_array_equal(sed_one, sed_all[10 * i:10 * i + 10])
+        for a, b_ in zip(morph_one, morph_all[10 * i:10 * i + 10]):
+            assert_array_equal(a, b_)
+
+
 def test_more_than_64_components_in_one_blend(amd):
     """the render stage of the fused kernel walks the components of a blend in groups of
     64 (one component per lane of metadata): 70 small overlapping boxes"""
