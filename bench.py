@@ -234,7 +234,7 @@ def main():
             },
             "roofline": roofline,
         }
-        if not args.no_cpu and not lite:
+        if not args.no_cpu and not lite and world == 1:  # reported at N = 1 only
             v, dt = cpu_baseline(scenes, args.cpu_blends, args.cpu_iters, e_rel)
             line["cpu_baseline"] = {
                 "value": round(v, 2),
