@@ -601,9 +601,13 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
             }
         }
 
-        if ((slots.size() / 64) % 2)
+        // the sweep processes four steps per loop iteration and requests plan entries
+        // up to three steps beyond the current iteration: pad to a multiple of four
+        // steps and append three idle steps that are read but never executed
+        while ((slots.size() / 64) % 4)
             for (int lane = 0; lane < 64; ++lane) slots.push_back(idle);
         dp.n_slots = (int32_t)(slots.size() / 64);
+        for (int extra = 0; extra < 3 * 64; ++extra) slots.push_back(idle);
         if ((rc = upload(&dp.slots, slots.data(), slots.size()))) return rc;
     }
     b->plans.push_back(dp);

@@ -775,30 +775,28 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
     const int4 *meta = reinterpret_cast<const int4 *>(slots) + lane * 2;
     const float4 *wts = reinterpret_cast<const float4 *>(slots) + lane * 2 + 1;
     // four steps per iteration, each plan entry requested three steps before it is used
-    // (register ping-pong, no rotation moves); the plan is padded to an even number of
-    // steps, reads past the end are clamped to the last step
-    const int last = n_slots - 1;
-    auto at = [&](int s) { return (int64_t)min(s, last) * 128; };
-    int4 a0 = meta[at(0)], a1 = meta[at(1)], a2 = meta[at(2)];
-    float4 w0 = wts[at(0)], w1 = wts[at(1)], w2 = wts[at(2)];
+    // (register ping-pong, no rotation moves).  The plan is padded to a multiple of four
+    // steps plus three idle steps, so neither the prefetch nor the loop needs a bound
+    // check inside an iteration.
+    int4 a0 = meta[0], a1 = meta[128], a2 = meta[256];
+    float4 w0 = wts[0], w1 = wts[128], w2 = wts[256];
     for (int s = 0; s < n_slots; s += 4) {
-        const int4 a3 = meta[at(s + 3)];
-        const float4 w3 = wts[at(s + 3)];
+        const int4 *m = meta + (int64_t)s * 128;
+        const float4 *w = wts + (int64_t)s * 128;
+        const int4 a3 = m[3 * 128];
+        const float4 w3 = w[3 * 128];
         sweep_step(us, a0, w0, one_minus_g);
         wave_lds_fence();
-        if (s + 1 >= n_slots) break;
-        a0 = meta[at(s + 4)];
-        w0 = wts[at(s + 4)];
+        a0 = m[4 * 128];
+        w0 = w[4 * 128];
         sweep_step(us, a1, w1, one_minus_g);
         wave_lds_fence();
-        if (s + 2 >= n_slots) break;
-        a1 = meta[at(s + 5)];
-        w1 = wts[at(s + 5)];
+        a1 = m[5 * 128];
+        w1 = w[5 * 128];
         sweep_step(us, a2, w2, one_minus_g);
         wave_lds_fence();
-        if (s + 3 >= n_slots) break;
-        a2 = meta[at(s + 6)];
-        w2 = wts[at(s + 6)];
+        a2 = m[6 * 128];
+        w2 = w[6 * 128];
         sweep_step(us, a3, w3, one_minus_g);
         wave_lds_fence();
     }
