@@ -666,6 +666,17 @@ def test_batch_invariance_at_benchmark_shape(amd):
             assert_array_equal(a, b_)
 
 
+def test_tiny_frames_and_single_band(amd):
+    """frames much smaller than a chunk of the fused kernel, one band, boxes larger than
+    the frame"""
+    rng = np.random.default_rng(43)
+    for (H, W), ks in (((8, 9), 5), ((17, 5), 3), ((3, 33), 7)):
+        boxes = [((5, 5), (1, 2)), ((11, 13), (-4, -5))]
+        specs, kernel, data, weights = _random_scene(rng, 1, H, W, boxes, kernel_shape=ks)
+        for path in PATHS:
+            _compare_steps(amd, specs, kernel, data, weights, 2, {}, {}, conv_path=path)
+
+
 def test_more_than_64_components_in_one_blend(amd):
     """the render stage of the fused kernel walks the components of a blend in groups of
     64 (one component per lane of metadata): 70 small overlapping boxes"""
