@@ -320,6 +320,20 @@ int smi_batch_get_timing(smi_batch *b, double *ms_per_phase, int32_t n_phases);
 /* FFT shape actually used (fft_h, fft_w) */
 int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w);
 
+/* ---------------------------------------------------------------------------------
+ * Multi-resolution rendering: the per-call part of ResolutionRenderer
+ * (renderer.py:478-545) for unrotated pixel grids.  The host builds the two linear
+ * operators once (scarlet_amd/renderer.py): A[C][n_a][Fy*Fx], the difference kernel
+ * shifted along y to every low-resolution row (renderer.py:341-353), and
+ * Pt[Fx][Fx*n_b], the transposed operator that shifts a padded model row to every
+ * low-resolution column (renderer.py:498-505).  A rendering of a padded model cube
+ * [C][Fy][Fx] is two dense products per band, out[C][n_a][n_b]. */
+typedef struct smi_resampler smi_resampler;
+int smi_resampler_create(const float *A, const float *Pt, int32_t C, int32_t n_a, int32_t n_b,
+                         int32_t Fy, int32_t Fx, smi_resampler **out);
+int smi_resampler_render(smi_resampler *r, const float *model, float *out);
+int smi_resampler_destroy(smi_resampler *r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,13 @@ from .psf import PSF, ImagePSF, FunctionPSF, GaussianPSF, MoffatPSF  # noqa: F40
 from .batch import BlendBatch, ComponentSpec, PointSourceSpec  # noqa: F401
 from .frame import Frame  # noqa: F401
 from .observation import Observation  # noqa: F401
-from .renderer import Renderer, NullRenderer, ConvolutionRenderer  # noqa: F401
+from .renderer import (  # noqa: F401
+    Renderer,
+    NullRenderer,
+    ConvolutionRenderer,
+    ResolutionRenderer,
+)
+from .wcs import LinearWCS  # noqa: F401
 from .spectrum import Spectrum, TabulatedSpectrum  # noqa: F401
 from .morphology import (  # noqa: F401
     Morphology,

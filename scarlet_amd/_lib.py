@@ -106,6 +106,13 @@ SYMBOLS = {
         [c_i32p, c_i32p, ctypes.c_int32, c_u8p, c_f64p, ctypes.c_int32, ctypes.c_int32, c_u8p,
          ctypes.c_double, ctypes.c_int32, c_i32p],
     ),
+    "smi_resampler_create": (
+        ctypes.c_int,
+        [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+         ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)],
+    ),
+    "smi_resampler_render": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
+    "smi_resampler_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "smi_batch_create": (
         ctypes.c_int,
         [ctypes.POINTER(BatchDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)],

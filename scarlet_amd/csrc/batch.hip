@@ -375,6 +375,42 @@ int smi_apply_filter_f64(const double *image, int32_t H, int32_t W, const double
                                 result);
 }
 
+struct smi_resampler {
+    smi::Resampler *impl = nullptr;
+};
+
+int smi_resampler_create(const float *A, const float *Pt, int32_t C, int32_t n_a, int32_t n_b,
+                         int32_t Fy, int32_t Fx, smi_resampler **out) {
+    SMI_REQUIRE(A && Pt && out, "null argument");
+    SMI_REQUIRE(C > 0 && n_a > 0 && n_b > 0 && Fy > 0 && Fx > 0, "bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device available");
+        return SMI_ERR_NO_DEVICE;
+    }
+    auto *h = new smi_resampler;
+    const int rc = resampler_create(A, Pt, C, n_a, n_b, Fy, Fx, &h->impl);
+    if (rc) {
+        resampler_destroy(h->impl);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return SMI_OK;
+}
+
+int smi_resampler_render(smi_resampler *r, const float *model, float *out) {
+    SMI_REQUIRE(r && r->impl && model && out, "null argument");
+    return resampler_render(r->impl, model, out);
+}
+
+int smi_resampler_destroy(smi_resampler *r) {
+    if (!r) return SMI_OK;
+    resampler_destroy(r->impl);
+    delete r;
+    return SMI_OK;
+}
+
 int smi_get_valid_monotonic_pixels_f32(int32_t i, int32_t j, const float *image, int32_t rows,
                                        int32_t cols, uint8_t *unchecked, uint8_t *orphans,
                                        double variance, int32_t *bounds, double thresh) {

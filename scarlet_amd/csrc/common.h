@@ -165,6 +165,12 @@ int mask_interpolate_host_buffers(const int32_t *row_idx, const int32_t *col_idx
                                   uint8_t *unchecked, T *model, int32_t rows, int32_t cols,
                                   uint8_t *orphans, double variance, int32_t recursive,
                                   int32_t *bounds);
+// multi-resolution rendering (resample.hip)
+struct Resampler;
+int resampler_create(const float *A, const float *Pt, int C, int n_a, int n_b, int Fy, int Fx,
+                     Resampler **out);
+int resampler_render(Resampler *r, const float *model, float *out);
+void resampler_destroy(Resampler *r);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);
 void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,

@@ -61,7 +61,23 @@ class Observation(Frame):
                 self.renderer = NullRenderer(self, model_frame)
             else:
                 assert self.psf is not None and model_frame.psf is not None
-                self.renderer = ConvolutionRenderer(self, model_frame, convolution_type="fft")
+                if self.wcs is model_frame.wcs:
+                    self.renderer = ConvolutionRenderer(self, model_frame, convolution_type="fft")
+                else:
+                    # different WCS objects: same grid up to a translation, or a change
+                    # of resolution / rotation (observation.py:88-107)
+                    from . import interpolation
+                    from .renderer import ResolutionRenderer
+
+                    assert self.wcs is not None and model_frame.wcs is not None
+                    angle, h = interpolation.get_angles(self.wcs, model_frame.wcs)
+                    same_res = abs(h - 1) < np.finfo(float).eps
+                    same_rot = (np.abs(angle[1]) ** 2) < np.finfo(float).eps
+                    if same_res and same_rot:
+                        self.renderer = ConvolutionRenderer(self, model_frame,
+                                                            convolution_type="fft")
+                    else:
+                        self.renderer = ResolutionRenderer(self, model_frame)
         else:
             assert isinstance(renderer, Renderer)
             self.renderer = renderer

@@ -102,3 +102,142 @@ class ConvolutionRenderer(Renderer):
     def __call__(self, model, *parameters):
         self.transform = self.get_model(*parameters)
         return self.transform(model, *parameters)
+
+
+class ResolutionRenderer(Renderer):
+    """Renders a high-resolution model into a low-resolution observation with a
+    different pixel scale (reference renderer.py:262-547): convolution with the
+    difference kernel between the observed PSF and the model PSF, and resampling onto
+    the observation's pixels, in one linear operator.
+
+    Set-up on the host as in the reference: the observed PSF is sinc-interpolated to the
+    model pixel scale, the difference kernel is padded to the FFT shape and Fourier-
+    shifted along y to every low-resolution row (``_resconv_op``).  The per-call part --
+    shifting the padded model along x to every low-resolution column and contracting
+    with the operator (renderer.py:478-545) -- is linear in the model; it runs on the
+    GPU as two dense products per band (``smi_resampler_*``).  Rotated grids are not
+    supported."""
+
+    def __init__(self, data_frame, model_frame, padding=10):
+        from . import interpolation
+
+        super().__init__(data_frame, model_frame)
+        self.angle, self.h = interpolation.get_angles(data_frame.wcs, model_frame.wcs)
+        self.isrot = (np.abs(self.angle[1]) ** 2) > np.finfo(float).eps
+        if self.isrot:
+            raise NotImplementedError("ResolutionRenderer between rotated pixel grids")
+        lr_shape = data_frame.shape[1:]
+        pixels = np.stack((np.arange(lr_shape[0]), np.arange(lr_shape[1])), axis=1)
+        coord_hr = data_frame.convert_pixel_to(model_frame, pixel=pixels)
+        diff_psf, psf_lr_hr = self.build_diffkernel(data_frame, model_frame)
+        self.small_axis = data_frame.Nx <= data_frame.Ny
+        if not self.small_axis:
+            raise NotImplementedError("ResolutionRenderer for observations wider than tall")
+        self._fft_shape = fft._get_fft_shape(psf_lr_hr, np.zeros(model_frame.shape), padding=3,
+                                             axes=[-2, -1], max=False)
+        if (self._fft_shape[-2] < diff_psf.shape[-2]) or (self._fft_shape[-1] < diff_psf.shape[-1]):
+            diff_psf = fft.Fourier(fft._centered(
+                diff_psf.image, np.array([diff_psf.shape[0] + 1, *self._fft_shape]) - 1))
+        self.diff_kernel = fft.Fourier(fft._pad(diff_psf.image, self._fft_shape, axes=(-2, -1)))
+        Fy, Fx = self._fft_shape
+        center_y = int(Fy / 2.0 - (Fy - model_frame.Ny) / 2.0) + ((Fy % 2) != 0) * (
+            (model_frame.Ny % 2) == 0)
+        center_x = int(Fx / 2.0 - (Fx - model_frame.Nx) / 2.0) - ((Fx % 2) != 0) * (
+            (model_frame.Nx % 2) == 0)
+        self.shifts = coord_hr.T.copy()
+        self.shifts[0] -= center_y
+        self.shifts[1] -= center_x
+        self.other_shifts = np.copy(self.shifts)
+        # the kernel shifted along y to every low-resolution row (renderer.py:341-353)
+        op = self._shift_along(self.diff_kernel.image, self.shifts[0], axis=1)  # (C, n_a, Fy, Fx)
+        self._resconv_op = (np.array(op, dtype=model_frame.dtype) * self.h**2).reshape(
+            op.shape[0], op.shape[1], -1)
+        self._device = None
+
+    def build_diffkernel(self, data_frame, model_frame):
+        """Difference kernel between the observed PSF, interpolated to the model pixels,
+        and the model PSF (renderer.py:365-412)."""
+        from . import interpolation
+
+        psf_hr = model_frame.psf.get_model()
+        psf_lr = data_frame.psf.get_model().astype(model_frame.dtype)
+        pad_shape = np.array((np.array(data_frame.shape[-2:]) + np.array(psf_lr.shape[-2:])) / 2
+                             ).astype(int) * 2 + 1
+        h_lr = interpolation.get_pixel_size(interpolation.get_affine(data_frame.wcs))
+        h_hr = interpolation.get_pixel_size(interpolation.get_affine(model_frame.wcs))
+        angle, _ = interpolation.get_angles(model_frame.wcs, data_frame.wcs)
+        psf_lr_hr = interpolation.sinc_interp_inplace(psf_lr, h_lr, h_hr, angle,
+                                                      pad_shape=pad_shape)
+        psf_hr = psf_hr / np.sum(psf_hr)
+        psf_lr_hr = psf_lr_hr / np.sum(psf_lr_hr)
+        return fft.match_psf(fft.Fourier(psf_lr_hr), fft.Fourier(psf_hr)), psf_hr
+
+    def _shift_along(self, cube, shifts, axis):
+        """``cube`` (C, Fy, Fx) Fourier-shifted along ``axis`` (1 = y, 2 = x) by every
+        entry of ``shifts`` (renderer.py:414-476, one-axis branches: real transform along
+        that axis, ramps of ``mk_shifter(real=True)``).  Returns (C, n, Fy, Fx) for
+        axis 1 and (C, Fy, Fx, n) for axis 2."""
+        from .interpolation import mk_shifter
+
+        F = self._fft_shape[axis - 1]
+        ramp = mk_shifter(self._fft_shape, real=True)[axis - 1]
+        spectrum = np.fft.rfft(np.fft.ifftshift(cube, axes=axis), axis=axis)
+        if axis == 1:
+            phase = np.exp(ramp[np.newaxis, :] * shifts[:, np.newaxis])  # (n, Fy/2+1)
+            shifted = spectrum[:, np.newaxis, :, :] * phase[np.newaxis, :, :, np.newaxis]
+            return np.fft.fftshift(np.fft.irfft(shifted, F, axis=2), axes=2)
+        phase = np.exp(ramp[:, np.newaxis] * shifts[np.newaxis, :])  # (Fx/2+1, n)
+        shifted = spectrum[:, :, :, np.newaxis] * phase[np.newaxis, np.newaxis, :, :]
+        return np.fft.fftshift(np.fft.irfft(shifted, F, axis=2), axes=2)
+
+    def _resampler(self):
+        """Device handle holding the two operators (built on first use)."""
+        if self._device is None:
+            import ctypes
+
+            from . import _lib
+
+            lib = _lib.load()
+            C, n_a, _ = self._resconv_op.shape
+            Fy, Fx = self._fft_shape
+            n_b = self.other_shifts.shape[1]
+            # operator that shifts one padded row to every low-resolution column: the
+            # reference's pipeline applied to the identity (row x' -> P[x, b, x'])
+            eye = np.eye(Fx, dtype=np.float64)[np.newaxis]  # (1, Fx rows, Fx)
+            P = self._shift_along(eye, -self.other_shifts[1], axis=2)[0]  # (x', x, b)
+            Pt = np.ascontiguousarray(P.reshape(Fx, Fx * n_b), dtype=np.float32)
+            A = np.ascontiguousarray(self._resconv_op, dtype=np.float32)
+            handle = ctypes.c_void_p()
+            _lib.check(lib.smi_resampler_create(
+                _lib.ptr(A, ctypes.c_float), _lib.ptr(Pt, ctypes.c_float), C, n_a, n_b, Fy, Fx,
+                ctypes.byref(handle)))
+            self._device = (lib, handle, (C, n_a, n_b))
+        return self._device
+
+    def get_model(self, *parameters):
+        def transform(model, *parameters):
+            import ctypes
+
+            from . import _lib
+
+            model_ = self.map_channels(model)
+            dtype = model_.dtype
+            padded = np.ascontiguousarray(fft._pad(model_, self._fft_shape, axes=(-2, -1)),
+                                          dtype=np.float32)
+            lib, handle, shape = self._resampler()
+            out = np.empty(shape, dtype=np.float32)
+            _lib.check(lib.smi_resampler_render(handle, _lib.ptr(padded, ctypes.c_float),
+                                                _lib.ptr(out, ctypes.c_float)))
+            return out.astype(dtype, copy=False)
+
+        return transform
+
+    def __call__(self, model, *parameters):
+        return self.get_model(*parameters)(model, *parameters)
+
+    def __del__(self):
+        try:
+            if self._device is not None:
+                self._device[0].smi_resampler_destroy(self._device[1])
+        except Exception:
+            pass

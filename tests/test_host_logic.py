@@ -265,3 +265,37 @@ def test_lite_host_utilities():
         a.update(0, None)
     psfs = np.stack([lite.integrated_circular_gaussian(sigma=s) for s in (0.8, 0.8001, 0.8)])
     assert lite.get_min_psf(psfs, thresh=0.01).shape[1] < 15
+
+
+def test_multiresolution_frames_and_renderer_setup():
+    """Frame.from_observations with WCSs and the ResolutionRenderer set-up (host side of
+    BASELINE config 5) reproduce the reference's model frames, PSFs and FFT shapes for
+    every pair of tests/test_multiresolution.py (golden); the WCS conversion round-trips"""
+    g = golden("multiresolution")
+
+    def wcs(k):
+        w = scarlet.LinearWCS(g["crpix_%d" % k], g["crval_%d" % k], g["pc_%d" % k], g["cdelt_%d" % k])
+        w.array_shape = g["crpix_%d" % k] * 2
+        return w
+
+    w = wcs(0)
+    pix = np.array([[0.0, 0.0], [10.5, 99.25], [130.0, 7.0]])
+    assert_allclose(w.world_to_pixel_values(w.pixel_to_world_values(pix)), pix, atol=1e-9)
+    # a subset here (the set-up of the big frames takes seconds each); the GPU test
+    # walks through all twenty
+    for tag in ("1_3_union", "1_4_intersection", "2_4_intersection", "3_4_union", "2_3_union"):
+        i, j, coverage = str(tag).split("_")
+        i, j = int(i), int(j)
+        obs_hr = scarlet.Observation(g["image_%d" % i][None], wcs=wcs(i),
+                                     psf=scarlet.ImagePSF(g["psf_%d" % i]), channels=["lr"])
+        obs_lr = scarlet.Observation(g["image_%d" % j][None], wcs=wcs(j),
+                                     psf=scarlet.ImagePSF(g["psf_%d" % j]), channels=["hr"])
+        frame = scarlet.Frame.from_observations([obs_lr, obs_hr], obs_id=1, coverage=coverage)
+        assert tuple(frame.shape) == tuple(g["frame_shape_%s" % tag]), tag
+        assert_allclose(frame.wcs.wcs.crpix, g["frame_crpix_%s" % tag])
+        assert_allclose(frame.psf.get_model(), g["model_psf_%s" % tag], atol=1e-12)
+        assert type(obs_lr.renderer) is scarlet.ResolutionRenderer
+        assert type(obs_hr.renderer).__name__ == str(g["hr_renderer_%s" % tag])
+        assert list(obs_lr.renderer._fft_shape) == list(g["fft_shape_%s" % tag])
+        n_lr = g["image_%d" % j].shape[0]
+        assert obs_lr.renderer._resconv_op.shape == (1, n_lr, int(np.prod(g["fft_shape_%s" % tag])))
