@@ -1,6 +1,10 @@
-"""Components: hyperspectral models inside a bounding box (reference
-scarlet/component.py).  ``get_model`` here is the host-side, inspection-time
-evaluation; during ``Blend.fit`` the same outer products are rendered on the GPU."""
+"""Components: hyperspectral models inside a bounding box.
+
+Same classes, constructor signatures and failure modes as the reference
+(scarlet/component.py:14-291) so that scripts written for it keep working; the bodies are
+this package's own.  ``get_model`` here is the host-side, inspection-time evaluation;
+during ``Blend.fit`` the same outer products are rendered on the GPU.
+"""
 
 import numpy as np
 
@@ -14,20 +18,34 @@ from .parameter import Parameter, relative_step
 from .spectrum import Spectrum
 
 
+def _update_children(component, rebuild_box):
+    """Run ``update()`` on every child; when one of them reports a changed box
+    (``UpdateException``), give the container its new box first and pass the exception
+    on -- the remaining children are not visited (component.py:172-185, 280-290)."""
+    for child in component.children:
+        try:
+            child.update()
+        except UpdateException:
+            component.bbox = rebuild_box()
+            raise
+
+
 class Component(Model):
+    """A model confined to ``bbox`` inside ``frame`` (default: the whole frame).  Keeps
+    the pair of slices that place the boxed model into the frame up to date whenever
+    either of the two changes."""
+
     def __init__(self, frame, *parameters, children=None, bbox=None):
         assert isinstance(frame, Frame)
-        if bbox is None:
-            bbox = frame.bbox
-        assert isinstance(bbox, Box)
-        self._bbox = bbox
-        self.frame = frame
+        assert bbox is None or isinstance(bbox, Box)
+        self._frame = frame
+        self._bbox = frame.bbox if bbox is None else bbox
+        self._reslice()
         super().__init__(*parameters, children=children)
 
     def _reslice(self):
-        self._model_frame_slices, self._model_slices = overlapped_slices(
-            self._frame.bbox, self._bbox
-        )
+        placement = overlapped_slices(self._frame.bbox, self._bbox)
+        self._model_frame_slices, self._model_slices = placement
 
     @property
     def bbox(self):
@@ -48,49 +66,47 @@ class Component(Model):
         self._reslice()
 
     def model_to_box(self, bbox=None, model=None):
-        """Embed the boxed model into (the part of) ``bbox`` it overlaps."""
-        if model is None:
-            model = self.get_model()
-        if bbox is None or bbox == self.frame.bbox:
-            bbox = self.frame.bbox
-            frame_sl, model_sl = self._model_frame_slices, self._model_slices
+        """Zero image of ``bbox`` (default: the frame) with the boxed ``model`` (default:
+        the current one) written into the overlap."""
+        model = self.get_model() if model is None else model
+        target = self.frame.bbox if bbox is None else bbox
+        if target == self.frame.bbox:
+            into, out_of = self._model_frame_slices, self._model_slices  # cached pair
         else:
-            frame_sl, model_sl = overlapped_slices(bbox, self.bbox)
-        out = np.zeros(bbox.shape, dtype=model.dtype)
-        out[frame_sl] = model[model_sl]
-        return out
+            into, out_of = overlapped_slices(target, self.bbox)
+        placed = np.zeros(target.shape, dtype=model.dtype)
+        placed[into] = model[out_of]
+        return placed
+
+    def _in_frame(self, model, frame):
+        """``model`` as is, or embedded into ``frame`` when one is given."""
+        return model if frame is None else self.model_to_box(frame.bbox, model)
 
 
 class FactorizedComponent(Component):
-    """Spectrum (C,) x morphology (h, w): the component the device loop fits."""
+    """Spectrum (C,) x morphology (h, w) or (1 | C, h, w): the component the device loop
+    fits."""
 
     def __init__(self, frame, spectrum, morphology):
         assert isinstance(spectrum, Spectrum)
         assert isinstance(morphology, Morphology)
-        bbox = spectrum.bbox @ morphology.bbox[-2:]
-        super().__init__(frame, children=[spectrum, morphology], bbox=bbox)
+        super().__init__(frame, children=[spectrum, morphology],
+                         bbox=self._joint_box(spectrum, morphology))
+
+    @staticmethod
+    def _joint_box(spectrum, morphology):
+        return spectrum.bbox @ morphology.bbox[-2:]
 
     def get_model(self, *parameters, frame=None):
         spectrum, morphology = self.get_models_of_children(*parameters)
-        if morphology.ndim == 2:
-            model = spectrum[:, None, None] * morphology[None, :, :]
-        elif morphology.ndim == 3:
-            model = spectrum[:, None, None] * morphology
-        else:
+        if morphology.ndim not in (2, 3):
             raise AttributeError("morphology must be 2D or 3D")
-        if frame is not None:
-            model = self.model_to_box(frame.bbox, model)
-        return model
+        # a 2-D morphology is shared by all channels, a 3-D one broadcasts over them
+        image = morphology if morphology.ndim == 3 else morphology[np.newaxis]
+        return self._in_frame(spectrum[:, np.newaxis, np.newaxis] * image, frame)
 
     def update(self):
-        for child in self.children:
-            try:
-                child.update()
-            except UpdateException as exc:
-                # follow the morphology's new box
-                spectrum, morphology = self.children
-                self.bbox = spectrum.bbox @ morphology.bbox[-2:]
-                raise exc
+        _update_children(self, lambda: self._joint_box(*self.children))
 
 
 class CubeComponent(Component):
@@ -98,59 +114,47 @@ class CubeComponent(Component):
     the device loop."""
 
     def __init__(self, frame, cube, bbox=None):
-        if isinstance(cube, Parameter):
-            assert cube.name == "cube"
-        else:
+        if not isinstance(cube, Parameter):
             cube = Parameter(cube, name="cube", step=relative_step,
                              constraint=PositivityConstraint())
+        assert cube.name == "cube"
         super().__init__(frame, cube, bbox=bbox)
 
     def get_model(self, *parameters, frame=None):
-        model = self.get_parameter(0, *parameters)
-        if frame is not None:
-            model = self.model_to_box(frame.bbox, model)
-        return model
+        return self._in_frame(self.get_parameter(0, *parameters), frame)
 
 
 class CombinedComponent(Component):
-    """Sum (or product) of child components over the first child's box."""
+    """Sum (or product) of child components of one frame, evaluated over the box it
+    was given at construction (the first child's) or after the last resize (their
+    union)."""
 
     def __init__(self, components, operation="add"):
         assert len(components)
         frame = components[0].frame
-        for c in components:
-            assert isinstance(c, Component)
-            assert c.frame is frame
-        super().__init__(frame, children=components, bbox=components[0].bbox)
+        assert all(isinstance(c, Component) and c.frame is frame for c in components)
         assert operation in ["add", "multiply"]
         self.operation = operation
+        super().__init__(frame, children=components, bbox=components[0].bbox)
 
     def get_model(self, *parameters, frame=None):
-        models = self.get_models_of_children(*parameters, frame=None)
-        bbox = self.bbox
-        model = np.zeros(bbox.shape)
-        for child, m in zip(self.children, models):
-            if child.bbox != bbox:
-                pad = tuple(
-                    (child.bbox.start[d] - bbox.start[d], bbox.stop[d] - child.bbox.stop[d])
-                    for d in range(bbox.D)
-                )
-                m = fast_zero_pad(m, pad)
-            if self.operation == "add":
-                model += m
-            else:
-                model *= m
-        if frame is not None:
-            model = self.model_to_box(frame.bbox, model)
-        return model
+        box = self.bbox
+        combine = np.add if self.operation == "add" else np.multiply
+        total = np.zeros(box.shape)
+        for child, part in zip(self.children,
+                               self.get_models_of_children(*parameters, frame=None)):
+            if child.bbox != box:
+                margins = tuple((lo - b_lo, b_hi - hi) for lo, hi, b_lo, b_hi in
+                                zip(child.bbox.start, child.bbox.stop, box.start, box.stop))
+                part = fast_zero_pad(part, margins)
+            combine(total, part, out=total)
+        return self._in_frame(total, frame)
+
+    def _union_box(self):
+        box = self.children[0].bbox.copy()
+        for c in self.children[1:]:
+            box |= c.bbox
+        return box
 
     def update(self):
-        for child in self.children:
-            try:
-                child.update()
-            except UpdateException as exc:
-                box = self.children[0].bbox.copy()
-                for c in self.children[1:]:
-                    box |= c.bbox
-                self.bbox = box
-                raise exc
+        _update_children(self, self._union_box)

@@ -132,10 +132,11 @@ class MonotonicityConstraint(Constraint):
         self.fit_center_radius = fit_center_radius
 
     def __call__(self, morph, step):
-        shape = morph.shape
-        center = (shape[0] // 2, shape[1] // 2)
-        if self.fit_center:
-            center = operator.get_center(morph, center, radius=self.fit_center_radius)
+        shape = tuple(morph.shape)
+        nominal = tuple(n // 2 for n in shape)
+        # optionally re-centre on the brightest pixel near the nominal centre
+        center = (operator.get_center(morph, nominal, radius=self.fit_center_radius)
+                  if self.fit_center else nominal)
         name = "operator.prox_weighted_monotonic"
         key = (shape, center, self.neighbor_weight, self.min_gradient)
         try:

@@ -99,37 +99,47 @@ class LiteComponent:
         kept as in the reference, lite/models.py:84-91.)"""
         if self.bg_thresh is None:
             return False
-        morph = self.morph
-        size = max(morph.shape)
-        dist = 0
-        while (np.all(morph[dist, :] == 0) and np.all(morph[-dist, :] == 0)
-               and np.all(morph[:, dist] == 0) and np.all(morph[:, -dist] == 0)):
-            dist += 1
-        new_size = initialization.get_minimal_boxsize(size - 2 * dist)
-        if new_size < size:
-            dist = (size - new_size) // 2
-            o = self.bbox.origin
-            self.bbox.origin = (o[0], o[1] + dist, o[2] + dist)
-            self.bbox.shape = (self.bbox.shape[0], new_size, new_size)
-            self._morph.shrink(dist)
-            self.slices = overlapped_slices(self.model_bbox, self.bbox)
+        size = max(self.morph.shape)
+        smaller = initialization.get_minimal_boxsize(size - 2 * self._empty_rings(self.morph))
+        if smaller < size:
+            inset = (size - smaller) // 2
+            self._morph.shrink(inset)
+            self._set_square(smaller, inset)
             return True
         model = self.get_model()
         edges = (model[:, 0], model[:, -1], model[0, :], model[-1, :])
         flux = np.array([np.sum(e) for e in edges])
         lit = np.array([np.sum(e > 0) for e in edges])
         with np.errstate(divide="ignore", invalid="ignore"):
-            grow = np.any(flux / lit > self.bg_thresh * self.bg_rms[:, None, None])
-        if grow:
-            new_size = initialization.get_minimal_boxsize(size + 1)
-            dist = (new_size - size) // 2
-            o = self.bbox.origin
-            self.bbox.origin = (o[0], o[1] - dist, o[2] - dist)
-            self.bbox.shape = (self.bbox.shape[0], new_size, new_size)
-            self._morph.grow(self.bbox.shape[1:], dist)
-            self.slices = overlapped_slices(self.model_bbox, self.bbox)
-            return True
-        return False
+            bright = np.any(flux / lit > self.bg_thresh * self.bg_rms[:, None, None])
+        if not bright:
+            return False
+        larger = initialization.get_minimal_boxsize(size + 1)
+        outset = (larger - size) // 2
+        self._set_square(larger, -outset)
+        self._morph.grow(self.bbox.shape[1:], outset)
+        return True
+
+    @staticmethod
+    def _empty_rings(morph):
+        """Number of rings the reference's peeling loop removes.  Its step ``d`` tests
+        rows / columns ``d`` and ``-d``, i.e. index 0 twice at d = 0 and the LAST one
+        only at d = 1, so with L empty leading and T empty trailing rows or columns it
+        stops at ``min(L, T + 1)``."""
+        filled = np.argwhere(np.asarray(morph) != 0)
+        if len(filled) == 0:
+            return max(morph.shape) // 2
+        leading = filled.min(axis=0).min()
+        trailing = (np.array(morph.shape) - 1 - filled.max(axis=0)).min()
+        return int(min(leading, trailing + 1))
+
+    def _set_square(self, side, inset):
+        """Make the spatial box a square of ``side`` pixels whose corner sits ``inset``
+        pixels further in (negative: further out) and refresh the placement slices."""
+        band0, y0, x0 = self.bbox.origin
+        self.bbox.origin = (band0, y0 + inset, x0 + inset)
+        self.bbox.shape = (self.bbox.shape[0], side, side)
+        self.slices = overlapped_slices(self.model_bbox, self.bbox)
 
     def __repr__(self):
         return type(self).__name__

@@ -28,31 +28,37 @@ def get_minimal_boxsize(size, min_size=21, increment=10):
     return boxsize
 
 
+def _empty_margin(image, thresh):
+    """Width of the frame of pixels <= ``thresh`` around ``image``: the largest ``d`` such
+    that the d outermost rows and columns on every side hold nothing above ``thresh``
+    (the whole image counts as margin when it is empty)."""
+    occupied = np.argwhere(np.asarray(image) > thresh)
+    if len(occupied) == 0:
+        return (min(image.shape) + 1) // 2
+    lo = occupied.min(axis=0)
+    hi = np.array(image.shape) - 1 - occupied.max(axis=0)
+    return int(min(lo.min(), hi.min()))
+
+
 class Morphology(Model):
+    """Spatial part of a factorized component inside ``bbox`` (default: the box of
+    ``frame``)."""
+
     def __init__(self, frame, *parameters, bbox=None):
         assert isinstance(frame, Frame)
+        assert bbox is None or isinstance(bbox, Box)
         self.frame = frame
-        if bbox is None:
-            bbox = frame.bbox
-        assert isinstance(bbox, Box)
-        self.bbox = bbox
+        self.bbox = frame.bbox if bbox is None else bbox
         super().__init__(*parameters)
 
     def shrink_box(self, image, thresh=0):
-        """Peel off empty borders; adopt the next smaller standard box size."""
+        """Peel off empty borders; adopt the next smaller standard box size
+        (morphology.py:50-67)."""
         size = max(image.shape)
-        dist = 0
-        while (
-            np.all(image[dist, :] <= thresh)
-            and np.all(image[-dist - 1, :] <= thresh)
-            and np.all(image[:, dist] <= thresh)
-            and np.all(image[:, -dist - 1] <= thresh)
-        ):
-            dist += 1
-        newsize = get_minimal_boxsize(size - 2 * dist)
+        newsize = get_minimal_boxsize(size - 2 * _empty_margin(image, thresh))
         if newsize < size:
-            dist = (size - newsize) // 2
-            self.bbox.origin = tuple(o + dist for o in self.bbox.origin)
+            inset = (size - newsize) // 2
+            self.bbox.origin = tuple(o + inset for o in self.bbox.origin)
             self.bbox.shape = (newsize, newsize)
 
 
@@ -65,11 +71,9 @@ class ImageMorphology(Morphology):
         else:
             image = Parameter(image, name="image", step=relative_step,
                               constraint=PositivityConstraint())
-        if bbox is None:
-            assert frame.bbox[1:].shape == image.shape
-            bbox = Box(image.shape)
-        else:
-            assert bbox.shape == image.shape
+        # without a box the image must cover the frame's spatial extent
+        assert image.shape == (frame.bbox[1:].shape if bbox is None else bbox.shape)
+        bbox = Box(image.shape) if bbox is None else bbox
         self.resizing = resizing
         self.shifting = shifting
         if shift is None:
@@ -185,15 +189,17 @@ class PointSourceMorphology(Morphology):
 
         assert frame.psf is not None and isinstance(frame.psf, PSF)
         self.psf = frame.psf
-        pixel_center = tuple(np.round(center).astype("int"))
-        bbox = self.psf.bbox + (0, *pixel_center)
+        # the PSF box, centred on the origin, moves to the pixel nearest the centre
+        cy, cx = (int(c) for c in np.rint(np.asarray(center, dtype=float)))
         self.center = prepare_param(center, name="center")
-        super().__init__(frame, self.center, bbox=bbox)
+        super().__init__(frame, self.center, bbox=self.psf.bbox + (0, cy, cx))
 
     def get_model(self, *parameters):
-        center = self.get_parameter(0, *parameters)
-        box_center = np.mean(self.bbox.bounds[1:], axis=1)
-        return self.psf.get_model(offset=np.asarray(center) - box_center)
+        """Model-frame PSF image evaluated at the sub-pixel offset of the centre from
+        the middle of the box."""
+        (y_lo, y_hi), (x_lo, x_hi) = self.bbox.bounds[1:]
+        middle = np.array([(y_lo + y_hi) / 2, (x_lo + x_hi) / 2])
+        return self.psf.get_model(offset=np.asarray(self.get_parameter(0, *parameters)) - middle)
 
     @property
     def integral(self):

@@ -47,48 +47,55 @@ class Observation(Frame):
         self._padding = padding
 
     def match(self, model_frame, renderer=None):
-        """Set up the mapping from ``model_frame`` to this observation: cast the
-        data to the model dtype and choose the renderer (same PSF object ->
-        ``NullRenderer``; otherwise ``ConvolutionRenderer``).  Returns ``self``."""
-        self.model_frame = model_frame
-        if self.dtype != model_frame.dtype:
-            self.dtype = model_frame.dtype
-            self.data = self.data.astype(model_frame.dtype)
-            if type(self.weights) is np.ndarray:
-                self.weights = self.weights.astype(model_frame.dtype)
-        if renderer is None:
-            if self.psf is model_frame.psf:
-                self.renderer = NullRenderer(self, model_frame)
-            else:
-                assert self.psf is not None and model_frame.psf is not None
-                if self.wcs is model_frame.wcs:
-                    self.renderer = ConvolutionRenderer(self, model_frame, convolution_type="fft")
-                else:
-                    # different WCS objects: same grid up to a translation, or a change
-                    # of resolution / rotation (observation.py:88-107)
-                    from . import interpolation
-                    from .renderer import ResolutionRenderer
-
-                    assert self.wcs is not None and model_frame.wcs is not None
-                    angle, h = interpolation.get_angles(self.wcs, model_frame.wcs)
-                    same_res = abs(h - 1) < np.finfo(float).eps
-                    same_rot = (np.abs(angle[1]) ** 2) < np.finfo(float).eps
-                    if same_res and same_rot:
-                        self.renderer = ConvolutionRenderer(self, model_frame,
-                                                            convolution_type="fft")
-                    else:
-                        self.renderer = ResolutionRenderer(self, model_frame)
-        else:
+        """Bind this observation to ``model_frame``: data and (array) weights take the
+        model's dtype, and ``self.renderer`` becomes ``renderer`` if one is given or the
+        default for the pair of frames (reference observation.py:58-113).  Returns
+        ``self`` so that ``Observation(...).match(frame)`` chains."""
+        if renderer is not None:
             assert isinstance(renderer, Renderer)
-            self.renderer = renderer
+        self.model_frame = model_frame
+        self._cast_to(model_frame.dtype)
+        self.renderer = self._default_renderer(model_frame) if renderer is None else renderer
         return self
+
+    def _cast_to(self, dtype):
+        if self.dtype == dtype:
+            return
+        self.dtype = dtype
+        self.data = self.data.astype(dtype)
+        # weights may be a masked array or another array-like; only plain arrays are cast
+        if type(self.weights) is np.ndarray:
+            self.weights = self.weights.astype(dtype)
+
+    def _default_renderer(self, model_frame):
+        """``NullRenderer`` for a shared PSF object; FFT convolution with the difference
+        kernel when the pixel grids agree (same WCS object, or WCSs that differ by a
+        translation only); ``ResolutionRenderer`` when scale or orientation differ."""
+        if self.psf is model_frame.psf:
+            return NullRenderer(self, model_frame)
+        assert self.psf is not None and model_frame.psf is not None
+        if self.wcs is not model_frame.wcs:
+            from . import interpolation
+            from .renderer import ResolutionRenderer
+
+            assert self.wcs is not None and model_frame.wcs is not None
+            (_, sin_rot), scale = interpolation.get_angles(self.wcs, model_frame.wcs)
+            tiny = np.finfo(float).eps
+            if abs(scale - 1) >= tiny or abs(sin_rot) ** 2 >= tiny:
+                return ResolutionRenderer(self, model_frame)
+        return ConvolutionRenderer(self, model_frame, convolution_type="fft")
 
     @property
     def noise_rms(self):
-        if not hasattr(self, "_noise_rms"):
-            self._noise_rms = 1 / np.sqrt(ma.masked_equal(self.weights, 0))
-            ma.set_fill_value(self._noise_rms, np.inf)
-        return self._noise_rms
+        """Per-pixel noise rms ``weights ** -1/2`` as a masked array: pixels of zero
+        weight are masked and read as infinite when filled."""
+        try:
+            return self._noise_rms
+        except AttributeError:
+            rms = 1 / np.sqrt(ma.masked_equal(self.weights, 0))
+            rms.fill_value = np.inf
+            self._noise_rms = rms
+            return rms
 
     @property
     def parameters(self):

@@ -33,12 +33,15 @@ def sort_by_radius(shape, center=None):
 def getOffsets(width, coords=None):
     """Flat-index offsets of the neighbours and the slice pairs that align a
     vector with its shifted copy (reference operator.py:512-527)."""
-    if coords is None:
-        coords = NEIGHBOR_COORDS
-    offsets = [width * y + x for y, x in coords]
-    slices = [slice(None, s) if s < 0 else slice(s, None) for s in offsets]
-    slicesInv = [slice(-s, None) if s < 0 else slice(None, -s) for s in offsets]
-    return offsets, slices, slicesInv
+    def aligned(offset):
+        # v[fwd] lines up with v[back] when v is compared with itself ``offset`` apart
+        if offset < 0:
+            return slice(None, offset), slice(-offset, None)
+        return slice(offset, None), slice(None, -offset)
+
+    offsets = [dy * width + dx for dy, dx in (NEIGHBOR_COORDS if coords is None else coords)]
+    pairs = [aligned(o) for o in offsets]
+    return offsets, [fwd for fwd, _ in pairs], [back for _, back in pairs]
 
 
 def diagonalizeArray(arr, shape=None, dtype=np.float64):
@@ -136,18 +139,16 @@ def _prox_weighted_monotonic(X, step, weights, didx, offsets, min_gradient=0.1):
 
 def prox_weighted_monotonic(shape, neighbor_weight="flat", min_gradient=0.1, center=None):
     """Build the monotonicity operator for images of ``shape``
-    (reference operator.py:62-96).  Returns ``f(X, step) -> X``."""
-    height, width = shape
-    didx = sort_by_radius(shape, center)
-    offsets = np.array([width * y + x for y, x in NEIGHBOR_COORDS])
-    weights = getRadialMonotonicWeights(shape, neighbor_weight=neighbor_weight, center=center)
-    return partial(
-        _prox_weighted_monotonic,
-        weights=weights,
-        didx=didx[1:],
-        offsets=offsets,
+    (reference operator.py:62-96).  Returns ``f(X, step) -> X``; the set-up tables are
+    bound as keyword arguments, so ``f.keywords`` exposes them as the reference does."""
+    order = sort_by_radius(shape, center)
+    tables = dict(
+        weights=getRadialMonotonicWeights(shape, neighbor_weight=neighbor_weight, center=center),
+        didx=order[1:],  # the peak itself has no brighter neighbour to be bounded by
+        offsets=np.array(getOffsets(shape[1])[0]),
         min_gradient=min_gradient,
     )
+    return partial(_prox_weighted_monotonic, **tables)
 
 
 _TABLES = {}
