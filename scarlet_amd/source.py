@@ -19,10 +19,32 @@ from .spectrum import TabulatedSpectrum
 logger = logging.getLogger("scarlet_amd.source")
 
 
+def _as_sequence(observations):
+    return observations if hasattr(observations, "__iter__") else (observations,)
+
+
 def _noise_rms(observations):
-    return np.concatenate(
-        [np.array(np.mean(obs.noise_rms, axis=(1, 2))) for obs in observations]
-    ).reshape(-1)
+    """Mean noise rms per channel, channels of all observations in a row."""
+    per_obs = [np.array(np.mean(obs.noise_rms, axis=(1, 2))) for obs in observations]
+    return np.concatenate(per_obs).reshape(-1)
+
+
+def _nearest_pixel(frame, sky_coord):
+    return np.round(frame.get_pixel(sky_coord)).astype("int")
+
+
+def _box_around(pixel, shape):
+    """2-D box of ``shape`` whose middle pixel (shape // 2) is ``pixel``."""
+    return Box(shape, origin=tuple(int(p) - n // 2 for p, n in zip(pixel, shape)))
+
+
+def _fitted_morphology(frame, sky_coord, image, bbox, shifting, resizing):
+    """The morphology every extended source is FITTED with, however it was initialised:
+    monotonic with 'angle' weights and no minimal gradient, not symmetric
+    (source.py:289-300, 480-496, 632-643)."""
+    return ExtendedSourceMorphology(
+        frame, frame.get_pixel(sky_coord), image, bbox=bbox, monotonic="angle",
+        symmetric=False, min_grad=0, shifting=shifting, resizing=resizing)
 
 
 class PointSource(FactorizedComponent):
@@ -30,14 +52,15 @@ class PointSource(FactorizedComponent):
     peak pixel of the observations, corrected for the PSF (source.py:92-128)."""
 
     def __init__(self, model_frame, sky_coord, observations):
-        if not hasattr(observations, "__iter__"):
-            observations = (observations,)
-        center = Parameter(np.array(model_frame.get_pixel(sky_coord), dtype=float),
-                           name="center", step=3e-2)
-        morphology = PointSourceMorphology(model_frame, center)
-        spectrum = init.get_pixel_spectrum(sky_coord, observations, correct_psf=True)
-        spectrum = TabulatedSpectrum(model_frame, spectrum, min_step=_noise_rms(observations))
-        super().__init__(model_frame, spectrum, morphology)
+        observations = _as_sequence(observations)
+        position = np.array(model_frame.get_pixel(sky_coord), dtype=float)
+        morphology = PointSourceMorphology(
+            model_frame, Parameter(position, name="center", step=3e-2))
+        amplitudes = init.get_pixel_spectrum(sky_coord, observations, correct_psf=True)
+        super().__init__(
+            model_frame,
+            TabulatedSpectrum(model_frame, amplitudes, min_step=_noise_rms(observations)),
+            morphology)
         self.center = morphology.center
 
 
@@ -46,34 +69,32 @@ class CompactExtendedSource(FactorizedComponent):
 
     def __init__(self, model_frame, sky_coord, observations, shifting=False, resizing=True,
                  boxsize=None):
-        if not hasattr(observations, "__iter__"):
-            observations = (observations,)
         assert model_frame.psf is not None
-        morph, bbox = self.init_morph(model_frame, sky_coord, boxsize=boxsize)
-        center = model_frame.get_pixel(sky_coord)
-        morphology = ExtendedSourceMorphology(model_frame, center, morph, bbox=bbox,
-                                              monotonic="angle", symmetric=False, min_grad=0,
-                                              shifting=shifting, resizing=resizing)
-        spectrum = init.get_pixel_spectrum(sky_coord, observations, correct_psf=True)
-        spectrum /= morph.sum()
-        spectrum = TabulatedSpectrum(model_frame, spectrum, min_step=_noise_rms(observations))
-        super().__init__(model_frame, spectrum, morphology)
+        observations = _as_sequence(observations)
+        image, bbox = self.init_morph(model_frame, sky_coord, boxsize=boxsize)
+        morphology = _fitted_morphology(model_frame, sky_coord, image, bbox, shifting, resizing)
+        # the PSF-corrected peak amplitude belongs to a unit-sum profile; the
+        # morphology is peak-normalised instead
+        amplitudes = init.get_pixel_spectrum(sky_coord, observations, correct_psf=True)
+        amplitudes /= image.sum()
+        super().__init__(
+            model_frame,
+            TabulatedSpectrum(model_frame, amplitudes, min_step=_noise_rms(observations)),
+            morphology)
         self.center = morphology.center
 
     @staticmethod
     def init_morph(frame, sky_coord, boxsize=None):
         """Band-averaged model PSF, peak-normalised, in a standard-size box."""
-        ci = np.round(frame.get_pixel(sky_coord)).astype("int")
+        pixel = _nearest_pixel(frame, sky_coord)
         psf = frame.psf.get_model().mean(axis=0)
-        psf_box = Box(psf.shape, origin=(ci[0] - psf.shape[0] // 2, ci[1] - psf.shape[1] // 2))
-        if boxsize is None:
-            boxsize = init.get_minimal_boxsize(max(psf.shape))
-        morph = np.zeros((boxsize, boxsize))
-        bbox = Box(morph.shape, origin=(ci[0] - boxsize // 2, ci[1] - boxsize // 2))
-        dst, src = overlapped_slices(bbox, psf_box)
-        morph[dst] = psf[src]
-        morph /= morph.max()
-        return morph, bbox
+        side = init.get_minimal_boxsize(max(psf.shape)) if boxsize is None else boxsize
+        bbox = _box_around(pixel, (side, side))
+        into, out_of = overlapped_slices(bbox, _box_around(pixel, psf.shape))
+        image = np.zeros(bbox.shape)
+        image[into] = psf[out_of]
+        image /= image.max()
+        return image, bbox
 
 
 class SingleExtendedSource(FactorizedComponent):
@@ -82,48 +103,46 @@ class SingleExtendedSource(FactorizedComponent):
 
     def __init__(self, model_frame, sky_coord, observations, thresh=1.0, shifting=False,
                  resizing=True, boxsize=None):
-        if not hasattr(observations, "__iter__"):
-            observations = (observations,)
-        spectra = init.get_pixel_spectrum(sky_coord, observations, concat=False)
-        spectrum = TabulatedSpectrum(model_frame, np.concatenate(spectra).reshape(-1),
+        observations = _as_sequence(observations)
+        per_obs = init.get_pixel_spectrum(sky_coord, observations, concat=False)
+        spectrum = TabulatedSpectrum(model_frame, np.concatenate(per_obs).reshape(-1),
                                      min_step=_noise_rms(observations))
-        image, std = init.build_initialization_image(observations, spectra=spectra)
-        morph, bbox = self.init_morph(model_frame, sky_coord, image, std, thresh=thresh,
+        coadd, coadd_rms = init.build_initialization_image(observations, spectra=per_obs)
+        image, bbox = self.init_morph(model_frame, sky_coord, coadd, coadd_rms, thresh=thresh,
                                       symmetric=True, monotonic="flat", min_grad=0,
                                       boxsize=boxsize)
-        center = model_frame.get_pixel(sky_coord)
-        morphology = ExtendedSourceMorphology(model_frame, center, morph, bbox=bbox,
-                                              monotonic="angle", symmetric=False, min_grad=0,
-                                              shifting=shifting, resizing=resizing)
+        morphology = _fitted_morphology(model_frame, sky_coord, image, bbox, shifting, resizing)
         super().__init__(model_frame, spectrum, morphology)
         self.center = morphology.center
 
     @staticmethod
     def init_morph(frame, sky_coord, detect, detect_std, thresh=1, symmetric=True,
                    monotonic="flat", min_grad=0, boxsize=None):
-        """Symmetric, monotonic cut-out of the detection image around the source."""
-        ci = np.round(frame.get_pixel(sky_coord)).astype("int")
-        im = detect.copy()
+        """Cut-out of the detection image around the source: symmetrised and made
+        monotonic about the nearest pixel, trimmed at ``thresh * detect_std``,
+        peak-normalised and never narrower than the model PSF."""
+        pixel = _nearest_pixel(frame, sky_coord)
+        profile = detect.copy()
         if symmetric:
-            im = operator.prox_uncentered_symmetry(im, 0, center=ci, algorithm="sdss")
+            profile = operator.prox_uncentered_symmetry(profile, 0, center=pixel, algorithm="sdss")
         if monotonic:
-            if monotonic is True:
-                monotonic = "angle"
-            prox = operator.prox_weighted_monotonic(im.shape, neighbor_weight=monotonic,
-                                                    center=ci, min_gradient=min_grad)
-            im = prox(np.ascontiguousarray(im), 0).reshape(im.shape)
-        morph, bbox = init.trim_morphology(ci, im, bg_thresh=detect_std * thresh, boxsize=boxsize)
-        if morph.sum() > 0:
-            morph /= morph.max()
+            weights = "angle" if monotonic is True else monotonic
+            sweep = operator.prox_weighted_monotonic(profile.shape, neighbor_weight=weights,
+                                                     center=pixel, min_gradient=min_grad)
+            profile = sweep(np.ascontiguousarray(profile), 0).reshape(profile.shape)
+        image, bbox = init.trim_morphology(pixel, profile, bg_thresh=detect_std * thresh,
+                                           boxsize=boxsize)
+        if image.sum() > 0:
+            image /= image.max()
         else:
+            # nothing above the threshold: a single lit pixel at the centre
             logger.warning(f"No flux in morphology model for source at {sky_coord}")
-            morph = CenterOnConstraint(tiny=1)(morph, 0)
+            image = CenterOnConstraint(tiny=1)(image, 0)
         if frame.psf is not None:
             # noisy initialisations leave a few pixels only: never narrower than the PSF
-            psf_morph, _ = CompactExtendedSource.init_morph(frame, sky_coord,
-                                                            boxsize=max(bbox.shape))
-            morph = np.maximum(morph, psf_morph)
-        return morph, bbox
+            floor, _ = CompactExtendedSource.init_morph(frame, sky_coord, boxsize=max(bbox.shape))
+            image = np.maximum(image, floor)
+        return image, bbox
 
 
 class MultiExtendedSource(CombinedComponent):
@@ -132,25 +151,25 @@ class MultiExtendedSource(CombinedComponent):
 
     def __init__(self, model_frame, sky_coord, observations, K=2, flux_percentiles=None,
                  thresh=1.0, shifting=False, resizing=True, boxsize=None):
-        if flux_percentiles is None:
-            flux_percentiles = (25,)
+        flux_percentiles = (25,) if flux_percentiles is None else flux_percentiles
         assert K == len(flux_percentiles) + 1
-        if not hasattr(observations, "__iter__"):
-            observations = (observations,)
-        base = ExtendedSource(model_frame, sky_coord, observations, thresh=thresh, boxsize=boxsize)
-        spectrum, morphology = base.children
-        spectrum = spectrum.get_parameter(0)._data
-        morphs, boxes = self.init_morphs(morphology, flux_percentiles)
-        center = model_frame.get_pixel(sky_coord)
-        noise_rms = _noise_rms(observations)
+        observations = _as_sequence(observations)
+        single = ExtendedSource(model_frame, sky_coord, observations, thresh=thresh,
+                                boxsize=boxsize)
+        single_spectrum, single_morphology = single.children
+        amplitudes = single_spectrum.get_parameter(0)._data
+        layers, boxes = self.init_morphs(single_morphology, flux_percentiles)
+        # every layer starts from the full spectrum, with ten times finer steps
+        min_step = _noise_rms(observations) / 10
         components = []
-        for k in range(K):
-            spec = TabulatedSpectrum(model_frame, spectrum.copy(), min_step=noise_rms / 10)
-            morph = ExtendedSourceMorphology(model_frame, center, morphs[k], bbox=boxes[k],
-                                             monotonic="angle", symmetric=False, min_grad=0,
-                                             shifting=shifting, resizing=resizing)
-            self.center = morph.center
-            components.append(FactorizedComponent(model_frame, spec, morph))
+        for layer, bbox in zip(layers, boxes):
+            morphology = _fitted_morphology(model_frame, sky_coord, layer, bbox, shifting,
+                                            resizing)
+            components.append(FactorizedComponent(
+                model_frame,
+                TabulatedSpectrum(model_frame, amplitudes.copy(), min_step=min_step),
+                morphology))
+            self.center = morphology.center
         super().__init__(components)
 
     @staticmethod
