@@ -334,6 +334,18 @@ int smi_resampler_create(const float *A, const float *Pt, int32_t C, int32_t n_a
 int smi_resampler_render(smi_resampler *r, const float *model, float *out);
 int smi_resampler_destroy(smi_resampler *r);
 
+/* The low-resolution observation as a further term of a fit (Blend._loss_func sums the
+ * log-likelihoods of all observations, blend.py:265-271; Observation.get_log_likelihood,
+ * observation.py:147-170).  `channels[C]` gives the model channel of every band of the
+ * resampler, `data` / `weights` are [C][n_a][n_b], `log_norm` is Observation.log_norm of
+ * that observation.  From then on every iteration renders the model cube through `r`,
+ * adds log_norm + chi^2 / 2 to the loss and the transposed operator applied to
+ * w (m - d) to the gradient image.  Batches of one blend only; `r` must outlive `b`. */
+int smi_batch_attach_lowres(smi_batch *b, smi_resampler *r, const int32_t *channels,
+                            const float *data, const float *weights, double log_norm);
+/* rendering [C][n_a][n_b] of the last forward / gradient / step call */
+int smi_batch_get_lowres_rendered(smi_batch *b, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -231,7 +231,10 @@ def resize_component(c):
 
 class Scene:
     def __init__(self, frame_shape, data, weights, kernel, components, dtype=np.float32,
-                 psf_shift=None):
+                 psf_shift=None, extra_observations=()):
+        # further observations of the same model (blend.py:265-271 sums their
+        # log-likelihoods), e.g. oracle.resample.LowResObservation
+        self.extra_observations = list(extra_observations)
         # ConvolutionRenderer(psf_shift=...) (renderer.py:175-177, 215-228): a free
         # sub-pixel shift of the difference kernel, step 1e-2, no constraint
         self.psf_shift = None if psf_shift is None else np.array(psf_shift, dtype=np.float64)
@@ -376,8 +379,12 @@ class Scene:
         model = self.get_model()
         rendered = self.render(model)
         loss = -self.log_likelihood(rendered)
-        self.loss.append(loss)
         G = self.model_gradient(rendered)
+        for obs in self.extra_observations:
+            term, upstream = obs.neg_log_likelihood(model)
+            loss = loss + term
+            G = G + obs.adjoint(upstream, self.frame_shape[0])
+        self.loss.append(loss)
         if self.psf_shift is not None:
             self.g_psf_shift = self.psf_shift_gradient(model, rendered)
         return loss, self.parameter_gradients(G)

@@ -354,6 +354,27 @@ class BlendBatch:
         loss = np.ascontiguousarray(np.broadcast_to(loss, (self.n_blends,)), dtype=np.float64)
         _lib.check(self._lib.smi_batch_set_previous_loss(self._h, _lib.ptr(loss, ctypes.c_double)))
 
+    def attach_lowres(self, resampler, channels, data, weights, log_norm):
+        """Add a second observation of the (single) blend on a coarser pixel grid as a
+        term of the loss and of the gradient.  ``resampler`` is the handle of a
+        ``ResolutionRenderer``'s device operators (``smi_resampler``), ``channels`` the
+        model channel of each of its bands, ``data`` / ``weights`` (C, n_a, n_b),
+        ``log_norm`` the observation's ``log_norm``."""
+        channels = np.ascontiguousarray(channels, dtype=np.int32)
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+        assert data.shape == weights.shape and data.shape[0] == len(channels)
+        self._lowres_shape = data.shape
+        _lib.check(self._lib.smi_batch_attach_lowres(
+            self._h, resampler, _lib.ptr(channels, ctypes.c_int32),
+            _lib.ptr(data, ctypes.c_float), _lib.ptr(weights, ctypes.c_float), float(log_norm)))
+
+    def lowres_rendered(self):
+        """Low-resolution rendering of the last forward / gradient / step call."""
+        out = np.empty(self._lowres_shape, dtype=np.float32)
+        _lib.check(self._lib.smi_batch_get_lowres_rendered(self._h, _lib.ptr(out, ctypes.c_float)))
+        return out
+
     def reset(self):
         _lib.check(self._lib.smi_batch_reset(self._h))
 

@@ -22,7 +22,7 @@ from .model import UpdateException
 from .morphology import PointSourceMorphology
 from .psf import GaussianPSF
 from .parameter import relative_step
-from .renderer import ConvolutionRenderer, NullRenderer
+from .renderer import ConvolutionRenderer, NullRenderer, ResolutionRenderer
 
 logger = logging.getLogger("scarlet_amd.blend")
 
@@ -85,19 +85,36 @@ class Blend(CombinedComponent):
         data = np.zeros(self.frame.shape, dtype=np.float32)
         weights = np.zeros(self.frame.shape, dtype=np.float32)
         kernels, covered = [None] * C, np.zeros(C, dtype=int)
+        self._lowres = None
         for obs in self.observations:
             r = obs.renderer
+            idx = [channels.index(c) for c in obs.channels]
+            covered[idx] += 1
+            if type(r) is ResolutionRenderer:
+                # coarser pixel grid: its own term of the loss (smi_batch_attach_lowres);
+                # in the merged cube its channels carry zero weight
+                if self._lowres is not None:
+                    raise NotImplementedError("more than one ResolutionRenderer observation")
+                self._lowres = (obs, idx)
+                continue
             if type(r) not in (NullRenderer, ConvolutionRenderer):
                 raise NotImplementedError(
                     "renderer {} cannot run on the device".format(type(r).__name__))
-            if tuple(obs.shape[1:]) != spatial:
-                raise NotImplementedError("observations must cover the model frame spatially")
             if any(not p.fixed for p in obs.parameters):
                 raise NotImplementedError("free renderer parameters with several observations")
-            idx = [channels.index(c) for c in obs.channels]
-            covered[idx] += 1
-            data[idx] = obs.data
-            weights[idx] = obs.weights
+            if tuple(obs.shape[1:]) == spatial:
+                data[idx] = obs.data
+                weights[idx] = obs.weights
+            else:
+                # the observation covers a part of the frame (renderer.py:130-161,
+                # match_shape): zero weight everywhere else
+                data_sl, model_sl = r.slices
+                if tuple(obs.data[data_sl].shape[1:]) != tuple(
+                        data[(slice(None),) + tuple(model_sl[1:])].shape[1:]):
+                    raise NotImplementedError("observation and model frame overlap differently")
+                for j, c in enumerate(idx):
+                    data[c][tuple(model_sl[1:])] = obs.data[j][tuple(data_sl[1:])]
+                    weights[c][tuple(model_sl[1:])] = obs.weights[j][tuple(data_sl[1:])]
             if isinstance(r, ConvolutionRenderer):
                 k = np.asarray(r.kernel_image(), dtype=np.float32)
                 for j, c in enumerate(idx):
@@ -199,6 +216,10 @@ class Blend(CombinedComponent):
         data, weights, kernel = self._observation()
         batch = BlendBatch(data[None], weights[None], [self._specs(comps)], kernel=kernel,
                            max_iter=max(capacity, 1))
+        if self._lowres is not None:
+            obs, idx = self._lowres
+            _, handle, _ = obs.renderer._resampler()
+            batch.attach_lowres(handle, idx, obs.data, obs.weights, obs.log_norm)
         self._upload_state(batch, comps)
         return batch
 
@@ -512,6 +533,9 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
             # of the whole loss history after a restart (blend.py:101, 198)
             self.blend, self.base, self.local, self.result = blend, 0, 0, None
             self.obs = blend._observation()
+            if blend._lowres is not None:
+                raise NotImplementedError(
+                    "fit_blends: blends with a ResolutionRenderer observation fit one by one")
 
         @property
         def total(self):

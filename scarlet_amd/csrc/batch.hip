@@ -119,6 +119,7 @@ struct smi_batch {
     float *scratch = nullptr;  // update-kernel state of boxes too large for the LDS
     int64_t n_morph = 0;
     bool have_components = false, have_obs = false, have_kernel = false;
+    smi::LowRes *lowres = nullptr;  // further observation on a coarser grid (one blend)
     // per blend
     int32_t *state = nullptr, *zero_state = nullptr, *n_loss = nullptr, *status_out = nullptr;
     double *loss_hist = nullptr, *last_loss = nullptr, *loss_partial = nullptr;
@@ -203,6 +204,7 @@ void refresh_view(smi_batch *b) {
     v.lite = b->scheme == SMI_SCHEME_FISTA || b->lite_flags;
     v.c_fista_step = b->c_fista_step;
     v.fista_t = b->fista_t;
+    v.extra_term = b->lowres ? lowres_term(b->lowres) : nullptr;
     for (const auto &pl : b->plans)
         if (!pl.slots) v.fast_plans = 0;
 }
@@ -404,6 +406,33 @@ int smi_resampler_render(smi_resampler *r, const float *model, float *out) {
     return resampler_render(r->impl, model, out);
 }
 
+int smi_batch_attach_lowres(smi_batch *b, smi_resampler *r, const int32_t *channels,
+                            const float *data, const float *weights, double log_norm) {
+    SMI_REQUIRE(b && r && channels && data && weights, "null argument");
+    SMI_REQUIRE(b->d.n_blends == 1, "a low-resolution observation needs a batch of one blend");
+    SMI_HIP(hipSetDevice(b->device));
+    if (b->lowres) {
+        lowres_destroy(b->lowres);
+        b->lowres = nullptr;
+    }
+    SMI_REQUIRE(r->impl, "resampler already destroyed");
+    int rc = lowres_create(r->impl, channels, data, weights, log_norm, b->d.H, b->d.W,
+                           &b->lowres);
+    if (rc) {
+        lowres_destroy(b->lowres);
+        b->lowres = nullptr;
+        return rc;
+    }
+    refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_get_lowres_rendered(smi_batch *b, float *out) {
+    SMI_REQUIRE(b && out, "null argument");
+    SMI_REQUIRE(b->lowres, "no low-resolution observation attached");
+    return lowres_get_rendered(b->lowres, out, b->stream);
+}
+
 int smi_resampler_destroy(smi_resampler *r) {
     if (!r) return SMI_OK;
     resampler_destroy(r->impl);
@@ -579,6 +608,7 @@ int smi_batch_destroy(smi_batch *b) {
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto e : b->events) (void)hipEventDestroy(e);
+    lowres_destroy(b->lowres);
     delete b;
     return SMI_OK;
 }
@@ -1132,6 +1162,7 @@ int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL)
     const int nb = v.nb, C = v.C, H = v.H, W = v.W;
     const size_t n_out = (size_t)nb * C * H * W;
     launch_render(v, b->P, b->stream);
+    if (b->lowres && (rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 0, b->stream))) return rc;
     float *tmp = nullptr;
     if (model || rendered) SMI_HIP(dev_alloc(&tmp, n_out));
     if (model) {
@@ -1160,11 +1191,15 @@ int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL)
                                hipMemcpyDeviceToHost, b->stream));
         SMI_HIP(hipMemcpyAsync(ln.data(), b->log_norm, nb * sizeof(double), hipMemcpyDeviceToHost,
                                b->stream));
+        double extra = 0.0;
+        if (b->lowres)
+            SMI_HIP(hipMemcpyAsync(&extra, lowres_term(b->lowres), sizeof(double),
+                                   hipMemcpyDeviceToHost, b->stream));
         SMI_HIP(hipStreamSynchronize(b->stream));
         for (int i = 0; i < nb; ++i) {
             double t = 0.0;
             for (int j = 0; j < v.n_partial; ++j) t += part[(size_t)i * v.n_partial + j];
-            logL[i] = -(ln[i] + 0.5 * t);
+            logL[i] = -(ln[i] + 0.5 * t + extra);
         }
     }
     SMI_HIP(hipGetLastError());
@@ -1176,15 +1211,22 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     if (rc) return rc;
     const BatchView v = unmasked_view(b);
     if (b->fused) {
+        if (b->lowres) {
+            launch_render(v, b->P, b->stream);
+            if ((rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 1, b->stream))) return rc;
+        }
         if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
                                     b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
             return rc;
     } else {
         launch_render(v, b->P, b->stream);
+        if (b->lowres && (rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 1, b->stream)))
+            return rc;
         if ((rc = convolve(b, v, 0))) return rc;
         launch_residual(v, b->Q, b->P, b->stream);
         if ((rc = convolve(b, v, 1))) return rc;
     }
+    if (b->lowres) lowres_add_gradient(b->lowres, b->Q, b->Py, b->Px, b->stream);
     if ((rc = launch_update(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_morph, 1, b->stream))) return rc;
     if ((rc = launch_point_sources(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_center, 1, b->stream)))
         return rc;
@@ -1221,6 +1263,11 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
         hipEvent_t *ev = timing ? &b->events[(size_t)i * 6] : nullptr;
         if (ev) SMI_HIP(hipEventRecord(ev[0], b->stream));
         if (b->fused) {
+            if (b->lowres) {
+                // the model cube itself is needed for the low-resolution observation
+                launch_render(v, b->P, b->stream);
+                if ((rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 1, b->stream))) return rc;
+            }
             // render + conv + residual/loss + conv^T in one LDS-resident kernel
             if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
             if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
@@ -1232,6 +1279,8 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
             if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
         } else {
             launch_render(v, b->P, b->stream);
+            if (b->lowres && (rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 1, b->stream)))
+                return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
             if ((rc = convolve(b, v, 0))) return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
@@ -1241,6 +1290,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
             if ((rc = convolve(b, v, 1))) return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
         }
+        if (b->lowres) lowres_add_gradient(b->lowres, b->Q, b->Py, b->Px, b->stream);
         if ((rc = launch_shift_backward(v, b->Q, it, nullptr, 0, b->stream))) return rc;
         if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, b->stream)))
             return rc;

@@ -134,6 +134,8 @@ struct BatchView {
     int32_t scheme;              // SMI_SCHEME_*; FISTA keeps z in m_sed / m_morph
     const float *c_fista_step;
     double *fista_t;             // [n_comp][2]
+    // a further observation of blend 0 (resample.hip): log_norm + chi^2 / 2 of that term
+    const double *extra_term;
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);
@@ -171,6 +173,14 @@ int resampler_create(const float *A, const float *Pt, int C, int n_a, int n_b, i
                      Resampler **out);
 int resampler_render(Resampler *r, const float *model, float *out);
 void resampler_destroy(Resampler *r);
+struct LowRes;
+int lowres_create(Resampler *r, const int32_t *channels, const float *data, const float *weights,
+                  double log_norm, int H, int W, LowRes **out);
+void lowres_destroy(LowRes *l);
+int lowres_evaluate(LowRes *l, const float *P, int Py, int Px, int backward, hipStream_t s);
+void lowres_add_gradient(LowRes *l, float *Q, int Py, int Px, hipStream_t s);
+const double *lowres_term(const LowRes *l);
+int lowres_get_rendered(LowRes *l, float *out, hipStream_t s);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);
 void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,

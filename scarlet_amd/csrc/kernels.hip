@@ -142,7 +142,8 @@ __global__ __launch_bounds__(64) void finalize_kernel(BatchView v, int it, float
         t += v.loss_partial[(int64_t)b * v.n_partial + i];
     t = wave_sum(t);
     if (threadIdx.x == 0) {
-        const double loss = v.log_norm[b] + 0.5 * t;
+        double loss = v.log_norm[b] + 0.5 * t;
+        if (v.extra_term) loss += v.extra_term[0];
         const int n = v.n_loss[b];
         const double prev = v.last_loss[b];
         if (n < v.hist_cap) v.loss_hist[(int64_t)b * v.hist_cap + n] = loss;

@@ -9,6 +9,8 @@ from numpy.testing import assert_allclose
 
 from conftest import hsc_scene
 
+RTOL = 1e-5  # north_star: 1e-5 relative in float32
+
 pytestmark = pytest.mark.gpu
 
 
@@ -573,3 +575,130 @@ def test_multiresolution_render_matches_the_reference():
         assert np.abs(rendered - ref).max() < 1e-5 * np.abs(ref).max(), tag
         assert sdr(rendered, g["image_%d" % j]) > 10
     print("largest deviation from the reference rendering: %.2e of the peak" % worst)
+
+
+def _lowres_operators(lowres):
+    """Dense device operators from the ORACLE's matrices (independent of the facade's
+    set-up): A [C][n_a][Fy Fx], Pt [Fx][Fx n_b]."""
+    C, n_a = lowres.op.shape[:2]
+    A = lowres.op.reshape(C, n_a, -1)
+    n_b, Fx, _ = lowres.Mx.shape
+    Pt = lowres.Mx.transpose(2, 1, 0).reshape(Fx, Fx * n_b)  # [x'][(x, b)]
+    return np.ascontiguousarray(A, dtype=np.float32), np.ascontiguousarray(Pt, dtype=np.float32)
+
+
+def test_lowres_term_on_the_device_matches_the_oracle():
+    """smi_batch_attach_lowres: loss, low-resolution rendering and gradients of a blend
+    with a second observation on a coarser grid, against the oracle (which is pinned to
+    the reference's float64 evaluation and finite differences, CPU suite); then 25
+    iterations of the loop against the oracle's trajectory."""
+    import ctypes
+
+    from conftest import golden
+    from multires_scene import build
+    from scarlet_amd import _lib
+    from scarlet_amd.batch import BlendBatch, ComponentSpec
+
+    g = golden("multires_fit")
+    scene, lowres, c_hr, _ = build(g)
+    lib = _lib.load()
+    A, Pt = _lowres_operators(lowres)
+    handle = ctypes.c_void_p()
+    _lib.check(lib.smi_resampler_create(
+        _lib.ptr(A, ctypes.c_float), _lib.ptr(Pt, ctypes.c_float), lowres.C, A.shape[1],
+        lowres.Mx.shape[0], lowres.Fy, lowres.Fx, ctypes.byref(handle)))
+    try:
+        for conv_path in ("auto", "rocfft"):
+            scene, lowres, c_hr, _ = build(g)
+            specs = [ComponentSpec(c.sed, c.morph, c.origin, sed_min_step=0.0)
+                     for c in scene.components]
+            batch = BlendBatch(scene.data[None], scene.weights[None], [specs],
+                               kernel=scene.kernel, max_iter=30, conv_path=conv_path)
+            batch.attach_lowres(handle, lowres.channels, lowres.data, lowres.weights,
+                                lowres.log_norm)
+            try:
+                model, rendered, logL = batch.forward()
+                loss, grads = scene.loss_and_gradients()
+                assert abs(-logL[0] - loss) < 2e-6 * abs(loss), conv_path
+                ref_lr = lowres.render(scene.get_model())
+                assert np.abs(batch.lowres_rendered() - ref_lr).max() < 1e-5 * np.abs(ref_lr).max()
+                g_sed, g_morph = batch.gradient()
+                for k, (r_sed, r_morph) in enumerate(grads):
+                    assert np.abs(g_sed[k] - r_sed).max() < RTOL * np.abs(r_sed).max(), (conv_path, k)
+                    assert np.abs(g_morph[k] - r_morph).max() < 2 * RTOL * np.abs(r_morph).max()
+                # the term matters: without it the gradient is a different one
+                scene.extra_observations = []
+                _, without = scene.loss_and_gradients()
+                assert np.abs(without[0][0] - grads[0][0]).max() > 0.1 * np.abs(grads[0][0]).max()
+                scene.extra_observations = [lowres]
+                scene.loss = []
+                # the loop
+                batch.fit(max_iter=25, e_rel=1e-9)
+                n_ref, _ = scene.fit(25, e_rel=1e-9)
+                hist = batch.loss_history()[0]
+                assert len(hist) == n_ref == 25
+                shift = lowres.log_norm + scene.log_norm
+                assert_allclose(hist - shift, np.array(scene.loss) - shift, rtol=5e-4)
+                assert hist[-1] < hist[0]
+                seds, morphs = batch.parameters()
+                for k, c in enumerate(scene.components):
+                    assert np.abs(seds[k] - c.sed).max() < 1e-3 * np.abs(c.sed).max()
+                    assert np.abs(morphs[k] - c.morph).max() < 2e-3
+            finally:
+                batch.close()
+    finally:
+        lib.smi_resampler_destroy(handle)
+
+
+def test_blend_fit_with_two_resolutions():
+    """The multi-resolution tutorial's shape of problem through the facade: a
+    high-resolution and a low-resolution Observation with their own WCS and PSF,
+    Frame.from_observations, sources, Blend.fit.  Loss history and parameters follow the
+    oracle, whose low-resolution operator is built from the REFERENCE's set-up quantities
+    (golden), so the facade's own WCS / PSF-interpolation set-up is part of what is
+    checked."""
+    import scarlet_amd as scarlet
+    from conftest import golden
+    from multires_scene import build
+
+    g = golden("multires_fit")
+    gm = golden("multiresolution")
+    i_hr, i_lr = int(g["i_hr"]), int(g["i_lr"])
+
+    def wcs(k):
+        w = scarlet.LinearWCS(gm["crpix_%d" % k], gm["crval_%d" % k], gm["pc_%d" % k],
+                              gm["cdelt_%d" % k])
+        w.array_shape = gm["crpix_%d" % k] * 2
+        return w
+
+    obs_hr = scarlet.Observation(g["data_hr"].astype(np.float32), wcs=wcs(i_hr),
+                                 psf=scarlet.ImagePSF(gm["psf_%d" % i_hr]), channels=["hr"],
+                                 weights=g["weights_hr"].astype(np.float32))
+    obs_lr = scarlet.Observation(g["data_lr"].astype(np.float32), wcs=wcs(i_lr),
+                                 psf=scarlet.ImagePSF(gm["psf_%d" % i_lr]), channels=["lr"],
+                                 weights=g["weights_lr"].astype(np.float32))
+    observations = [obs_lr, obs_hr]
+    frame = scarlet.Frame.from_observations(observations, obs_id=1, coverage="union")
+    assert tuple(frame.shape) == tuple(g["frame_shape"])
+    assert list(frame.channels) == [str(c) for c in g["channels"]]
+    sources = []
+    for k in range(int(g["n_components"])):
+        oy, ox = (int(v) for v in g["origin_%d" % k])
+        spectrum = scarlet.TabulatedSpectrum(frame, g["sed_%d" % k].astype(np.float32))
+        morphology = scarlet.ExtendedSourceMorphology(
+            frame, (oy + 7, ox + 7), g["morph_%d" % k].copy(),
+            bbox=scarlet.Box((15, 15), origin=(oy, ox)), resizing=False)
+        sources.append(scarlet.FactorizedComponent(frame, spectrum, morphology))
+    blend = scarlet.Blend(sources, observations)
+    n, logL = blend.fit(20, e_rel=1e-9)
+
+    scene, lowres, _, _ = build(g)
+    n_ref, logL_ref = scene.fit(20, e_rel=1e-9)
+    assert n == n_ref == 20
+    shift = lowres.log_norm + scene.log_norm
+    assert_allclose(np.array(blend.loss) - shift, np.array(scene.loss) - shift, rtol=1e-3)
+    assert abs(logL - logL_ref) < 1e-4 * abs(logL_ref)
+    for src, c in zip(sources, scene.components):
+        sed = np.asarray(src.children[0].parameters[0])
+        assert np.abs(sed - c.sed).max() < 2e-3 * np.abs(c.sed).max()
+        assert src.children[1].parameters[0].m is not None

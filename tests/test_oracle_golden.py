@@ -385,3 +385,36 @@ def test_fit_increases_likelihood(hsc):
     assert -sc.loss[-1] > -sc.loss[0]
     for c in sc.components:
         assert c.morph.max() == 1.0 and c.morph.min() >= 0 and np.all(c.sed > 0)
+
+
+def test_multiresolution_fit_term_golden():
+    """Two observations, one on a coarser grid (ResolutionRenderer): the oracle's
+    restatement of the per-call path (oracle/resample.py) against the reference's own
+    float64 evaluation -- model, both renderings, both log-likelihoods -- and its analytic
+    gradient against central finite differences of the reference's total -logL."""
+    from multires_scene import build
+
+    g = golden("multires_fit")
+    scene, lowres, c_hr, ((dy0, dy1), (dx0, dx1), (my0, my1), (mx0, mx1)) = build(g)
+    model = scene.get_model()
+    assert_allclose(model, g["model"], rtol=0, atol=1e-12 * np.abs(g["model"]).max())
+    peak_lr = np.abs(g["rendered_lr"]).max()
+    assert_allclose(lowres.render(model), g["rendered_lr"], rtol=0, atol=1e-12 * peak_lr)
+    rendered = scene.render(model)
+    assert_allclose(rendered[c_hr, my0:my1, mx0:mx1], g["rendered_hr"][0, dy0:dy1, dx0:dx1],
+                    rtol=0, atol=1e-12 * np.abs(g["rendered_hr"]).max())
+    assert_allclose(lowres.log_norm, g["log_norm_lr"], rtol=1e-13)
+    term, _ = lowres.neg_log_likelihood(model)
+    assert_allclose(-term, g["logL_lr"], rtol=1e-12)
+    loss, grads = scene.loss_and_gradients()
+    assert_allclose(-loss, g["logL_hr"] + g["logL_lr"], rtol=1e-12)
+    # adjoint identity <R m, u> = <m, R^T u>
+    rng = np.random.default_rng(5)
+    m = rng.normal(size=model.shape)
+    u = rng.normal(size=g["rendered_lr"].shape)
+    assert_allclose(np.sum(lowres.render(m) * u), np.sum(m * lowres.adjoint(u, model.shape[0])),
+                    rtol=1e-11)
+    for k, (g_sed, g_morph) in enumerate(grads):
+        fd_sed, fd_morph = g["fd_%d" % (3 * k)], g["fd_%d" % (3 * k + 1)]
+        assert np.abs(g_sed - fd_sed).max() < 1e-7 * np.abs(fd_sed).max()
+        assert np.abs(g_morph - fd_morph).max() < 1e-6 * np.abs(fd_morph).max()
