@@ -13,38 +13,14 @@ PSFs and the linear part of every WCS) in tests/golden/multiresolution.npz.
 """
 import os
 import sys
-import tempfile
-import types
 
 import numpy as np
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import conda_reference  # noqa: E402
 
-# NumPy aliases the reference still uses
-for name, target in (("asscalar", "asarray"), ("alen", "asarray"), ("msort", "sort"),
-                     ("sometrue", "any"), ("alltrue", "all"), ("product", "prod"),
-                     ("cumproduct", "cumprod"), ("round_", "round"), ("asfarray", "asarray")):
-    if not hasattr(np, name):
-        setattr(np, name, getattr(np, target))
-for name, t in (("float", float), ("int", int), ("bool", bool), ("object", object),
-                ("complex", complex), ("str", str)):
-    if name not in np.__dict__:
-        setattr(np, name, t)
-
-# only the autograd / proxmin shims: astropy must be the real one
-shim_dir = tempfile.mkdtemp()
-for pkg in ("autograd", "proxmin"):
-    os.symlink(os.path.join(HERE, "shims", pkg), os.path.join(shim_dir, pkg))
-sys.path[:0] = [shim_dir, REPO, "/root/reference"]
-for modname in ("scarlet.operators_pybind11", "scarlet.detect_pybind11"):
-    sys.modules[modname] = types.ModuleType(modname)
-for f in ("prox_weighted_monotonic", "apply_filter", "get_valid_monotonic_pixels",
-          "linear_interpolate_invalid_pixels"):
-    setattr(sys.modules["scarlet.operators_pybind11"], f, None)
-for f in ("get_footprints", "get_connected_pixels", "get_connected_multipeak"):
-    setattr(sys.modules["scarlet.detect_pybind11"], f, None)
-import scarlet  # noqa: E402
+scarlet = conda_reference.load()
+REPO = conda_reference.REPO
 
 d = np.load("/root/reference/data/test_resampling/Multiresolution_tests.npz", allow_pickle=True)
 images, psfs, wcss = d["images"], d["psf"], d["wcs"]

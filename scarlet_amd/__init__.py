@@ -33,7 +33,7 @@ from .renderer import (  # noqa: F401
     ConvolutionRenderer,
     ResolutionRenderer,
 )
-from .wcs import LinearWCS  # noqa: F401
+from .wcs import LinearWCS, TanWCS  # noqa: F401
 from .spectrum import Spectrum, TabulatedSpectrum  # noqa: F401
 from .morphology import (  # noqa: F401
     Morphology,

@@ -22,12 +22,19 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <utility>
 
 #include "common.h"
 
 namespace smi {
 
 static thread_local std::string g_error;
+// rocFFT plans shared by all batches of the process: (device, Fy, Fx, transforms) -> (fwd, inv)
+static std::mutex g_plan_mutex;
+static std::map<std::tuple<int, int, int, int>, std::pair<rocfft_plan, rocfft_plan>> g_plans;
 void set_error(const std::string &msg) { g_error = msg; }
 
 static int next_fast_len(int n) {
@@ -67,6 +74,27 @@ static hipError_t dev_alloc(T **p, size_t n) {
 }  // namespace smi
 
 using namespace smi;
+
+// (forward, inverse) real 2-D plans for `count` transforms of Fy x Fx; created once per
+// process: a plan costs ~0.3 s of run-time kernel compilation and is immutable
+static int cached_plans(int device, int Fy, int Fx, int count, rocfft_plan *fwd,
+                        rocfft_plan *inv) {
+    std::lock_guard<std::mutex> guard(g_plan_mutex);
+    auto &cached = g_plans[std::make_tuple(device, Fy, Fx, count)];
+    if (!cached.first) {
+        const size_t lengths[2] = {(size_t)Fx, (size_t)Fy};
+        SMI_FFT(rocfft_plan_create(&cached.first, rocfft_placement_notinplace,
+                                   rocfft_transform_type_real_forward, rocfft_precision_single,
+                                   2, lengths, (size_t)count, nullptr));
+        SMI_FFT(rocfft_plan_create(&cached.second, rocfft_placement_notinplace,
+                                   rocfft_transform_type_real_inverse, rocfft_precision_single,
+                                   2, lengths, (size_t)count, nullptr));
+    }
+    *fwd = cached.first;
+    if (inv) *inv = cached.second;
+    return SMI_OK;
+}
+
 
 struct smi_batch {
     smi_batch_desc d{};
@@ -529,16 +557,21 @@ static int batch_create_impl(const smi_batch_desc *desc, int device, smi_batch *
         SMI_HIP(hipMemset(b->Q, 0, n_real * sizeof(float)));
     }
     if (padded) {
-        SMI_FFT(rocfft_setup());
+        {
+            // once per process: every call re-opens rocFFT's run-time kernel cache
+            std::lock_guard<std::mutex> guard(g_plan_mutex);
+            static bool rocfft_ready = false;
+            if (!rocfft_ready) {
+                SMI_FFT(rocfft_setup());
+                rocfft_ready = true;
+            }
+        }
         const size_t n_cplx = (size_t)nb * C * b->Fy * b->Fxh;
         SMI_HIP(dev_alloc(&b->S, n_cplx));
-        const size_t lengths[2] = {(size_t)b->Fx, (size_t)b->Fy};
-        SMI_FFT(rocfft_plan_create(&b->plan_fwd, rocfft_placement_notinplace,
-                                   rocfft_transform_type_real_forward, rocfft_precision_single,
-                                   2, lengths, (size_t)nb * C, nullptr));
-        SMI_FFT(rocfft_plan_create(&b->plan_inv, rocfft_placement_notinplace,
-                                   rocfft_transform_type_real_inverse, rocfft_precision_single,
-                                   2, lengths, (size_t)nb * C, nullptr));
+        {
+            const int rc_plans = cached_plans(device, b->Fy, b->Fx, nb * C, &b->plan_fwd, &b->plan_inv);
+            if (rc_plans) return rc_plans;
+        }
         size_t w1 = 0, w2 = 0;
         SMI_FFT(rocfft_plan_get_work_buffer_size(b->plan_fwd, &w1));
         SMI_FFT(rocfft_plan_get_work_buffer_size(b->plan_inv, &w2));
@@ -584,8 +617,6 @@ int smi_batch_destroy(smi_batch *b) {
     if (!b) return SMI_OK;
     (void)hipSetDevice(b->device);
     (void)hipDeviceSynchronize();
-    if (b->plan_fwd) rocfft_plan_destroy(b->plan_fwd);
-    if (b->plan_inv) rocfft_plan_destroy(b->plan_inv);
     if (b->info) rocfft_execution_info_destroy(b->info);
     for (auto &pl : b->plans) {
         (void)hipFree(pl.level_start);
@@ -805,10 +836,7 @@ int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
     launch_wrap_kernel(d_kern, d_pad, n_img, ph, pw, b->Fy, b->Fx, scale, b->stream);
     if (!b->Khat) SMI_HIP(dev_alloc(&b->Khat, n_cplx));
     rocfft_plan plan = nullptr;
-    const size_t lengths[2] = {(size_t)b->Fx, (size_t)b->Fy};
-    SMI_FFT(rocfft_plan_create(&plan, rocfft_placement_notinplace,
-                               rocfft_transform_type_real_forward, rocfft_precision_single, 2,
-                               lengths, (size_t)n_img, nullptr));
+    if ((rc = cached_plans(b->device, b->Fy, b->Fx, n_img, &plan, nullptr))) return rc;
     size_t wb = 0;
     SMI_FFT(rocfft_plan_get_work_buffer_size(plan, &wb));
     rocfft_execution_info info = nullptr;
@@ -823,7 +851,6 @@ int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
     SMI_FFT(rocfft_execute(plan, ins, outs, info));
     SMI_HIP(hipStreamSynchronize(b->stream));
     rocfft_execution_info_destroy(info);
-    rocfft_plan_destroy(plan);
     if (work) (void)hipFree(work);
     (void)hipFree(d_pad);
     (void)hipFree(d_kern);

@@ -1040,6 +1040,33 @@ __global__ __launch_bounds__(64) void sweep_kernel(T *img, int n_pix, const int3
     for (int i = lane; i < n_pix; i += 64) img[i] = buf[i];
 }
 
+// The same sweep for images beyond the LDS (initialisation runs it on the whole detection
+// image, e.g. 282 x 282 doubles): one workgroup of 1024 threads working in global memory,
+// level by level; a workgroup-scope fence + barrier makes a level's writes visible to the
+// next one (one CU, one L1).
+template <typename T>
+__global__ __launch_bounds__(1024) void sweep_global_kernel(T *image, const int32_t *level_start,
+                                                            int n_levels, int E,
+                                                            const int32_t *pix, const int32_t *cnt,
+                                                            const int32_t *nbr, const T *wt,
+                                                            T one_minus_g) {
+    volatile T *img = image;
+    for (int l = 0; l < n_levels; ++l) {
+        const int s = level_start[l], e = level_start[l + 1];
+        for (int q = s + (int)threadIdx.x; q < e; q += 1024) {
+            const int p = pix[q];
+            const int n = cnt[q];
+            T ref = 0;
+            for (int j = 0; j < n; ++j)
+                ref = add_rn(ref, mul_rn(img[nbr[(int64_t)j * E + q]], wt[(int64_t)j * E + q]));
+            const T lim = mul_rn(ref, one_minus_g);
+            if (lim < img[p]) img[p] = lim;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void apply_filter_kernel(const T *image, int H, int W,
                                                            const T *values, int n_taps,
@@ -1194,7 +1221,6 @@ struct DevBuf {
 template <typename T>
 int sweep_host_buffers(T *flat_img, int32_t n_pix, const SweepPlanHost &plan, T min_gradient) {
     const size_t lds = (size_t)n_pix * sizeof(T);
-    SMI_REQUIRE(lds <= 160 * 1024, "prox_weighted_monotonic: image does not fit the 160 KiB LDS");
     if (plan.n_entries == 0) return SMI_OK;
     DevBuf<T> d_img, d_wt;
     DevBuf<int32_t> d_ls, d_pix, d_cnt, d_nbr;
@@ -1206,13 +1232,18 @@ int sweep_host_buffers(T *flat_img, int32_t n_pix, const SweepPlanHost &plan, T 
     SMI_HIP(d_pix.upload(plan.pix.data(), plan.pix.size()));
     SMI_HIP(d_cnt.upload(plan.cnt.data(), plan.cnt.size()));
     SMI_HIP(d_nbr.upload(plan.nbr.data(), plan.nbr.size()));
-    auto kern = sweep_kernel<T>;
-    SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const T omg = (T)1 - min_gradient;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(64), lds, 0, d_img.p, n_pix, d_ls.p,
-                       (int)plan.level_start.size() - 1, plan.n_entries, d_pix.p, d_cnt.p,
-                       d_nbr.p, d_wt.p, omg);
+    const int n_levels = (int)plan.level_start.size() - 1;
+    if (lds <= 160 * 1024) {
+        auto kern = sweep_kernel<T>;
+        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64), lds, 0, d_img.p, n_pix, d_ls.p, n_levels,
+                           plan.n_entries, d_pix.p, d_cnt.p, d_nbr.p, d_wt.p, omg);
+    } else {
+        hipLaunchKernelGGL(sweep_global_kernel<T>, dim3(1), dim3(1024), 0, 0, d_img.p, d_ls.p,
+                           n_levels, plan.n_entries, d_pix.p, d_cnt.p, d_nbr.p, d_wt.p, omg);
+    }
     SMI_HIP(hipGetLastError());
     SMI_HIP(hipMemcpy(flat_img, d_img.p, (size_t)n_pix * sizeof(T), hipMemcpyDeviceToHost));
     return SMI_OK;

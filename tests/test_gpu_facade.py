@@ -702,3 +702,73 @@ def test_blend_fit_with_two_resolutions():
         sed = np.asarray(src.children[0].parameters[0])
         assert np.abs(sed - c.sed).max() < 2e-3 * np.abs(c.sed).max()
         assert src.children[1].parameters[0].m is not None
+
+
+def test_multiresolution_tutorial_scene():
+    """docs/tutorials/multiresolution.ipynb up to and including ``blend.fit``: 5-band HSC
+    cut-out + HST F814W cut-out (gnomonic WCSs whose reference pixels lie thousands of
+    pixels outside the images), ``Frame.from_observations(..., coverage="intersection",
+    model_psf=GaussianPSF(0.6))``, ``ExtendedSource`` initialisation from both
+    observations, ``set_spectra_to_match``.  Everything up to the fit is compared with
+    the reference's own run (golden); the fit must then raise the likelihood of both
+    observations.  (Source positions: bright HST peaks instead of the sep catalogue.)"""
+    import scarlet_amd as scarlet
+    from conftest import golden
+
+    g = golden("multires_tutorial")
+
+    def wcs(tag, n):
+        return scarlet.TanWCS(g["crpix_" + tag], g["crval_" + tag], g["pc_" + tag],
+                              g["cdelt_" + tag], array_shape=(n, n))
+
+    obs_hst = scarlet.Observation(g["data_hst"].copy(), wcs=wcs("hst", 250),
+                                  psf=scarlet.ImagePSF(g["psf_hst"].copy()),
+                                  channels=[str(c) for c in g["channels_hst"]], weights=None)
+    obs_hsc = scarlet.Observation(g["data_hsc"].copy(), wcs=wcs("hsc", 50),
+                                  psf=scarlet.ImagePSF(g["psf_hsc"].copy()),
+                                  channels=[str(c) for c in g["channels_hsc"]], weights=None)
+    observations = [obs_hsc, obs_hst]
+    frame = scarlet.Frame.from_observations(observations, coverage="intersection",
+                                            model_psf=scarlet.GaussianPSF(sigma=0.6))
+    assert tuple(frame.shape) == tuple(g["frame_shape"])
+    assert_allclose(frame.wcs.wcs.crpix, g["frame_crpix"])
+    assert type(obs_hsc.renderer).__name__ == str(g["hsc_renderer"])
+    assert type(obs_hst.renderer).__name__ == str(g["hst_renderer"])
+    assert list(obs_hsc.renderer._fft_shape) == list(g["hsc_fft_shape"])
+    assert np.abs(obs_hsc.renderer.shifts - g["hsc_shifts"]).max() < 1e-7
+    k = obs_hst.renderer.diff_kernel.image
+    assert np.abs(k - g["hst_kernel"]).max() < 1e-6 * np.abs(g["hst_kernel"]).max()
+
+    # the conversion pixel -> sky of the catalogue
+    ra_dec = obs_hst.get_sky_coord(g["pixel_hst"])
+    assert np.abs(ra_dec - g["ra_dec"]).max() < 1e-11
+    sources = [scarlet.ExtendedSource(frame, sky, observations, thresh=0.1) for sky in ra_dec]
+    scarlet.initialization.set_spectra_to_match(sources, observations)
+    for j, src in enumerate(sources):
+        assert tuple(src.bbox.origin) == tuple(g["origin_%d" % j]), j
+        assert tuple(src.bbox.shape) == tuple(g["shape_%d" % j]), j
+        morph = np.asarray(src.parameters[1])
+        assert np.abs(morph - g["morph_%d" % j]).max() < 2e-5, j
+        spectrum = np.asarray(src.parameters[0])
+        assert_allclose(spectrum, g["spectrum_%d" % j], rtol=2e-4)
+    blend = scarlet.Blend(sources, observations)
+    model = blend.get_model()
+    assert_allclose(model.sum(axis=(1, 2)), g["model_sum"], rtol=2e-4)
+    rendered_hsc = obs_hsc.render(model)
+    rendered_hst = obs_hst.render(model)
+    assert np.abs(rendered_hsc - g["rendered_hsc"]).max() < 3e-4 * np.abs(g["rendered_hsc"]).max()
+    assert np.abs(rendered_hst - g["rendered_hst"]).max() < 3e-4 * np.abs(g["rendered_hst"]).max()
+    logL_hsc = obs_hsc.get_log_likelihood(model)
+    logL_hst = obs_hst.get_log_likelihood(model)
+    assert abs(logL_hsc - g["logL_hsc"]) < 1e-3 * abs(g["logL_hsc"])
+    assert abs(logL_hst - g["logL_hst"]) < 1e-3 * abs(g["logL_hst"])
+
+    n, logL = blend.fit(20, e_rel=1e-6)
+    assert n == 20
+    # the first recorded loss is the reference's initial -logL (sum over observations)
+    assert abs(blend.loss[0] + g["logL_hsc"] + g["logL_hst"]) < 1e-3 * abs(blend.loss[0])
+    assert logL > -blend.loss[0]
+    after = blend.get_model()
+    assert obs_hsc.get_log_likelihood(after) > logL_hsc
+    assert obs_hst.get_log_likelihood(after) > logL_hst
+    assert abs(obs_hsc.get_log_likelihood(after) + obs_hst.get_log_likelihood(after) - logL) < 2e-3 * abs(logL) + 2.0

@@ -56,6 +56,23 @@ def test_sweep_bit_exact(amd, dtype, shape):
         assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("dtype,shape,center", [(np.float64, (190, 170), (70, 101)),
+                                                (np.float32, (282, 282), (116, 162))])
+def test_sweep_bit_exact_beyond_the_lds(amd, dtype, shape, center):
+    """Initialisation sweeps the whole detection image about the source's pixel (not the
+    middle): images larger than the 160 KiB LDS take the global-memory kernel."""
+    from oracle import proxops
+
+    assert shape[0] * shape[1] * np.dtype(dtype).itemsize > 160 * 1024
+    rng = np.random.default_rng(shape[0])
+    for mode, g in (("angle", 0.0), ("flat", 0.1)):
+        w, didx, off = proxops.monotonic_operator(shape, mode, center)
+        x0 = rng.random(shape).astype(dtype)
+        want = proxops.sweep(x0.copy(), w, off, didx, g)
+        got = amd.operator._native_sweep(x0.copy(), w, off, didx, g)
+        assert_array_equal(got, want)
+
+
 def test_sweep_reference_known_answers(amd):
     """reference tests/test_constraint.py:92-135 through the product classes"""
     from test_oracle_golden import MONO_NEAREST, MONO_ANGLE, MONO_ANGLE_G25

@@ -299,3 +299,34 @@ def test_multiresolution_frames_and_renderer_setup():
         assert list(obs_lr.renderer._fft_shape) == list(g["fft_shape_%s" % tag])
         n_lr = g["image_%d" % j].shape[0]
         assert obs_lr.renderer._resconv_op.shape == (1, n_lr, int(np.prod(g["fft_shape_%s" % tag])))
+
+
+def test_tan_wcs_matches_astropy():
+    """Gnomonic WCS against astropy's conversions (golden: the two cut-outs of the
+    multi-resolution tutorial, whose reference pixels lie 1800 to 30000 pixels outside the
+    images, sampled inside and around the images).  The flat-sky LinearWCS is NOT good
+    enough there, which is why TanWCS exists."""
+    from conftest import golden
+    from scarlet_amd.wcs import LinearWCS, TanWCS
+
+    g = golden("multires_tutorial")
+    for tag in ("hsc", "hst"):
+        args = (g["crpix_" + tag], g["crval_" + tag], g["pc_" + tag], g["cdelt_" + tag])
+        w = TanWCS(*args)
+        sky = w.pixel_to_world_values(g["sample_pix_" + tag])
+        assert np.abs(sky - g["sample_sky_" + tag]).max() < 1e-12  # degrees
+        back = w.world_to_pixel_values(g["sample_sky_" + tag])
+        assert np.abs(back - g["sample_back_" + tag]).max() < 1e-7  # pixels
+        assert np.abs(back - g["sample_pix_" + tag]).max() < 1e-7
+        flat = LinearWCS(*args).world_to_pixel_values(g["sample_sky_" + tag])
+        assert np.abs(flat - g["sample_back_" + tag]).max() > 0.1
+        # header round trip and the facade's interface
+        header = {"CRPIX1": args[0][0], "CRPIX2": args[0][1], "CRVAL1": args[1][0],
+                  "CRVAL2": args[1][1], "CD1_1": args[2][0][0], "CD1_2": args[2][0][1],
+                  "CD2_1": args[2][1][0], "CD2_2": args[2][1][1], "NAXIS1": 50, "NAXIS2": 40}
+        h = TanWCS.from_header(header)
+        assert h.array_shape == (40, 50) and h.celestial is h
+        assert np.abs(h.pixel_to_world_values(g["sample_pix_" + tag]) - sky).max() < 1e-12
+        moved = h.deepcopy()
+        moved.wcs.crpix -= (3, 5)
+        assert np.abs(moved.world_to_pixel_values(sky) - (back - (3, 5))).max() < 1e-7
