@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--cpu-blends", type=int, default=16)
     ap.add_argument("--cpu-iters", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sub-ranges", type=int, default=0,
+                    help="ranges of blends stepped on streams of their own (0 = library default)")
     ap.add_argument("--phases", action="store_true", help="print the per-phase device times")
     ap.add_argument("--loop", default="blend", choices=["blend", "lite-adaprox", "lite-fista"],
                     help="ablation: run the scarlet.lite loop (LiteBlend.fit semantics) on the "
@@ -130,7 +132,8 @@ def main():
         ]
     data = np.stack([s["data"] for s in scenes])
     weights = np.stack([s["weights"] for s in scenes])
-    total_it = args.warmup + args.steps
+    # W warm-up + K timed iterations, then K more for the instrumented roofline pass
+    total_it = args.warmup + 2 * args.steps
     batch = BlendBatch(
         data, weights, comps, kernel=None if args.null_renderer else kern[2],
         max_iter=total_it + 1, fft_shape=args.fft, device=local_rank, conv_path=args.conv_path,
@@ -139,6 +142,7 @@ def main():
     prox_max_iter = 1 if lite else 10  # lite applies the proximal operator once
     stream = torch.cuda.Stream(device=local_rank)
     batch.set_stream(stream.cuda_stream)
+    batch.set_sub_ranges(args.sub_ranges)
 
     # warm-up iterations 0 .. W-1 (untimed), then K timed iterations of the same fit
     batch.step(0, args.warmup, e_rel=e_rel, prox_max_iter=prox_max_iter, check_convergence=False)
@@ -147,7 +151,6 @@ def main():
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    batch.enable_timing(True)  # HIP events around every phase, on the batch stream
     ev0.record(stream)
     batch.step(args.warmup, args.steps, e_rel=e_rel, prox_max_iter=prox_max_iter,
                check_convergence=False)
@@ -165,8 +168,19 @@ def main():
     logL = np.array([-l[-1] for l in loss])
     n_iter_all, logL_all = sdist.gather_results(n_iter, logL)  # the only collective
 
+    # Roofline pass: K further iterations of the same fit with HIP events around every
+    # kernel, all blends in ONE range.  In the timed region above ranges of blends run on
+    # streams of their own and their kernels share the chip, so the duration of a single
+    # launch there says nothing about the kernel; `value` is not affected by this pass.
+    ranges_timed = batch.sub_ranges()
+    batch.set_sub_ranges(1)
+    batch.enable_timing(True)  # HIP events around every phase, on the batch stream
+    batch.step(args.warmup + args.steps, args.steps, e_rel=e_rel, prox_max_iter=prox_max_iter,
+               check_convergence=False)
+    torch.cuda.synchronize()
     phases = {k: round(v, 4) for k, v in batch.timing().items()}  # mean ms over the K steps
     batch.enable_timing(False)
+    batch.set_sub_ranges(args.sub_ranges)
 
     if rank == 0:
         blend_iters = world * nb * args.steps
@@ -200,6 +214,9 @@ def main():
             "kernel": k_name,
             "algorithmic_bytes_per_launch": k_bytes * nb,
             "ms_per_launch": round(k_ms, 4),
+            "measured": "HIP events on the batch stream over %d further iterations of the same "
+                        "fit, one range of %d blends per launch (the timed region runs %d "
+                        "ranges concurrently)" % (args.steps, nb, ranges_timed),
             "whole_iteration": {
                 "algorithmic_bytes_per_blend_iteration": bytes_per,
                 "ms": round(ms_iter, 4),
@@ -230,6 +247,7 @@ def main():
                 "blends_per_gpu": nb,
                 "components_per_blend": 10,
                 "parallelism": "blend-sharded x%d, no data-path collective" % world,
+                "sub_ranges_per_gpu": ranges_timed,
                 "mean_logL": float(np.mean(logL_all)),
             },
             "roofline": roofline,

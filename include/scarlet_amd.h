@@ -292,6 +292,15 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
 
 /* Blocking.  n_active: blends still iterating; error: index of the first blend
  * whose parameters became non-finite, or -1. */
+/* Blends are independent, so a step can run ranges of blends on streams of their own:
+ * while one range's update kernel drains, the others' next convolution fills the chip.
+ * n = 0 (default): automatic (2 ranges for >= 256 blends on the fused path, else 1);
+ * point sources, free shifts and a low-resolution observation keep it at 1.  Results are
+ * identical for every n.  The caller's stream (smi_batch_set_stream) still brackets the
+ * step: the ranges start after its pending work and it waits for all of them. */
+int smi_batch_set_sub_ranges(smi_batch *b, int32_t n);
+int smi_batch_get_sub_ranges(smi_batch *b, int32_t *n);
+
 int smi_batch_status(smi_batch *b, int32_t *n_active, int32_t *first_error);
 /* per-blend state: 0 iterating, 1 in its last iteration, 2 converged (stopping rule),
  * 3 stopped with non-finite parameters (Model.check_parameters, model.py:153-165) */

@@ -354,6 +354,16 @@ class BlendBatch:
         loss = np.ascontiguousarray(np.broadcast_to(loss, (self.n_blends,)), dtype=np.float64)
         _lib.check(self._lib.smi_batch_set_previous_loss(self._h, _lib.ptr(loss, ctypes.c_double)))
 
+    def set_sub_ranges(self, n):
+        """Split every step into ``n`` ranges of blends on streams of their own (0 =
+        automatic).  Results do not depend on ``n``."""
+        _lib.check(self._lib.smi_batch_set_sub_ranges(self._h, int(n)))
+
+    def sub_ranges(self):
+        n = ctypes.c_int32()
+        _lib.check(self._lib.smi_batch_get_sub_ranges(self._h, ctypes.byref(n)))
+        return n.value
+
     def attach_lowres(self, resampler, channels, data, weights, log_norm):
         """Add a second observation of the (single) blend on a coarser pixel grid as a
         term of the loss and of the gradient.  ``resampler`` is the handle of a

@@ -148,6 +148,12 @@ struct smi_batch {
     int64_t n_morph = 0;
     bool have_components = false, have_obs = false, have_kernel = false;
     smi::LowRes *lowres = nullptr;  // further observation on a coarser grid (one blend)
+    // ranges of blends stepped on streams of their own (blends are independent): the tail
+    // of one range's update kernel overlaps the next iteration's convolution of the others
+    int n_sub = 0;  // 0 = automatic
+    std::vector<int32_t> h_comp_start;
+    std::vector<hipStream_t> sub_streams;
+    std::vector<hipEvent_t> sub_events;  // [0] fork, [1 + s] join of range s
     // per blend
     int32_t *state = nullptr, *zero_state = nullptr, *n_loss = nullptr, *status_out = nullptr;
     double *loss_hist = nullptr, *last_loss = nullptr, *loss_partial = nullptr;
@@ -233,6 +239,8 @@ void refresh_view(smi_batch *b) {
     v.c_fista_step = b->c_fista_step;
     v.fista_t = b->fista_t;
     v.extra_term = b->lowres ? lowres_term(b->lowres) : nullptr;
+    v.blend0 = 0;
+    v.comp0 = 0;
     for (const auto &pl : b->plans)
         if (!pl.slots) v.fast_plans = 0;
 }
@@ -639,6 +647,8 @@ int smi_batch_destroy(smi_batch *b) {
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto e : b->events) (void)hipEventDestroy(e);
+    for (auto e : b->sub_events) (void)hipEventDestroy(e);
+    for (auto st : b->sub_streams) (void)hipStreamDestroy(st);
     lowres_destroy(b->lowres);
     delete b;
     return SMI_OK;
@@ -716,6 +726,7 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
 int smi_batch_set_observation(smi_batch *b, const float *data, const float *weights) {
     SMI_REQUIRE(b && data && weights, "null argument");
     SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
     const size_t n = (size_t)b->d.n_blends * b->d.C * b->d.H * b->d.W;
     if (!b->own_obs) b->data = b->weights = nullptr;
     int rc;
@@ -786,6 +797,7 @@ int smi_batch_set_fista_state(smi_batch *b, const float *z_sed, const float *z_m
 int smi_batch_set_observation_device(smi_batch *b, const float *d_data, const float *d_weights) {
     SMI_REQUIRE(b && d_data && d_weights, "null argument");
     SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
     if (b->own_obs) {
         (void)hipFree(b->data);
         (void)hipFree(b->weights);
@@ -806,6 +818,7 @@ int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
     SMI_REQUIRE(b && kernel, "null argument");
     SMI_REQUIRE(!b->null_renderer, "batch was created without a kernel (NullRenderer)");
     SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
     const int n_img = (b->d.kernel_per_blend ? b->d.n_blends : 1) * b->d.kernel_bands;
     const int ph = b->d.kernel_h, pw = b->d.kernel_w;
     SMI_REQUIRE(ph <= b->Fy && pw <= b->Fx, "kernel larger than the FFT shape");
@@ -872,6 +885,7 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
                     c->morph && c->sed_min_step && c->morph_step && c->prox_flags,
                 "missing component array");
     SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
     const int n = b->d.n_components, nb = b->d.n_blends, C = b->d.C;
     std::vector<int32_t> start(nb + 1, 0);
     std::vector<int64_t> moff(n + 1, 0);
@@ -910,6 +924,7 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         SMI_REQUIRE(C <= 64, "more than 64 bands");
     }
     for (int i = 0; i < nb; ++i) start[i + 1] += start[i];
+    b->h_comp_start = start;
     b->lite_flags = false;
     for (int k = 0; k < n; ++k)
         if (c->prox_flags[k] & (SMI_PROX_FIT_CENTER | SMI_PROX_BG_THRESH)) b->lite_flags = true;
@@ -1098,6 +1113,7 @@ int smi_batch_set_moments(smi_batch *b, const float *m_sed, const float *v_sed,
                           const float *vhat_morph) {
     SMI_REQUIRE(b && b->have_components, "components not set");
     SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
     const float *src[6] = {m_sed, v_sed, vhat_sed, m_morph, v_morph, vhat_morph};
     for (int i = 0; i < 6; ++i) {
         const size_t cnt = i < 3 ? (size_t)b->d.n_components * b->d.C : (size_t)b->n_morph;
@@ -1269,6 +1285,99 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     return SMI_OK;
 }
 
+// number of blend ranges a step is split into
+static int sub_ranges(const smi_batch *b) {
+    const bool plain = b->fused && b->n_point == 0 && b->n_shift == 0 && !b->lowres;
+    if (!plain) return 1;
+    const int nb = b->d.n_blends;
+    int n = b->n_sub > 0 ? b->n_sub : (nb >= 256 ? 2 : 1);
+    return std::max(1, std::min(n, nb));
+}
+
+// The fused path with the batch split into ranges of blends, each on its own stream.
+static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter, float e_rel,
+                           int32_t min_iter, int32_t prox_max_iter, int check) {
+    int rc;
+    while ((int)b->sub_streams.size() < n_sub) {
+        hipStream_t st;
+        SMI_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        b->sub_streams.push_back(st);
+    }
+    while ((int)b->sub_events.size() < n_sub + 1) {
+        hipEvent_t e;
+        SMI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b->sub_events.push_back(e);
+    }
+    const bool timing = b->timing;
+    if (timing) {
+        const size_t need = (size_t)n_iter * 6;
+        while (b->events.size() < need) {
+            hipEvent_t e;
+            SMI_HIP(hipEventCreate(&e));
+            b->events.push_back(e);
+        }
+    }
+    const int nb = b->d.n_blends;
+    std::vector<BatchView> views(n_sub, b->view);
+    for (int s = 0; s < n_sub; ++s) {
+        const int lo = (int)((int64_t)s * nb / n_sub), hi = (int)((int64_t)(s + 1) * nb / n_sub);
+        views[s].blend0 = lo;
+        views[s].nb = hi - lo;
+        views[s].comp0 = b->h_comp_start[lo];
+        views[s].n_comp = b->h_comp_start[hi] - b->h_comp_start[lo];
+    }
+    SMI_HIP(hipEventRecord(b->sub_events[0], b->stream));
+    for (int s = 0; s < n_sub; ++s)
+        SMI_HIP(hipStreamWaitEvent(b->sub_streams[s], b->sub_events[0], 0));
+    for (int i = 0; i < n_iter; ++i) {
+        const int it = it0 + i;
+        for (int s = 0; s < n_sub; ++s) {
+            const BatchView &v = views[s];
+            hipStream_t st = b->sub_streams[s];
+            // phase times are those of range 0 (its kernels overlap the other ranges')
+            hipEvent_t *ev = timing && s == 0 ? &b->events[(size_t)i * 6] : nullptr;
+            if (ev) SMI_HIP(hipEventRecord(ev[0], st));
+            if (ev) SMI_HIP(hipEventRecord(ev[1], st));
+            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
+                                        b->d.kernel_per_blend, b->Q, 0, nullptr, st)))
+                return rc;
+            if (ev) SMI_HIP(hipEventRecord(ev[2], st));
+            launch_finalize(v, it, e_rel, min_iter, check, st);
+            if (ev) SMI_HIP(hipEventRecord(ev[3], st));
+            if (ev) SMI_HIP(hipEventRecord(ev[4], st));
+            if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, st)))
+                return rc;
+            if (check) launch_advance(v, st);
+            if (ev) SMI_HIP(hipEventRecord(ev[5], st));
+        }
+    }
+    for (int s = 0; s < n_sub; ++s) {
+        SMI_HIP(hipEventRecord(b->sub_events[1 + s], b->sub_streams[s]));
+        SMI_HIP(hipStreamWaitEvent(b->stream, b->sub_events[1 + s], 0));
+    }
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+static int collect_phase_times(smi_batch *b, int n_iter) {
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    for (int p = 0; p < 6; ++p) b->phase_ms[p] = 0.0;
+    for (int i = 0; i < n_iter; ++i) {
+        hipEvent_t *ev = &b->events[(size_t)i * 6];
+        for (int p = 0; p < 5; ++p) {
+            float ms = 0.f;
+            SMI_HIP(hipEventElapsedTime(&ms, ev[p], ev[p + 1]));
+            b->phase_ms[p] += ms;
+        }
+        float tot = 0.f;
+        SMI_HIP(hipEventElapsedTime(&tot, ev[0], ev[5]));
+        b->phase_ms[5] += tot;
+    }
+    for (int p = 0; p < 6; ++p) b->phase_ms[p] /= n_iter;
+    b->timed_iters = n_iter;
+    return SMI_OK;
+}
+
 int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32_t min_iter,
                    int32_t prox_max_iter, int32_t check_convergence) {
     int rc = ready(b);
@@ -1277,6 +1386,12 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
     const BatchView &v = b->view;
     const int check = check_convergence != 0;
     const bool timing = b->timing;
+    const int n_sub = sub_ranges(b);
+    if (n_sub > 1) {
+        if ((rc = step_sub_ranges(b, n_sub, it0, n_iter, e_rel, min_iter, prox_max_iter, check)))
+            return rc;
+        return timing && n_iter > 0 ? collect_phase_times(b, n_iter) : SMI_OK;
+    }
     if (timing) {
         const size_t need = (size_t)n_iter * 6;
         while (b->events.size() < need) {
@@ -1329,23 +1444,19 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
         if (ev) SMI_HIP(hipEventRecord(ev[5], b->stream));
     }
     SMI_HIP(hipGetLastError());
-    if (timing && n_iter > 0) {
-        SMI_HIP(hipStreamSynchronize(b->stream));
-        for (int p = 0; p < 6; ++p) b->phase_ms[p] = 0.0;
-        for (int i = 0; i < n_iter; ++i) {
-            hipEvent_t *ev = &b->events[(size_t)i * 6];
-            for (int p = 0; p < 5; ++p) {
-                float ms = 0.f;
-                SMI_HIP(hipEventElapsedTime(&ms, ev[p], ev[p + 1]));
-                b->phase_ms[p] += ms;
-            }
-            float tot = 0.f;
-            SMI_HIP(hipEventElapsedTime(&tot, ev[0], ev[5]));
-            b->phase_ms[5] += tot;
-        }
-        for (int p = 0; p < 6; ++p) b->phase_ms[p] /= n_iter;
-        b->timed_iters = n_iter;
-    }
+    if (timing && n_iter > 0) return collect_phase_times(b, n_iter);
+    return SMI_OK;
+}
+
+int smi_batch_set_sub_ranges(smi_batch *b, int32_t n) {
+    SMI_REQUIRE(b && n >= 0, "bad argument");
+    b->n_sub = n;
+    return SMI_OK;
+}
+
+int smi_batch_get_sub_ranges(smi_batch *b, int32_t *n) {
+    SMI_REQUIRE(b && n, "null argument");
+    *n = sub_ranges(b);
     return SMI_OK;
 }
 

@@ -136,6 +136,9 @@ struct BatchView {
     double *fista_t;             // [n_comp][2]
     // a further observation of blend 0 (resample.hip): log_norm + chi^2 / 2 of that term
     const double *extra_term;
+    // sub-range launches (one stream per range of blends): the grids cover `nb` blends /
+    // `n_comp` components starting at these offsets; all arrays stay whole-batch
+    int32_t blend0, comp0;
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);

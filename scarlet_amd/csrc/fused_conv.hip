@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     const int total = gridDim.x;
     int lid = blockIdx.x;
     if (total % 8 == 0) lid = (blockIdx.x % 8) * (total / 8) + blockIdx.x / 8;
-    const int b = lid / v.C, c = lid - b * v.C;
+    const int b = lid / v.C + v.blend0, c = lid % v.C;
     if (v.state[b] >= 2) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;

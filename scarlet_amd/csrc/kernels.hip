@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kPixBlock) void residual_kernel(BatchView v, const 
 // loss bookkeeping + convergence test of Blend._callback (blend.py:294-299)
 __global__ __launch_bounds__(64) void finalize_kernel(BatchView v, int it, float e_rel,
                                                       int min_iter, int check) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x + v.blend0;
     if (v.state[b] >= 2) return;
     double t = 0.0;
     for (int i = threadIdx.x; i < v.n_partial; i += 64)
@@ -251,7 +251,7 @@ struct CompCtx {
 
 __device__ __forceinline__ CompCtx comp_ctx(const BatchView &v) {
     CompCtx c;
-    c.k = blockIdx.x;
+    c.k = blockIdx.x + v.comp0;
     c.lane = threadIdx.x;
     c.b = v.c_blend[c.k];
     c.C = v.C;
@@ -1109,7 +1109,8 @@ void launch_finalize(const BatchView &v, int32_t it, float e_rel, int32_t min_it
 }
 
 void launch_advance(const BatchView &v, hipStream_t s) {
-    hipLaunchKernelGGL(advance_kernel, dim3((v.nb + 255) / 256), dim3(256), 0, s, v.state, v.nb);
+    hipLaunchKernelGGL(advance_kernel, dim3((v.nb + 255) / 256), dim3(256), 0, s,
+                       v.state + v.blend0, v.nb);
 }
 
 void launch_count_active(const int32_t *state, int32_t nb, int32_t *out, hipStream_t s) {

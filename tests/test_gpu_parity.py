@@ -683,6 +683,55 @@ def test_batch_invariance_at_benchmark_shape(amd):
             assert_array_equal(a, b_)
 
 
+def test_sub_ranges_on_streams_do_not_change_results(amd):
+    """smi_batch_set_sub_ranges: ranges of blends stepped on streams of their own give
+    bit-identical losses, iteration counts and parameters for every number of ranges,
+    ragged blends (different component counts, an empty one) and convergence freezing
+    included; the automatic choice is 2 ranges from 256 blends on."""
+    from scarlet_amd import synthetic
+
+    kern = synthetic.psfs()
+    scenes = synthetic.make_batch(range(900, 937), kernel=kern)
+    keep = [10 - (i % 4) if i != 5 else 0 for i in range(len(scenes))]
+
+    def run(n_sub):
+        comps = [[amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                                    sed_min_step=s["noise_rms"]) for k in range(keep[i])]
+                 for i, s in enumerate(scenes)]
+        b = amd.BlendBatch(np.stack([s["data"] for s in scenes]),
+                           np.stack([s["weights"] for s in scenes]), comps, kernel=kern[2],
+                           max_iter=60)
+        b.set_sub_ranges(n_sub)
+        assert b.sub_ranges() == max(n_sub, 1)
+        n_iter, logL = b.fit(max_iter=60, e_rel=1e-3)
+        out = n_iter, logL, b.loss_history(), b.parameters(), b.moments()
+        b.close()
+        return out
+
+    ref = run(1)
+    assert len(set(ref[0].tolist())) > 2  # blends stop at different iterations
+    for n_sub in (2, 3, 7, 37):
+        got = run(n_sub)
+        assert_array_equal(got[0], ref[0])
+        assert_array_equal(got[1], ref[1])
+        for a, b_ in zip(got[2], ref[2]):
+            assert_array_equal(a, b_)
+        assert_array_equal(got[3][0], ref[3][0])
+        for a, b_ in zip(got[3][1], ref[3][1]):
+            assert_array_equal(a, b_)
+        for key, want in ref[4].items():
+            if isinstance(want, np.ndarray):
+                assert_array_equal(got[4][key], want)
+            else:
+                for a, b_ in zip(got[4][key], want):
+                    assert_array_equal(a, b_)
+    small = amd.BlendBatch(scenes[0]["data"][None], scenes[0]["weights"][None],
+                           [[amd.ComponentSpec(scenes[0]["seds"][0], scenes[0]["morphs"][0],
+                                               scenes[0]["origins"][0])]], kernel=kern[2], max_iter=2)
+    assert small.sub_ranges() == 1
+    small.close()
+
+
 def test_tiny_frames_and_single_band(amd):
     """frames much smaller than a chunk of the fused kernel, one band, boxes larger than
     the frame"""
