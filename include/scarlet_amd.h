@@ -349,11 +349,13 @@ int smi_resampler_destroy(smi_resampler *r);
  * resampler, `data` / `weights` are [C][n_a][n_b], `log_norm` is Observation.log_norm of
  * that observation.  From then on every iteration renders the model cube through `r`,
  * adds log_norm + chi^2 / 2 to the loss and the transposed operator applied to
- * w (m - d) to the gradient image.  Batches of one blend only; `r` must outlive `b`. */
+ * w (m - d) to the gradient image.  Every call adds one observation (at most 8).  Batches
+ * of one blend only; `r` must outlive `b`. */
 int smi_batch_attach_lowres(smi_batch *b, smi_resampler *r, const int32_t *channels,
                             const float *data, const float *weights, double log_norm);
-/* rendering [C][n_a][n_b] of the last forward / gradient / step call */
-int smi_batch_get_lowres_rendered(smi_batch *b, float *out);
+/* rendering [C][n_a][n_b] of the index-th attached observation in the last forward /
+ * gradient / step call */
+int smi_batch_get_lowres_rendered(smi_batch *b, int32_t index, float *out);
 
 #ifdef __cplusplus
 }

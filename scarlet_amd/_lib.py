@@ -116,7 +116,7 @@ SYMBOLS = {
     "smi_batch_attach_lowres": (
         ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i32p, c_f32p, c_f32p, ctypes.c_double]
     ),
-    "smi_batch_get_lowres_rendered": (ctypes.c_int, [ctypes.c_void_p, c_f32p]),
+    "smi_batch_get_lowres_rendered": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_f32p]),
     "smi_batch_create": (
         ctypes.c_int,
         [ctypes.POINTER(BatchDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)],

@@ -365,8 +365,8 @@ class BlendBatch:
         return n.value
 
     def attach_lowres(self, resampler, channels, data, weights, log_norm):
-        """Add a second observation of the (single) blend on a coarser pixel grid as a
-        term of the loss and of the gradient.  ``resampler`` is the handle of a
+        """Add a further observation of the (single) blend on a coarser pixel grid as a
+        term of the loss and of the gradient (every call adds one).  ``resampler`` is the handle of a
         ``ResolutionRenderer``'s device operators (``smi_resampler``), ``channels`` the
         model channel of each of its bands, ``data`` / ``weights`` (C, n_a, n_b),
         ``log_norm`` the observation's ``log_norm``."""
@@ -374,15 +374,17 @@ class BlendBatch:
         data = np.ascontiguousarray(data, dtype=np.float32)
         weights = np.ascontiguousarray(weights, dtype=np.float32)
         assert data.shape == weights.shape and data.shape[0] == len(channels)
-        self._lowres_shape = data.shape
+        self._lowres_shapes = getattr(self, "_lowres_shapes", []) + [data.shape]
         _lib.check(self._lib.smi_batch_attach_lowres(
             self._h, resampler, _lib.ptr(channels, ctypes.c_int32),
             _lib.ptr(data, ctypes.c_float), _lib.ptr(weights, ctypes.c_float), float(log_norm)))
 
-    def lowres_rendered(self):
-        """Low-resolution rendering of the last forward / gradient / step call."""
-        out = np.empty(self._lowres_shape, dtype=np.float32)
-        _lib.check(self._lib.smi_batch_get_lowres_rendered(self._h, _lib.ptr(out, ctypes.c_float)))
+    def lowres_rendered(self, index=0):
+        """Rendering of the ``index``-th attached observation in the last forward /
+        gradient / step call."""
+        out = np.empty(self._lowres_shapes[index], dtype=np.float32)
+        _lib.check(self._lib.smi_batch_get_lowres_rendered(self._h, index,
+                                                           _lib.ptr(out, ctypes.c_float)))
         return out
 
     def reset(self):

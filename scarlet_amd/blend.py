@@ -85,7 +85,7 @@ class Blend(CombinedComponent):
         data = np.zeros(self.frame.shape, dtype=np.float32)
         weights = np.zeros(self.frame.shape, dtype=np.float32)
         kernels, covered = [None] * C, np.zeros(C, dtype=int)
-        self._lowres = None
+        self._lowres = []
         for obs in self.observations:
             r = obs.renderer
             idx = [channels.index(c) for c in obs.channels]
@@ -93,9 +93,7 @@ class Blend(CombinedComponent):
             if type(r) is ResolutionRenderer:
                 # coarser pixel grid: its own term of the loss (smi_batch_attach_lowres);
                 # in the merged cube its channels carry zero weight
-                if self._lowres is not None:
-                    raise NotImplementedError("more than one ResolutionRenderer observation")
-                self._lowres = (obs, idx)
+                self._lowres.append((obs, idx))
                 continue
             if type(r) not in (NullRenderer, ConvolutionRenderer):
                 raise NotImplementedError(
@@ -216,8 +214,7 @@ class Blend(CombinedComponent):
         data, weights, kernel = self._observation()
         batch = BlendBatch(data[None], weights[None], [self._specs(comps)], kernel=kernel,
                            max_iter=max(capacity, 1))
-        if self._lowres is not None:
-            obs, idx = self._lowres
+        for obs, idx in self._lowres:
             _, handle, _ = obs.renderer._resampler()
             batch.attach_lowres(handle, idx, obs.data, obs.weights, obs.log_norm)
         self._upload_state(batch, comps)
@@ -533,7 +530,7 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
             # of the whole loss history after a restart (blend.py:101, 198)
             self.blend, self.base, self.local, self.result = blend, 0, 0, None
             self.obs = blend._observation()
-            if blend._lowres is not None:
+            if blend._lowres:
                 raise NotImplementedError(
                     "fit_blends: blends with a ResolutionRenderer observation fit one by one")
 

@@ -147,7 +147,9 @@ struct smi_batch {
     float *scratch = nullptr;  // update-kernel state of boxes too large for the LDS
     int64_t n_morph = 0;
     bool have_components = false, have_obs = false, have_kernel = false;
-    smi::LowRes *lowres = nullptr;  // further observation on a coarser grid (one blend)
+    // further observations on coarser grids (one blend) and their loss terms (device)
+    std::vector<smi::LowRes *> lowres;
+    double *extra_terms = nullptr;
     // ranges of blends stepped on streams of their own (blends are independent): the tail
     // of one range's update kernel overlaps the next iteration's convolution of the others
     int n_sub = 0;  // 0 = automatic
@@ -238,7 +240,8 @@ void refresh_view(smi_batch *b) {
     v.lite = b->scheme == SMI_SCHEME_FISTA || b->lite_flags;
     v.c_fista_step = b->c_fista_step;
     v.fista_t = b->fista_t;
-    v.extra_term = b->lowres ? lowres_term(b->lowres) : nullptr;
+    v.extra_term = b->extra_terms;
+    v.n_extra = (int32_t)b->lowres.size();
     v.blend0 = 0;
     v.comp0 = 0;
     for (const auto &pl : b->plans)
@@ -442,31 +445,36 @@ int smi_resampler_render(smi_resampler *r, const float *model, float *out) {
     return resampler_render(r->impl, model, out);
 }
 
+static constexpr int kMaxLowRes = 8;
+
 int smi_batch_attach_lowres(smi_batch *b, smi_resampler *r, const int32_t *channels,
                             const float *data, const float *weights, double log_norm) {
     SMI_REQUIRE(b && r && channels && data && weights, "null argument");
     SMI_REQUIRE(b->d.n_blends == 1, "a low-resolution observation needs a batch of one blend");
-    SMI_HIP(hipSetDevice(b->device));
-    if (b->lowres) {
-        lowres_destroy(b->lowres);
-        b->lowres = nullptr;
-    }
     SMI_REQUIRE(r->impl, "resampler already destroyed");
+    SMI_REQUIRE((int)b->lowres.size() < kMaxLowRes, "too many low-resolution observations");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    if (!b->extra_terms) {
+        SMI_HIP(dev_alloc(&b->extra_terms, kMaxLowRes));
+        SMI_HIP(hipMemset(b->extra_terms, 0, kMaxLowRes * sizeof(double)));
+    }
+    LowRes *l = nullptr;
     int rc = lowres_create(r->impl, channels, data, weights, log_norm, b->d.H, b->d.W,
-                           &b->lowres);
+                           b->extra_terms + b->lowres.size(), &l);
     if (rc) {
-        lowres_destroy(b->lowres);
-        b->lowres = nullptr;
+        lowres_destroy(l);
         return rc;
     }
+    b->lowres.push_back(l);
     refresh_view(b);
     return SMI_OK;
 }
 
-int smi_batch_get_lowres_rendered(smi_batch *b, float *out) {
+int smi_batch_get_lowres_rendered(smi_batch *b, int32_t index, float *out) {
     SMI_REQUIRE(b && out, "null argument");
-    SMI_REQUIRE(b->lowres, "no low-resolution observation attached");
-    return lowres_get_rendered(b->lowres, out, b->stream);
+    SMI_REQUIRE(index >= 0 && index < (int)b->lowres.size(), "no such low-resolution observation");
+    return lowres_get_rendered(b->lowres[index], out, b->stream);
 }
 
 int smi_resampler_destroy(smi_resampler *r) {
@@ -649,7 +657,8 @@ int smi_batch_destroy(smi_batch *b) {
     for (auto e : b->events) (void)hipEventDestroy(e);
     for (auto e : b->sub_events) (void)hipEventDestroy(e);
     for (auto st : b->sub_streams) (void)hipStreamDestroy(st);
-    lowres_destroy(b->lowres);
+    for (auto *l : b->lowres) lowres_destroy(l);
+    if (b->extra_terms) (void)hipFree(b->extra_terms);
     delete b;
     return SMI_OK;
 }
@@ -1198,6 +1207,19 @@ int smi_batch_set_stream(smi_batch *b, void *stream) {
     return SMI_OK;
 }
 
+// every attached low-resolution observation: rendering, loss term and (backward) gradient
+static int lowres_evaluate_all(smi_batch *b, int backward) {
+    for (auto *l : b->lowres) {
+        const int rc = lowres_evaluate(l, b->P, b->Py, b->Px, backward, b->stream);
+        if (rc) return rc;
+    }
+    return SMI_OK;
+}
+
+static void lowres_add_all(smi_batch *b) {
+    for (auto *l : b->lowres) lowres_add_gradient(l, b->Q, b->Py, b->Px, b->stream);
+}
+
 int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL) {
     int rc = ready(b);
     if (rc) return rc;
@@ -1205,7 +1227,7 @@ int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL)
     const int nb = v.nb, C = v.C, H = v.H, W = v.W;
     const size_t n_out = (size_t)nb * C * H * W;
     launch_render(v, b->P, b->stream);
-    if (b->lowres && (rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 0, b->stream))) return rc;
+    if ((rc = lowres_evaluate_all(b, 0))) return rc;
     float *tmp = nullptr;
     if (model || rendered) SMI_HIP(dev_alloc(&tmp, n_out));
     if (model) {
@@ -1234,15 +1256,16 @@ int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL)
                                hipMemcpyDeviceToHost, b->stream));
         SMI_HIP(hipMemcpyAsync(ln.data(), b->log_norm, nb * sizeof(double), hipMemcpyDeviceToHost,
                                b->stream));
-        double extra = 0.0;
-        if (b->lowres)
-            SMI_HIP(hipMemcpyAsync(&extra, lowres_term(b->lowres), sizeof(double),
+        std::vector<double> terms(b->lowres.size(), 0.0);
+        if (!terms.empty())
+            SMI_HIP(hipMemcpyAsync(terms.data(), b->extra_terms, terms.size() * sizeof(double),
                                    hipMemcpyDeviceToHost, b->stream));
         SMI_HIP(hipStreamSynchronize(b->stream));
         for (int i = 0; i < nb; ++i) {
             double t = 0.0;
             for (int j = 0; j < v.n_partial; ++j) t += part[(size_t)i * v.n_partial + j];
-            logL[i] = -(ln[i] + 0.5 * t + extra);
+            for (double e : terms) t += 2.0 * e;
+            logL[i] = -(ln[i] + 0.5 * t);
         }
     }
     SMI_HIP(hipGetLastError());
@@ -1254,22 +1277,21 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     if (rc) return rc;
     const BatchView v = unmasked_view(b);
     if (b->fused) {
-        if (b->lowres) {
+        if (!b->lowres.empty()) {
             launch_render(v, b->P, b->stream);
-            if ((rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 1, b->stream))) return rc;
+            if ((rc = lowres_evaluate_all(b, 1))) return rc;
         }
         if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
                                     b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
             return rc;
     } else {
         launch_render(v, b->P, b->stream);
-        if (b->lowres && (rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 1, b->stream)))
-            return rc;
+        if ((rc = lowres_evaluate_all(b, 1))) return rc;
         if ((rc = convolve(b, v, 0))) return rc;
         launch_residual(v, b->Q, b->P, b->stream);
         if ((rc = convolve(b, v, 1))) return rc;
     }
-    if (b->lowres) lowres_add_gradient(b->lowres, b->Q, b->Py, b->Px, b->stream);
+    lowres_add_all(b);
     if ((rc = launch_update(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_morph, 1, b->stream))) return rc;
     if ((rc = launch_point_sources(v, b->Q, 0, 0.f, 0, b->g_sed, b->g_center, 1, b->stream)))
         return rc;
@@ -1287,7 +1309,7 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
 
 // number of blend ranges a step is split into
 static int sub_ranges(const smi_batch *b) {
-    const bool plain = b->fused && b->n_point == 0 && b->n_shift == 0 && !b->lowres;
+    const bool plain = b->fused && b->n_point == 0 && b->n_shift == 0 && b->lowres.empty();
     if (!plain) return 1;
     const int nb = b->d.n_blends;
     int n = b->n_sub > 0 ? b->n_sub : (nb >= 256 ? 2 : 1);
@@ -1405,10 +1427,10 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
         hipEvent_t *ev = timing ? &b->events[(size_t)i * 6] : nullptr;
         if (ev) SMI_HIP(hipEventRecord(ev[0], b->stream));
         if (b->fused) {
-            if (b->lowres) {
-                // the model cube itself is needed for the low-resolution observation
+            if (!b->lowres.empty()) {
+                // the model cube itself is needed for the low-resolution observations
                 launch_render(v, b->P, b->stream);
-                if ((rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 1, b->stream))) return rc;
+                if ((rc = lowres_evaluate_all(b, 1))) return rc;
             }
             // render + conv + residual/loss + conv^T in one LDS-resident kernel
             if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
@@ -1421,8 +1443,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
             if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
         } else {
             launch_render(v, b->P, b->stream);
-            if (b->lowres && (rc = lowres_evaluate(b->lowres, b->P, b->Py, b->Px, 1, b->stream)))
-                return rc;
+            if ((rc = lowres_evaluate_all(b, 1))) return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
             if ((rc = convolve(b, v, 0))) return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
@@ -1432,7 +1453,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
             if ((rc = convolve(b, v, 1))) return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
         }
-        if (b->lowres) lowres_add_gradient(b->lowres, b->Q, b->Py, b->Px, b->stream);
+        lowres_add_all(b);
         if ((rc = launch_shift_backward(v, b->Q, it, nullptr, 0, b->stream))) return rc;
         if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, b->stream)))
             return rc;

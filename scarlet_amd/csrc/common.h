@@ -134,8 +134,9 @@ struct BatchView {
     int32_t scheme;              // SMI_SCHEME_*; FISTA keeps z in m_sed / m_morph
     const float *c_fista_step;
     double *fista_t;             // [n_comp][2]
-    // a further observation of blend 0 (resample.hip): log_norm + chi^2 / 2 of that term
+    // further observations of blend 0 (resample.hip): log_norm + chi^2 / 2 of each
     const double *extra_term;
+    int32_t n_extra;
     // sub-range launches (one stream per range of blends): the grids cover `nb` blends /
     // `n_comp` components starting at these offsets; all arrays stay whole-batch
     int32_t blend0, comp0;
@@ -178,11 +179,10 @@ int resampler_render(Resampler *r, const float *model, float *out);
 void resampler_destroy(Resampler *r);
 struct LowRes;
 int lowres_create(Resampler *r, const int32_t *channels, const float *data, const float *weights,
-                  double log_norm, int H, int W, LowRes **out);
+                  double log_norm, int H, int W, double *term_slot, LowRes **out);
 void lowres_destroy(LowRes *l);
 int lowres_evaluate(LowRes *l, const float *P, int Py, int Px, int backward, hipStream_t s);
 void lowres_add_gradient(LowRes *l, float *Q, int Py, int Px, hipStream_t s);
-const double *lowres_term(const LowRes *l);
 int lowres_get_rendered(LowRes *l, float *out, hipStream_t s);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);

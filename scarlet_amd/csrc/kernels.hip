@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(BatchView v, int it, float
     t = wave_sum(t);
     if (threadIdx.x == 0) {
         double loss = v.log_norm[b] + 0.5 * t;
-        if (v.extra_term) loss += v.extra_term[0];
+        for (int i = 0; i < v.n_extra; ++i) loss += v.extra_term[i];
         const int n = v.n_loss[b];
         const double prev = v.last_loss[b];
         if (n < v.hist_cap) v.loss_hist[(int64_t)b * v.hist_cap + n] = loss;

@@ -238,20 +238,20 @@ struct LowRes {
     int H = 0, W = 0, y0 = 0, x0 = 0;
     int32_t *channels = nullptr;
     float *data = nullptr, *weights = nullptr, *resid = nullptr, *gpad = nullptr;
-    double *term = nullptr;
+    double *term = nullptr;  // slot of the batch's array of extra loss terms (not owned)
     double log_norm = 0.0;
 };
 
 void lowres_destroy(LowRes *l) {
     if (!l) return;
     for (void *p : {(void *)l->channels, (void *)l->data, (void *)l->weights, (void *)l->resid,
-                    (void *)l->gpad, (void *)l->term})
+                    (void *)l->gpad})
         if (p) (void)hipFree(p);
     delete l;
 }
 
 int lowres_create(Resampler *r, const int32_t *channels, const float *data, const float *weights,
-                  double log_norm, int H, int W, LowRes **out) {
+                  double log_norm, int H, int W, double *term_slot, LowRes **out) {
     SMI_REQUIRE(r->Fy >= H && r->Fx >= W, "resampler FFT shape smaller than the model frame");
     auto *l = new LowRes;
     *out = l;
@@ -264,7 +264,7 @@ int lowres_create(Resampler *r, const int32_t *channels, const float *data, cons
     SMI_HIP(hipMalloc((void **)&l->weights, n * sizeof(float)));
     SMI_HIP(hipMalloc((void **)&l->resid, n * sizeof(float)));
     SMI_HIP(hipMalloc((void **)&l->gpad, r->C * plane * sizeof(float)));
-    SMI_HIP(hipMalloc((void **)&l->term, sizeof(double)));
+    l->term = term_slot;
     SMI_HIP(hipMemcpy(l->channels, channels, r->C * sizeof(int32_t), hipMemcpyHostToDevice));
     SMI_HIP(hipMemcpy(l->data, data, n * sizeof(float), hipMemcpyHostToDevice));
     SMI_HIP(hipMemcpy(l->weights, weights, n * sizeof(float), hipMemcpyHostToDevice));
@@ -310,8 +310,6 @@ void lowres_add_gradient(LowRes *l, float *Q, int Py, int Px, hipStream_t s) {
     hipLaunchKernelGGL(lowres_add_kernel, dim3((l->H * l->W + 255) / 256, r->C), dim3(256), 0, s,
                        l->gpad, r->Fy, r->Fx, l->y0, l->x0, l->channels, l->H, l->W, Q, Py, Px);
 }
-
-const double *lowres_term(const LowRes *l) { return l->term; }
 
 int lowres_get_rendered(LowRes *l, float *out, hipStream_t s) {
     Resampler *r = l->r;

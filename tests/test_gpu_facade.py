@@ -646,6 +646,33 @@ def test_lowres_term_on_the_device_matches_the_oracle():
                     assert np.abs(morphs[k] - c.morph).max() < 2e-3
             finally:
                 batch.close()
+        # several observations: the same one split into two with disjoint weights is the
+        # same likelihood (log_norm counts every unmasked pixel once)
+        scene, lowres, c_hr, _ = build(g)
+        specs = [ComponentSpec(c.sed, c.morph, c.origin, sed_min_step=0.0)
+                 for c in scene.components]
+        batch = BlendBatch(scene.data[None], scene.weights[None], [specs], kernel=scene.kernel,
+                           max_iter=4)
+        half = np.zeros(lowres.weights.shape, dtype=bool)
+        half[:, ::2] = True
+        import oracle.resample as resample
+        for mask in (half, ~half):
+            part = resample.LowResObservation.__new__(resample.LowResObservation)
+            part.weights = lowres.weights * mask
+            batch.attach_lowres(handle, lowres.channels, lowres.data, part.weights,
+                                resample.LowResObservation.log_norm.fget(part))
+        try:
+            _, _, logL = batch.forward()
+            loss, grads = scene.loss_and_gradients()
+            assert abs(-logL[0] - loss) < 2e-6 * abs(loss)
+            both = batch.lowres_rendered(0), batch.lowres_rendered(1)
+            assert_allclose(both[0], both[1], rtol=0, atol=0)
+            g_sed, g_morph = batch.gradient()
+            for k, (r_sed, r_morph) in enumerate(grads):
+                assert np.abs(g_sed[k] - r_sed).max() < RTOL * np.abs(r_sed).max()
+                assert np.abs(g_morph[k] - r_morph).max() < 2 * RTOL * np.abs(r_morph).max()
+        finally:
+            batch.close()
     finally:
         lib.smi_resampler_destroy(handle)
 
