@@ -290,8 +290,6 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph);
 int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
                    int32_t min_iter, int32_t prox_max_iter, int32_t check_convergence);
 
-/* Blocking.  n_active: blends still iterating; error: index of the first blend
- * whose parameters became non-finite, or -1. */
 /* Blends are independent, so a step can run ranges of blends on streams of their own:
  * while one range's update kernel drains, the others' next convolution fills the chip.
  * n = 0 (default): automatic (2 ranges for >= 256 blends on the fused path, else 1);
@@ -301,6 +299,8 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
 int smi_batch_set_sub_ranges(smi_batch *b, int32_t n);
 int smi_batch_get_sub_ranges(smi_batch *b, int32_t *n);
 
+/* Blocking.  n_active: blends still iterating; error: index of the first blend
+ * whose parameters became non-finite, or -1. */
 int smi_batch_status(smi_batch *b, int32_t *n_active, int32_t *first_error);
 /* per-blend state: 0 iterating, 1 in its last iteration, 2 converged (stopping rule),
  * 3 stopped with non-finite parameters (Model.check_parameters, model.py:153-165) */
@@ -321,7 +321,9 @@ int smi_batch_reset(smi_batch *b);
 
 /* Mean device time in milliseconds of the dominant kernel family per iteration,
  * measured with hipEvents on the batch stream during the last smi_batch_step call
- * when timing was enabled with smi_batch_enable_timing(b, 1).
+ * when timing was enabled with smi_batch_enable_timing(b, 1); with several ranges of
+ * blends (smi_batch_set_sub_ranges) the times are those of the first range, whose
+ * kernels share the chip with the other ranges'.
  * phase: 0 render, 1 forward conv, 2 residual, 3 adjoint conv, 4 update, 5 total */
 int smi_batch_enable_timing(smi_batch *b, int32_t on);
 int smi_batch_get_timing(smi_batch *b, double *ms_per_phase, int32_t n_phases);
