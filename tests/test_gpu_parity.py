@@ -725,6 +725,21 @@ def test_sub_ranges_on_streams_do_not_change_results(amd):
             else:
                 for a, b_ in zip(got[4][key], want):
                     assert_array_equal(a, b_)
+    # the automatic choice at the benchmark's scale: two ranges from 256 blends on
+    many = synthetic.make_batch(range(3000, 3256), kernel=kern)
+    hist = []
+    for n_sub in (0, 1):
+        comps = [[amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                                    sed_min_step=s["noise_rms"]) for k in range(10)] for s in many]
+        b = amd.BlendBatch(np.stack([s["data"] for s in many]),
+                           np.stack([s["weights"] for s in many]), comps, kernel=kern[2],
+                           max_iter=5)
+        b.set_sub_ranges(n_sub)
+        assert b.sub_ranges() == (2 if n_sub == 0 else 1)
+        b.step(0, 4, e_rel=1e-3)
+        hist.append(np.array(b.loss_history()))
+        b.close()
+    assert_array_equal(hist[0], hist[1])
     small = amd.BlendBatch(scenes[0]["data"][None], scenes[0]["weights"][None],
                            [[amd.ComponentSpec(scenes[0]["seds"][0], scenes[0]["morphs"][0],
                                                scenes[0]["origins"][0])]], kernel=kern[2], max_iter=2)
