@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -32,9 +33,8 @@
 namespace smi {
 
 static thread_local std::string g_error;
-// rocFFT plans shared by all batches of the process: (device, Fy, Fx, transforms) -> (fwd, inv)
+// rocFFT plans kept between batches (see PlanCache below)
 static std::mutex g_plan_mutex;
-static std::map<std::tuple<int, int, int, int>, std::pair<rocfft_plan, rocfft_plan>> g_plans;
 void set_error(const std::string &msg) { g_error = msg; }
 
 static int next_fast_len(int n) {
@@ -75,26 +75,104 @@ static hipError_t dev_alloc(T **p, size_t n) {
 
 using namespace smi;
 
-// (forward, inverse) real 2-D plans for `count` transforms of Fy x Fx; created once per
-// process: a plan costs ~0.3 s of run-time kernel compilation and is immutable
-static int cached_plans(int device, int Fy, int Fx, int count, rocfft_plan *fwd,
-                        rocfft_plan *inv) {
-    std::lock_guard<std::mutex> guard(g_plan_mutex);
-    auto &cached = g_plans[std::make_tuple(device, Fy, Fx, count)];
-    if (!cached.first) {
-        const size_t lengths[2] = {(size_t)Fx, (size_t)Fy};
-        SMI_FFT(rocfft_plan_create(&cached.first, rocfft_placement_notinplace,
-                                   rocfft_transform_type_real_forward, rocfft_precision_single,
-                                   2, lengths, (size_t)count, nullptr));
-        SMI_FFT(rocfft_plan_create(&cached.second, rocfft_placement_notinplace,
-                                   rocfft_transform_type_real_inverse, rocfft_precision_single,
-                                   2, lengths, (size_t)count, nullptr));
-    }
-    *fwd = cached.first;
-    if (inv) *inv = cached.second;
+// ---------------------------------------------------------------------------------------
+// rocFFT plans.  Creating a plan costs ~0.3 s of run-time kernel compilation, and a fit
+// with box resizing, or an initialisation that renders every source, builds many batches
+// of the same FFT shape one after the other: plans are kept between batches.
+//
+// Only ONE FFT shape per device is kept, and idle plans of another shape are destroyed
+// before new ones are made, because rocFFT 7.2 returns wrong transforms from a plan
+// created while a plan with the transposed complex shape is alive -- (Fy, Fx) next to
+// (Fx / 2, 2 Fy), e.g. 60 x 60 next to 30 x 120, 64 x 64 next to 32 x 128
+// (tools/rocfft_repro/repro.cpp shows it with rocFFT alone).  Batches that are alive at
+// the same time with different shapes get plans of their own, and an automatically chosen
+// shape steps aside (next fast length) if it is the transposed partner of a live one.
+// ---------------------------------------------------------------------------------------
+struct PlanPair {
+    rocfft_plan fwd = nullptr, inv = nullptr;
+};
+
+struct PlanCache {
+    int Fy = 0, Fx = 0, refs = 0;        // shape of the kept plans, batches using them
+    std::map<int, PlanPair> by_count;    // number of transforms -> plans
+};
+
+static std::map<int, PlanCache> g_plan_cache;                       // per device
+static std::map<std::tuple<int, int, int>, int> g_live_shapes;      // (device, Fy, Fx) -> batches
+
+static int make_plans(int Fy, int Fx, int count, PlanPair *p) {
+    const size_t lengths[2] = {(size_t)Fx, (size_t)Fy};
+    SMI_FFT(rocfft_plan_create(&p->fwd, rocfft_placement_notinplace,
+                               rocfft_transform_type_real_forward, rocfft_precision_single, 2,
+                               lengths, (size_t)count, nullptr));
+    SMI_FFT(rocfft_plan_create(&p->inv, rocfft_placement_notinplace,
+                               rocfft_transform_type_real_inverse, rocfft_precision_single, 2,
+                               lengths, (size_t)count, nullptr));
     return SMI_OK;
 }
 
+static void destroy_plans(PlanPair *p) {
+    if (p->fwd) rocfft_plan_destroy(p->fwd);
+    if (p->inv) rocfft_plan_destroy(p->inv);
+    p->fwd = p->inv = nullptr;
+}
+
+// a live batch on this device whose complex shape is the transpose of (Fy, Fx)'s?
+static bool transposed_partner_alive(int device, int Fy, int Fx) {
+    for (const auto &kv : g_live_shapes) {
+        if (kv.second <= 0 || std::get<0>(kv.first) != device) continue;
+        const int Ly = std::get<1>(kv.first), Lx = std::get<2>(kv.first);
+        if (Fy == Lx / 2 && Fx / 2 == Ly) return true;
+    }
+    return false;
+}
+
+// Called with the FFT shape a new rocFFT-path batch wants.  Drops idle plans of other
+// shapes, moves an automatically chosen shape out of the way of a live transposed partner,
+// registers the batch as alive and says whether it may use the kept plans (`shared`).
+static int plans_enter(int device, bool shape_is_fixed, int *Fy, int *Fx, bool *shared) {
+    std::lock_guard<std::mutex> guard(g_plan_mutex);
+    PlanCache &c = g_plan_cache[device];
+    if (c.refs == 0 && (c.Fy != *Fy || c.Fx != *Fx)) {
+        for (auto &kv : c.by_count) destroy_plans(&kv.second);
+        c.by_count.clear();
+        c.Fy = c.Fx = 0;
+    }
+    while (transposed_partner_alive(device, *Fy, *Fx)) {
+        SMI_REQUIRE(!shape_is_fixed,
+                    "this FFT shape cannot coexist with a live batch of the transposed shape "
+                    "(rocFFT returns wrong transforms); close that batch or choose another shape");
+        *Fy = next_fast_len(*Fy + 1);
+    }
+    if (c.Fy == 0) {
+        c.Fy = *Fy;
+        c.Fx = *Fx;
+    }
+    *shared = c.Fy == *Fy && c.Fx == *Fx;
+    if (*shared) ++c.refs;
+    ++g_live_shapes[std::make_tuple(device, *Fy, *Fx)];
+    return SMI_OK;
+}
+
+static void plans_leave(int device, int Fy, int Fx, bool shared) {
+    std::lock_guard<std::mutex> guard(g_plan_mutex);
+    if (shared) --g_plan_cache[device].refs;
+    auto it = g_live_shapes.find(std::make_tuple(device, Fy, Fx));
+    if (it != g_live_shapes.end() && --it->second <= 0) g_live_shapes.erase(it);
+}
+
+// plans for `count` transforms: the kept ones (`shared`) or fresh ones the caller owns
+static int plans_get(int device, int Fy, int Fx, int count, bool shared, PlanPair *out) {
+    if (!shared) return make_plans(Fy, Fx, count, out);
+    std::lock_guard<std::mutex> guard(g_plan_mutex);
+    PlanPair &p = g_plan_cache[device].by_count[count];
+    if (!p.fwd) {
+        const int rc = make_plans(Fy, Fx, count, &p);
+        if (rc) return rc;
+    }
+    *out = p;
+    return SMI_OK;
+}
 
 struct smi_batch {
     smi_batch_desc d{};
@@ -111,6 +189,7 @@ struct smi_batch {
     float2 *S = nullptr, *Khat = nullptr;
     void *work = nullptr;
     rocfft_plan plan_fwd = nullptr, plan_inv = nullptr;
+    bool plans_registered = false, plans_shared = false;  // see PlanCache
     rocfft_execution_info info = nullptr;
     // observation
     float *data = nullptr, *weights = nullptr;
@@ -559,8 +638,14 @@ static int batch_create_impl(const smi_batch_desc *desc, int device, smi_batch *
         }
         SMI_REQUIRE(desc->conv_path != 2 || b->fused, "fused convolution not available for this shape");
     }
-    b->Fxh = b->Fx / 2 + 1;
     const bool padded = !b->null_renderer && !b->fused;
+    if (padded) {
+        const bool fixed = desc->fft_h > 0 && desc->fft_w > 0;
+        const int rc_enter = plans_enter(device, fixed, &b->Fy, &b->Fx, &b->plans_shared);
+        if (rc_enter) return rc_enter;
+        b->plans_registered = true;
+    }
+    b->Fxh = b->Fx / 2 + 1;
     b->Py = padded ? b->Fy : H;
     b->Px = padded ? b->Fx : W;
     const size_t n_real = (size_t)nb * C * b->Py * b->Px;
@@ -585,7 +670,10 @@ static int batch_create_impl(const smi_batch_desc *desc, int device, smi_batch *
         const size_t n_cplx = (size_t)nb * C * b->Fy * b->Fxh;
         SMI_HIP(dev_alloc(&b->S, n_cplx));
         {
-            const int rc_plans = cached_plans(device, b->Fy, b->Fx, nb * C, &b->plan_fwd, &b->plan_inv);
+            PlanPair pp;
+            const int rc_plans = plans_get(device, b->Fy, b->Fx, nb * C, b->plans_shared, &pp);
+            b->plan_fwd = pp.fwd;
+            b->plan_inv = pp.inv;
             if (rc_plans) return rc_plans;
         }
         size_t w1 = 0, w2 = 0;
@@ -634,6 +722,15 @@ int smi_batch_destroy(smi_batch *b) {
     (void)hipSetDevice(b->device);
     (void)hipDeviceSynchronize();
     if (b->info) rocfft_execution_info_destroy(b->info);
+    if (b->plans_registered) {
+        if (!b->plans_shared) {
+            PlanPair own;
+            own.fwd = b->plan_fwd;
+            own.inv = b->plan_inv;
+            destroy_plans(&own);
+        }
+        plans_leave(b->device, b->Fy, b->Fx, b->plans_shared);
+    }
     for (auto &pl : b->plans) {
         (void)hipFree(pl.level_start);
         (void)hipFree(pl.pix);
@@ -857,8 +954,9 @@ int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
     const float scale = 1.0f / ((float)b->Fy * (float)b->Fx);
     launch_wrap_kernel(d_kern, d_pad, n_img, ph, pw, b->Fy, b->Fx, scale, b->stream);
     if (!b->Khat) SMI_HIP(dev_alloc(&b->Khat, n_cplx));
-    rocfft_plan plan = nullptr;
-    if ((rc = cached_plans(b->device, b->Fy, b->Fx, n_img, &plan, nullptr))) return rc;
+    PlanPair kp;
+    if ((rc = plans_get(b->device, b->Fy, b->Fx, n_img, b->plans_shared, &kp))) return rc;
+    rocfft_plan plan = kp.fwd;
     size_t wb = 0;
     SMI_FFT(rocfft_plan_get_work_buffer_size(plan, &wb));
     rocfft_execution_info info = nullptr;
@@ -873,6 +971,7 @@ int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
     SMI_FFT(rocfft_execute(plan, ins, outs, info));
     SMI_HIP(hipStreamSynchronize(b->stream));
     rocfft_execution_info_destroy(info);
+    if (!b->plans_shared) destroy_plans(&kp);
     if (work) (void)hipFree(work);
     (void)hipFree(d_pad);
     (void)hipFree(d_kern);

@@ -793,6 +793,59 @@ def test_large_frame_uses_rocfft(amd):
         amd.BlendBatch(data[None], weights[None], [[]], kernel=kernel, conv_path="fused")
 
 
+def test_rocfft_shapes_with_transposed_partners(amd):
+    """rocFFT 7.2 returns wrong transforms from a plan made while a plan of the transposed
+    complex shape is alive ((Fy, Fx) next to (Fx / 2, 2 Fy); tools/rocfft_repro).  The
+    library keeps plans of one FFT shape only between batches and moves an automatically
+    chosen shape out of the way of a live partner: both orders, one after the other and
+    alive at the same time, must agree with the oracle."""
+    from oracle import pgm
+
+    rng = np.random.default_rng(77)
+
+    def scene(C, H, W, p):
+        yy, xx = np.mgrid[:p, :p] - p // 2
+        kernel = np.exp(-(yy**2 + xx**2) / 2.0)[None].astype(np.float32)
+        kernel /= kernel.sum()
+        data = rng.normal(0, 1, (C, H, W)).astype(np.float32)
+        weights = np.ones((C, H, W), np.float32)
+        morph = rng.random((9, 9)).astype(np.float32)
+        sed = rng.uniform(0.5, 2, C).astype(np.float32)
+        batch = amd.BlendBatch(data[None], weights[None], [[amd.ComponentSpec(sed, morph, (2, 12))]],
+                               kernel=kernel, max_iter=2, conv_path="rocfft")
+        sc = pgm.Scene((C, H, W), data, weights, kernel, [pgm.Component(sed.copy(), morph.copy(), (2, 12))])
+        return batch, sc.render(sc.get_model())
+
+    def check(batch, ref):
+        _, rendered, _ = batch.forward()
+        assert rel_err(rendered[0], ref) < RTOL, batch.fft_shape
+
+    wide, square = (2, 14, 104, 13), (2, 54, 54, 3)  # FFT shapes (30, 120) and (60, 60)
+    for first, second in ((wide, square), (square, wide)):
+        a, ref_a = scene(*first)
+        check(a, ref_a)
+        a.close()
+        b, ref_b = scene(*second)  # after the other shape: plans of one shape only are kept
+        check(b, ref_b)
+        b.close()
+    for first, second in ((wide, square), (square, wide)):
+        a, ref_a = scene(*first)
+        b, ref_b = scene(*second)  # while the other is alive: steps aside
+        assert a.fft_shape in ((30, 120), (60, 60)) and b.fft_shape not in ((30, 120), (60, 60))
+        check(b, ref_b)
+        check(a, ref_a)
+        a.close()
+        b.close()
+    # an explicit shape cannot step aside: refused instead of silently wrong
+    a, _ = scene(*wide)
+    with pytest.raises(Exception, match="transposed"):
+        amd.BlendBatch(np.zeros((1, 2, 54, 54), np.float32), np.ones((1, 2, 54, 54), np.float32),
+                       [[amd.ComponentSpec(np.ones(2, np.float32), np.ones((5, 5), np.float32), (3, 3))]],
+                       kernel=np.ones((1, 3, 3), np.float32) / 9, max_iter=2, conv_path="rocfft",
+                       fft_shape=(60, 60))
+    a.close()
+
+
 def test_blend_without_components_and_mixed_batch(amd):
     """a batch where one blend has no components at all"""
     from oracle import pgm
