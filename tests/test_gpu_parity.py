@@ -4,6 +4,7 @@ states; integer/index work and the monotonic sweep / apply_filter are bit exact.
 """
 
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -1084,3 +1085,24 @@ def test_lite_loop_vs_the_reference_run(amd, hsc, kind, path):
     loss = -np.array(batch.loss_history()[0])
     assert_allclose(loss, g["loss"][:10], rtol=3e-4)
     assert_allclose(loss[:4], g["loss"][:4], rtol=3e-5)
+
+
+# ---------------------------------------------------------------- random configurations
+@pytest.mark.parametrize("tool,args", [("fuzz_vs_oracle.py", ["24", "5"]),
+                                       ("fuzz_batches.py", ["24", "5"]),
+                                       ("fuzz_lite.py", ["16", "5"])])
+def test_random_configurations_against_the_oracle(amd, tool, args):
+    """tools/fuzz_*.py with a fixed seed: random frame / box / kernel shapes, band counts,
+    weightings, sparsity, point sources, shifts, ragged batches, sub-ranges, lite loops --
+    forward, gradients and a few iterations against the oracle.  (This is the harness that
+    found the rocFFT transposed-shape defect.)"""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "worst deviations" in out.stdout
+    assert "OVER" not in out.stdout, out.stdout[-3000:]

@@ -1,0 +1,114 @@
+"""Random BATCHES of blends with mixed features, GPU against the oracle: ragged numbers of
+components, L0 / L1 members of the chain, centre floors, point sources, free Fourier
+shifts, several sub-ranges on streams, a few iterations of the loop.  Development aid.
+
+    python tools/fuzz_batches.py [n_batches] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import pgm  # noqa: E402
+from scarlet_amd import _lib  # noqa: E402
+from scarlet_amd.batch import BlendBatch, ComponentSpec, PointSourceSpec  # noqa: E402
+from test_gpu_parity import rel_err  # noqa: E402
+
+n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+worst = dict(chi=0.0, sed=0.0, morph=0.0, center=0.0, shift=0.0)
+bad = []
+for n in range(n_batches):
+    C = int(rng.integers(1, 7))
+    H, W = int(rng.integers(30, 110)), int(rng.integers(30, 110))
+    nb = int(rng.integers(1, 7))
+    p = int(rng.choice([5, 9, 15, 21]))
+    yy, xx = np.mgrid[:p, :p] - p // 2
+    sig = rng.uniform(0.8, 2.0, C)
+    kernel = np.stack([np.exp(-(yy**2 + xx**2) / (2 * s**2)) for s in sig]).astype(np.float32)
+    kernel /= kernel.sum(axis=(1, 2))[:, None, None]
+    feature = str(rng.choice(["plain", "sparse", "points", "shifts"]))
+    data = rng.normal(0, 1, (nb, C, H, W)).astype(np.float32)
+    weights = rng.uniform(0.5, 2.0, (nb, C, H, W)).astype(np.float32)
+    specs, scenes = [], []
+    for b in range(nb):
+        K = int(rng.integers(0 if nb > 1 else 1, 7))
+        bs, comps = [], []
+        for k in range(K):
+            sed = rng.uniform(0.3, 3.0, C).astype(np.float32)
+            if feature == "points" and rng.random() < 0.5:
+                center = np.array([rng.uniform(8, H - 8), rng.uniform(8, W - 8)])
+                bs.append(PointSourceSpec(sed, center, 1.1, sed_min_step=0.01))
+                comps.append(pgm.PointComponent(sed.copy(), center.copy(), 1.1, sed_min_step=0.01))
+                continue
+            h = w = int(rng.choice([11, 15, 21, 31]))
+            if feature != "shifts":
+                h, w = int(rng.integers(5, 45)), int(rng.integers(5, 45))
+            oy = int(rng.integers(-3, max(H - h + 3, -2)))
+            ox = int(rng.integers(-3, max(W - w + 3, -2)))
+            y, x = np.mgrid[:h, :w]
+            s = rng.uniform(1.2, 5.0)
+            morph = np.exp(-((y - h // 2) ** 2 + (x - w // 2) ** 2) / (2 * s**2))
+            morph = (morph * rng.uniform(0.9, 1.1, morph.shape)).astype(np.float32)
+            morph /= morph.max()
+            kw, okw, flags = {}, {}, _lib.PROX_EXTENDED_SOURCE
+            if feature == "sparse":
+                kind = str(rng.choice(["l0", "l1"]))
+                typ = str(rng.choice(["absolute", "relative"]))
+                thresh = float(rng.choice([0.02, 0.1]))
+                tiny = float(rng.choice([1e-6, 1e-3]))
+                flags |= _lib.PROX_L1 if kind == "l1" else _lib.PROX_L0
+                flags |= _lib.PROX_L_RELATIVE if typ == "relative" else 0
+                kw, okw = dict(l_thresh=thresh, center_floor=tiny), dict(sparsity=(kind, thresh, typ), tiny=tiny)
+            if feature == "shifts" and rng.random() < 0.6:
+                shift = rng.uniform(-0.4, 0.4, 2)
+                kw, okw = dict(shift=shift), dict(shift=shift.copy())
+            bs.append(ComponentSpec(sed, morph, (oy, ox), sed_min_step=0.01, prox_flags=flags, **kw))
+            comps.append(pgm.Component(sed.copy(), morph.copy(), (oy, ox), sed_min_step=0.01, **okw))
+        specs.append(bs)
+        scenes.append(pgm.Scene((C, H, W), data[b], weights[b], kernel, comps))
+    n_sub = int(rng.integers(1, 4))
+    desc = "%s nb=%d C=%d %dx%d p=%d comps=%s sub=%d" % (
+        feature, nb, C, H, W, p, [len(s) for s in specs], n_sub)
+    batch = BlendBatch(data, weights, specs, kernel=kernel, max_iter=8)
+    batch.set_sub_ranges(n_sub)
+    n_it = 5
+    try:
+        batch.step(0, n_it, e_rel=1e-3)
+        losses = batch.loss_history()
+        seds, morphs = batch.parameters()
+        centers = batch.centers() if feature in ("points", "shifts") else None
+        dev = dict(chi=0.0, sed=0.0, morph=0.0, center=0.0, shift=0.0)
+        k0 = 0
+        for b, sc in enumerate(scenes):
+            for it in range(n_it):
+                sc.step(it, 1e-3)
+            chi = np.array(losses[b]) - sc.log_norm
+            chi_ref = np.array(sc.loss) - sc.log_norm
+            dev["chi"] = max(dev["chi"], np.abs(chi / chi_ref - 1).max())
+            for j, c in enumerate(sc.components):
+                k = k0 + j
+                dev["sed"] = max(dev["sed"], rel_err(seds[k], c.sed))
+                if isinstance(c, pgm.PointComponent):
+                    dev["center"] = max(dev["center"], np.abs(centers["center"][k] - c.center).max())
+                else:
+                    dev["morph"] = max(dev["morph"], np.abs(morphs[k] - c.morph).max())
+                    if c.shift is not None:
+                        dev["shift"] = max(dev["shift"], np.abs(centers["center"][k] - c.shift).max())
+            k0 += len(sc.components)
+    finally:
+        batch.close()
+    for key, val in dev.items():
+        worst[key] = max(worst[key], float(val))
+    limits = dict(chi=3e-4, sed=2e-3, morph=5e-3, center=2e-3, shift=2e-3)
+    over = {k: float(v) for k, v in dev.items() if v > limits[k]}
+    if over:
+        bad.append((n, desc, over))
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(n, desc, {k: "%.1e" % v for k, v in dev.items()})
+print("batches: %d; worst deviations: %s" % (n_batches, {k: "%.2e" % v for k, v in worst.items()}))
+for entry in bad:
+    print("OVER", entry)
