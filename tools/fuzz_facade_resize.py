@@ -1,0 +1,89 @@
+"""Random scenes through the facade's Blend.fit WITH box resizing (shrink / grow hooks every
+10 iterations, optimizer restarts) against the oracle's Scene.fit(resizing=True): the
+boxes after the fit, the loss history and the iteration count.  Development aid.
+
+    python tools/fuzz_facade_resize.py [n_scenes] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from oracle import fftconv, pgm  # noqa: E402
+import scarlet_amd as scarlet  # noqa: E402
+
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+bad, worst = [], dict(chi_early=0.0, chi_end=0.0)
+for n in range(n_scenes):
+    C = int(rng.integers(1, 6))
+    H, W = int(rng.integers(60, 120)), int(rng.integers(60, 120))
+    K = int(rng.integers(1, 5))
+    filters = ["b%d" % c for c in range(C)]
+    sigma_obs = rng.uniform(1.2, 2.0)
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * C)
+    yy, xx = np.mgrid[:21, :21] - 10
+    obs_psf = np.exp(-(yy**2 + xx**2) / (2 * sigma_obs**2))[None].repeat(C, 0).astype(np.float32)
+    frame = scarlet.Frame((C, H, W), psf=model_psf, channels=filters)
+    noise = 0.05
+    truth = np.zeros((C, H, W), np.float32)
+    layout = []
+    for k in range(K):
+        true_sigma = rng.uniform(1.5, 6.0)
+        box = int(rng.choice([21, 31, 41]))  # some too small for the source, some too large
+        cy, cx = int(rng.integers(25, H - 25)), int(rng.integers(25, W - 25))
+        y, x = np.mgrid[:H, :W]
+        sed = rng.uniform(1.0, 5.0, C).astype(np.float32)
+        truth += sed[:, None, None] * np.exp(-((y - cy) ** 2 + (x - cx) ** 2) / (2 * true_sigma**2))[None]
+        by, bx = np.mgrid[:box, :box] - box // 2
+        start = np.exp(-(by**2 + bx**2) / (2 * (true_sigma * rng.uniform(0.7, 1.3)) ** 2))
+        layout.append((sed * rng.uniform(0.8, 1.2, C).astype(np.float32), start / start.max(),
+                       (cy - box // 2, cx - box // 2), box))
+    obs0 = scarlet.Observation(np.zeros((C, H, W), np.float32), psf=scarlet.ImagePSF(obs_psf.copy()),
+                               weights=np.ones((C, H, W), np.float32), channels=filters).match(frame)
+    kernel = obs0.renderer.diff_kernel.image.astype(np.float32)
+    images = (fftconv.convolve(truth, kernel, axes=(1, 2))
+              + rng.normal(0, noise, truth.shape)).astype(np.float32)
+    weights = np.full((C, H, W), 1 / noise**2, np.float32)
+    obs = scarlet.Observation(images, psf=scarlet.ImagePSF(obs_psf.copy()), weights=weights,
+                              channels=filters).match(frame)
+    sources, comps = [], []
+    for sed, start, (oy, ox), box in layout:
+        bbox = scarlet.Box((C, box, box), origin=(0, oy, ox))
+        spectrum = scarlet.TabulatedSpectrum(frame, sed.copy(), bbox=bbox[0], min_step=noise)
+        morphology = scarlet.ExtendedSourceMorphology(
+            frame, (oy + box // 2, ox + box // 2), start.copy(), bbox=bbox[1:], monotonic="angle",
+            resizing=True)
+        sources.append(scarlet.FactorizedComponent(frame, spectrum, morphology))
+        comps.append(pgm.Component(sed.copy(), start.copy(), (oy, ox), sed_min_step=noise))
+    blend = scarlet.Blend(sources, obs)
+    max_iter = int(rng.choice([25, 45]))
+    n_it, logL = blend.fit(max_iter, e_rel=1e-6)
+    scene = pgm.Scene((C, H, W), images, weights, kernel, comps)
+    n_ref, logL_ref = scene.fit(max_iter, e_rel=1e-6, resizing=True)
+    desc = "C=%d %dx%d K=%d boxes=%s -> %s it=%d" % (
+        C, H, W, K, [l[3] for l in layout], [c.morph.shape[0] for c in scene.components], n_ref)
+    problems = {}
+    if n_it != n_ref:
+        problems["n_iter"] = (n_it, n_ref)
+    for src, c in zip(sources, scene.components):
+        m = src.children[1]
+        if m.parameters[0].shape != c.morph.shape or tuple(m.bbox.origin) != tuple(c.origin):
+            problems["box"] = (m.parameters[0].shape, tuple(m.bbox.origin), c.morph.shape, c.origin)
+    if not problems:
+        chi = np.array(blend.loss) - scene.log_norm
+        chi_ref = np.array(scene.loss) - scene.log_norm
+        early = np.abs(chi[:12] / chi_ref[:12] - 1).max()
+        end = abs(chi[-1] / chi_ref[-1] - 1)
+        worst["chi_early"], worst["chi_end"] = max(worst["chi_early"], early), max(worst["chi_end"], end)
+        if early > 5e-4 or end > 1e-2:
+            problems["chi"] = (float(early), float(end))
+    if problems:
+        bad.append((n, desc, problems))
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(n, desc, problems or "ok")
+print("facade scenes with resizing: %d; worst %s" % (n_scenes, {k: "%.2e" % v for k, v in worst.items()}))
+for entry in bad:
+    print("OVER", entry)
