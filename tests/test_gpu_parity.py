@@ -1092,7 +1092,8 @@ def test_lite_loop_vs_the_reference_run(amd, hsc, kind, path):
                                        ("fuzz_batches.py", ["24", "5"]),
                                        ("fuzz_lite.py", ["16", "5"]),
                                        ("fuzz_facade_resize.py", ["8", "5"]),
-                                       ("fuzz_seam1.py", ["60", "5"])])
+                                       ("fuzz_seam1.py", ["60", "5"]),
+                                       ("fuzz_resampler.py", ["16", "5"])])
 def test_random_configurations_against_the_oracle(amd, tool, args):
     """tools/fuzz_*.py with a fixed seed: random frame / box / kernel shapes, band counts,
     weightings, sparsity, point sources, shifts, ragged batches, sub-ranges, lite loops,

@@ -25,6 +25,10 @@ for n in range(n_scenes):
     C = int(rng.integers(1, 9))
     H, W = int(rng.integers(12, 150)), int(rng.integers(12, 150))
     K = int(rng.integers(1, 13))
+    big = bool(os.environ.get("FUZZ_BIG"))  # boxes beyond the register-resident update kernels
+    if big:
+        H, W = int(rng.integers(90, 220)), int(rng.integers(90, 220))
+        K = int(rng.integers(1, 5))
     null = rng.random() < 0.15
     per_band = rng.random() < 0.5
     p = int(rng.choice([3, 5, 9, 15, 21, 31, 41]))
@@ -41,6 +45,8 @@ for n in range(n_scenes):
     specs, comps = [], []
     for k in range(K):
         h, w = int(rng.integers(3, 62)), int(rng.integers(3, 62))
+        if big:
+            h, w = int(rng.integers(55, 126)), int(rng.integers(55, 126))
         oy, ox = int(rng.integers(-h // 2, H - h // 2)), int(rng.integers(-w // 2, W - w // 2))
         y, x = np.mgrid[:h, :w]
         s = rng.uniform(1.0, 6.0)
