@@ -17,16 +17,8 @@ import scarlet_amd as scarlet  # noqa: E402
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 bad, worst = [], dict(chi_early=0.0, chi_end=0.0)
-for n in range(n_scenes):
-    C = int(rng.integers(1, 6))
-    H, W = int(rng.integers(60, 120)), int(rng.integers(60, 120))
+def make_scene(C, H, W, filters, obs_psf, frame, kernel):
     K = int(rng.integers(1, 5))
-    filters = ["b%d" % c for c in range(C)]
-    sigma_obs = rng.uniform(1.2, 2.0)
-    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * C)
-    yy, xx = np.mgrid[:21, :21] - 10
-    obs_psf = np.exp(-(yy**2 + xx**2) / (2 * sigma_obs**2))[None].repeat(C, 0).astype(np.float32)
-    frame = scarlet.Frame((C, H, W), psf=model_psf, channels=filters)
     noise = 0.05
     truth = np.zeros((C, H, W), np.float32)
     layout = []
@@ -41,9 +33,6 @@ for n in range(n_scenes):
         start = np.exp(-(by**2 + bx**2) / (2 * (true_sigma * rng.uniform(0.7, 1.3)) ** 2))
         layout.append((sed * rng.uniform(0.8, 1.2, C).astype(np.float32), start / start.max(),
                        (cy - box // 2, cx - box // 2), box))
-    obs0 = scarlet.Observation(np.zeros((C, H, W), np.float32), psf=scarlet.ImagePSF(obs_psf.copy()),
-                               weights=np.ones((C, H, W), np.float32), channels=filters).match(frame)
-    kernel = obs0.renderer.diff_kernel.image.astype(np.float32)
     images = (fftconv.convolve(truth, kernel, axes=(1, 2))
               + rng.normal(0, noise, truth.shape)).astype(np.float32)
     weights = np.full((C, H, W), 1 / noise**2, np.float32)
@@ -58,32 +47,55 @@ for n in range(n_scenes):
             resizing=True)
         sources.append(scarlet.FactorizedComponent(frame, spectrum, morphology))
         comps.append(pgm.Component(sed.copy(), start.copy(), (oy, ox), sed_min_step=noise))
-    blend = scarlet.Blend(sources, obs)
-    max_iter = int(rng.choice([25, 45]))
-    n_it, logL = blend.fit(max_iter, e_rel=1e-6)
     scene = pgm.Scene((C, H, W), images, weights, kernel, comps)
-    n_ref, logL_ref = scene.fit(max_iter, e_rel=1e-6, resizing=True)
-    desc = "C=%d %dx%d K=%d boxes=%s -> %s it=%d" % (
-        C, H, W, K, [l[3] for l in layout], [c.morph.shape[0] for c in scene.components], n_ref)
-    problems = {}
-    if n_it != n_ref:
-        problems["n_iter"] = (n_it, n_ref)
-    for src, c in zip(sources, scene.components):
-        m = src.children[1]
-        if m.parameters[0].shape != c.morph.shape or tuple(m.bbox.origin) != tuple(c.origin):
-            problems["box"] = (m.parameters[0].shape, tuple(m.bbox.origin), c.morph.shape, c.origin)
-    if not problems:
-        chi = np.array(blend.loss) - scene.log_norm
-        chi_ref = np.array(scene.loss) - scene.log_norm
-        early = np.abs(chi[:12] / chi_ref[:12] - 1).max()
-        end = abs(chi[-1] / chi_ref[-1] - 1)
-        worst["chi_early"], worst["chi_end"] = max(worst["chi_early"], early), max(worst["chi_end"], end)
-        if early > 5e-4 or end > 1e-2:
-            problems["chi"] = (float(early), float(end))
-    if problems:
-        bad.append((n, desc, problems))
-    if os.environ.get("FUZZ_VERBOSE"):
-        print(n, desc, problems or "ok")
+    return scarlet.Blend(sources, obs), scene, sources, [l[3] for l in layout]
+
+
+for n in range(n_scenes):
+    C = int(rng.integers(1, 6))
+    H, W = int(rng.integers(60, 120)), int(rng.integers(60, 120))
+    filters = ["b%d" % c for c in range(C)]
+    sigma_obs = rng.uniform(1.2, 2.0)
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * C)
+    yy, xx = np.mgrid[:21, :21] - 10
+    obs_psf = np.exp(-(yy**2 + xx**2) / (2 * sigma_obs**2))[None].repeat(C, 0).astype(np.float32)
+    frame = scarlet.Frame((C, H, W), psf=model_psf, channels=filters)
+    obs0 = scarlet.Observation(np.zeros((C, H, W), np.float32), psf=scarlet.ImagePSF(obs_psf.copy()),
+                               weights=np.ones((C, H, W), np.float32), channels=filters).match(frame)
+    kernel = obs0.renderer.diff_kernel.image.astype(np.float32)
+    # one blend through Blend.fit, or several through fit_blends (one device batch, blends
+    # restarting at different times)
+    n_blends = 1 if rng.random() < 0.5 else int(rng.integers(2, 5))
+    made = [make_scene(C, H, W, filters, obs_psf, frame, kernel) for _ in range(n_blends)]
+    max_iter = int(rng.choice([25, 45]))
+    if n_blends == 1:
+        results = [made[0][0].fit(max_iter, e_rel=1e-6)]
+    else:
+        results = scarlet.fit_blends([m[0] for m in made], max_iter, e_rel=1e-6)
+    for j, ((blend, scene, sources, boxes), (n_it, logL)) in enumerate(zip(made, results)):
+        n_ref, logL_ref = scene.fit(max_iter, e_rel=1e-6, resizing=True)
+        desc = "%s C=%d %dx%d boxes=%s -> %s it=%d" % (
+            "fit" if n_blends == 1 else "fit_blends[%d/%d]" % (j, n_blends), C, H, W, boxes,
+            [c.morph.shape[0] for c in scene.components], n_ref)
+        problems = {}
+        if n_it != n_ref:
+            problems["n_iter"] = (n_it, n_ref)
+        for src, c in zip(sources, scene.components):
+            m = src.children[1]
+            if m.parameters[0].shape != c.morph.shape or tuple(m.bbox.origin) != tuple(c.origin):
+                problems["box"] = (m.parameters[0].shape, tuple(m.bbox.origin), c.morph.shape, c.origin)
+        if not problems:
+            chi = np.array(blend.loss) - scene.log_norm
+            chi_ref = np.array(scene.loss) - scene.log_norm
+            early = np.abs(chi[:12] / chi_ref[:12] - 1).max()
+            end = abs(chi[-1] / chi_ref[-1] - 1)
+            worst["chi_early"], worst["chi_end"] = max(worst["chi_early"], early), max(worst["chi_end"], end)
+            if early > 5e-4 or end > 1e-2:
+                problems["chi"] = (float(early), float(end))
+        if problems:
+            bad.append((n, desc, problems))
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(n, desc, problems or "ok")
 print("facade scenes with resizing: %d; worst %s" % (n_scenes, {k: "%.2e" % v for k, v in worst.items()}))
 for entry in bad:
     print("OVER", entry)
