@@ -137,7 +137,13 @@ enum {
     /* the image morphology is moved by a free sub-pixel Fourier shift
      * (ExtendedSource(shifting=True): morphology.py:124-130, 673-676; fft.shift,
      * fft.py:399-428): `center` holds the initial shift (y, x), `shift_step` its step */
-    SMI_COMPONENT_SHIFTING = 1 << 17
+    SMI_COMPONENT_SHIFTING = 1 << 17,
+    /* Parameter(fixed=True) (parameter.py:38-39, blend.py:107-115): the parameter stays in
+     * X but its gradient is taken as zero; the step (nothing) and the proximal operator
+     * are still applied, as proxmin does with the expanded zero gradient.  FIXED_MORPH
+     * fixes the image of an extended source or the centre of a point source. */
+    SMI_COMPONENT_FIXED_SED = 1 << 18,
+    SMI_COMPONENT_FIXED_MORPH = 1 << 19
 };
 #define SMI_PROX_EXTENDED_SOURCE \
     (SMI_PROX_MONOTONIC | SMI_PROX_POSITIVE | SMI_PROX_CENTER_ON | SMI_PROX_NORM_MAX)

@@ -39,7 +39,12 @@ class Component:
         shift_step=1e-1,
         sparsity=None,
         tiny=1e-6,
+        fixed=(False, False),
     ):
+        # Parameter(fixed=True) for (spectrum, image): it stays in X, autograd is not asked
+        # for its gradient and adaprox sees zeros instead (blend.py:107-115); the step
+        # (nothing) and the proximal operator are applied all the same
+        self.fixed = tuple(fixed)
         # optional L0 / L1 member of the chain and the CenterOnConstraint floor
         self.sparsity, self.tiny = sparsity, tiny
         # ExtendedSourceMorphology(shifting=True): the sub-pixel offset of the centre
@@ -362,14 +367,22 @@ class Scene:
             boxed[bs] = G[fs]
             g_sed = np.einsum("cyx,yx->c", boxed, c.model_morph())
             g_morph = np.einsum("c,cyx->yx", c.sed, boxed)
+            fixed_sed, fixed_morph = getattr(c, "fixed", (False, False))
+            if fixed_sed:
+                g_sed = np.zeros_like(g_sed)
             if isinstance(c, PointComponent):
                 # second entry is d/d(center) for a point source
                 g_morph = c.center_gradient(g_morph)
+                if fixed_morph:
+                    g_morph = np.zeros_like(g_morph)
             elif c.shift is not None:
                 # pull the gradient back through the Fourier shift; third entry d/d(shift)
                 op = fftconv.ShiftOperator(c.morph.shape, c.shift)
-                out.append((g_sed, op.adjoint(g_morph), op.shift_gradient(c.morph, g_morph)))
+                pulled = np.zeros_like(g_morph) if fixed_morph else op.adjoint(g_morph)
+                out.append((g_sed, pulled, op.shift_gradient(c.morph, g_morph)))
                 continue
+            if fixed_morph and not isinstance(c, PointComponent):
+                g_morph = np.zeros_like(g_morph)
             out.append((g_sed, g_morph))
         return out
 

@@ -29,6 +29,8 @@ PROX_L_RELATIVE = 1024  # L0/L1 threshold x step of the proximal sub-iteration
 SCHEME_AMSGRAD, SCHEME_FISTA = 0, 1
 COMPONENT_POINT_SOURCE = 1 << 16  # PointSource: morphology = model PSF at a free centre
 COMPONENT_SHIFTING = 1 << 17  # image morphology moved by a free Fourier shift
+COMPONENT_FIXED_SED = 1 << 18
+COMPONENT_FIXED_MORPH = 1 << 19
 PROX_EXTENDED_SOURCE = PROX_MONOTONIC | PROX_POSITIVE | PROX_CENTER_ON | PROX_NORM_MAX
 
 ERR_ARITHMETIC = -4

@@ -14,6 +14,7 @@ from functools import partial
 import numpy as np
 import numpy.ma as ma
 
+from . import _lib
 from .batch import BlendBatch, ComponentSpec, PointSourceSpec
 from .bbox import overlapped_slices
 from .component import CombinedComponent, FactorizedComponent
@@ -159,13 +160,18 @@ class Blend(CombinedComponent):
                     shift_kw = dict(shift=np.asarray(shift), shift_step=0.0 if shift.fixed else const)
             if sed.prior is not None or image.prior is not None:
                 raise NotImplementedError("priors are not supported on the device")
-            if sed.fixed or image.fixed:
-                raise NotImplementedError("fixed parameters are not supported on the device")
-            s_const, s_rel, s_min = _step_rule(sed.step, "spectrum")
-            if not (isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20):
+            # Parameter(fixed=True) stays in X with a zero gradient (blend.py:107-115); its
+            # step is never used and may be missing
+            s_const, s_rel, s_min = (0.0, 0.0, 0.0) if sed.fixed and sed.step is None else \
+                _step_rule(sed.step, "spectrum")
+            free_form = isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20
+            if not free_form and not (sed.fixed and sed.constraint is None and np.all(np.asarray(sed) > 1e-20)):
                 raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
-            m_const, m_rel, m_min = _step_rule(image.step, "morphology")
+            m_const, m_rel, m_min = (0.0, 0.0, 0.0) if image.fixed and image.step is None else \
+                _step_rule(image.step, "morphology")
             flags = device_flags(image.constraint)
+            flags["flags"] |= (_lib.COMPONENT_FIXED_SED if sed.fixed else 0) | (
+                _lib.COMPONENT_FIXED_MORPH if image.fixed else 0)
             if flags["zero"] != 0:
                 raise NotImplementedError("PositivityConstraint(zero != 0) on a morphology")
             specs.append(
@@ -193,14 +199,15 @@ class Blend(CombinedComponent):
         if not (isinstance(psf, GaussianPSF) and psf.integrate and psf.is_same):
             raise NotImplementedError(
                 "point sources need a pixel-integrated GaussianPSF model PSF with one sigma")
-        if sed.prior is not None or center.prior is not None or sed.fixed or center.fixed:
-            raise NotImplementedError("priors / fixed parameters are not supported on the device")
+        if sed.prior is not None or center.prior is not None:
+            raise NotImplementedError("priors are not supported on the device")
         if center.constraint is not None:
             raise NotImplementedError("constraints on a point-source centre are not supported")
         if not (isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20):
             raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
         s_const, s_rel, s_min = _step_rule(sed.step, "spectrum")
-        c_const, c_rel, _ = _step_rule(center.step, "center")
+        c_const, c_rel, _ = (0.0, 0.0, 0.0) if center.fixed and center.step is None else \
+            _step_rule(center.step, "center")
         if c_rel:
             raise NotImplementedError("relative steps for a point-source centre")
         spec = PointSourceSpec(
@@ -208,6 +215,9 @@ class Blend(CombinedComponent):
             boxsize=morphology.bbox.shape[-1],
             sed_min_step=np.maximum(np.asarray(s_min, dtype=np.float64), s_const),
             sed_rel_step=s_rel, center_step=c_const, origin=morphology.bbox.origin[-2:])
+        # Parameter(fixed=True): zero gradient for that parameter (blend.py:107-115)
+        spec.prox_flags |= (_lib.COMPONENT_FIXED_SED if sed.fixed else 0) | (
+            _lib.COMPONENT_FIXED_MORPH if center.fixed else 0)
         return spec
 
     def _build_batch(self, comps, capacity):

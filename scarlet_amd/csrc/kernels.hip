@@ -334,6 +334,15 @@ __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompC
     return g_sed;
 }
 
+// Parameter(fixed=True): the optimizer sees a zero gradient (blend.py:107-115)
+__device__ __forceinline__ float hold_fixed(const BatchView &v, const CompCtx &c, float g_sed,
+                                            float *us) {
+    const int flags = v.c_flags[c.k];
+    if (flags & SMI_COMPONENT_FIXED_MORPH)
+        for (int i = c.lane; i < c.N; i += 64) us[i] = 0.f;
+    return (flags & SMI_COMPONENT_FIXED_SED) ? 0.f : g_sed;
+}
+
 // spectrum (spectrum.py:54-56): relative step, AMSGrad, positivity at 1e-20.
 // FISTA (lite/parameters.py:134-150): y = z - step / sum(morph^2) g, x' = max(y, 1e-20),
 // z' = x + (1 + (t - 1) / t') (x' - x).  The new spectrum is also left in
@@ -480,13 +489,15 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     float *us = v.scratch ? lds_dyn : zs + npad;  // candidate (and g_morph before that)
     int32_t *lvl = reinterpret_cast<int32_t *>(us + npad);  // level_start of the plan
 
-    const float g_sed = gather_gradient(v, c, G, us);
+    float g_sed = gather_gradient(v, c, G, us);
     __syncthreads();
     if (grad_only) {
         if (lane < c.C) g_sed_out[(int64_t)c.k * c.C + lane] = g_sed;
         for (int i = lane; i < N; i += 64) g_morph_out[c.moff + i] = us[i];
         return;
     }
+    g_sed = hold_fixed(v, c, g_sed, us);
+    __syncthreads();
     const float e2 = e_rel * e_rel;
     __shared__ float sed_new[64];
     const bool fista = v.scheme == SMI_SCHEME_FISTA;
@@ -690,7 +701,10 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
             return;
         }
         __shared__ float sed_new[64];
-        bad = update_spectrum(v, c, g_sed, it, e_rel * e_rel, prox_max_iter, 1.f, sed_new);
+        const int fixed = v.c_flags[c.k];  // Parameter(fixed=True): zero gradient
+        if (fixed & SMI_COMPONENT_FIXED_MORPH) gy = gx = 0.0;
+        bad = update_spectrum(v, c, (fixed & SMI_COMPONENT_FIXED_SED) ? 0.f : g_sed, it,
+                              e_rel * e_rel, prox_max_iter, 1.f, sed_new);
         const double b1 = v.b1, b2 = v.b2, eps = v.eps, alpha = v.c_morph_step[c.k];
         double upd[2];
 #pragma unroll
@@ -814,7 +828,7 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
     const int lane = c.lane, N = c.N;
     float *us = lds_dyn;
 
-    const float g_sed = gather_gradient(v, c, G, us);
+    const float g_sed = hold_fixed(v, c, gather_gradient(v, c, G, us), us);
     __syncthreads();
     const float e2 = e_rel * e_rel;
     __shared__ float sed_new[64];

@@ -799,3 +799,49 @@ def test_multiresolution_tutorial_scene():
     assert obs_hsc.get_log_likelihood(after) > logL_hsc
     assert obs_hst.get_log_likelihood(after) > logL_hst
     assert abs(obs_hsc.get_log_likelihood(after) + obs_hst.get_log_likelihood(after) - logL) < 2e-3 * abs(logL) + 2.0
+
+
+def test_fixed_parameters(hsc):
+    """Parameter(fixed=True) (parameter.py:38-39): the reference keeps it in X and hands
+    adaprox a zero gradient for it (blend.py:107-115), so its value changes only through
+    its proximal operator -- not at all for a spectrum above the floor or an image that
+    already satisfies its constraints.  Fixed spectrum of source 0, fixed image of source 1;
+    everything else follows the oracle with the same flags."""
+    import scarlet_amd as scarlet
+
+    blend, obs = build_blend(hsc, resizing=False)
+    comps = components_of(blend)
+    sed0 = comps[0].children[0].parameters[0]
+    img1 = comps[1].children[1].parameters[0]
+    sed0.fixed = True
+    img1.fixed = True
+    before_sed, before_img = np.array(sed0), np.array(img1)
+    free_before = np.array(comps[1].children[0].parameters[0])
+    n, logL = blend.fit(15, e_rel=1e-9)
+    assert_array_equal = np.testing.assert_array_equal
+    assert_array_equal(np.array(sed0), before_sed)
+    # the image goes through its proximal chain (monotonic, normalised): a fixed point
+    assert np.abs(np.array(img1) - before_img).max() < 1e-6
+    assert np.abs(np.array(comps[1].children[0].parameters[0]) - free_before).max() > 1e-3
+    assert sed0.m is not None and not np.any(sed0.m) and not np.any(sed0.v)
+
+    sc = hsc_scene(hsc)
+    for c in sc.components:
+        c.source = None
+    sc.components[0].fixed = (True, False)
+    sc.components[1].fixed = (False, True)
+    n_ref, logL_ref = sc.fit(15, e_rel=1e-9)
+    assert n == n_ref == 15
+    chi = np.array(blend.loss) - sc.log_norm
+    chi_ref = np.array(sc.loss) - sc.log_norm
+    assert_allclose(chi, chi_ref, rtol=5e-4)
+    # a fixed spectrum without constraint or step, as a user would write it
+    frame = obs.model_frame
+    comp = comps[2]
+    plain = scarlet.Parameter(np.array(comp.children[0].parameters[0]), name="spectrum", fixed=True)
+    spectrum = scarlet.TabulatedSpectrum(frame, plain, bbox=comp.children[0].bbox)
+    replaced = scarlet.FactorizedComponent(frame, spectrum, comp.children[1])
+    blend2 = scarlet.Blend([replaced], obs)
+    keep = np.array(plain)
+    blend2.fit(5, e_rel=1e-9)
+    assert_array_equal(np.array(plain), keep)

@@ -66,8 +66,13 @@ for n in range(n_batches):
             if feature == "shifts" and rng.random() < 0.6:
                 shift = rng.uniform(-0.4, 0.4, 2)
                 kw, okw = dict(shift=shift), dict(shift=shift.copy())
+            # Parameter(fixed=True) on the spectrum and / or the image of some components
+            fixed = (bool(rng.random() < 0.2), bool(rng.random() < 0.2))
+            flags |= (_lib.COMPONENT_FIXED_SED if fixed[0] else 0) | (
+                _lib.COMPONENT_FIXED_MORPH if fixed[1] else 0)
             bs.append(ComponentSpec(sed, morph, (oy, ox), sed_min_step=0.01, prox_flags=flags, **kw))
-            comps.append(pgm.Component(sed.copy(), morph.copy(), (oy, ox), sed_min_step=0.01, **okw))
+            comps.append(pgm.Component(sed.copy(), morph.copy(), (oy, ox), sed_min_step=0.01,
+                                       fixed=fixed, **okw))
         specs.append(bs)
         scenes.append(pgm.Scene((C, H, W), data[b], weights[b], kernel, comps))
     n_sub = int(rng.integers(1, 4))
