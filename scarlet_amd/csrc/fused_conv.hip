@@ -33,9 +33,13 @@ using fftk::st;
 
 namespace {
 
-constexpr int kThreads = 1024;
+#ifndef SMI_CONV_THREADS  // experiment knobs: workgroup size and row pairs per chunk
+#define SMI_CONV_THREADS 1024
+#define SMI_CONV_PAIRS 32
+#endif
+constexpr int kThreads = SMI_CONV_THREADS;
 constexpr int kF2 = 16;      // second radix of every 1-D transform
-constexpr int kPairs = 32;   // row pairs per chunk (64 rows)
+constexpr int kPairs = SMI_CONV_PAIRS;   // row pairs per chunk (64 rows)
 
 template <int FY1, int FX1>
 struct Cfg {
