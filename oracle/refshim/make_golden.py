@@ -562,6 +562,66 @@ def synthetic_cfg2(scarlet):
     )
 
 
+def init_synthetic(scarlet):
+    """``init_all_sources`` of the reference on three synthetic scenes that take branches
+    the quickstart scene does not: faint sources that fall back to one component or to a
+    compact source, non-default thresholds, a single band, sources near the frame
+    edge.  Stored: the data (seeded generator below), the centres and, per scene, the
+    initialised components and the log-likelihood of the initial model."""
+    from scarlet.initialization import init_all_sources
+
+    out = {}
+    settings = [
+        dict(seed=11, C=5, H=70, W=64, n=5, max_components=2, min_snr=50, thresh=1.0),
+        dict(seed=12, C=1, H=56, W=60, n=4, max_components=1, min_snr=20, thresh=0.5),
+        dict(seed=13, C=3, H=80, W=72, n=6, max_components=2, min_snr=30, thresh=2.0),
+    ]
+    for t, cfg in enumerate(settings):
+        rng = np.random.default_rng(cfg["seed"])
+        C, H, W = cfg["C"], cfg["H"], cfg["W"]
+        filters = ["f%d" % c for c in range(C)]
+        yy, xx = np.mgrid[:25, :25] - 12
+        psfs = np.stack([np.exp(-(yy**2 + xx**2) / (2 * s**2)) for s in rng.uniform(1.5, 2.2, C)])
+        psfs = (psfs / psfs.sum(axis=(1, 2))[:, None, None]).astype(np.float32)
+        y, x = np.mgrid[:H, :W]
+        images = np.zeros((C, H, W))
+        centers = []
+        for k in range(cfg["n"]):
+            cy, cx = rng.uniform(6, H - 6), rng.uniform(6, W - 6)
+            sig = rng.uniform(1.8, 4.5)
+            amp = rng.choice([0.02, 0.1, 1.0, 8.0]) * rng.uniform(0.5, 1.5, C)
+            images += amp[:, None, None] * np.exp(-((y - cy) ** 2 + (x - cx) ** 2) / (2 * sig**2))
+            centers.append((float(np.round(cy)), float(np.round(cx))))
+        noise = 0.05
+        images = (images + rng.normal(0, noise, images.shape)).astype(np.float32)
+        weights = np.full(images.shape, 1 / noise**2, dtype=np.float32)
+        model_psf = scarlet.GaussianPSF(sigma=(0.8,) * C)
+        frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters)
+        obs = scarlet.Observation(images, psf=scarlet.ImagePSF(psfs.copy()), weights=weights,
+                                  channels=filters).match(frame)
+        sources, skipped = init_all_sources(
+            frame, centers, obs, max_components=cfg["max_components"], min_snr=cfg["min_snr"],
+            thresh=cfg["thresh"], fallback=True, silent=True, set_spectra=True)
+        blend = scarlet.Blend(sources, obs)
+        model = blend.get_model()
+        seds, morphs, origins, min_steps, source_of = _sources_to_arrays(sources, scarlet)
+        tag = "s%d_" % t
+        out.update({tag + "images": images, tag + "weights": weights, tag + "psfs": psfs,
+                    tag + "centers": np.array(centers), tag + "n_comp": len(seds),
+                    tag + "skipped": np.array(skipped, dtype=int),
+                    tag + "source_of": np.array(source_of),
+                    tag + "kinds": np.array([type(s).__name__ for s in sources]),
+                    tag + "logL": obs.get_log_likelihood(model),
+                    tag + "settings": np.array([cfg["max_components"], cfg["min_snr"], cfg["thresh"]])})
+        for k, (sd, m, o, ms) in enumerate(zip(seds, morphs, origins, min_steps)):
+            out[tag + "sed_%d" % k], out[tag + "morph_%d" % k] = sd, m
+            out[tag + "origin_%d" % k], out[tag + "min_step_%d" % k] = np.array(o), ms
+        print("init_synthetic scene %d: %s -> %d components, skipped %s, logL %.3f" % (
+            t, [type(s).__name__ for s in sources], len(seds), skipped, out[tag + "logL"]))
+    out["n_scenes"] = len(settings)
+    np.savez_compressed(os.path.join(OUT, "init_synthetic.npz"), **out)
+
+
 def main(which=None):
     from oracle.refshim.load_reference import load
 
@@ -571,7 +631,7 @@ def main(which=None):
         operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
         hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, hsc_shifting=hsc_shifting, lite=lite,
         hsc_psf_shift=hsc_psf_shift,
-        synthetic_cfg2=synthetic_cfg2,
+        synthetic_cfg2=synthetic_cfg2, init_synthetic=init_synthetic,
     )
     for name, fn in jobs.items():
         if which and name not in which:

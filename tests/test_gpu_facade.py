@@ -845,3 +845,47 @@ def test_fixed_parameters(hsc):
     keep = np.array(plain)
     blend2.fit(5, e_rel=1e-9)
     assert_array_equal(np.array(plain), keep)
+
+
+def test_initialisation_of_synthetic_scenes_matches_reference():
+    """init_all_sources on three synthetic scenes the reference initialised itself
+    (golden init_synthetic.npz): faint and bright sources, one / three / five bands,
+    max_components 1 and 2, thresholds 0.5 / 1 / 2, sources near the frame edge -- the
+    same source classes, boxes, morphologies, spectra, steps and initial log-likelihood."""
+    import scarlet_amd as scarlet
+    from conftest import golden
+    from scarlet_amd.initialization import init_all_sources
+
+    g = golden("init_synthetic")
+    for t in range(int(g["n_scenes"])):
+        tag = "s%d_" % t
+        images, weights, psfs = g[tag + "images"], g[tag + "weights"], g[tag + "psfs"]
+        C = images.shape[0]
+        filters = ["f%d" % c for c in range(C)]
+        max_components, min_snr, thresh = g[tag + "settings"]
+        frame = scarlet.Frame(images.shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * C), channels=filters)
+        obs = scarlet.Observation(images.copy(), psf=scarlet.ImagePSF(psfs.copy()),
+                                  weights=weights.copy(), channels=filters).match(frame)
+        centers = [tuple(c) for c in g[tag + "centers"]]
+        sources, skipped = init_all_sources(
+            frame, centers, obs, max_components=int(max_components), min_snr=float(min_snr),
+            thresh=float(thresh), fallback=True, silent=True, set_spectra=True)
+        assert list(skipped) == list(g[tag + "skipped"])
+        assert [type(s).__name__ for s in sources] == [str(k) for k in g[tag + "kinds"]], t
+        blend = scarlet.Blend(sources, obs)
+        comps = components_of(blend)
+        assert len(comps) == int(g[tag + "n_comp"])
+        for k, comp in enumerate(comps):
+            sed = np.asarray(comp.children[0].parameters[0])
+            morph = np.asarray(comp.children[1].parameters[0])
+            ref_morph, ref_sed = g[tag + "morph_%d" % k], g[tag + "sed_%d" % k]
+            assert morph.shape == ref_morph.shape, (t, k)
+            assert tuple(comp.children[1].bbox.origin) == tuple(g[tag + "origin_%d" % k]), (t, k)
+            assert np.abs(morph - ref_morph).max() < 1e-5, (t, k)
+            assert np.abs(sed - ref_sed).max() < 3e-4 * np.abs(ref_sed).max() + 1e-6, (t, k)
+            step = comp.children[0].parameters[0].step
+            assert_allclose(step.keywords["minimum"], g[tag + "min_step_%d" % k], rtol=1e-5)
+        logL0 = obs.get_log_likelihood(blend.get_model())
+        assert abs(logL0 - float(g[tag + "logL"])) < 1e-3 * abs(float(g[tag + "logL"])) + 0.5, t
+        n, logL = blend.fit(30, e_rel=1e-4)
+        assert logL > logL0
