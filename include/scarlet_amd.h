@@ -204,6 +204,9 @@ typedef struct smi_components {
     const float *fista_step;    /* [n_components] FistaParameter.step                */
                                 /* (lite/initialization.py:308-312); NULL unless the */
                                 /* batch runs SMI_SCHEME_FISTA                       */
+    const float *sym_strength;  /* [n_components] strength of SMI_PROX_SYMMETRY         */
+                                /* (SymmetryConstraint(strength), constraint.py:262-273,*/
+                                /* operator.py:274-293); NULL = 1                        */
 } smi_components;
 
 int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out);

@@ -322,7 +322,8 @@ def morph_chain(morph, step=0, monotonic="angle", min_gradient=0.0, symmetric=Fa
     if monotonic is not None:
         x = prox_monotonic(x, step, monotonic, min_gradient)
     if symmetric:
-        x = prox_soft_symmetry(x, step)
+        # True = SymmetryConstraint() (strength 1); a number = SymmetryConstraint(strength)
+        x = prox_soft_symmetry(x, step, 1 if symmetric is True else symmetric)
     if sparsity is not None:
         kind, thresh, type = sparsity
         x = (prox_hard if kind == "l0" else prox_soft)(x, step, thresh, type)

@@ -19,7 +19,8 @@ class ComponentSpec:
     def __init__(self, sed, morph, origin, sed_min_step=0.0, sed_rel_step=1e-2,
                  morph_step=1e-2, morph_rel_step=0.0, prox_flags=_lib.PROX_EXTENDED_SOURCE,
                  neighbor_weight="angle", min_gradient=0.0, l_thresh=0.0, shift=None,
-                 shift_step=1e-1, center_floor=1e-6, bg_level=None, fista_step=0.0):
+                 shift_step=1e-1, center_floor=1e-6, bg_level=None, fista_step=0.0,
+                 sym_strength=1.0):
         self.sed = np.asarray(sed, dtype=np.float32)
         self.morph = np.ascontiguousarray(morph, dtype=np.float32)
         self.origin = (int(origin[0]), int(origin[1]))
@@ -44,6 +45,7 @@ class ComponentSpec:
             self.bg_level = np.broadcast_to(np.asarray(bg_level, dtype=np.float32), self.sed.shape)
             self.prox_flags |= _lib.PROX_BG_THRESH
         self.fista_step = float(fista_step)
+        self.sym_strength = float(sym_strength)  # SymmetryConstraint(strength)
         if shift is not None:
             self.center = np.array(shift, dtype=np.float64).reshape(2)
             self.prox_flags |= _lib.COMPONENT_SHIFTING
@@ -207,6 +209,7 @@ class BlendBatch:
                           for c in flat]) if flat else np.zeros((0, C))
             ),
             fista_step=_lib.f32([c.fista_step for c in flat]),
+            sym_strength=_lib.f32([c.sym_strength for c in flat]),
         )
         comps = _lib.Components()
         for name, ctype in _lib.Components._fields_:

@@ -186,6 +186,7 @@ class Blend(CombinedComponent):
                     min_gradient=flags["min_gradient"],
                     l_thresh=flags["l_thresh"],
                     center_floor=flags["center_floor"],
+                    sym_strength=flags["sym_strength"],
                     **shift_kw,
                 )
             )

@@ -206,7 +206,7 @@ def device_flags(constraint):
     (user callables, other orders, repeats) -- there is no host fallback.
     """
     out = dict(flags=0, neighbor_weight=None, min_gradient=0.0, zero=0.0, l_thresh=0.0,
-               center_floor=1e-6)
+               center_floor=1e-6, sym_strength=1.0)
     if constraint is None:
         return out
     if isinstance(constraint, ConstraintChain):
@@ -241,9 +241,8 @@ def device_flags(constraint):
             out["neighbor_weight"] = c.neighbor_weight
             out["min_gradient"] = float(c.min_gradient)
         elif isinstance(c, SymmetryConstraint):
-            if c.strength != 1:
-                raise NotImplementedError("SymmetryConstraint(strength != 1) on the device")
             out["flags"] |= _lib.PROX_SYMMETRY
+            out["sym_strength"] = float(c.strength)
         elif isinstance(c, (L0Constraint, L1Constraint)):
             if out["flags"] & (_lib.PROX_L0 | _lib.PROX_L1):
                 raise NotImplementedError("L0 and L1 constraints in one chain")

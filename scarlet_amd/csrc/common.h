@@ -128,6 +128,7 @@ struct BatchView {
     const int32_t *c_shift_fft;  // (Fy, Fx) per component, fft.py:116-167 with padding 10
     // scarlet.lite: centre floor, background threshold levels [n_comp][C], FISTA
     const float *c_center_floor;
+    const float *c_sym_strength;  // SymmetryConstraint(strength)
     const float *c_bg_level;
     float *scratch;              // 3 * n_morph floats when the largest box exceeds the LDS
     int32_t lite;                // FISTA, or a component with FIT_CENTER / BG_THRESH

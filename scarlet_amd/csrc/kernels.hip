@@ -427,7 +427,8 @@ __device__ __forceinline__ int fit_center_index(const float *us, const CompCtx &
 // final positivity / centre / normalisation pass (constraint.py:262-273, 117-145)
 __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCtx &c, int flags,
                                                          float lthresh, const float *sed_new,
-                                                         const float *bg_level) {
+                                                         const float *bg_level,
+                                                         float strength = 1.f) {
     const int h = c.h, w = c.w, N = c.N, lane = c.lane;
     if (flags & SMI_PROX_BG_THRESH) {
         // lite/models.py:222-228: zero where the model stays below the background
@@ -441,20 +442,30 @@ __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCt
         __syncthreads();
     }
     if (flags & SMI_PROX_SYMMETRY) {
-        // prox_soft_symmetry, strength 1 (operator.py:274-293): even axes are
+        // prox_soft_symmetry (operator.py:274-293), x <- s/2 (x + rot180 x) + (1 - s) x: even axes are
         // padded by one trailing zero before the 180-degree rotation
         const int hp = h + !(h & 1), wp = w + !(w & 1);
+        const float s = strength, keep = 1.f - strength;
         for (int i = lane; i < N; i += 64) {
             const int y = i / w, x = i - y * w;
             const int py = hp - 1 - y, px = wp - 1 - x;
             const bool has = py < h && px < w;
             const int j = py * w + px;
-            if (!has) {
-                us[i] = 0.5f * us[i];
+            if (s == 1.f) {
+                if (!has) {
+                    us[i] = 0.5f * us[i];
+                } else if (j >= i) {
+                    const float a = 0.5f * (us[i] + us[j]);
+                    us[i] = a;
+                    us[j] = a;
+                }
+            } else if (!has) {
+                // 0.5 s (x + 0) + (1 - s) x
+                us[i] = 0.5f * s * us[i] + keep * us[i];
             } else if (j >= i) {
-                const float a = 0.5f * (us[i] + us[j]);
-                us[i] = a;
-                us[j] = a;
+                const float xi = us[i], xj = us[j];
+                us[i] = 0.5f * s * (xi + xj) + keep * xi;
+                us[j] = 0.5f * s * (xj + xi) + keep * xj;
             }
         }
         __syncthreads();
@@ -579,7 +590,8 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         if (monotonic)
             sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
                                        pl.nbr, pl.wt, one_minus_g, lane);
-        chain_symmetry_threshold(us, c, flags, lthresh, sed_new, bg_level);
+        chain_symmetry_threshold(us, c, flags, lthresh, sed_new, bg_level,
+                                 (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[c.k] : 1.f);
         float mx = -INFINITY, sm = 0.f;
         for (int i = lane; i < N; i += 64) {
             float u = us[i];
@@ -929,7 +941,8 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
         }
         if (monotonic) sweep_slots(us, slots, n_slots, one_minus_g, lane);
         chain_symmetry_threshold(us, c, LITE ? flags : (flags & ~SMI_PROX_BG_THRESH), lthresh,
-                                 sed_new, bg_level);
+                                 sed_new, bg_level,
+                                 (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[c.k] : 1.f);
         float mx = -INFINITY, sm = 0.f;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {

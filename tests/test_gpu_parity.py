@@ -1120,3 +1120,24 @@ def test_random_configurations_against_the_oracle(amd, tool, args):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "OVER" not in out.stdout, out.stdout[-3000:]
     assert any(word in out.stdout for word in ("worst", "mismatches: 0")), out.stdout[-2000:]
+
+
+def test_symmetry_strength(amd):
+    """SymmetryConstraint(strength) (constraint.py:262-273; operator.py:274-293): the
+    reference's known answers for strength 1 and 0.5 (tests/test_constraint.py:137-161)
+    through the facade class, and the constraint inside the device chain for even and odd
+    boxes against the oracle."""
+    from scarlet_amd import _lib
+    from scarlet_amd.constraint import SymmetryConstraint, device_flags
+
+    x = np.arange(25, dtype=float).reshape(5, 5)
+    assert_allclose(SymmetryConstraint()(x.copy(), 0), np.full((5, 5), 12.0))
+    assert_allclose(SymmetryConstraint(strength=0.5)(x.copy(), 0), x * 0.5 + 6.0)
+    assert device_flags(SymmetryConstraint(0.5))["sym_strength"] == 0.5
+    rng = np.random.default_rng(17)
+    boxes = [((21, 21), (3, 5)), ((20, 31), (20, 25)), ((25, 34), (30, -4))]
+    specs, kernel, data, weights = _random_scene(rng, 3, 64, 72, boxes, kernel_shape=15)
+    flags = _lib.PROX_EXTENDED_SOURCE | _lib.PROX_SYMMETRY
+    for strength in (0.5, 0.2):
+        _compare_steps(amd, specs, kernel, data, weights, 3, dict(sym_strength=strength),
+                       dict(symmetric=strength), flags=flags)

@@ -57,9 +57,12 @@ for n in range(n_scenes):
         mode = str(rng.choice(["angle", "flat", "nearest"]))
         g = float(rng.choice([0.0, 0.1]))
         sym = bool(rng.random() < 0.3)
+        if sym and rng.random() < 0.5:
+            sym = float(rng.choice([0.25, 0.5, 0.9]))  # SymmetryConstraint(strength)
         flags = _lib.PROX_EXTENDED_SOURCE | (_lib.PROX_SYMMETRY if sym else 0)
         specs.append(ComponentSpec(sed, morph, (oy, ox), sed_min_step=0.01, prox_flags=flags,
-                                   neighbor_weight=mode, min_gradient=g))
+                                   neighbor_weight=mode, min_gradient=g,
+                                   sym_strength=1.0 if sym is True or not sym else sym))
         comps.append(pgm.Component(sed.copy(), morph.copy(), (oy, ox), sed_min_step=0.01,
                                    monotonic=mode, min_gradient=g, symmetric=sym))
     desc = "C=%d HxW=%dx%d K=%d kernel=%s" % (C, H, W, K, None if null else kernel.shape)
