@@ -5,7 +5,9 @@ NumPy aliases the reference still uses, the autograd / proxmin shims (but NOT th
 stand-in: astropy must be the real one), stubs for the two compiled extension modules.
 ``scarlet = conda_reference.load()``.
 """
+import atexit
 import os
+import shutil
 import sys
 import tempfile
 import types
@@ -28,6 +30,7 @@ for name, t in (("float", float), ("int", int), ("bool", bool), ("object", objec
 
 # only the autograd / proxmin shims: astropy must be the real one
 shim_dir = tempfile.mkdtemp()
+atexit.register(shutil.rmtree, shim_dir, ignore_errors=True)
 for pkg in ("autograd", "proxmin"):
     os.symlink(os.path.join(HERE, "shims", pkg), os.path.join(shim_dir, pkg))
 sys.path[:0] = [shim_dir, REPO, "/root/reference"]
