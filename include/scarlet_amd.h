@@ -207,6 +207,9 @@ typedef struct smi_components {
     const float *sym_strength;  /* [n_components] strength of SMI_PROX_SYMMETRY         */
                                 /* (SymmetryConstraint(strength), constraint.py:262-273,*/
                                 /* operator.py:274-293); NULL = 1                        */
+    const int32_t *chain_repeat;/* [n_components] ConstraintChain(repeat) (constraint.py:  */
+                                /* 60-80): the whole chain applied that many times per     */
+                                /* proximal evaluation; NULL = 1                           */
 } smi_components;
 
 int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out);

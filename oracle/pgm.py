@@ -92,7 +92,8 @@ class Component:
     def morph_prox(self, x, step):
         """ExtendedSourceMorphology chain (morphology.py:644-670)."""
         return proxops.morph_chain(
-            x, step, self.monotonic, self.min_gradient, self.symmetric, self.sparsity, self.tiny
+            x, step, self.monotonic, self.min_gradient, self.symmetric, self.sparsity, self.tiny,
+            getattr(self, "chain_repeat", 1),
         )
 
 

@@ -312,13 +312,17 @@ def prox_threshold(x, step=0):
 
 
 def morph_chain(morph, step=0, monotonic="angle", min_gradient=0.0, symmetric=False,
-                sparsity=None, tiny=1e-6):
+                sparsity=None, tiny=1e-6, repeat=1):
     """The ``ExtendedSourceMorphology`` constraint chain (morphology.py:644-670):
     Monotonicity -> [Symmetry] -> Positivity -> CenterOn -> Normalization("max"),
     optionally with an ``L0Constraint`` / ``L1Constraint`` (``sparsity`` =
     ("l0" | "l1", thresh, type), constraint.py:117-145) after the symmetry, the order a
     user chain must have to run on the device."""
     x = morph
+    if repeat > 1:  # ConstraintChain(repeat) (constraint.py:60-80): the whole chain again
+        for _ in range(repeat):
+            x = morph_chain(x, step, monotonic, min_gradient, symmetric, sparsity, tiny)
+        return x
     if monotonic is not None:
         x = prox_monotonic(x, step, monotonic, min_gradient)
     if symmetric:

@@ -187,6 +187,7 @@ class Blend(CombinedComponent):
                     l_thresh=flags["l_thresh"],
                     center_floor=flags["center_floor"],
                     sym_strength=flags["sym_strength"],
+                    chain_repeat=flags["chain_repeat"],
                     **shift_kw,
                 )
             )

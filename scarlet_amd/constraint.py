@@ -203,15 +203,14 @@ def device_flags(constraint):
 
     Returns ``dict(flags, neighbor_weight, min_gradient, zero, l_thresh)`` or
     raises ``NotImplementedError`` for chains the device kernel cannot express
-    (user callables, other orders, repeats) -- there is no host fallback.
+    (user callables, other orders) -- there is no host fallback.
     """
     out = dict(flags=0, neighbor_weight=None, min_gradient=0.0, zero=0.0, l_thresh=0.0,
-               center_floor=1e-6, sym_strength=1.0)
+               center_floor=1e-6, sym_strength=1.0, chain_repeat=1)
     if constraint is None:
         return out
     if isinstance(constraint, ConstraintChain):
-        if constraint.repeat != 1:
-            raise NotImplementedError("ConstraintChain(repeat>1) is not supported on the device")
+        out["chain_repeat"] = int(constraint.repeat)
         items = list(constraint.constraints)
     else:
         items = [constraint]

@@ -575,35 +575,46 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     const float lthresh =
         v.c_lthresh[c.k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
     const float *bg_level = v.c_bg_level ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;
+    const int repeat = v.c_chain_repeat ? v.c_chain_repeat[c.k] : 1;
     __syncthreads();
     for (int i = lane; i < N; i += 64) rs[i] = rs[i] / pmax;
 
     for (int tau = 0; tau < prox_max_iter; ++tau) {
         for (int i = lane; i < N; i += 64) us[i] = zs[i] - rs[i] * (zs[i] - xs[i]);
         __syncthreads();
-        // ConstraintChain (constraint.py:76-80) in the order of morphology.py:644-670
-        if (fit_center) {
-            pl = v.plans[plan_id + fit_center_index(us, c)];
-            for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
-            __syncthreads();
-        }
-        if (monotonic)
-            sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
-                                       pl.nbr, pl.wt, one_minus_g, lane);
-        chain_symmetry_threshold(us, c, flags, lthresh, sed_new, bg_level,
-                                 (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[c.k] : 1.f);
-        float mx = -INFINITY, sm = 0.f;
-        for (int i = lane; i < N; i += 64) {
-            float u = us[i];
-            if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
-            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
-            us[i] = u;
-            mx = fmaxf(mx, u);
-            sm += u;
-        }
+        // ConstraintChain (constraint.py:76-80) in the order of morphology.py:644-670,
+        // `repeat` times over (constraint.py:60-80); the last normalisation is folded into
+        // the convergence pass below
         float div = 1.f;
-        if (flags & SMI_PROX_NORM_MAX) div = wave_max(mx);
-        if (flags & SMI_PROX_NORM_SUM) div = wave_sum(sm);
+        for (int rep = 0; rep < repeat; ++rep) {
+            if (fit_center) {
+                pl = v.plans[plan_id + fit_center_index(us, c)];
+                for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
+                __syncthreads();
+            }
+            if (monotonic)
+                sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
+                                           pl.nbr, pl.wt, one_minus_g, lane);
+            chain_symmetry_threshold(us, c, flags, lthresh, sed_new, bg_level,
+                                     (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[c.k] : 1.f);
+            float mx = -INFINITY, sm = 0.f;
+            for (int i = lane; i < N; i += 64) {
+                float u = us[i];
+                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
+                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
+                us[i] = u;
+                mx = fmaxf(mx, u);
+                sm += u;
+            }
+            div = 1.f;
+            if (flags & SMI_PROX_NORM_MAX) div = wave_max(mx);
+            if (flags & SMI_PROX_NORM_SUM) div = wave_sum(sm);
+            if (rep + 1 < repeat) {
+                if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
+                    for (int i = lane; i < N; i += 64) us[i] = us[i] / div;
+                __syncthreads();
+            }
+        }
         float d2 = 0.f, z2 = 0.f;
         for (int i = lane; i < N; i += 64) {
             const float u = (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM)) ? us[i] / div : us[i];
@@ -1176,7 +1187,8 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
                   int32_t prox_max_iter, float *g_sed_out, float *g_morph_out,
                   int32_t grad_only, hipStream_t s) {
     if (v.n_comp == 0) return SMI_OK;
-    if (!grad_only && v.fast_plans && v.max_box_pixels <= 64 * 59) {
+    // chains that repeat take the general kernel (the register-resident ones apply it once)
+    if (!grad_only && v.fast_plans && v.max_box_pixels <= 64 * 59 && !v.c_chain_repeat) {
         const int n = v.max_box_pixels;
         if (n <= 64 * 7)
             launch_update_reg<7>(v, G, it, e_rel, prox_max_iter, s);

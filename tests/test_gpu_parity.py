@@ -521,7 +521,8 @@ def _random_scene(rng, C, H, W, boxes, kernel_shape=None, **comp_kw):
     return specs, kernel, data, weights
 
 
-def _compare_steps(amd, specs, kernel, data, weights, n_it, comp_kw, ocomp_kw, flags=None, **batch_kw):
+def _compare_steps(amd, specs, kernel, data, weights, n_it, comp_kw, ocomp_kw, flags=None,
+                   oracle_attrs=None, **batch_kw):
     from oracle import pgm
 
     comps = [amd.ComponentSpec(s * 0.8, m, o, sed_min_step=0.05, **({"prox_flags": flags} if flags is not None else {}), **comp_kw)
@@ -530,6 +531,9 @@ def _compare_steps(amd, specs, kernel, data, weights, n_it, comp_kw, ocomp_kw, f
     sc = pgm.Scene(data.shape, data, weights, kernel,
                    [pgm.Component((s * 0.8).astype(np.float32), m.copy(), o, sed_min_step=0.05, **ocomp_kw)
                     for s, m, o in specs])
+    for c in sc.components:
+        for name, value in (oracle_attrs or {}).items():
+            setattr(c, name, value)
     batch.step(0, n_it, e_rel=1e-3)
     for it in range(n_it):
         sc.step(it, 1e-3)
@@ -1141,3 +1145,28 @@ def test_symmetry_strength(amd):
     for strength in (0.5, 0.2):
         _compare_steps(amd, specs, kernel, data, weights, 3, dict(sym_strength=strength),
                        dict(symmetric=strength), flags=flags)
+
+
+def test_constraint_chain_repeat(amd):
+    """ConstraintChain(*constraints, repeat=n) (constraint.py:60-80): the chain applied n
+    times per proximal evaluation -- through the facade class on the host, and inside the
+    device loop (general update kernel) against the oracle."""
+    from scarlet_amd import _lib
+    from scarlet_amd.constraint import (ConstraintChain, NormalizationConstraint,
+                                        PositivityConstraint, SymmetryConstraint, device_flags)
+
+    chain = ConstraintChain(SymmetryConstraint(0.5), PositivityConstraint(),
+                            NormalizationConstraint("max"), repeat=3)
+    x = np.arange(25, dtype=float).reshape(5, 5) - 3
+    once = ConstraintChain(*chain.constraints)
+    assert_allclose(chain(x.copy(), 0), once(once(once(x.copy(), 0), 0), 0))
+    assert device_flags(chain)["chain_repeat"] == 3
+    rng = np.random.default_rng(23)
+    boxes = [((21, 21), (3, 5)), ((20, 31), (20, 25)), ((25, 34), (30, -4))]
+    specs, kernel, data, weights = _random_scene(rng, 3, 64, 72, boxes, kernel_shape=15)
+    flags = _lib.PROX_EXTENDED_SOURCE | _lib.PROX_SYMMETRY
+    batch, sc = _compare_steps(amd, specs, kernel, data, weights, 3,
+                               dict(sym_strength=0.5, chain_repeat=3),
+                               dict(symmetric=0.5), flags=flags,
+                               oracle_attrs=dict(chain_repeat=3))
+    batch.close()
