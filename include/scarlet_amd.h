@@ -207,6 +207,8 @@ typedef struct smi_components {
     const float *sym_strength;  /* [n_components] strength of SMI_PROX_SYMMETRY         */
                                 /* (SymmetryConstraint(strength), constraint.py:262-273,*/
                                 /* operator.py:274-293); NULL = 1                        */
+    const float *pos_floor;     /* [n_components] PositivityConstraint(zero) of the       */
+                                /* morphology (constraint.py:83-92); NULL = 0              */
     const int32_t *chain_repeat;/* [n_components] ConstraintChain(repeat) (constraint.py:  */
                                 /* 60-80): the whole chain applied that many times per     */
                                 /* proximal evaluation; NULL = 1                           */

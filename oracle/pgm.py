@@ -93,7 +93,7 @@ class Component:
         """ExtendedSourceMorphology chain (morphology.py:644-670)."""
         return proxops.morph_chain(
             x, step, self.monotonic, self.min_gradient, self.symmetric, self.sparsity, self.tiny,
-            getattr(self, "chain_repeat", 1),
+            getattr(self, "chain_repeat", 1), getattr(self, "morph_zero", 0),
         )
 
 

@@ -312,7 +312,7 @@ def prox_threshold(x, step=0):
 
 
 def morph_chain(morph, step=0, monotonic="angle", min_gradient=0.0, symmetric=False,
-                sparsity=None, tiny=1e-6, repeat=1):
+                sparsity=None, tiny=1e-6, repeat=1, zero=0):
     """The ``ExtendedSourceMorphology`` constraint chain (morphology.py:644-670):
     Monotonicity -> [Symmetry] -> Positivity -> CenterOn -> Normalization("max"),
     optionally with an ``L0Constraint`` / ``L1Constraint`` (``sparsity`` =
@@ -321,7 +321,7 @@ def morph_chain(morph, step=0, monotonic="angle", min_gradient=0.0, symmetric=Fa
     x = morph
     if repeat > 1:  # ConstraintChain(repeat) (constraint.py:60-80): the whole chain again
         for _ in range(repeat):
-            x = morph_chain(x, step, monotonic, min_gradient, symmetric, sparsity, tiny)
+            x = morph_chain(x, step, monotonic, min_gradient, symmetric, sparsity, tiny, 1, zero)
         return x
     if monotonic is not None:
         x = prox_monotonic(x, step, monotonic, min_gradient)
@@ -331,7 +331,7 @@ def morph_chain(morph, step=0, monotonic="angle", min_gradient=0.0, symmetric=Fa
     if sparsity is not None:
         kind, thresh, type = sparsity
         x = (prox_hard if kind == "l0" else prox_soft)(x, step, thresh, type)
-    x = prox_positivity(x, step)
+    x = prox_positivity(x, step, zero)  # PositivityConstraint(zero), constraint.py:83-92
     x = prox_center_on(x, step, tiny)
     x = prox_normalization(x, step, "max")
     return x

@@ -20,7 +20,7 @@ class ComponentSpec:
                  morph_step=1e-2, morph_rel_step=0.0, prox_flags=_lib.PROX_EXTENDED_SOURCE,
                  neighbor_weight="angle", min_gradient=0.0, l_thresh=0.0, shift=None,
                  shift_step=1e-1, center_floor=1e-6, bg_level=None, fista_step=0.0,
-                 sym_strength=1.0, chain_repeat=1):
+                 sym_strength=1.0, chain_repeat=1, pos_floor=0.0):
         self.sed = np.asarray(sed, dtype=np.float32)
         self.morph = np.ascontiguousarray(morph, dtype=np.float32)
         self.origin = (int(origin[0]), int(origin[1]))
@@ -47,6 +47,7 @@ class ComponentSpec:
         self.fista_step = float(fista_step)
         self.sym_strength = float(sym_strength)  # SymmetryConstraint(strength)
         self.chain_repeat = int(chain_repeat)  # ConstraintChain(repeat)
+        self.pos_floor = float(pos_floor)  # PositivityConstraint(zero) of the morphology
         if shift is not None:
             self.center = np.array(shift, dtype=np.float64).reshape(2)
             self.prox_flags |= _lib.COMPONENT_SHIFTING
@@ -212,6 +213,7 @@ class BlendBatch:
             fista_step=_lib.f32([c.fista_step for c in flat]),
             sym_strength=_lib.f32([c.sym_strength for c in flat]),
             chain_repeat=np.ascontiguousarray([c.chain_repeat for c in flat], dtype=np.int32),
+            pos_floor=_lib.f32([c.pos_floor for c in flat]),
         )
         comps = _lib.Components()
         for name, ctype in _lib.Components._fields_:

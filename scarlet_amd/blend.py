@@ -172,8 +172,6 @@ class Blend(CombinedComponent):
             flags = device_flags(image.constraint)
             flags["flags"] |= (_lib.COMPONENT_FIXED_SED if sed.fixed else 0) | (
                 _lib.COMPONENT_FIXED_MORPH if image.fixed else 0)
-            if flags["zero"] != 0:
-                raise NotImplementedError("PositivityConstraint(zero != 0) on a morphology")
             specs.append(
                 ComponentSpec(
                     np.asarray(sed), np.asarray(image), morphology.bbox.origin[-2:],
@@ -188,6 +186,7 @@ class Blend(CombinedComponent):
                     center_floor=flags["center_floor"],
                     sym_strength=flags["sym_strength"],
                     chain_repeat=flags["chain_repeat"],
+                    pos_floor=flags["zero"],
                     **shift_kw,
                 )
             )

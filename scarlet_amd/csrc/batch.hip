@@ -220,6 +220,7 @@ struct smi_batch {
     float *c_center_floor = nullptr, *c_bg_level = nullptr, *c_fista_step = nullptr;
     float *c_sym_strength = nullptr;
     int32_t *c_chain_repeat = nullptr;
+    float *c_pos_floor = nullptr;
     double *fista_t = nullptr;
     int scheme = SMI_SCHEME_AMSGRAD;
     bool include_log_norm = true;
@@ -318,6 +319,7 @@ void refresh_view(smi_batch *b) {
     v.c_center_floor = b->c_center_floor;
     v.c_sym_strength = b->c_sym_strength;
     v.c_chain_repeat = b->c_chain_repeat;
+    v.c_pos_floor = b->c_pos_floor;
     v.c_bg_level = b->c_bg_level;
     v.scheme = b->scheme;
     v.lite = b->scheme == SMI_SCHEME_FISTA || b->lite_flags;
@@ -750,7 +752,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
                     b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
-                    b->c_shift_step, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_bg_level,
+                    b->c_shift_step, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_pos_floor, b->c_bg_level,
                     b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans};
     for (void *p : bufs)
@@ -1070,6 +1072,7 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     UP(c_center_floor, c->center_floor ? c->center_floor : cfloor.data(), n);
     std::vector<float> full_strength(n, 1.f);
     UP(c_sym_strength, c->sym_strength ? c->sym_strength : full_strength.data(), n);
+    UP(c_pos_floor, c->pos_floor ? c->pos_floor : zeros_n.data(), n);
     bool repeats = false;
     for (int k = 0; k < n && c->chain_repeat; ++k) {
         SMI_REQUIRE(c->chain_repeat[k] >= 1, "chain_repeat must be >= 1");

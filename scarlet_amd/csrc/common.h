@@ -129,6 +129,7 @@ struct BatchView {
     // scarlet.lite: centre floor, background threshold levels [n_comp][C], FISTA
     const float *c_center_floor;
     const float *c_sym_strength;  // SymmetryConstraint(strength)
+    const float *c_pos_floor;  // PositivityConstraint(zero) of the morphology
     const int32_t *c_chain_repeat;  // ConstraintChain(repeat); nullptr when every chain runs once
     const float *c_bg_level;
     float *scratch;              // 3 * n_morph floats when the largest box exceeds the LDS

@@ -571,6 +571,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     const float one_minus_g = 1.f - v.c_min_grad[c.k];
     const int ctr = (c.h / 2) * c.w + (c.w / 2);
     const float cfloor = v.c_center_floor[c.k];
+    const float pfloor = v.c_pos_floor[c.k];  // PositivityConstraint(zero)
     // relative thresholds scale with the step of the sub-iteration, gamma = alpha / max(psi)
     const float lthresh =
         v.c_lthresh[c.k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
             float mx = -INFINITY, sm = 0.f;
             for (int i = lane; i < N; i += 64) {
                 float u = us[i];
-                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
+                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
                 if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
                 us[i] = u;
                 mx = fmaxf(mx, u);
@@ -933,6 +934,7 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
     const float lthresh =
         v.c_lthresh[c.k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
     const float cfloor = v.c_center_floor[c.k];
+    const float pfloor = v.c_pos_floor[c.k];  // PositivityConstraint(zero)
     const float *bg_level =
         (LITE && v.c_bg_level) ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;
     if (lane == 0) us[(v.max_box_pixels + 3) & ~3] = 0.f;  // spare cell for idle sweep lanes
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
             const int i = lane + 64 * j;
             if (i < N) {
                 float u = us[i];
-                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
+                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
                 if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
                 mx = fmaxf(mx, u);
                 sm += u;
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
             const int i = lane + 64 * j;
             if (i < N) {
                 float u = us[i];  // second read instead of NPL more registers
-                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, 0.f);
+                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
                 if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
                 if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
                     u = (u == div && (flags & SMI_PROX_NORM_MAX)) ? 1.f : u * rdiv;

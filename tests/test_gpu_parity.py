@@ -1170,3 +1170,13 @@ def test_constraint_chain_repeat(amd):
                                dict(symmetric=0.5), flags=flags,
                                oracle_attrs=dict(chain_repeat=3))
     batch.close()
+    # PositivityConstraint(zero=0.02) on the morphology (constraint.py:83-92), in both
+    # update kernels (the repeating chain takes the general one)
+    assert device_flags(ConstraintChain(PositivityConstraint(zero=0.02)))["zero"] == 0.02
+    for repeat in (1, 2):
+        batch, sc = _compare_steps(amd, specs, kernel, data, weights, 3,
+                                   dict(pos_floor=0.02, chain_repeat=repeat), dict(),
+                                   oracle_attrs=dict(morph_zero=0.02, chain_repeat=repeat))
+        # floored before the normalisation by the maximum: no pixel is left at zero
+        assert min(float(m.min()) for m in batch.parameters()[1]) > 0.005
+        batch.close()
