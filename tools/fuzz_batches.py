@@ -66,6 +66,12 @@ for n in range(n_batches):
             if feature == "shifts" and rng.random() < 0.6:
                 shift = rng.uniform(-0.4, 0.4, 2)
                 kw, okw = dict(shift=shift), dict(shift=shift.copy())
+            attrs = {}
+            if feature == "plain" and rng.random() < 0.4:
+                # ConstraintChain(repeat), PositivityConstraint(zero) of the morphology
+                repeat, floor = int(rng.choice([1, 2, 3])), float(rng.choice([0.0, 0.01]))
+                kw = dict(chain_repeat=repeat, pos_floor=floor)
+                attrs = dict(chain_repeat=repeat, morph_zero=floor)
             # Parameter(fixed=True) on the spectrum and / or the image of some components
             fixed = (bool(rng.random() < 0.2), bool(rng.random() < 0.2))
             flags |= (_lib.COMPONENT_FIXED_SED if fixed[0] else 0) | (
@@ -73,6 +79,8 @@ for n in range(n_batches):
             bs.append(ComponentSpec(sed, morph, (oy, ox), sed_min_step=0.01, prox_flags=flags, **kw))
             comps.append(pgm.Component(sed.copy(), morph.copy(), (oy, ox), sed_min_step=0.01,
                                        fixed=fixed, **okw))
+            for name, value in attrs.items():
+                setattr(comps[-1], name, value)
         specs.append(bs)
         scenes.append(pgm.Scene((C, H, W), data[b], weights[b], kernel, comps))
     n_sub = int(rng.integers(1, 4))
