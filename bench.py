@@ -1,24 +1,45 @@
 """Benchmark: PGM iterations/sec over batched blends (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg1|cfg5] [--weak]
 
 A step = one proximal-gradient iteration (render -> FFT convolution -> weighted
 residual/loss -> adjoint convolution -> gradient gather -> AMSGrad -> prox chain)
-of EVERY blend of the rank's batch.  Workload = BASELINE.json configs[2]'s batch
-of 1024 synthetic 5-band 128x128 blends with 10 ExtendedSource components each
-(SURVEY.md section 8d), per GPU (weak scaling: rank r fits seeds
-1234 + 1024 r + b).  Inputs are resident in HBM before the timed region.
+of EVERY blend of the job.  The timed region is iterations 0 .. K-1 of a FRESH fit
+(fixed-iteration fit from the initial parameters); the W warm-up
+iterations run on the same batch beforehand and the parameters and optimizer state are
+put back to their initial values before the clock starts, so the expensive early
+iterations (up to 10 proximal sub-iterations each) are inside the timed region.
+
+Workloads (BASELINE.json configs):
+  cfg3 (default)  configs[2]: 1024 synthetic 5-band 128x128 blends IN TOTAL, 10
+                  ExtendedSource components (41x41) each, seeds 1234 + b for global
+                  blend b; rank r of N fits the contiguous shard
+                  ``dist.shard_range(1024, r, N)`` (strong scaling, 128 blends per GPU
+                  at N = 8).  At N = 1 this is configs[1]'s scene as a 1024-blend batch.
+                  ``--weak`` gives every rank 1024 blends of its own instead.
+  cfg1            configs[0]'s scene (tests/golden/hsc_cosmos_35.npz: 5x58x48, 10
+                  components in boxes 21^2..61^2, per-band 43^2 difference kernel)
+                  replicated into a batch.
+  cfg5            configs[4]: the multi-resolution operator (tools/bench_cfg5.py).
+
+``python bench.py --gpus N`` without a torchrun environment starts its own N ranks
+(``torch.distributed.run``, one per GPU; when the box has fewer GPUs than N the ranks
+share GPUs over gloo -- a functional check, flagged in ``config``).
 
 Output: ONE JSON line on rank 0 with the contract's fields plus
-  roofline     algorithmic bytes per blend-iteration x blend-iterations / device time
-               of the timed region (HIP events on the batch stream), against 8 TB/s
-  cpu_baseline the CPU oracle (NumPy/C port of the reference loop) timed on this
-               host, single thread, on a bounded sample of the same workload.
+  roofline     dominant kernel: algorithmic bytes per launch / mean launch duration
+               (HIP events on the batch stream over the same K iterations, replayed
+               in one range of blends), at the FFT shape the kernel runs; counter-derived
+               fields from profiles/ (HBM traffic, VALU busy); `bound` is what the
+               counters say binds the kernel
+  cpu_baseline the CPU oracle (NumPy/C port of the reference loop) timed on this host:
+               one thread, and a process pool over all usable host cores.
 """
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,96 +48,166 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# SURVEY.md section 8d / BASELINE.md section 3: algorithmic bytes per blend-iteration
-# (C=5, 128x128, K=10 boxes of 41x41, F=180x180 in the accounting):
-#   B0    = 4 [2 N_pix + 8 P_el]            = 1 194 880   (N_pix = 81 920, P_el = 16 860)
-#   B_fft = 4 transforms + 2 kernel reads   = 5 474 880
-# split by kernel: the convolution kernel owns B_fft + data/weights + one parameter read,
-# the update kernel owns the parameter write-back and the m/v/vhat read+write.
-BYTES_FFT_PATH = 6_669_760
-BYTES_NULL_PATH = 1_194_880
-BYTES_CONV_KERNEL = 5_474_880 + 4 * (2 * 81_920 + 16_860)   # 6 197 680
-BYTES_UPDATE_KERNEL = 4 * 7 * 16_860                        #   472 080
 HBM_PEAK_GBS = 8000.0
+F32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CUs x 128 lanes x 2 flop x 2.4 GHz
 
 
-def build_scenes(n_blends, seed0, device=0):
-    """Synthetic scenes; the noiseless truth is rendered on the GPU."""
-    from scarlet_amd import synthetic
+def algorithmic_bytes(C, H, W, box_pixels, Fy, Fx, kernel_bands):
+    """SURVEY.md 8d per blend-iteration, float32, with the FFT shape given.
 
-    kern = synthetic.psfs()
-    return kern, synthetic.make_batch(range(seed0, seed0 + n_blends), kernel=kern, device=device)
+    B0    = 4 [2 N_pix + P_el (read) + P_el (write) + 6 P_el (m, v, vhat r/w)]
+    B_fft = 4 transforms x (real input 4 C Fy Fx + half spectrum 8 C Fy (Fx/2+1))
+            + 2 reads of the kernel spectrum
+    per kernel: the convolution kernel owns B_fft, data + weights and one parameter read;
+    the update kernel the parameter write-back, the moments and its gather of the
+    gradient image over every box (4 C N_k per component)."""
+    n_pix = C * H * W
+    p_el = sum(n + C for n in box_pixels)
+    spec = 8 * Fy * (Fx // 2 + 1)
+    b0 = 4 * (2 * n_pix + 8 * p_el)
+    b_fft = 4 * (4 * C * Fy * Fx + C * spec) + 2 * kernel_bands * spec
+    gather = 4 * C * sum(box_pixels)
+    return dict(
+        whole=b0 + b_fft,
+        conv=b_fft + 4 * (2 * n_pix + p_el),
+        update=4 * 7 * p_el + gather,
+        null=b0,
+    )
 
 
-def cpu_baseline(scenes, n_blends, n_iter, e_rel):
-    """Time the oracle (port of the reference loop) on the host: `n_blends` blends x
-    `n_iter` iterations, one thread.  The oracle is only the thing being timed as the
-    CPU baseline here; it is never part of the GPU path."""
+def fft_flops(C, Fy, Fx):
+    """Real-input 2-D transforms of one blend-iteration: 4 x C x 2.5 N log2 N."""
+    n = Fy * Fx
+    return 4 * C * 2.5 * n * np.log2(n)
+
+
+# ----------------------------------------------------------------- CPU baseline
+def _oracle_fit(args):
+    """`n_iter` oracle iterations of one scene (worker of the CPU baseline)."""
+    kind, seed, n_iter, e_rel = args
     from oracle import pgm
 
-    t0 = time.perf_counter()
-    done = 0
-    for s in scenes[:n_blends]:
+    if kind == "cfg1":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import golden, hsc_scene
+
+        sc = hsc_scene(golden("hsc_cosmos_35"))
+    else:
+        from scarlet_amd import synthetic
+
+        s = synthetic.make_blend(seed)
         sc = pgm.Scene(
             s["data"].shape, s["data"], s["weights"], s["diff_kernel"],
             [pgm.Component(s["seds"][k].copy(), s["morphs"][k].copy(), s["origins"][k],
-                           sed_min_step=s["noise_rms"]) for k in range(len(s["morphs"]))],
-        )
-        for it in range(n_iter):
-            sc.step(it, e_rel)
-            done += 1
-    dt = time.perf_counter() - t0
-    return done / dt, dt
+                           sed_min_step=s["noise_rms"]) for k in range(len(s["morphs"]))])
+    t0 = time.perf_counter()
+    for it in range(n_iter):
+        sc.step(it, e_rel)
+    return n_iter, time.perf_counter() - t0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--blends", type=int, default=1024, help="blends per GPU")
-    ap.add_argument("--null-renderer", action="store_true", help="ablation: no PSF convolution")
-    ap.add_argument("--fft", type=int, nargs=2, default=None, help="override FFT shape")
-    ap.add_argument("--conv-path", default="auto", choices=["auto", "rocfft", "fused"])
-    ap.add_argument("--cpu-blends", type=int, default=16)
-    ap.add_argument("--cpu-iters", type=int, default=150)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--sub-ranges", type=int, default=0,
-                    help="ranges of blends stepped on streams of their own (0 = library default)")
-    ap.add_argument("--phases", action="store_true", help="print the per-phase device times")
-    ap.add_argument("--loop", default="blend", choices=["blend", "lite-adaprox", "lite-fista"],
-                    help="ablation: run the scarlet.lite loop (LiteBlend.fit semantics) on the "
-                         "same scenes instead of Blend.fit's")
-    args = ap.parse_args()
+def usable_cores():
+    """Hardware threads this process may use: the affinity mask, capped by the cgroup
+    CPU quota (a container sees all of the host's threads in os.cpu_count())."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    return n, quota
 
-    import torch
-    from scarlet_amd import BlendBatch, ComponentSpec, dist as sdist
 
-    # SCARLET_AMD_DIST_BACKEND=gloo + SCARLET_AMD_SHARE_GPU=1 let several ranks share one GPU
-    # (used only to exercise the multi-rank code path on a single-GPU box)
-    backend = os.environ.get("SCARLET_AMD_DIST_BACKEND")
-    share = os.environ.get("SCARLET_AMD_SHARE_GPU") == "1"
-    if share:
-        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
-    rank, local_rank, world = sdist.env_rank()
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    if share:
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    sdist.init_process_group(backend=backend, device_index=local_rank)
-    assert world == args.gpus, "launch with torchrun --nproc-per-node == --gpus"
-    e_rel = 1e-3  # Blend.fit default; tolerance of the prox sub-iterations
+def cpu_baseline(kind, n_blends, n_iter, e_rel, pool_seconds=12.0):
+    """The oracle (port of the reference loop) on the host, same workload from it = 0:
+    (a) one thread, >= `n_blends` blends x `n_iter` iterations (about 8 s); (b) one worker process per
+    usable core, every worker fitting whole blends (`OMP_NUM_THREADS=1`).  The oracle is
+    only the thing being timed here; it is never part of the GPU path."""
+    import multiprocessing as mp
 
-    nb = args.blends
-    kern, scenes = build_scenes(nb, 1234 + rank * nb, device=local_rank)
+    done, busy = 0, 0.0
+    t0 = time.perf_counter()
+    b = 0
+    while b < n_blends or (busy < 8.0 and b < 512):  # at least `n_blends`, about 8 s
+        n, dt = _oracle_fit((kind, 1234 + b, n_iter, e_rel))
+        done += n
+        busy += dt
+        b += 1
+    n_blends = b
+    wall1 = time.perf_counter() - t0
+    single = done / busy  # iteration loop only (scene construction excluded)
 
-    lite = args.loop != "blend"
-    if lite:
+    n_aff, quota = usable_cores()
+    workers = max(1, min(n_aff, int(quota) if quota else n_aff))
+    # a profiler's preload must not follow into the pool's processes
+    scrub = {k: os.environ.pop(k) for k in list(os.environ)
+             if k in ("LD_PRELOAD", "HSA_TOOLS_LIB") or k.startswith(("ROCP", "ROCPROF"))}
+    threads = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS",
+                                               "MKL_NUM_THREADS")}
+    for k in threads:
+        os.environ[k] = "1"
+    pool_rate, pool_note = None, ""
+    try:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            pool.map(_oracle_fit, [(kind, 1234, 2, e_rel)] * workers)  # imports, library loads
+            per_worker = max(1, int(round(pool_seconds * single / n_iter)))
+            jobs = [(kind, 5000 + j, n_iter, e_rel) for j in range(workers * per_worker)]
+            t0 = time.perf_counter()
+            res = pool.map(_oracle_fit, jobs, chunksize=per_worker)
+            wall = time.perf_counter() - t0
+        its, busy_pool = sum(r[0] for r in res), sum(r[1] for r in res)
+        # all workers are busy for the whole map (equal shares); the iteration loops alone
+        # (scene construction excluded, as for the lone thread) took busy_pool / workers
+        pool_rate = its / (busy_pool / workers)
+        pool_note = ("%d worker processes x %d blends x %d iterations, %.1f s wall incl. scene "
+                     "construction (%.0f/s by wall clock); per-worker rate %.2f of the lone "
+                     "thread's" % (workers, per_worker, n_iter, wall, its / wall,
+                                   its / busy_pool / single))
+    finally:
+        os.environ.update(scrub)
+        for k, v in threads.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    out = {
+        "value": round(pool_rate if pool_rate else single, 2),
+        "unit": "blend-iterations/s",
+        "cores": workers if pool_rate else 1,
+        "kind": "port",
+        "sample": "NumPy/C oracle, iterations 0..%d of the same workload; %s" % (
+            n_iter - 1, pool_note),
+        "single_thread": {
+            "value": round(single, 2), "cores": 1,
+            "sample": "%d blends x %d iterations, %.1f s" % (n_blends, n_iter, wall1)},
+        "host": {"affinity_threads": n_aff, "cgroup_cpu_quota": quota,
+                 "os_cpu_count": os.cpu_count()},
+    }
+    return out
+
+
+# ------------------------------------------------------------------- workloads
+def build_cfg3(lo, hi, device, lite_loop):
+    """ComponentSpecs + observation of the synthetic blends with global indices lo..hi-1."""
+    from scarlet_amd import ComponentSpec, synthetic
+
+    kern = synthetic.psfs()
+    scenes = synthetic.make_batch(range(1234 + lo, 1234 + hi), kernel=kern, device=device)
+    if lite_loop:
         # LiteFactorizedComponent defaults (lite/models.py:143-180, lite/initialization.py:250-318)
         from scarlet_amd import _lib as slib
 
         flags = (slib.PROX_MONOTONIC | slib.PROX_FIT_CENTER | slib.PROX_CENTER_ON | slib.PROX_NORM_MAX)
-        extra = (dict(fista_step=1.0 / (2 * 400.0)) if args.loop == "lite-fista" else {})
+        extra = (dict(fista_step=1.0 / (2 * 400.0)) if lite_loop == "lite-fista" else {})
         comps = [
             [ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k], prox_flags=flags,
                            sed_min_step=s["noise_rms"] / 10, center_floor=1e-20,
@@ -132,80 +223,192 @@ def main():
         ]
     data = np.stack([s["data"] for s in scenes])
     weights = np.stack([s["weights"] for s in scenes])
-    # W warm-up + K timed iterations, then K more for the instrumented roofline pass
-    total_it = args.warmup + 2 * args.steps
+    return data, weights, comps, kern[2]
+
+
+def build_cfg1(n):
+    """`n` copies of the quickstart blend (initial sources as the reference's
+    init_all_sources made them; golden fixture)."""
+    from scarlet_amd import ComponentSpec
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hsc_cosmos_35.npz"))
+    one = [ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
+                         sed_min_step=g["min_step_%d" % k]) for k in range(int(g["n_comp"]))]
+    data = np.broadcast_to(g["images"], (n,) + g["images"].shape)
+    weights = np.broadcast_to(g["weights"], (n,) + g["weights"].shape)
+    return np.ascontiguousarray(data), np.ascontiguousarray(weights), [one] * n, g["diff_kernel"]
+
+
+def counters(kernel):
+    """Counter-derived figures of the dominant kernel from the committed rocprofv3 PMC
+    summaries (profiles/hbm_traffic.json, written by tools/hbm_counters.py)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as fh:
+        return json.load(fh).get(kernel, {})
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script."""
+    import torch
+    from scarlet_amd import dist as sdist
+
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus:
+        env["SCARLET_AMD_SHARE_GPU"] = "1"
+        env["SCARLET_AMD_DIST_BACKEND"] = "gloo"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = sdist.launch_command(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg1", "cfg5"])
+    ap.add_argument("--blends", type=int, default=1024,
+                    help="blends of the whole job (per GPU with --weak)")
+    ap.add_argument("--weak", action="store_true", help="--blends per GPU instead of in total")
+    ap.add_argument("--null-renderer", action="store_true", help="ablation: no PSF convolution")
+    ap.add_argument("--fft", type=int, nargs=2, default=None, help="override FFT shape")
+    ap.add_argument("--conv-path", default="auto", choices=["auto", "rocfft", "fused"])
+    ap.add_argument("--cpu-blends", type=int, default=12)
+    ap.add_argument("--cpu-iters", type=int, default=0, help="0 = --steps")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--steady", action="store_true",
+                    help="round-1 window: time iterations W .. W+K-1 of the warmed-up fit")
+    ap.add_argument("--sub-ranges", type=int, default=0,
+                    help="ranges of blends stepped on streams of their own (0 = library default)")
+    ap.add_argument("--loop", default="blend", choices=["blend", "lite-adaprox", "lite-fista"],
+                    help="ablation: run the scarlet.lite loop (LiteBlend.fit semantics) on the "
+                         "same scenes instead of Blend.fit's")
+    args = ap.parse_args()
+
+    if args.config == "cfg5":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_cfg5
+
+        return bench_cfg5.main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    from scarlet_amd import BlendBatch, dist as sdist
+
+    # SCARLET_AMD_DIST_BACKEND=gloo + SCARLET_AMD_SHARE_GPU=1 let several ranks share one GPU
+    # (exercises the multi-rank path on a single-GPU box; self_launch sets them)
+    backend = os.environ.get("SCARLET_AMD_DIST_BACKEND")
+    share = os.environ.get("SCARLET_AMD_SHARE_GPU") == "1"
+    rank, local_rank, world = sdist.env_rank()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    sdist.init_process_group(backend=backend, device_index=local_rank)
+    e_rel = 1e-3  # Blend.fit default; tolerance of the prox sub-iterations
+
+    n_total = args.blends * world if args.weak else args.blends
+    lo, hi = sdist.shard_range(n_total, rank, world)
+    nb = hi - lo
+    lite = args.loop != "blend"
+    if args.config == "cfg1":
+        data, weights, comps, kernel = build_cfg1(nb)
+    else:
+        data, weights, comps, kernel = build_cfg3(lo, hi, local_rank, args.loop if lite else None)
+    K, Wm = args.steps, args.warmup
     batch = BlendBatch(
-        data, weights, comps, kernel=None if args.null_renderer else kern[2],
-        max_iter=total_it + 1, fft_shape=args.fft, device=local_rank, conv_path=args.conv_path,
+        data, weights, comps, kernel=None if args.null_renderer else kernel,
+        max_iter=max(K, Wm) + (Wm + K if args.steady else 0) + 1, fft_shape=args.fft,
+        device=local_rank, conv_path=args.conv_path,
         scheme="fista" if args.loop == "lite-fista" else "amsgrad", log_norm=not lite,
     )
     prox_max_iter = 1 if lite else 10  # lite applies the proximal operator once
     stream = torch.cuda.Stream(device=local_rank)
     batch.set_stream(stream.cuda_stream)
     batch.set_sub_ranges(args.sub_ranges)
+    seds0, morphs0 = batch.parameters()
+    zs = np.zeros_like(seds0)
+    zm = [np.zeros_like(m) for m in morphs0]
 
-    # warm-up iterations 0 .. W-1 (untimed), then K timed iterations of the same fit
-    batch.step(0, args.warmup, e_rel=e_rel, prox_max_iter=prox_max_iter, check_convergence=False)
+    def fresh():
+        """parameters and optimizer state of iteration 0"""
+        batch.set_parameters(seds0, morphs0)
+        batch.set_moments(zs, zs, zs, zm, zm, zm)
+        if args.loop == "lite-fista":
+            batch.set_fista_state(seds0, morphs0, np.ones((len(seds0), 2)))
+        batch.reset()
+
+    def run(it0, n):
+        batch.step(it0, n, e_rel=e_rel, prox_max_iter=prox_max_iter, check_convergence=False)
+
+    # W untimed warm-up iterations, then the state of iteration 0 again
+    run(0, Wm)
+    torch.cuda.synchronize()
+    it0 = 0
+    if args.steady:
+        it0 = Wm
+    else:
+        fresh()
     torch.cuda.synchronize()
     sdist.barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
-    batch.step(args.warmup, args.steps, e_rel=e_rel, prox_max_iter=prox_max_iter,
-               check_convergence=False)
-    ev1.record(stream)
+    run(it0, K)
     torch.cuda.synchronize()
     sdist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = sdist.max_over_ranks(elapsed)
-    dev_ms = ev0.elapsed_time(ev1)
+    elapsed = sdist.max_over_ranks(time.perf_counter() - t0)
 
     active, err = batch.status()
     assert err < 0, "non-finite parameters in blend %d" % err
     loss = batch.loss_history()
-    n_iter = np.array([len(l) for l in loss], dtype=np.int32)
-    logL = np.array([-l[-1] for l in loss])
-    n_iter_all, logL_all = sdist.gather_results(n_iter, logL)  # the only collective
+    if args.steady:
+        loss = [l[Wm:] for l in loss]
+    # the only collective: the packed per-blend records of all ranks
+    rec = sdist.gather_records(sdist.pack_records(loss, batch.states(), K))
+    assert len(rec) == n_total and np.all(rec["n_iter"] == K)
 
-    # Roofline pass: K further iterations of the same fit with HIP events around every
-    # kernel, all blends in ONE range.  In the timed region above ranges of blends run on
+    # Roofline pass: the SAME K iterations again with HIP events around every kernel, all
+    # of the rank's blends in ONE range.  In the timed region ranges of blends run on
     # streams of their own and their kernels share the chip, so the duration of a single
     # launch there says nothing about the kernel; `value` is not affected by this pass.
     ranges_timed = batch.sub_ranges()
+    if not args.steady:
+        fresh()
     batch.set_sub_ranges(1)
     batch.enable_timing(True)  # HIP events around every phase, on the batch stream
-    batch.step(args.warmup + args.steps, args.steps, e_rel=e_rel, prox_max_iter=prox_max_iter,
-               check_convergence=False)
+    run(it0 + (K if args.steady else 0), K)
     torch.cuda.synchronize()
     phases = {k: round(v, 4) for k, v in batch.timing().items()}  # mean ms over the K steps
     batch.enable_timing(False)
-    batch.set_sub_ranges(args.sub_ranges)
+    fft_shape = batch.fft_shape
 
     if rank == 0:
-        blend_iters = world * nb * args.steps
-        value = blend_iters / elapsed
-        bytes_per = BYTES_NULL_PATH if args.null_renderer else BYTES_FFT_PATH
-        ms_iter = dev_ms / args.steps  # device time of one iteration of the whole batch
+        value = n_total * K / elapsed
+        C, H, W = data.shape[1:]
+        boxes = [c.morph.size for c in comps[0]]
+        kb = 0 if args.null_renderer else kernel.shape[-3]
+        Fy, Fx = fft_shape if not args.null_renderer else (0, 0)
+        by = algorithmic_bytes(C, H, W, boxes, Fy, Fx, kb)
+        by_survey = algorithmic_bytes(C, H, W, boxes, 180, 180, kb) if args.config == "cfg3" else by
+        bytes_per = by["null"] if args.null_renderer else by["whole"]
+        ms_iter = elapsed / K * 1e3
         fused = (not args.null_renderer) and phases["render"] < 0.05 * phases["conv"]
         if fused:
-            # dominant kernel: fused_conv_kernel (render + conv + residual + conv^T)
-            k_name, k_bytes, k_ms = "fused_conv_kernel", BYTES_CONV_KERNEL, phases["conv"]
+            k_name, k_bytes, k_ms = "fused_conv_kernel", by["conv"], phases["conv"]
         elif args.null_renderer:
-            k_name, k_bytes, k_ms = "update_kernel_reg", BYTES_UPDATE_KERNEL, phases["update"]
+            k_name, k_bytes, k_ms = "update_kernel_reg", by["update"], phases["update"]
         else:
             # rocFFT pipeline: no single dominant kernel of ours; price the whole iteration
-            k_name, k_bytes, k_ms = "whole iteration (rocFFT pipeline)", bytes_per, ms_iter
+            k_name, k_bytes, k_ms = "whole iteration (rocFFT pipeline)", bytes_per, phases["total"]
         achieved = k_bytes * nb / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                rec = json.load(fh).get(k_name)
-            if rec:  # measured with rocprofv3 --pmc (profiles/), bytes per launch
-                traffic = rec["bytes_per_blend"] * nb
+        cnt = counters(k_name) if args.config == "cfg3" and nb == 1024 else {}
+        traffic = cnt["bytes_per_blend"] * nb if "bytes_per_blend" in cnt else None
         roofline = {
-            "bound": "hbm",
+            "bound": cnt.get("bound", "hbm"),
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -213,55 +416,79 @@ def main():
             "traffic": traffic,
             "kernel": k_name,
             "algorithmic_bytes_per_launch": k_bytes * nb,
+            "algorithmic_bytes_per_blend": k_bytes,
+            "fft_shape_priced": [Fy, Fx],
             "ms_per_launch": round(k_ms, 4),
-            "measured": "HIP events on the batch stream over %d further iterations of the same "
-                        "fit, one range of %d blends per launch (the timed region runs %d "
-                        "ranges concurrently)" % (args.steps, nb, ranges_timed),
+            "hbm_frac_measured": (round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                  if traffic else None),
+            "valu_busy": cnt.get("valu_busy"),
+            "flops_frac": (round(fft_flops(C, Fy, Fx) * nb / (k_ms * 1e-3) / 1e12
+                                 / F32_VECTOR_PEAK_TFLOPS, 5) if fused else None),
+            "measured": "HIP events on the batch stream, iterations %d..%d replayed in one "
+                        "range of %d blends per launch (the timed region runs %d range(s) "
+                        "concurrently)" % (it0 + (K if args.steady else 0),
+                                           it0 + (K if args.steady else 0) + K - 1, nb,
+                                           ranges_timed),
+            "kernels": {
+                "fused_conv_kernel": {
+                    "ms": phases["conv"], "algorithmic_bytes_per_blend": by["conv"],
+                    "frac": round(by["conv"] * nb / (phases["conv"] * 1e-3) / 8e12, 5)
+                    if fused else None},
+                "update_kernel_reg": {
+                    "ms": phases["update"], "algorithmic_bytes_per_blend": by["update"],
+                    "frac": round(by["update"] * nb / (phases["update"] * 1e-3) / 8e12, 5)},
+            },
             "whole_iteration": {
                 "algorithmic_bytes_per_blend_iteration": bytes_per,
                 "ms": round(ms_iter, 4),
-                "achieved": round(bytes_per * nb / (ms_iter * 1e-3) / 1e9, 2),
-                "frac": round(bytes_per * nb / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "achieved": round(bytes_per * n_total / world / (ms_iter * 1e-3) / 1e9, 2),
+                "frac": round(bytes_per * n_total / world / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "frac_survey_F180": round(by_survey["whole"] * n_total / world
+                                          / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             },
             "phases_ms": phases,
         }
+        if args.config == "cfg1":
+            what = ("configs[0] scene (hsc_cosmos_35: 5x58x48, 10 components, boxes 21^2..61^2, "
+                    "per-band 43x43 kernel) replicated: %d blends in total" % n_total)
+        else:
+            what = ("configs[2]: %d independent 5-band 128x128 blends in total%s, 10 "
+                    "ExtendedSource components (41x41) each" % (
+                        n_total, " (%d per GPU)" % args.blends if args.weak else ""))
         line = {
             "metric": "PGM iters/sec over batched blends; achieved HBM GB/s vs roofline",
             "value": round(value, 1),
             "unit": "blend-iterations/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": round(ms_iter, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[2] batch on one GPU: %d independent 5-band 128x128 blends "
-                            "per GPU, 10 ExtendedSource components (41x41) each, %s" % (
-                                nb, "NullRenderer ablation" if args.null_renderer
-                                else "ConvolutionRenderer FFT %dx%d" % batch.fft_shape),
+                "workload": "%s, %s; iterations %d..%d of a fit from the initial parameters" % (
+                    what, "NullRenderer ablation" if args.null_renderer
+                    else "ConvolutionRenderer FFT %dx%d" % fft_shape, it0, it0 + K - 1),
                 "loop": args.loop,
-                "blends_per_gpu": nb,
-                "components_per_blend": 10,
-                "parallelism": "blend-sharded x%d, no data-path collective" % world,
+                "blends_total": n_total,
+                "blends_per_gpu": [sdist.shard_range(n_total, r, world)[1]
+                                   - sdist.shard_range(n_total, r, world)[0] for r in range(world)],
+                "components_per_blend": len(comps[0]),
+                "parallelism": "contiguous blend shards x%d, no data-path collective, one "
+                               "all-gather of {n_iter, converged, logL, loss_hist[%d]} per "
+                               "blend%s" % (world, K, " (ranks share GPUs over gloo: functional "
+                                            "check, not a scaling point)" if share else ""),
                 "sub_ranges_per_gpu": ranges_timed,
-                "mean_logL": float(np.mean(logL_all)),
+                "mean_logL": float(np.mean(rec["logL"])),
             },
             "roofline": roofline,
         }
         if not args.no_cpu and not lite and world == 1:  # reported at N = 1 only
-            v, dt = cpu_baseline(scenes, args.cpu_blends, args.cpu_iters, e_rel)
-            line["cpu_baseline"] = {
-                "value": round(v, 2),
-                "unit": "blend-iterations/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": "%d blends x %d iterations of the same workload, NumPy/C oracle, "
-                          "1 thread, %.1f s" % (args.cpu_blends, args.cpu_iters, dt),
-            }
+            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_blends,
+                                                args.cpu_iters or K, e_rel)
         print(json.dumps(line), flush=True)
     batch.close()
     if world > 1:

@@ -69,6 +69,7 @@ class Blend(CombinedComponent):
         self.observations = observations if hasattr(observations, "__iter__") else (observations,)
         super().__init__(self.sources)
         self.loss = []
+        self.device = 0  # GPU the fit runs on
 
     # ------------------------------------------------------------------ device
     def _observation(self):
@@ -224,7 +225,7 @@ class Blend(CombinedComponent):
     def _build_batch(self, comps, capacity):
         data, weights, kernel = self._observation()
         batch = BlendBatch(data[None], weights[None], [self._specs(comps)], kernel=kernel,
-                           max_iter=max(capacity, 1))
+                           max_iter=max(capacity, 1), device=self.device)
         for obs, idx in self._lowres:
             _, handle, _ = obs.renderer._resampler()
             batch.attach_lowres(handle, idx, obs.data, obs.weights, obs.log_norm)
@@ -422,7 +423,8 @@ class Blend(CombinedComponent):
         while it < max_iter:
             comps = _flatten(self.sources)
             batch = BlendBatch(data[None], weights[None], [self._specs(comps)],
-                               kernel=stamp(renderer.kernel_image()), max_iter=max(max_iter - it, 1))
+                               kernel=stamp(renderer.kernel_image()), max_iter=max(max_iter - it, 1),
+                               device=self.device)
             self._upload_state(batch, comps)
             batch.set_optimizer(**opt)
             restart = False
@@ -508,8 +510,57 @@ class Blend(CombinedComponent):
         return self.frame.bbox
 
 
-def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
-    """Fit many independent ``Blend`` objects together on one GPU.
+def _export_state(blend):
+    """What a fit changes on a Blend, as plain picklable data: the loss history and, per
+    factorized component, the box of the morphology and both children's Parameters
+    (values, m / v / vhat / std, halved steps after a resize)."""
+    comps = _flatten(blend.sources)
+    return dict(loss=list(blend.loss),
+                comps=[(c.children[1].bbox.origin, c.children[1].bbox.shape,
+                        c.children[0]._parameters, c.children[1]._parameters) for c in comps])
+
+
+def _refresh_boxes(node):
+    """Boxes of the containers after their morphologies changed (component.py:172-185,
+    280-290: only a container below which a box changed gets a new one)."""
+    if isinstance(node, FactorizedComponent):
+        box = node._joint_box(*node.children)
+        changed = box != node.bbox
+        if changed:
+            node.bbox = box
+        return changed
+    changed = [_refresh_boxes(c) for c in node.children]
+    if any(changed) and isinstance(node, CombinedComponent):
+        node.bbox = node._union_box()
+    return any(changed)
+
+
+def _import_state(blend, state):
+    """Apply ``_export_state`` of another process' copy of ``blend``."""
+    blend.loss[:] = state["loss"]
+    for comp, (origin, shape, p_spec, p_morph) in zip(_flatten(blend.sources), state["comps"]):
+        spectrum, morphology = comp.children
+        morphology.bbox.origin, morphology.bbox.shape = tuple(origin), tuple(shape)
+        for mine, theirs in zip(spectrum._parameters, p_spec):
+            mine[...] = theirs
+            mine.__dict__.update(theirs.__dict__)
+        # a resized image is a new Parameter (morphology.py:155-163, 180-193); a parameter
+        # the morphology also holds by name (``shift``) keeps its identity
+        new = []
+        for mine, theirs in zip(morphology._parameters, p_morph):
+            if mine.shape == theirs.shape:
+                mine[...] = theirs
+                mine.__dict__.update(theirs.__dict__)
+                new.append(mine)
+            else:
+                new.append(theirs)
+        morphology._parameters = tuple(new)
+    for src in blend.sources:
+        _refresh_boxes(src)
+
+
+def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, devices=None, **alg_kwargs):
+    """Fit many independent ``Blend`` objects together.
 
     Equivalent to ``[b.fit(max_iter, e_rel, min_iter, **alg_kwargs) for b in blends]``
     -- same per-blend iteration counts, losses, parameter and optimizer-state side
@@ -519,10 +570,67 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
     and the restart it triggers (blend.py:196-198, 284-292) stay per blend: after every
     round the blends are regrouped by their own iteration counter.
 
+    ``devices``: where the blends run (the reference's unit is the per-blend
+    loop of ``testing/api.py:216-224``).  ``None`` / an int: one GPU.  A list of GPU
+    indices: contiguous shards ``dist.shard_range(len(blends), i, len(devices))``, one
+    host thread per GPU.  ``"ranks"``: one process per GPU under ``torch.distributed``
+    (every rank holds the same list of blends): rank r fits its shard on GPU LOCAL_RANK
+    and the fitted state of every blend is all-gathered, so all ranks return the same
+    results and hold the same parameters.  Results do not depend on the partition.
+
     Returns the list of ``(n_iter, logL)`` tuples; a blend whose parameters turned
-    non-finite gets the ``ArithmeticError`` instance instead of a tuple (and keeps the
-    state of its last iteration), the others continue.
+    non-finite gets ``(n_iter, nan)`` (and keeps the state of its last iteration), the
+    others continue; ``fit_blends.errors`` lists ``(index, ArithmeticError)`` of the last call.
     """
+    blends = list(blends)
+    kw = dict(max_iter=max_iter, e_rel=e_rel, min_iter=min_iter, **alg_kwargs)
+    fit_blends.errors = []
+    if isinstance(devices, str):
+        if devices != "ranks":
+            raise ValueError("devices must be None, an int, a list of GPU indices or 'ranks'")
+        from . import dist as sdist
+
+        rank, local_rank, world = sdist.env_rank()
+        lo, hi = sdist.shard_range(len(blends), rank, world)
+        mine, errs = _fit_blends_on(blends[lo:hi], local_rank, **kw)
+        parts = sdist.gather_objects(
+            dict(lo=lo, results=mine, errors=[(lo + i, str(e)) for i, e in errs],
+                 states=[_export_state(b) for b in blends[lo:hi]]))
+        out = []
+        for part in parts:
+            out.extend(part["results"])
+            fit_blends.errors.extend((i, ArithmeticError(msg)) for i, msg in part["errors"])
+            if part["lo"] != lo:
+                for blend, state in zip(blends[part["lo"]:], part["states"]):
+                    _import_state(blend, state)
+                    for p in blend.parameters:
+                        if p.v is not None:
+                            p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
+        return out
+    if devices is None or np.isscalar(devices) or len(devices) == 1:
+        device = 0 if devices is None else int(devices if np.isscalar(devices) else devices[0])
+        out, fit_blends.errors = _fit_blends_on(blends, device, **kw)
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    from .dist import shard_range
+
+    cuts = [shard_range(len(blends), i, len(devices)) for i in range(len(devices))]
+    with ThreadPoolExecutor(len(devices)) as pool:
+        jobs = [pool.submit(_fit_blends_on, blends[lo:hi], int(dev), **kw)
+                for (lo, hi), dev in zip(cuts, devices)]
+        out = []
+        for (lo, _), job in zip(cuts, jobs):
+            part, errs = job.result()
+            out.extend(part)
+            fit_blends.errors.extend((lo + i, e) for i, e in errs)
+    return out
+
+
+fit_blends.errors = []
+
+
+def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
+    """``fit_blends`` of ``blends`` on GPU ``device``: (results, [(index, error)])."""
     if alg_kwargs.get("callback") is not None:
         raise NotImplementedError("callback= needs the host-stepped mode of Blend.fit")
     scheme = alg_kwargs.pop("scheme", "amsgrad")
@@ -567,7 +675,7 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
                 np.stack([r.obs[0] for r in group]), np.stack([r.obs[1] for r in group]),
                 [r.blend._specs(c) for r, c in zip(group, comps)],
                 kernel=None if kshape is None else np.stack([r.obs[2] for r in group]),
-                max_iter=n)
+                max_iter=n, device=device)
             try:
                 flat = [c for cs in comps for c in cs]
                 Blend._upload_state(batch, flat)
@@ -601,14 +709,15 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
                     r.base, r.local = len(blend.loss), 0
                 elif state == 2 or r.total >= max_iter:
                     r.result = True
-    out = []
-    for r in runs:
-        if isinstance(r.result, Exception):
-            out.append(r.result)
-            continue
+    out, errors = [], []
+    for i, r in enumerate(runs):
         blend = r.blend
+        if isinstance(r.result, Exception):
+            errors.append((i, r.result))
+            out.append((len(blend.loss), float("nan")))
+            continue
         for p in blend.parameters:
             if p.v is not None:
                 p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
         out.append((len(blend.loss), -blend.loss[-1]))
-    return out
+    return out, errors

@@ -1431,7 +1431,10 @@ static int sub_ranges(const smi_batch *b) {
     const bool plain = b->fused && b->n_point == 0 && b->n_shift == 0 && b->lowres.empty();
     if (!plain) return 1;
     const int nb = b->d.n_blends;
-    int n = b->n_sub > 0 ? b->n_sub : (nb >= 256 ? 2 : 1);
+    // measured on MI355X (bench.py --blends N --sub-ranges n, 100 iterations): 128 blends 450 k
+    // blend-it/s in one range, 508 k in two, 337 k in three; 256 blends 599 / 628 / 487 k (4);
+    // 1024 blends 705 / 751 / 748 k -- two ranges from a config-3 shard (128 blends) on
+    int n = b->n_sub > 0 ? b->n_sub : (nb >= 128 ? 2 : 1);
     return std::max(1, std::min(n, nb));
 }
 

@@ -30,6 +30,21 @@ void set_error(const std::string &msg);
         }                                                                          \
     } while (0)
 
+// Raise a kernel's dynamic-LDS limit to `lds` bytes on the CURRENT device.  Function
+// attributes live per device, so one process driving several GPUs (fit_blends(devices=...))
+// has to configure each of them; `configured` is the caller's static per-kernel table.
+constexpr int kMaxDevices = 32;
+inline int ensure_dynamic_lds(const void *kern, size_t lds, size_t (&configured)[kMaxDevices]) {
+    int dev = 0;
+    SMI_HIP(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < kMaxDevices;
+    if (!tracked || lds > configured[dev]) {
+        SMI_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (tracked) configured[dev] = lds;
+    }
+    return SMI_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Level-ordered plan of one monotonic operator (one box shape x weighting).
 //

@@ -561,13 +561,9 @@ int launch_impl(const BatchView &v, const float2 *Kt, int k_bands, int k_per_ble
                 int mode, long long *dbg, hipStream_t s) {
     using C = Cfg<FY1, FX1>;
     auto kern = fused_conv_kernel<FY1, FX1>;
-    static bool configured = false;
-    if (!configured) {
-        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)C::lds_bytes));
-        configured = true;
-    }
+    static size_t configured[kMaxDevices] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), C::lds_bytes, configured))
+        return rc;
     hipLaunchKernelGGL(kern, dim3(v.nb * v.C), dim3(kThreads), C::lds_bytes, s, v, Kt, k_bands,
                        k_per_blend, out, mode, dbg);
     return SMI_OK;

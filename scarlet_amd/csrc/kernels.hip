@@ -1206,12 +1206,9 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
     }
     const size_t lds = update_lds_bytes(v);
     SMI_REQUIRE(lds <= 160 * 1024, "component box too large for the LDS-resident update");
-    static size_t configured = 0;
-    if (lds > configured) {
-        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(update_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    static size_t configured[kMaxDevices] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(update_kernel), lds, configured))
+        return rc;
     hipLaunchKernelGGL(update_kernel, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
                        prox_max_iter, g_sed_out, g_morph_out, grad_only);
     return SMI_OK;

@@ -300,19 +300,21 @@ size_t shift_lds_bytes(const BatchView &v) {
 
 }  // namespace
 
+static int configure_shift_kernels(size_t lds) {
+    static size_t cfg_backward[kMaxDevices] = {}, cfg_forward[kMaxDevices] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(shift_backward_kernel), lds,
+                                    cfg_backward))
+        return rc;
+    return ensure_dynamic_lds(reinterpret_cast<const void *>(shift_forward_kernel), lds,
+                              cfg_forward);
+}
+
 int launch_shift_backward(const BatchView &v, const float *G, int32_t it, double *g_shift_out,
                           int32_t grad_only, hipStream_t s) {
     if (v.n_shift == 0 || v.n_comp == 0) return SMI_OK;
     const size_t lds = shift_lds_bytes(v);
     SMI_REQUIRE(lds <= 160 * 1024, "shifting component box too large for the LDS");
-    static size_t configured = 0;
-    if (lds > configured) {
-        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(shift_backward_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(shift_forward_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    if (int rc = configure_shift_kernels(lds)) return rc;
     hipLaunchKernelGGL(shift_backward_kernel, dim3(v.n_comp), dim3(kT), lds, s, v, G, it,
                        g_shift_out, grad_only);
     return SMI_OK;
@@ -322,14 +324,7 @@ int launch_shift_forward(const BatchView &v, int32_t respect_state, hipStream_t 
     if (v.n_shift == 0 || v.n_comp == 0) return SMI_OK;
     const size_t lds = shift_lds_bytes(v);
     SMI_REQUIRE(lds <= 160 * 1024, "shifting component box too large for the LDS");
-    static size_t configured = 0;
-    if (lds > configured) {
-        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(shift_backward_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(shift_forward_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    if (int rc = configure_shift_kernels(lds)) return rc;
     hipLaunchKernelGGL(shift_forward_kernel, dim3(v.n_comp), dim3(kT), lds, s, v, respect_state);
     return SMI_OK;
 }
