@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscarlet_amd.so")
+# SCARLET_AMD_LIB: another build of the same library (A/B comparisons, tools/ab_compare.py)
+LIB_PATH = os.environ.get("SCARLET_AMD_LIB") or os.path.join(_HERE, "libscarlet_amd.so")
 
 PROX_MONOTONIC = 1
 PROX_SYMMETRY = 2

@@ -236,6 +236,9 @@ struct smi_batch {
     // of one range's update kernel overlaps the next iteration's convolution of the others
     int n_sub = 0;  // 0 = automatic
     std::vector<int32_t> h_comp_start;
+    // work items of the register-resident update kernels (common.h, BatchView::work)
+    int32_t *work_items = nullptr;
+    std::vector<int32_t> h_work_start;  // [kNumUpdateClasses][n_blends + 1]
     std::vector<hipStream_t> sub_streams;
     std::vector<hipEvent_t> sub_events;  // [0] fork, [1 + s] join of range s
     // per blend
@@ -329,6 +332,10 @@ void refresh_view(smi_batch *b) {
     v.n_extra = (int32_t)b->lowres.size();
     v.blend0 = 0;
     v.comp0 = 0;
+    v.work = b->work_items;
+    v.work0 = 0;
+    v.work_start = b->h_work_start.data();
+    v.nb_total = b->d.n_blends;
     for (const auto &pl : b->plans)
         if (!pl.slots) v.fast_plans = 0;
 }
@@ -754,7 +761,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
                     b->c_shift_step, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_pos_floor, b->c_bg_level,
                     b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out,
-                    b->loss_hist, b->last_loss, b->loss_partial, b->d_plans};
+                    b->loss_hist, b->last_loss, b->loss_partial, b->d_plans, b->work_items};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto e : b->events) (void)hipEventDestroy(e);
@@ -788,8 +795,7 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
     if ((rc = upload(&dp.nbr, hp.nbr.data(), hp.nbr.size()))) return rc;
     if ((rc = upload(&dp.wt, wt.data(), wt.size()))) return rc;
     if (hp.max_terms <= 4 && h * w <= 16380) {
-        // slot layout of the fast update kernel: every level padded to 64-lane steps,
-        // an even number of steps in total
+        // slot layout of the fast update kernel: every level padded to 64-lane steps
         const uint32_t spare = (uint32_t)(((h * w + 3) & ~3) * 4);
         SweepSlotEntry idle{};
         idle.p_n0 = spare | (spare << 16);
@@ -819,7 +825,6 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
                 }
             }
         }
-
         // the sweep processes four steps per loop iteration and requests plan entries
         // up to three steps beyond the current iteration: pad to a multiple of four
         // steps and append three idle steps that are read but never executed
@@ -1174,6 +1179,30 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     if (b->g_center) SMI_HIP(hipFree(b->g_center));
     SMI_HIP(dev_alloc(&b->g_center, (size_t)n * 2 + 2));  // never empty: a batch may hold no component
     SMI_HIP(hipMemset(b->g_center, 0, ((size_t)n * 2 + 2) * sizeof(double)));
+    // work list of the register-resident update kernels: components by size class, then
+    // blend (BatchView::work)
+    {
+        std::vector<std::vector<int32_t>> items(kNumUpdateClasses);
+        b->h_work_start.assign((size_t)kNumUpdateClasses * (nb + 1), 0);
+        for (int i = 0; i < nb; ++i) {
+            for (int k = start[i]; k < start[i + 1]; ++k) {
+                if (c->prox_flags[k] & SMI_COMPONENT_POINT_SOURCE) continue;
+                const int cls = update_class(c->box_h[k] * c->box_w[k]);
+                if (cls >= 0) items[cls].push_back(k);  // else: such a batch takes the general kernel
+            }
+            for (int cls = 0; cls < kNumUpdateClasses; ++cls)
+                b->h_work_start[(size_t)cls * (nb + 1) + i + 1] = (int32_t)items[cls].size();
+        }
+        std::vector<int32_t> work;
+        int32_t base = 0;
+        for (int cls = 0; cls < kNumUpdateClasses; ++cls) {
+            for (int i = 0; i <= nb; ++i) b->h_work_start[(size_t)cls * (nb + 1) + i] += base;
+            work.insert(work.end(), items[cls].begin(), items[cls].end());
+            base += (int32_t)items[cls].size();
+        }
+        work.push_back(-1);  // never empty
+        if ((rc = upload(&b->work_items, work.data(), work.size()))) return rc;
+    }
     b->have_components = true;
     const int keep = b->view.max_box_pixels;
     refresh_view(b);

@@ -84,6 +84,22 @@ struct alignas(16) SweepSlotEntry {
     float w[4];
 };
 
+// Size classes of the register-resident update kernel: a box of N pixels runs in the
+// instantiation with the smallest NPL >= N / 64 (lane l owns pixels l, l + 64, ...), so
+// every box of class c has more than 64 * kUpdateNpl[c - 1] pixels.  The reference's
+// standard boxes (21 + 10 k pixels a side, morphology.py / initialization.py:173-177)
+// 21^2 .. 61^2 map onto one class each.
+constexpr int kNumUpdateClasses = 5;
+constexpr int kUpdateNpl[kNumUpdateClasses] = {7, 16, 27, 42, 59};
+inline int update_class(int n_pix) {
+    for (int c = 0; c < kNumUpdateClasses; ++c)
+        if (n_pix <= 64 * kUpdateNpl[c]) return c;
+    return -1;
+}
+// LDS floats of one component's image in that kernel: all 64 * NPL pixel slots of the
+// class (slots beyond the box hold zeros, so the loops need no bounds) + the spare cell
+inline int update_image_stride(int n_pix) { return 64 * kUpdateNpl[update_class(n_pix)] + 4; }
+
 struct SweepPlanDev {
     int32_t h = 0, w = 0, n_entries = 0, max_terms = 0, n_levels = 0;
     int32_t n_slots = 0;
@@ -158,6 +174,14 @@ struct BatchView {
     // sub-range launches (one stream per range of blends): the grids cover `nb` blends /
     // `n_comp` components starting at these offsets; all arrays stay whole-batch
     int32_t blend0, comp0;
+    // work list of the register-resident update kernels: the component of every workgroup,
+    // sorted by size class, then blend (point sources have their own kernel and are not
+    // listed).  `work_start` is a HOST array [kNumUpdateClasses][nb_total + 1]: first
+    // entry of every blend within a class (prefix sums), for the launch ranges.
+    const int32_t *work;
+    int32_t work0;
+    const int32_t *work_start;
+    int32_t nb_total;
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);

@@ -423,6 +423,13 @@ __device__ __forceinline__ int fit_center_index(const float *us, const CompCtx &
     return best;
 }
 
+// LDS data that only one wave touches: LDS operations of one wave execute in order, so between a
+// step's writes and the next step's reads only the LDS counter has to drain.  Unlike
+// __syncthreads() this leaves the global loads of the plan prefetch in flight.
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // the element-wise members of the chain that act on the LDS image `us` before the
 // final positivity / centre / normalisation pass (constraint.py:262-273, 117-145)
 __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCtx &c, int flags,
@@ -439,7 +446,7 @@ __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCt
             for (int b = 0; b < c.C; ++b) below = below && (sed_new[b] * u < bg_level[b]);
             if (below) us[i] = 0.f;
         }
-        __syncthreads();
+        wave_lds_fence();  // a wave only touches its own image
     }
     if (flags & SMI_PROX_SYMMETRY) {
         // prox_soft_symmetry (operator.py:274-293), x <- s/2 (x + rot180 x) + (1 - s) x: even axes are
@@ -468,7 +475,7 @@ __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCt
                 us[j] = 0.5f * s * (xj + xi) + keep * xj;
             }
         }
-        __syncthreads();
+        wave_lds_fence();  // a wave only touches its own image
     }
     if (flags & (SMI_PROX_L1 | SMI_PROX_L0)) {
         for (int i = lane; i < N; i += 64) {
@@ -785,88 +792,223 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
 // itself ("+ 0 * own value", exact for finite values); idle lanes point at a spare
 // cell behind the image that always holds 0, so the loop body has no branches:
 // ~35 instructions per level instead of ~65 (the sweep is VALU-issue bound).
-__device__ __forceinline__ void sweep_step(float *us, const int4 a, const float4 wv,
+// -- buffer addressing ------------------------------------------------------------
+// A component's slices of the packed arrays (morph, m, v, vhat), a band plane of the
+// gradient image and the sweep plan are addressed through buffer descriptors built
+// from wave-uniform values: lanes beyond the box / outside the frame read 0 and their
+// stores are dropped by the bounds check, so the per-pixel loops are straight-line code
+// and all loads of a group are in flight together (the phase is bound by memory latency).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, uint32_t byte_off, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), r, byte_off, 0, 0);
+}
+constexpr uint32_t kOutOfRange = 0x80000000u;
+
+__device__ __forceinline__ CompCtx comp_ctx(const BatchView &v, int k, int lane) {
+    CompCtx c;
+    c.k = k;
+    c.lane = lane;
+    c.b = v.c_blend[k];
+    c.C = v.C;
+    c.h = v.c_h[k];
+    c.w = v.c_w[k];
+    c.N = c.h * c.w;
+    c.oy = v.c_oy[k];
+    c.ox = v.c_ox[k];
+    c.moff = v.c_moff[k];
+    c.pre = v.n_shift && (v.c_flags[k] & SMI_COMPONENT_SHIFTING);
+    c.morph_out = (c.pre ? v.morph_param : v.morph) + c.moff;
+    c.morph = c.morph_out;
+    c.sed = v.sed + (int64_t)k * c.C;
+    return c;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+
+// Between two steps of the sweep.  The LDS executes the DS instructions of ONE wave in the
+// order they were issued, so a step's reads see the previous step's writes without the
+// wave waiting for those writes to retire: only the compiler has to keep the order.
+#ifndef SMI_SWEEP_DRAIN
+#define SMI_SWEEP_DRAIN 0
+#endif
+__device__ __forceinline__ void sweep_fence() {
+#if SMI_SWEEP_DRAIN
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+
+__device__ __forceinline__ void sweep_step(float *us, const u32x3 a, const u32x4 wb,
                                            float one_minus_g) {
     char *base = reinterpret_cast<char *>(us);
     float *pp = reinterpret_cast<float *>(base + (a.x & 0xffff));
     const float cur = *pp;
-    const float u0 = *reinterpret_cast<float *>(base + ((unsigned)a.x >> 16));
+    const float u0 = *reinterpret_cast<float *>(base + (a.x >> 16));
     const float u1 = *reinterpret_cast<float *>(base + (a.y & 0xffff));
-    const float u2 = *reinterpret_cast<float *>(base + ((unsigned)a.y >> 16));
+    const float u2 = *reinterpret_cast<float *>(base + (a.y >> 16));
     const float u3 = *reinterpret_cast<float *>(base + (a.z & 0xffff));
-    float ref = __fadd_rn(0.f, __fmul_rn(u0, wv.x));
-    ref = __fadd_rn(ref, __fmul_rn(u1, wv.y));
-    ref = __fadd_rn(ref, __fmul_rn(u2, wv.z));
-    ref = __fadd_rn(ref, __fmul_rn(u3, wv.w));
+    float ref = __fadd_rn(0.f, __fmul_rn(u0, __uint_as_float(wb.x)));
+    ref = __fadd_rn(ref, __fmul_rn(u1, __uint_as_float(wb.y)));
+    ref = __fadd_rn(ref, __fmul_rn(u2, __uint_as_float(wb.z)));
+    ref = __fadd_rn(ref, __fmul_rn(u3, __uint_as_float(wb.w)));
     const float lim = __fmul_rn(ref, one_minus_g);
     if (lim < cur) *pp = lim;
 }
 
-// Single-wave workgroups: LDS operations of one wave execute in order, so between a
-// step's writes and the next step's reads only the LDS counter has to drain.  Unlike
-// __syncthreads() this leaves the global loads of the plan prefetch in flight.
-__device__ __forceinline__ void wave_lds_fence() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
+// `slots` must be wave-uniform: the plan is read through a buffer descriptor (lane l at
+// byte 32 l of every 2-KB step, the step offset in a scalar register), which takes the
+// address arithmetic of the prefetch out of the vector unit.
 __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slots, int n_slots,
                                             float one_minus_g, int lane) {
-    const int4 *meta = reinterpret_cast<const int4 *>(slots) + lane * 2;
-    const float4 *wts = reinterpret_cast<const float4 *>(slots) + lane * 2 + 1;
+    // uniformity made explicit, or the compiler wraps every load in a waterfall loop
+    const uint64_t sp = reinterpret_cast<uint64_t>(slots);
+    // (the builtin returns a signed int: go through uint32_t, or the low half sign-extends)
+    const uint32_t sp_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sp);
+    const uint32_t sp_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sp >> 32));
+    const uint64_t sp_u = (uint64_t)sp_lo | ((uint64_t)sp_hi << 32);
+    n_slots = __builtin_amdgcn_readfirstlane(n_slots);
+    const rsrc_t r = make_rsrc(reinterpret_cast<const void *>(sp_u), (uint32_t)(n_slots + 3) * 2048u);
+    const uint32_t vo = (uint32_t)lane * 32u;
+    // three dwords: a fourth, dead one would be handed to another temporary while the load
+    // is still in flight and force an early wait
+    auto meta = [&](int step) { return __builtin_amdgcn_raw_buffer_load_b96(r, vo, step * 2048, 0); };
+    auto wts = [&](int step) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, vo + 16u, step * 2048, 0);
+    };
     // four steps per iteration, each plan entry requested three steps before it is used
     // (register ping-pong, no rotation moves).  The plan is padded to a multiple of four
     // steps plus three idle steps, so neither the prefetch nor the loop needs a bound
     // check inside an iteration.
-    int4 a0 = meta[0], a1 = meta[128], a2 = meta[256];
-    float4 w0 = wts[0], w1 = wts[128], w2 = wts[256];
+    // issued in the order of the steady state (entry, weights, step by step): the wait
+    // counter at the loop head is the minimum over both ways into the loop
+    u32x3 a0 = meta(0);
+    u32x4 w0 = wts(0);
+    __builtin_amdgcn_sched_barrier(0);
+    u32x3 a1 = meta(1);
+    u32x4 w1 = wts(1);
+    __builtin_amdgcn_sched_barrier(0);
+    u32x3 a2 = meta(2);
+    u32x4 w2 = wts(2);
+    __builtin_amdgcn_sched_barrier(0);
     for (int s = 0; s < n_slots; s += 4) {
-        const int4 *m = meta + (int64_t)s * 128;
-        const float4 *w = wts + (int64_t)s * 128;
-        const int4 a3 = m[3 * 128];
-        const float4 w3 = w[3 * 128];
+        const u32x3 a3 = meta(s + 3);
+        const u32x4 w3 = wts(s + 3);
         sweep_step(us, a0, w0, one_minus_g);
-        wave_lds_fence();
-        a0 = m[4 * 128];
-        w0 = w[4 * 128];
+        sweep_fence();
+        a0 = meta(s + 4);
+        w0 = wts(s + 4);
         sweep_step(us, a1, w1, one_minus_g);
-        wave_lds_fence();
-        a1 = m[5 * 128];
-        w1 = w[5 * 128];
+        sweep_fence();
+        a1 = meta(s + 5);
+        w1 = wts(s + 5);
         sweep_step(us, a2, w2, one_minus_g);
-        wave_lds_fence();
-        a2 = m[6 * 128];
-        w2 = w[6 * 128];
+        sweep_fence();
+        a2 = meta(s + 6);
+        w2 = wts(s + 6);
         sweep_step(us, a3, w3, one_minus_g);
-        wave_lds_fence();
+        sweep_fence();
     }
 }
 
+// occupancy the register allocator has to reach (waves per SIMD): three arrays of NPL
+// registers + the sweep's prefetch; without the cap the scheduler trades waves for ILP
+#ifndef SMI_WAVES
+#define SMI_WAVES __attribute__((amdgpu_waves_per_eu(NPL <= 16 ? 4 : NPL <= 27 ? 3 : 2)))
+#endif
 // MODE 0: Blend.fit, 1: lite with AdaproxParameter, 2: lite with FistaParameter
+//
+// One wavefront per component; the components of a launch all belong to one size class
+// (`work` lists them class by class, common.h), so the per-pixel loops carry no bounds
+// for the first kFull slots and a small box never runs through a large box's loops.
 template <int NPL, int MODE>
-__global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float *G, int it,
-                                                        float e_rel, int prox_max_iter) {
+__global__ __launch_bounds__(64) SMI_WAVES void update_kernel_reg(BatchView v, const float *G,
+                                                                  int it, float e_rel,
+                                                                  int prox_max_iter) {
     constexpr bool LITE = MODE != 0;
-    const CompCtx c = comp_ctx(v);
-    if (v.state[c.b] >= 2) return;
-    if (v.n_point && (v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
-    const int lane = c.lane, N = c.N;
-    float *us = lds_dyn;
-
-    const float g_sed = hold_fixed(v, c, gather_gradient(v, c, G, us), us);
-    __syncthreads();
-    const float e2 = e_rel * e_rel;
-    __shared__ float sed_new[64];
     constexpr bool fista = MODE == 2;
+    // every box of this size class has more than 64 * kFull pixels (common.h)
+    constexpr int kFull = NPL == 7 ? 0 : NPL == 16 ? 7 : NPL == 27 ? 16 : NPL == 42 ? 27 : 42;
+    const int lane = threadIdx.x;
+    const int k = v.work[blockIdx.x + v.work0];
+    const CompCtx c = comp_ctx(v, k, lane);
+    if (v.state[c.b] >= 2) return;
+    const int N = c.N;
+    float *us = lds_dyn;
+    __shared__ float sed_new[64];
+    const float e2 = e_rel * e_rel;
     if (fista) prox_max_iter = 1;  // FistaParameter applies the prox once
 
-    const int flags = v.c_flags[c.k];
-    const int plan_id = v.c_plan[c.k];
+    const int flags = v.c_flags[k];
+    const int plan_id = v.c_plan[k];
+    const uint32_t nbytes = (uint32_t)N * 4u;
     float xs[NPL], rs[NPL], zs[NPL];
+
+    // ---- gradient: xs = sum_c sed_c G_c[box], g_sed (lane c) = sum_yx G_c morph
+    // (lite/models.py:206-216; slice of G into the box, zero outside the frame: blend.py:30-46)
+    {
+        const rsrc_t r_morph = make_rsrc(c.morph, nbytes);
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) zs[j] = buf_load(r_morph, (uint32_t)(lane + 64 * j) * 4u);
+    }
+    float g_sed = 0.f;
+    if (c.pre) {
+        const rsrc_t r_g = make_rsrc(v.g_morph_buf + c.moff, nbytes);
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) xs[j] = buf_load(r_g, (uint32_t)(lane + 64 * j) * 4u);
+        g_sed = lane < c.C ? v.g_sed_buf[(int64_t)k * c.C + lane] : 0.f;
+    } else {
+        // byte offset of each of the lane's pixels inside a band plane of G (or out of
+        // range), parked in the LDS image, which is not needed before the prox loop
+        uint32_t *goff = reinterpret_cast<uint32_t *>(us);
+        const float inv_w = 1.0f / (float)c.w;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int i = lane + 64 * j;
+            // exact for i < 2^20: the float quotient is off by < 1e-6 relative
+            const int y = (int)(((float)i + 0.5f) * inv_w);
+            const int x = i - y * c.w;
+            const int fy = y + c.oy, fx = x + c.ox;
+            const bool ok = (j < kFull || i < N) && (unsigned)fy < (unsigned)v.H &&
+                            (unsigned)fx < (unsigned)v.W;
+            goff[i] = ok ? (uint32_t)(fy * v.Fx + fx) * 4u : kOutOfRange;
+            xs[j] = 0.f;
+        }
+        const int64_t plane = (int64_t)v.Fy * v.Fx;
+        for (int cb = 0; cb < c.C; ++cb) {
+            const rsrc_t r_g = make_rsrc(G + ((int64_t)c.b * c.C + cb) * plane, (uint32_t)plane * 4u);
+            float g[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) g[j] = buf_load(r_g, goff[lane + 64 * j]);
+            const float s = c.sed[cb];
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                xs[j] = fmaf(s, g[j], xs[j]);
+                acc = fmaf(g[j], zs[j], acc);
+            }
+            const float t = wave_sum(acc);
+            if (lane == cb) g_sed = t;
+        }
+    }
+    // Parameter(fixed=True): the optimizer sees a zero gradient (blend.py:107-115)
+    if (flags & SMI_COMPONENT_FIXED_MORPH) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) xs[j] = 0.f;
+    }
+    if (flags & SMI_COMPONENT_FIXED_SED) g_sed = 0.f;
+
     float msum = 0.f, msum2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
-        const int i = lane + 64 * j;
-        zs[j] = i < N ? c.morph[i] : 0.f;
         msum += zs[j];
         msum2 = fmaf(zs[j], zs[j], msum2);
     }
@@ -876,44 +1018,82 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
         msum2 = wave_sum(msum2);
         const float so = lane < c.C ? c.sed[lane] : 0.f;
         ssum2 = wave_sum(so * so);
-        t_old = (float)v.fista_t[2 * (int64_t)c.k + 1];
+        t_old = (float)v.fista_t[2 * (int64_t)k + 1];
     }
     int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, sed_new);
-    const float alpha = fmaxf(v.c_morph_step[c.k], v.c_morph_rel[c.k] * (wave_sum(msum) / (float)N));
+    const float alpha = fmaxf(v.c_morph_step[k], v.c_morph_rel[k] * (wave_sum(msum) / (float)N));
     float pmax = 0.f;
+    const rsrc_t r_m = make_rsrc(v.m_morph + c.moff, nbytes);
     if (fista) {
-        const float step = v.c_fista_step[c.k] / ssum2;
+        const float step = v.c_fista_step[k] / ssum2;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) rs[j] = buf_load(r_m, (uint32_t)(lane + 64 * j) * 4u);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            const int i = lane + 64 * j;
-            xs[j] = 0.f;
+            xs[j] = rs[j] - step * xs[j];
             rs[j] = 0.f;
-            if (i < N) xs[j] = v.m_morph[c.moff + i] - step * us[i];
             zs[j] = xs[j];
         }
         pmax = 1.f;
     } else {
+        // AMSGrad moments (lite/parameters.py:274-291), CH pixels per lane at a time; the
+        // loads of the next group are issued before the stores of this one
+        const rsrc_t r_v = make_rsrc(v.v_morph + c.moff, nbytes);
+        const rsrc_t r_vh = make_rsrc(v.vh_morph + c.moff, nbytes);
+        constexpr int CH = NPL <= 6 ? NPL : 6;
+        const float b1 = v.b1, b2 = v.b2, eps = v.eps;
+        float cm[CH], cv[CH], cvh[CH];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int i = lane + 64 * j;
-            xs[j] = 0.f;
-            rs[j] = 0.f;
-            if (i < N) {
-                const float g = us[i];
-                const float m = (1.f - v.b1) * g + v.b1 * v.m_morph[c.moff + i];
-                const float vv = (1.f - v.b2) * g * g + v.b2 * v.v_morph[c.moff + i];
-                const float vh = it == 0 ? vv : fmaxf(v.vh_morph[c.moff + i], vv);
-                v.m_morph[c.moff + i] = m;
-                v.v_morph[c.moff + i] = vv;
-                v.vh_morph[c.moff + i] = vh;
-                const float psi = sqrtf(fmaxf(vh, v.eps));
-                float upd = alpha * m / psi;
-                if (it == 0) upd /= 10.f;
-                xs[j] = zs[j] - upd;
-                zs[j] = xs[j];
-                rs[j] = psi;
-                pmax = fmaxf(pmax, psi);
+        for (int u = 0; u < CH; ++u) {
+            const uint32_t off = (uint32_t)(lane + 64 * u) * 4u;
+            cm[u] = buf_load(r_m, off);
+            cv[u] = buf_load(r_v, off);
+            cvh[u] = buf_load(r_vh, off);
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < NPL; j0 += CH) {
+            float nm[CH], nv[CH], nvh[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                nm[u] = nv[u] = nvh[u] = 0.f;
+                if (j0 + CH + u < NPL) {
+                    const uint32_t off = (uint32_t)(lane + 64 * (j0 + CH + u)) * 4u;
+                    nm[u] = buf_load(r_m, off);
+                    nv[u] = buf_load(r_v, off);
+                    nvh[u] = buf_load(r_vh, off);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = j0 + u;
+                if (j < NPL) {
+                    const uint32_t off = (uint32_t)(lane + 64 * j) * 4u;
+                    const float g = xs[j];
+                    const float m = (1.f - b1) * g + b1 * cm[u];
+                    const float vv = (1.f - b2) * g * g + b2 * cv[u];
+                    const float vh = it == 0 ? vv : fmaxf(cvh[u], vv);
+                    buf_store(r_m, off, m);
+                    buf_store(r_v, off, vv);
+                    buf_store(r_vh, off, vh);
+                    const float psi = sqrtf(fmaxf(vh, eps));
+                    float upd = alpha * m / psi;
+                    if (it == 0) upd /= 10.f;
+                    xs[j] = zs[j] - upd;
+                    zs[j] = xs[j];
+                    // slots beyond the box: x = z = 0 (loads returned 0), psi must not count
+                    const bool in_box = j < kFull || lane + 64 * j < N;
+                    rs[j] = in_box ? psi : 0.f;
+                    pmax = fmaxf(pmax, rs[j]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                cm[u] = nm[u];
+                cv[u] = nv[u];
+                cvh[u] = nvh[u];
+            }
+            // keep the scheduler from hoisting every group's loads to the top (registers)
+            __builtin_amdgcn_sched_barrier(0);
         }
         pmax = wave_max(pmax);
     }
@@ -929,44 +1109,39 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
         slots = v.plans[plan_id].slots;
         n_slots = v.plans[plan_id].n_slots;
     }
-    const float one_minus_g = 1.f - v.c_min_grad[c.k];
+    const float one_minus_g = 1.f - v.c_min_grad[k];
     const int ctr = (c.h / 2) * c.w + (c.w / 2);
     const float lthresh =
-        v.c_lthresh[c.k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
-    const float cfloor = v.c_center_floor[c.k];
-    const float pfloor = v.c_pos_floor[c.k];  // PositivityConstraint(zero)
+        v.c_lthresh[k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
+    const float cfloor = v.c_center_floor[k];
+    const float pfloor = v.c_pos_floor[k];  // PositivityConstraint(zero)
     const float *bg_level =
-        (LITE && v.c_bg_level) ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;
-    if (lane == 0) us[(v.max_box_pixels + 3) & ~3] = 0.f;  // spare cell for idle sweep lanes
-    __syncthreads();
+        (LITE && v.c_bg_level) ? v.c_bg_level + (int64_t)k * c.C : nullptr;
+    wave_lds_fence();  // the offsets parked in `us` have been consumed
 
     for (int tau = 0; tau < prox_max_iter; ++tau) {
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int i = lane + 64 * j;
-            if (i < N) us[i] = zs[j] - rs[j] * (zs[j] - xs[j]);
-        }
-        __syncthreads();
+        for (int j = 0; j < NPL; ++j) us[lane + 64 * j] = zs[j] - rs[j] * (zs[j] - xs[j]);
+        wave_lds_fence();
         if (fit_center) {
-            const SweepPlanDev &pl = v.plans[plan_id + fit_center_index(us, c)];
+            const int centre = __builtin_amdgcn_readfirstlane(fit_center_index(us, c));
+            const SweepPlanDev &pl = v.plans[plan_id + centre];
             slots = pl.slots;
             n_slots = pl.n_slots;
         }
         if (monotonic) sweep_slots(us, slots, n_slots, one_minus_g, lane);
         chain_symmetry_threshold(us, c, LITE ? flags : (flags & ~SMI_PROX_BG_THRESH), lthresh,
                                  sed_new, bg_level,
-                                 (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[c.k] : 1.f);
+                                 (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[k] : 1.f);
         float mx = -INFINITY, sm = 0.f;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int i = lane + 64 * j;
-            if (i < N) {
-                float u = us[i];
-                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
-                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
-                mx = fmaxf(mx, u);
-                sm += u;
-            }
+            float u = us[i];
+            if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
+            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
+            mx = (j < kFull || i < N) ? fmaxf(mx, u) : mx;
+            sm += (j < kFull || i < N) ? u : 0.f;
         }
         float div = 1.f;
         if (flags & SMI_PROX_NORM_MAX) div = wave_max(mx);
@@ -979,39 +1154,39 @@ __global__ __launch_bounds__(64) void update_kernel_reg(BatchView v, const float
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int i = lane + 64 * j;
-            if (i < N) {
-                float u = us[i];  // second read instead of NPL more registers
-                if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
-                if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
-                if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
-                    u = (u == div && (flags & SMI_PROX_NORM_MAX)) ? 1.f : u * rdiv;
-                d2 += (u - zs[j]) * (u - zs[j]);
-                z2 += zs[j] * zs[j];
-                zs[j] = u;
-            }
+            float u = us[i];  // second read instead of NPL more registers
+            if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
+            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
+            if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
+                u = (u == div && (flags & SMI_PROX_NORM_MAX)) ? 1.f : u * rdiv;
+            if (!(j < kFull || i < N)) u = 0.f;  // slots beyond the box stay zero
+            d2 += (u - zs[j]) * (u - zs[j]);
+            z2 += zs[j] * zs[j];
+            zs[j] = u;
         }
         d2 = wave_sum(d2);
         z2 = wave_sum(z2);
-        __syncthreads();
         if (d2 <= e2 * z2) break;
     }
     float omega = 0.f;
     if (fista) {
         const float tn = 0.5f * (1.f + sqrtf(1.f + 4.f * t_old * t_old));
         omega = 1.f + (t_old - 1.f) / tn;
-        if (lane == 0) v.fista_t[2 * (int64_t)c.k + 1] = (double)tn;
+        if (lane == 0) v.fista_t[2 * (int64_t)k + 1] = (double)tn;
+    }
+    const rsrc_t r_out = make_rsrc(c.morph_out, nbytes);
+    if (fista) {
+        float xo[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) xo[j] = buf_load(r_out, (uint32_t)(lane + 64 * j) * 4u);
+#pragma unroll
+        for (int j = 0; j < NPL; ++j)
+            buf_store(r_m, (uint32_t)(lane + 64 * j) * 4u, xo[j] + omega * (zs[j] - xo[j]));
     }
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
-        const int i = lane + 64 * j;
-        if (i < N) {
-            if (fista) {
-                const float xo = c.morph[i];
-                v.m_morph[c.moff + i] = xo + omega * (zs[j] - xo);
-            }
-            c.morph_out[i] = zs[j];
-            bad |= !isfinite(zs[j]);
-        }
+        buf_store(r_out, (uint32_t)(lane + 64 * j) * 4u, zs[j]);
+        bad |= !isfinite(zs[j]);
     }
     if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
 }
@@ -1172,16 +1347,19 @@ static size_t update_lds_bytes(const BatchView &v) {
 
 template <int NPL>
 static void launch_update_reg(const BatchView &v, const float *G, int32_t it, float e_rel,
-                              int32_t prox_max_iter, hipStream_t s) {
-    const size_t lds = (size_t)(((v.max_box_pixels + 3) & ~3) + 4) * sizeof(float);
+                              int32_t prox_max_iter, int32_t item0, int32_t n_items,
+                              hipStream_t s) {
+    BatchView vi = v;
+    vi.work0 = item0;
+    const size_t lds = (size_t)(64 * NPL + 4) * sizeof(float);
     if (v.scheme == SMI_SCHEME_FISTA)
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 2>), dim3(v.n_comp), dim3(64), lds, s, v, G,
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 2>), dim3(n_items), dim3(64), lds, s, vi, G,
                            it, e_rel, prox_max_iter);
     else if (v.lite)
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 1>), dim3(v.n_comp), dim3(64), lds, s, v, G,
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 1>), dim3(n_items), dim3(64), lds, s, vi, G,
                            it, e_rel, prox_max_iter);
     else
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 0>), dim3(v.n_comp), dim3(64), lds, s, v, G,
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 0>), dim3(n_items), dim3(64), lds, s, vi, G,
                            it, e_rel, prox_max_iter);
 }
 
@@ -1191,17 +1369,20 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
     if (v.n_comp == 0) return SMI_OK;
     // chains that repeat take the general kernel (the register-resident ones apply it once)
     if (!grad_only && v.fast_plans && v.max_box_pixels <= 64 * 59 && !v.c_chain_repeat) {
-        const int n = v.max_box_pixels;
-        if (n <= 64 * 7)
-            launch_update_reg<7>(v, G, it, e_rel, prox_max_iter, s);
-        else if (n <= 64 * 16)
-            launch_update_reg<16>(v, G, it, e_rel, prox_max_iter, s);
-        else if (n <= 64 * 27)
-            launch_update_reg<27>(v, G, it, e_rel, prox_max_iter, s);
-        else if (n <= 64 * 42)
-            launch_update_reg<42>(v, G, it, e_rel, prox_max_iter, s);
-        else
-            launch_update_reg<59>(v, G, it, e_rel, prox_max_iter, s);
+        // one launch per size class that has components in this range of blends, the
+        // largest boxes (longest sweeps) first
+        for (int cls = kNumUpdateClasses - 1; cls >= 0; --cls) {
+            const int32_t *start = v.work_start + (size_t)cls * (v.nb_total + 1);
+            const int lo = start[v.blend0], hi = start[v.blend0 + v.nb];
+            if (hi <= lo) continue;
+            switch (cls) {
+                case 0: launch_update_reg<kUpdateNpl[0]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
+                case 1: launch_update_reg<kUpdateNpl[1]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
+                case 2: launch_update_reg<kUpdateNpl[2]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
+                case 3: launch_update_reg<kUpdateNpl[3]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
+                default: launch_update_reg<kUpdateNpl[4]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
+            }
+        }
         return SMI_OK;
     }
     const size_t lds = update_lds_bytes(v);
