@@ -396,7 +396,8 @@ def main():
         by_survey = algorithmic_bytes(C, H, W, boxes, 180, 180, kb) if args.config == "cfg3" else by
         bytes_per = by["null"] if args.null_renderer else by["whole"]
         ms_iter = elapsed / K * 1e3
-        fused = (not args.null_renderer) and phases["render"] < 0.05 * phases["conv"]
+        # the fused path has no kernel between the loss and the update (conv_adj = 0)
+        fused = (not args.null_renderer) and phases["conv_adj"] < 0.05 * phases["conv"]
         if fused:
             k_name, k_bytes, k_ms = "fused_conv_kernel", by["conv"], phases["conv"]
         elif args.null_renderer:

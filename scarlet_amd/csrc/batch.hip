@@ -1385,7 +1385,7 @@ int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL)
     }
     if (b->fused) {
         // mode 1: rendered cube to Q (compact) and the loss partials
-        if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
+        if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
                                     b->d.kernel_per_blend, b->Q, 1, nullptr, b->stream)))
             return rc;
     } else if ((rc = convolve(b, v, 0))) {
@@ -1425,11 +1425,9 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     if (rc) return rc;
     const BatchView v = unmasked_view(b);
     if (b->fused) {
-        if (!b->lowres.empty()) {
-            launch_render(v, b->P, b->stream);
-            if ((rc = lowres_evaluate_all(b, 1))) return rc;
-        }
-        if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
+        launch_render(v, b->P, b->stream);
+        if ((rc = lowres_evaluate_all(b, 1))) return rc;
+        if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
                                     b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
             return rc;
     } else {
@@ -1510,8 +1508,9 @@ static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter,
             // phase times are those of range 0 (its kernels overlap the other ranges')
             hipEvent_t *ev = timing && s == 0 ? &b->events[(size_t)i * 6] : nullptr;
             if (ev) SMI_HIP(hipEventRecord(ev[0], st));
+            launch_render(v, b->P, st);
             if (ev) SMI_HIP(hipEventRecord(ev[1], st));
-            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
+            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
                                         b->d.kernel_per_blend, b->Q, 0, nullptr, st)))
                 return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], st));
@@ -1578,14 +1577,11 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
         hipEvent_t *ev = timing ? &b->events[(size_t)i * 6] : nullptr;
         if (ev) SMI_HIP(hipEventRecord(ev[0], b->stream));
         if (b->fused) {
-            if (!b->lowres.empty()) {
-                // the model cube itself is needed for the low-resolution observations
-                launch_render(v, b->P, b->stream);
-                if ((rc = lowres_evaluate_all(b, 1))) return rc;
-            }
-            // render + conv + residual/loss + conv^T in one LDS-resident kernel
+            launch_render(v, b->P, b->stream);
+            if ((rc = lowres_evaluate_all(b, 1))) return rc;
+            // conv + residual/loss + conv^T in one LDS-resident kernel
             if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
-            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->Kt, b->d.kernel_bands,
+            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
                                         b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
                 return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));

@@ -1,13 +1,16 @@
 // LDS-resident PSF convolution + likelihood for one (blend, band) per workgroup.
 //
 // Replaces, for frames whose padded band fits the 160 KiB LDS of a CU, the chain
-//   render -> rocFFT R2C -> x K^ -> rocFFT C2R -> residual/loss -> rocFFT R2C ->
-//   x conj(K^) -> rocFFT C2R
+//   rocFFT R2C -> x K^ -> rocFFT C2R -> residual/loss -> rocFFT R2C -> x conj(K^) ->
+//   rocFFT C2R
 // (renderer.py:247-259 / fft.py:368-396 forward, its transpose backward,
 // observation.py:147-170 in between) by ONE kernel that keeps the half-spectrum of
 // the band in LDS from the first row transform to the last: per blend-iteration the
-// only HBM traffic left is data + weights (read once), the morphologies (L2) and the
-// gradient image (written once).
+// only HBM traffic left is the model cube, data and weights (read once) and the
+// gradient image (written once).  The model cube itself comes from render_kernel
+// (kernels.hip): rendering inside this kernel made every 64-row chunk wait, at a
+// workgroup barrier, for the wavefront whose rows intersect the most component boxes
+// (22 % of the kernel's time); plain rows are fetched one chunk ahead instead.
 //
 // Layout: T[kx][y], kx in [0, FX/2]; element y of a column sits at y + y / 16 and the
 // column stride SY is 16 mod 32 complex, so that the 16 lanes that own a column and the
@@ -244,13 +247,14 @@ __device__ __forceinline__ float &zref(float2 *Z, int SX, int r, int x) {
 
 extern __shared__ __attribute__((aligned(16))) float2 lds_conv[];
 
+// model: the model cube [nb][C][H][W] (render_kernel)
 // mode 0: full (writes the gradient image G[nb][C][H][W] and the loss partial)
 // mode 1: forward only (writes the rendered cube instead and the loss partial)
 template <int FY1, int FX1>
-__global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const float2 *Kt,
-                                                              int k_bands, int k_per_blend,
-                                                              float *out, int mode,
-                                                              long long *dbg) {
+__global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const float *model,
+                                                              const float2 *Kt, int k_bands,
+                                                              int k_per_blend, float *out,
+                                                              int mode, long long *dbg) {
     using C = Cfg<FY1, FX1>;
     // XCD-aware placement: consecutive logical ids (the bands of one blend) share an
     // XCD and therefore its L2 (morphologies, data of neighbouring bands)
@@ -286,133 +290,51 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         cv.posx[kx] = (uint32_t)pos<FX1>(kx) | ((uint32_t)pos<FX1>((C::FX - kx) % C::FX) << 16);
     const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
                                C::FY * C::NKX;
-    const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
     const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
-    // component metadata of the blend, one component per lane (groups of 64), fetched
-    // once with vector loads and broadcast later with v_readlane: the per-component
-    // scalar loads were the latency chain of the render stage
-    auto lane_meta = [&](int k0, int &oy, int &ox, int &hh, int &ww, int &mo, float &sd) {
-        const int k = k0 + lane;
-        const bool ok = k < ce;
-        oy = ok ? v.c_oy[k] : 0;
-        ox = ok ? v.c_ox[k] : 0;
-        hh = ok ? v.c_h[k] : 0;
-        ww = ok ? v.c_w[k] : 0;
-        mo = ok ? (int)v.c_moff[k] : 0;  // packed morphology offsets fit 31 bits
-        sd = ok ? v.sed[(int64_t)k * v.C + c] : 0.f;
-    };
     __syncthreads();
 #define SMI_STAMP(i) if (dbg && tid == 0 && blockIdx.x == 0) dbg[i] = clock64()
     SMI_STAMP(0);
 
-    // ---- A: render (blend.py:200-244) and forward row transforms ----------------
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        const int y0 = ch * 2 * kPairs;
-        // Pixel-owner render: wave `wv` owns kRows consecutive rows of the chunk, lane l
-        // the columns l, l + 64, ...; the pixels accumulate in registers, components in
-        // ascending order (the summation order of blend.py:30-46), and are written to the
-        // row-pair scratch once.  A component whose box misses the wave's rows is skipped
-        // with a wave-uniform test; box rows are contiguous in memory, so the loads of a
-        // wave are coalesced.  No zero fill, no read-modify-write in LDS, no barriers
-        // between components.
+    // ---- A: model rows (blend.py:200-244, rendered by render_kernel) and their forward
+    // row transforms.  Wave w owns the row pairs 2w, 2w + 1 of a chunk, lane l the columns
+    // l, l + 64, ...; the rows of the next chunk are requested before this chunk's
+    // transforms, so that their latency hides behind them.
+    {
         constexpr int kWaves = kThreads / 64;
         constexpr int kRows = 2 * kPairs / kWaves;
         static_assert(2 * kPairs % kWaves == 0 && kRows % 2 == 0, "rows per wave");
-        auto render = [&](auto xs_tag) {
-        constexpr int kXs = decltype(xs_tag)::value;
-        // components whose loads are in flight together: 24 values per lane
-        constexpr int kAhead = 24 / (kRows * kXs) > 0 ? 24 / (kRows * kXs) : 1;
-        const int wv = tid >> 6;
-        const int wr0 = y0 + wv * kRows;
-        float acc[kRows][kXs];
+        const float *mband = model + ((int64_t)b * v.C + c) * H * W;
+        float mrow[kRows][kXIter];
+        auto fetch = [&](int y0) {
 #pragma unroll
-        for (int j = 0; j < kRows; ++j)
+            for (int j = 0; j < kRows; ++j) {
+                const int y = y0 + wave * kRows + j;
 #pragma unroll
-            for (int q = 0; q < kXs; ++q) acc[j][q] = 0.f;
-        if (ch == 0) SMI_STAMP(6);
-        for (int kb = cs; kb < ce; kb += 64) {
-            int l_oy, l_ox, l_h, l_w, l_mo;
-            float l_sed;
-            lane_meta(kb, l_oy, l_ox, l_h, l_w, l_mo, l_sed);
-            const int kend = min(ce, kb + 64);
-            // components of this group whose box touches the wave's rows (wave-uniform)
-            unsigned long long rel = 0;
-            for (int k = kb; k < kend; ++k) {
-                const int kl = k - kb;
-                const int oy = __builtin_amdgcn_readlane(l_oy, kl);
-                const int hh = __builtin_amdgcn_readlane(l_h, kl);
-                const int ox = __builtin_amdgcn_readlane(l_ox, kl);
-                const int w = __builtin_amdgcn_readlane(l_w, kl);
-                const bool hit = min(min(wr0 + kRows, H), oy + hh) > max(wr0, oy) &&
-                                 min(W, ox + w) > max(0, ox);
-                if (hit) rel |= 1ull << kl;
-            }
-            // kAhead components per round: all of their loads are issued before the first
-            // is consumed (one memory latency per round), then they are added in order
-            while (rel) {
-                float mv[kAhead][kRows][kXs];
-                float sd[kAhead];
-                unsigned inside[kAhead];  // bit j * kXs + q: pixel (j, q) lies in the box
-                unsigned long long pend = rel;
-#pragma unroll
-                for (int g = 0; g < kAhead; ++g) {
-                    const bool have = pend != 0;
-                    const int kl = have ? __builtin_ctzll(pend) : 0;
-                    pend &= pend - 1;
-                    const int oy = __builtin_amdgcn_readlane(l_oy, kl);
-                    const int hh = __builtin_amdgcn_readlane(l_h, kl);
-                    const int ox = __builtin_amdgcn_readlane(l_ox, kl);
-                    const int w = __builtin_amdgcn_readlane(l_w, kl);
-                    const int r_lo = max(wr0, oy), r_hi = min(min(wr0 + kRows, H), oy + hh);
-                    const int x_lo = max(0, ox), x_hi = min(W, ox + w);
-                    sd[g] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_sed), kl));
-                    const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
-                    inside[g] = 0;
-#pragma unroll
-                    for (int j = 0; j < kRows; ++j) {
-                        const int rr = wr0 + j;
-                        const bool row_ok = have && rr >= r_lo && rr < r_hi;
-#pragma unroll
-                        for (int q = 0; q < kXs; ++q) {
-                            const int x = lane + 64 * q;
-                            const bool ok = row_ok && x >= x_lo && x < x_hi;
-                            mv[g][j][q] = ok ? mbase[(rr - oy) * w + (x - ox)] : 0.f;
-                            inside[g] |= ok ? 1u << (j * kXs + q) : 0u;
-                        }
-                    }
+                for (int q = 0; q < kXIter; ++q) {
+                    const int x = lane + 64 * q;
+                    mrow[j][q] = (x < W && y < H) ? mband[(int64_t)y * W + x] : 0.f;
                 }
-#pragma unroll
-                for (int g = 0; g < kAhead; ++g)
-#pragma unroll
-                    for (int j = 0; j < kRows; ++j)
-#pragma unroll
-                        for (int q = 0; q < kXs; ++q)
-                            if (inside[g] & (1u << (j * kXs + q)))  // pixels outside stay untouched
-                                acc[j][q] = fmaf(sd[g], mv[g][j][q], acc[j][q]);
-                rel = pend;
-            }
-        }
-        if (ch == 0) SMI_STAMP(7);
-#pragma unroll
-        for (int j = 0; j < kRows; j += 2)
-#pragma unroll
-            for (int q = 0; q < kXs; ++q) {
-                const int x = lane + 64 * q;
-                if (x < C::SX)
-                    cv.Z[((wr0 - y0 + j) >> 1) * C::SX + x] = make_float2(acc[j][q], acc[j + 1][q]);
             }
         };
-        // columns beyond W are never read by the row transform (pass_stride prunes them)
-        if (W <= 64)
-            render(std::integral_constant<int, 1>{});
-        else if (W <= 128)
-            render(std::integral_constant<int, 2>{});
-        else
-            render(std::integral_constant<int, (C::SX + 63) / 64>{});
-        __syncthreads();
-        if (ch == 0) SMI_STAMP(8);
-        cv.rows_forward(y0, W);
-        if (ch == 0) SMI_STAMP(9);
+        fetch(0);
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int y0 = ch * 2 * kPairs;
+#pragma unroll
+            for (int j = 0; j < kRows; j += 2)
+#pragma unroll
+                for (int q = 0; q < kXIter; ++q) {
+                    const int x = lane + 64 * q;
+                    // columns beyond W are never read by the row transform (pass_stride prunes them)
+                    if (x < C::SX)
+                        cv.Z[((wave * kRows + j) >> 1) * C::SX + x] =
+                            make_float2(mrow[j][q], mrow[j + 1][q]);
+                }
+            __syncthreads();
+            if (ch + 1 < n_chunks) fetch(y0 + 2 * kPairs);
+            if (ch == 0) SMI_STAMP(8);
+            cv.rows_forward(y0, W);
+            if (ch == 0) SMI_STAMP(9);
+        }
     }
     SMI_STAMP(1);
     // ---- B: columns, x K^ --------------------------------------------------------
@@ -557,15 +479,15 @@ __global__ void stamp_dft_y(const double2 *A, float2 *Kt, int ph, int NKX, doubl
 }
 
 template <int FY1, int FX1>
-int launch_impl(const BatchView &v, const float2 *Kt, int k_bands, int k_per_blend, float *out,
-                int mode, long long *dbg, hipStream_t s) {
+int launch_impl(const BatchView &v, const float *model, const float2 *Kt, int k_bands,
+                int k_per_blend, float *out, int mode, long long *dbg, hipStream_t s) {
     using C = Cfg<FY1, FX1>;
     auto kern = fused_conv_kernel<FY1, FX1>;
     static size_t configured[kMaxDevices] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), C::lds_bytes, configured))
         return rc;
-    hipLaunchKernelGGL(kern, dim3(v.nb * v.C), dim3(kThreads), C::lds_bytes, s, v, Kt, k_bands,
-                       k_per_blend, out, mode, dbg);
+    hipLaunchKernelGGL(kern, dim3(v.nb * v.C), dim3(kThreads), C::lds_bytes, s, v, model, Kt,
+                       k_bands, k_per_blend, out, mode, dbg);
     return SMI_OK;
 }
 
@@ -637,9 +559,10 @@ bool fused_conv_choose(int ny, int nx, int *Fy, int *Fx) {
     return best != 0;
 }
 
-int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float2 *Kt, int k_bands,
-                      int k_per_blend, float *out, int mode, long long *dbg, hipStream_t s) {
-    SMI_FUSED_DISPATCH(launch_impl, v, Kt, k_bands, k_per_blend, out, mode, dbg, s)
+int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float *model, const float2 *Kt,
+                      int k_bands, int k_per_blend, float *out, int mode, long long *dbg,
+                      hipStream_t s) {
+    SMI_FUSED_DISPATCH(launch_impl, v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s)
     set_error("fused convolution: FFT shape not instantiated");
     return SMI_ERR_INVALID;
 }

@@ -61,37 +61,93 @@ __device__ __forceinline__ int wave_or(int v) {
 
 // ---------------------------------------------------------------------------
 // Blend.get_model (blend.py:200-244, component.py:160-164): scatter-add of the
-// boxed outer products sed (x) morph, written straight into the zero-padded FFT
-// input cube P[nb][C][Fy][Fx] (image at the origin; the padding stays zero).
+// boxed outer products sed (x) morph into the model cube P[nb][C][Fy][Fx] (image at
+// the origin; for the rocFFT path Fy x Fx is the zero-padded FFT input and the padding
+// stays zero, for the fused path the cube is compact).
+//
+// Pixel-owner: one wavefront per pair of frame rows, lane l the columns l, l + 64 of a
+// 128-column strip; every pixel accumulates its components in ascending order (the
+// summation order of blend.py:30-46) in registers and is written once.  Component
+// metadata sits one component per lane and is broadcast with v_readlane; a component
+// whose box misses the wave's rows or strip is skipped with a wave-uniform test; box
+// rows are contiguous in memory, so a wave's loads are coalesced.  The kernel stays
+// below 64 VGPRs on purpose: that is what a SIMD has left beside the four wavefronts of
+// fused_conv_kernel, so render waves of one range of blends run in the issue slots the
+// convolution of another range leaves idle.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kPixBlock) void render_kernel(BatchView v, float *P) {
-    const int b = blockIdx.y;
+constexpr int kRenderRows = 2, kRenderWaves = 4;
+__global__ __launch_bounds__(64 * kRenderWaves) void render_kernel(BatchView v, float *P) {
+    const int b = blockIdx.y + v.blend0;
     if (v.state[b] >= 2) return;
-    const int pix = blockIdx.x * kPixBlock + threadIdx.x;
-    const int y = pix / v.W, x = pix - y * v.W;
-    const bool inside = pix < v.H * v.W;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int y0 = (blockIdx.x * kRenderWaves + wave) * kRenderRows;
+    if (y0 >= v.H) return;
     const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
-    for (int c0 = 0; c0 < v.C; c0 += kBandChunk) {
-        float acc[kBandChunk];
+    const int H = v.H, W = v.W;
+    for (int x0 = 0; x0 < W; x0 += 128) {
+        for (int c0 = 0; c0 < v.C; c0 += kBandChunk) {
+            const int nc = min(kBandChunk, v.C - c0);
+            float acc[kRenderRows][2][kBandChunk];
 #pragma unroll
-        for (int j = 0; j < kBandChunk; ++j) acc[j] = 0.f;
-        const int nc = min(kBandChunk, v.C - c0);
-        for (int k = cs; k < ce; ++k) {
-            const int yy = y - v.c_oy[k], xx = x - v.c_ox[k];
-            const int w = v.c_w[k];
-            if (inside && (unsigned)yy < (unsigned)v.c_h[k] && (unsigned)xx < (unsigned)w) {
-                const float mv = v.morph[v.c_moff[k] + (int64_t)yy * w + xx];
-                const float *sed = v.sed + (int64_t)k * v.C + c0;
+            for (int r = 0; r < kRenderRows; ++r)
 #pragma unroll
-                for (int j = 0; j < kBandChunk; ++j)
-                    if (j < nc) acc[j] = fmaf(sed[j], mv, acc[j]);
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < kBandChunk; ++j) acc[r][q][j] = 0.f;
+            for (int kb = cs; kb < ce; kb += 64) {
+                const int kk = kb + lane;
+                const bool have = kk < ce;
+                const int l_oy = have ? v.c_oy[kk] : 0, l_ox = have ? v.c_ox[kk] : 0;
+                const int l_h = have ? v.c_h[kk] : 0, l_w = have ? v.c_w[kk] : 0;
+                const int l_mo = have ? (int)v.c_moff[kk] : 0;  // packed offsets fit 31 bits
+                const int kend = min(ce, kb + 64);
+                for (int k = kb; k < kend; ++k) {
+                    const int kl = k - kb;
+                    const int oy = __builtin_amdgcn_readlane(l_oy, kl);
+                    const int hh = __builtin_amdgcn_readlane(l_h, kl);
+                    const int ox = __builtin_amdgcn_readlane(l_ox, kl);
+                    const int w = __builtin_amdgcn_readlane(l_w, kl);
+                    const int r_lo = max(y0, oy), r_hi = min(min(y0 + kRenderRows, H), oy + hh);
+                    const int x_lo = max(x0, ox), x_hi = min(min(x0 + 128, W), ox + w);
+                    if (r_hi <= r_lo || x_hi <= x_lo) continue;  // wave-uniform
+                    const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
+                    float mv[kRenderRows][2];
+                    bool ok[kRenderRows][2];
+#pragma unroll
+                    for (int r = 0; r < kRenderRows; ++r)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int yy = y0 + r, xx = x0 + lane + 64 * q;
+                            ok[r][q] = yy >= r_lo && yy < r_hi && xx >= x_lo && xx < x_hi;
+                            mv[r][q] = ok[r][q] ? mbase[(yy - oy) * w + (xx - ox)] : 0.f;
+                        }
+                    const float *sed = v.sed + (int64_t)k * v.C + c0;
+#pragma unroll
+                    for (int j = 0; j < kBandChunk; ++j) {
+                        if (j >= nc) break;
+                        const float sd = sed[j];
+#pragma unroll
+                        for (int r = 0; r < kRenderRows; ++r)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q)
+                                if (ok[r][q])  // pixels outside the box stay untouched
+                                    acc[r][q][j] = fmaf(sd, mv[r][q], acc[r][q][j]);
+                    }
+                }
             }
-        }
-        if (inside) {
 #pragma unroll
-            for (int j = 0; j < kBandChunk; ++j)
-                if (j < nc)
-                    P[(((int64_t)b * v.C + c0 + j) * v.Fy + y) * v.Fx + x] = acc[j];
+            for (int j = 0; j < kBandChunk; ++j) {
+                if (j >= nc) break;
+#pragma unroll
+                for (int r = 0; r < kRenderRows; ++r)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int yy = y0 + r, xx = x0 + lane + 64 * q;
+                        if (yy < H && xx < W)
+                            P[(((int64_t)b * v.C + c0 + j) * v.Fy + yy) * v.Fx + xx] = acc[r][q][j];
+                    }
+            }
         }
     }
 }
@@ -1310,7 +1366,9 @@ static inline int pix_blocks(const BatchView &v) {
 }
 
 void launch_render(const BatchView &v, float *P, hipStream_t s) {
-    hipLaunchKernelGGL(render_kernel, dim3(pix_blocks(v), v.nb), dim3(kPixBlock), 0, s, v, P);
+    const int rows_per_block = kRenderRows * kRenderWaves;
+    hipLaunchKernelGGL(render_kernel, dim3((v.H + rows_per_block - 1) / rows_per_block, v.nb),
+                       dim3(64 * kRenderWaves), 0, s, v, P);
 }
 
 void launch_residual(const BatchView &v, const float *Q, float *R, hipStream_t s) {

@@ -7,6 +7,7 @@ kern = synthetic.psfs()
 scenes = synthetic.make_batch(range(1234, 1234 + nb), kernel=kern)
 comps = [[ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k], sed_min_step=s["noise_rms"]) for k in range(10)] for s in scenes]
 b = BlendBatch(np.stack([s["data"] for s in scenes]), np.stack([s["weights"] for s in scenes]), comps, kernel=kern[2], max_iter=64)
+b.set_sub_ranges(1)
 lib = _lib.load()
 out = (ctypes.c_longlong * 16)()
 lib.smi_debug_fused_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
