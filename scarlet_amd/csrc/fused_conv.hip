@@ -54,12 +54,10 @@ struct Cfg {
     // alternate between the two halves of the 64 banks
     static constexpr int SY = ((FY + FY / kF2 + 15) / 32) * 32 + 16;
     static constexpr int SX = FX + 1;  // row-pair stride of the scratch (complex), odd
-    // + twiddle tables tw[k1 * 16 + n2] = exp(-2 pi i n2 k1 / F) for both axes and the
-    //   digit-swapped positions of +kx and -kx for the Hermitian row separation
+    // + twiddle tables tw[k1 * 16 + n2] = exp(-2 pi i n2 k1 / F) for both axes
     static_assert(SY >= FY + FY / kF2 && SY % 32 == 16, "column stride");
     static constexpr size_t lds_bytes =
-        sizeof(float2) * ((size_t)NKX * SY + (size_t)kPairs * SX + FY + FX) +
-        sizeof(uint32_t) * (size_t)((NKX + 3) & ~3);
+        sizeof(float2) * ((size_t)NKX * SY + (size_t)kPairs * SX + FY + FX);
 };
 
 // ---- one radix-F1 pass over elements a[16 n1 + n2] -----------------------------
@@ -147,8 +145,35 @@ template <int FY1, int FX1>
 struct Conv {
     using C = Cfg<FY1, FX1>;
     float2 *T, *Z, *twy, *twx;
-    uint32_t *posx;  // pos(kx) | pos(-kx) << 16
     int tid;
+    // Hermitian separation / recombination: work item (pair j, frequency kx) = tid + 1024 r
+    // has the same j = tid % kPairs and kx = tid / kPairs + (kThreads / kPairs) r in every
+    // call, so the LDS offsets of its operands are computed once per kernel: the scratch
+    // elements of +kx and -kx (digit-swapped positions) and the column element of row 2j of
+    // chunk 0 (chunk ch lies kChunkStep elements further down the column).
+    static constexpr int kSepIter = (C::NKX * kPairs + kThreads - 1) / kThreads;
+    static constexpr int kChunkStep = 2 * kPairs + 2 * kPairs / kF2;  // sk(y + 64) - sk(y)
+    static_assert(kThreads % kPairs == 0 && (2 * kPairs) % kF2 == 0, "separation mapping");
+    int sep_za[kSepIter], sep_zb[kSepIter];  // element offsets into Z
+
+    __device__ __forceinline__ void init_separation() {
+        const int j = tid % kPairs;
+#pragma unroll
+        for (int r = 0; r < kSepIter; ++r) {
+            const int kx = sep_kx(r);
+            const int kxc = kx < C::NKX ? kx : 0;
+            sep_za[r] = j * C::SX + pos<FX1>(kxc);
+            sep_zb[r] = j * C::SX + pos<FX1>((C::FX - kxc) % C::FX);
+        }
+    }
+    __device__ __forceinline__ int sep_kx(int r) const {
+        return tid / kPairs + (kThreads / kPairs) * r;
+    }
+    // element offset into T of (kx, row 2j of chunk ch), or -1 beyond the last column
+    __device__ __forceinline__ int sep_t(int r, int ch) const {
+        const int kx = sep_kx(r);
+        return kx < C::NKX ? kx * C::SY + sk(2 * (tid % kPairs)) + ch * kChunkStep : -1;
+    }
 
     // column transforms fused with the spectral product:
     //   T <- IFFT_y( FFT_y(T) * K )   for every column kx, K in digit-swapped order.
@@ -187,47 +212,47 @@ struct Conv {
 
     // forward row transforms of the chunk in Z (pairs of real rows as re/im) and
     // Hermitian separation into T[kx][y0 + 2j], T[kx][y0 + 2j + 1]
-    __device__ __forceinline__ void rows_forward(int y0, int W) {
+    __device__ __forceinline__ void rows_forward(int ch, int W, long long *stamp = nullptr) {
         for (int b = tid; b < kPairs * kF2; b += kThreads)
             pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
         lds_barrier();
+        if (stamp) stamp[0] = clock64();
         for (int b = tid; b < kPairs * FX1; b += kThreads)
             pass_block<false>(Z + (b % kPairs) * C::SX, b / kPairs);
         lds_barrier();
-        for (int b = tid; b < C::NKX * kPairs; b += kThreads) {
-            const int j = b % kPairs, kx = b / kPairs;
-            const int y = y0 + 2 * j;
-            if (y + 1 < C::FY) {
-                const float2 *z = Z + j * C::SX;
-                const uint32_t pp = posx[kx];
-                const float2 za = z[pp & 0xffff];
-                const float2 zb = z[pp >> 16];
+        if (stamp) stamp[1] = clock64();
+        const int y = ch * 2 * kPairs + 2 * (tid % kPairs);
+        const bool row_ok = y + 1 < C::FY;
+#pragma unroll
+        for (int r = 0; r < kSepIter; ++r)
+            if (row_ok && sep_t(r, ch) >= 0) {
+                const float2 za = Z[sep_za[r]];
+                const float2 zb = Z[sep_zb[r]];
                 // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^)
-                float2 *t = T + kx * C::SY + sk(y);
+                float2 *t = T + sep_t(r, ch);
                 t[0] = make_float2(za.x + zb.x, za.y - zb.y);
                 t[1] = make_float2(za.y + zb.y, zb.x - za.x);
             }
-        }
         lds_barrier();
     }
 
     // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
-    __device__ __forceinline__ void rows_inverse(int y0) {
-        for (int b = tid; b < C::NKX * kPairs; b += kThreads) {
-            const int j = b % kPairs, kx = b / kPairs;
-            const int y = y0 + 2 * j;
-            float2 xa = make_float2(0.f, 0.f), xb = xa;
-            if (y + 1 < C::FY) {
-                const float2 *t = T + kx * C::SY + sk(y);
-                xa = t[0];
-                xb = t[1];
+    __device__ __forceinline__ void rows_inverse(int ch) {
+        const int y = ch * 2 * kPairs + 2 * (tid % kPairs);
+        const bool row_ok = y + 1 < C::FY;
+#pragma unroll
+        for (int r = 0; r < kSepIter; ++r)
+            if (sep_kx(r) < C::NKX) {
+                float2 xa = make_float2(0.f, 0.f), xb = xa;
+                if (row_ok) {
+                    const float2 *t = T + sep_t(r, ch);
+                    xa = t[0];
+                    xb = t[1];
+                }
+                Z[sep_za[r]] = make_float2(xa.x - xb.y, xa.y + xb.x);  // Xa + i Xb
+                if (sep_kx(r) != 0 && 2 * sep_kx(r) != C::FX)          // conj(Xa) + i conj(Xb)
+                    Z[sep_zb[r]] = make_float2(xa.x + xb.y, xb.x - xa.y);
             }
-            float2 *z = Z + j * C::SX;
-            const uint32_t pp = posx[kx];
-            z[pp & 0xffff] = make_float2(xa.x - xb.y, xa.y + xb.x);  // Xa + i Xb
-            if (kx != 0 && 2 * kx != C::FX)                          // conj(Xa) + i conj(Xb)
-                z[pp >> 16] = make_float2(xa.x + xb.y, xb.x - xa.y);
-        }
         lds_barrier();
         for (int b = tid; b < kPairs * FX1; b += kThreads)
             pass_block<true>(Z + (b % kPairs) * C::SX, b / kPairs);
@@ -285,9 +310,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FX, &s, &co);
         cv.twx[j] = make_float2(co, -s);
     }
-    cv.posx = reinterpret_cast<uint32_t *>(cv.twx + C::FX);
-    for (int kx = tid; kx < C::NKX; kx += kThreads)
-        cv.posx[kx] = (uint32_t)pos<FX1>(kx) | ((uint32_t)pos<FX1>((C::FX - kx) % C::FX) << 16);
+    cv.init_separation();
     const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
                                C::FY * C::NKX;
     const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
             __syncthreads();
             if (ch + 1 < n_chunks) fetch(y0 + 2 * kPairs);
             if (ch == 0) SMI_STAMP(8);
-            cv.rows_forward(y0, W);
+            cv.rows_forward(ch, W, (dbg && tid == 0 && blockIdx.x == 0 && ch == 0) ? dbg + 6 : nullptr);
             if (ch == 0) SMI_STAMP(9);
         }
     }
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                 }
             }
         }
-        cv.rows_inverse(y0);
+        cv.rows_inverse(ch);
 #pragma unroll
         for (int j = 0; j < kRows; ++j) {
             const int r = wave + j * (kThreads / 64);
@@ -389,7 +412,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
             }
         }
         __syncthreads();
-        cv.rows_forward(y0, W);
+        cv.rows_forward(ch, W);
     }
     {
         double *part = reinterpret_cast<double *>(cv.Z);  // Z is free between stages
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     // ---- D: gradient image rows -----------------------------------------------------
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int y0 = ch * 2 * kPairs;
-        cv.rows_inverse(y0);
+        cv.rows_inverse(ch);
         for (int r = wave; r < 2 * kPairs; r += kThreads / 64) {
             const int y = y0 + r;
             if (y >= H) break;
@@ -499,8 +522,7 @@ bool fused_conv_supported(int Fy, int Fx) {
     if (!ok(Fy) || !ok(Fx)) return false;
     const size_t sy = (size_t)((Fy + Fy / kF2 + 15) / 32) * 32 + 16;
     const size_t lds = sizeof(float2) * ((size_t)(Fx / 2 + 1) * sy +
-                                         (size_t)kPairs * (Fx + 1) + Fy + Fx) +
-                       sizeof(uint32_t) * (size_t)((Fx / 2 + 1 + 3) & ~3);
+                                         (size_t)kPairs * (Fx + 1) + Fy + Fx);
     return lds <= 160 * 1024;
 }
 

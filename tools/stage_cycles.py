@@ -20,4 +20,4 @@ names = ["A rows fwd+render", "B columns", "C inv+resid+fwd", "B' columns", "D r
 for i, n in enumerate(names):
     print("%-22s %8d cycles" % (n, t[i + 1] - t[i]))
 print("total", t[5] - t[0])
-print("chunk0 A: setup", t[6]-t[0], "render (registers)", t[7]-t[6], "store + barrier", t[8]-t[7], "rows_fwd", t[9]-t[8])
+print("chunk0 rows_forward: stride pass", t[6]-t[8], "block pass", t[7]-t[6], "separation", t[9]-t[7])
