@@ -40,6 +40,7 @@ class Component:
         sparsity=None,
         tiny=1e-6,
         fixed=(False, False),
+        state_dtype=np.float64,
     ):
         # Parameter(fixed=True) for (spectrum, image): it stays in X, autograd is not asked
         # for its gradient and adaprox sees zeros instead (blend.py:107-115); the step
@@ -67,13 +68,18 @@ class Component:
         # components with the same (not None) `source` id form one
         # CombinedComponent, e.g. a MultiExtendedSource (source.py:615-717)
         self.source = source
-        # blend.py:154-160: float64 zeros
-        self.m_sed = np.zeros(sed.shape)
-        self.v_sed = np.zeros(sed.shape)
-        self.vhat_sed = np.zeros(sed.shape)
-        self.m_morph = np.zeros(morph.shape)
-        self.v_morph = np.zeros(morph.shape)
-        self.vhat_morph = np.zeros(morph.shape)
+        # blend.py:154-160: float64 zeros.  ``state_dtype=np.float32`` is NOT the
+        # reference: it restates the device's arithmetic (float32 moments, float32
+        # optimizer arithmetic) so that a test can tell how much of a difference between
+        # the device and the reference-faithful oracle is the precision of the state and
+        # how much anything else (tests/test_gpu_parity.py::test_hsc_fit_follows_*)
+        self.state_dtype = np.dtype(state_dtype)
+        self.m_sed = np.zeros(sed.shape, dtype=state_dtype)
+        self.v_sed = np.zeros(sed.shape, dtype=state_dtype)
+        self.vhat_sed = np.zeros(sed.shape, dtype=state_dtype)
+        self.m_morph = np.zeros(morph.shape, dtype=state_dtype)
+        self.v_morph = np.zeros(morph.shape, dtype=state_dtype)
+        self.vhat_morph = np.zeros(morph.shape, dtype=state_dtype)
 
     def model_morph(self):
         """What enters the model: the image, Fourier-shifted if ``shift`` is free."""
@@ -518,6 +524,12 @@ def adaprox_update(it, x, g, m, v, vhat, alpha, prox, e_rel, prox_max_iter=10,
     up to ``prox_max_iter`` proximal sub-iterations in the metric ``psi`` with
     step ``gamma = alpha / max(psi)``, stopped when the relative squared
     change drops to ``e_rel**2``.  ``x`` is updated in place."""
+    if m.dtype == np.float32:
+        # float32-state mode (device arithmetic, see Component): keep NumPy from
+        # promoting the update to float64 through a float64 gradient / step
+        g = np.asarray(g, dtype=np.float32)
+        alpha = np.float32(alpha) if np.ndim(alpha) == 0 else np.asarray(alpha, np.float32)
+        b1, b2, eps = np.float32(b1), np.float32(b2), np.float32(eps)
     phi, psi = amsgrad_phi_psi(it, g, m, v, vhat, b1, b2, eps)
     if it > 0:
         x -= alpha * phi / psi

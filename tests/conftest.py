@@ -24,8 +24,9 @@ def hsc():
     return golden("hsc_cosmos_35")
 
 
-def hsc_scene(g, dtype64=False):
-    """oracle.pgm.Scene of the quickstart blend from the golden fixture."""
+def hsc_scene(g, dtype64=False, state_dtype=np.float64):
+    """oracle.pgm.Scene of the quickstart blend from the golden fixture.
+    ``state_dtype=np.float32``: the oracle's float32-state mode (device arithmetic)."""
     from oracle import pgm
 
     n = int(g["n_comp"])
@@ -35,7 +36,8 @@ def hsc_scene(g, dtype64=False):
         morph = g["morph64_%d" % k] if dtype64 else g["morph_%d" % k]
         comps.append(
             pgm.Component(sed.copy(), morph.copy(), g["origin_%d" % k],
-                          sed_min_step=g["min_step_%d" % k], source=int(g["source_of"][k]))
+                          sed_min_step=g["min_step_%d" % k], source=int(g["source_of"][k]),
+                          state_dtype=state_dtype)
         )
     dt = np.float64 if dtype64 else np.float32
     images = g["images"].astype(dt)

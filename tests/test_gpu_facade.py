@@ -62,12 +62,13 @@ def test_blend_fit_matches_oracle(hsc):
     n, logL = blend.fit(40, e_rel=1e-4)
     sc = hsc_scene(hsc)
     n_ref, logL_ref = sc.fit(40, e_rel=1e-4)
-    assert n == len(blend.loss) and abs(n - n_ref) <= 2
-    m = min(n, n_ref, 12)
-    chi = np.array(blend.loss[:m]) - sc.log_norm
-    chi_ref = np.array(sc.loss[:m]) - sc.log_norm
-    assert_allclose(chi, chi_ref, rtol=2e-4)
-    assert abs((logL + sc.log_norm) - (logL_ref + sc.log_norm)) < 2e-3 * abs(logL_ref + sc.log_norm)
+    # bounds measured on MI355X, see test_hsc_fit_follows_the_oracle_for_all_iterations:
+    # the same iterations, 8e-6 at the start, a transient of ~2e-4 around iteration 25
+    assert n == len(blend.loss) == n_ref
+    chi = np.array(blend.loss) - sc.log_norm
+    chi_ref = np.array(sc.loss) - sc.log_norm
+    assert_allclose(chi[:12], chi_ref[:12], rtol=2e-5)
+    assert_allclose(chi, chi_ref, rtol=5e-4)
     assert_allclose(blend.log_likelihood[-1], logL)
     # side effects the reference promises (blend.py:153-163, 189-192)
     for p in blend.parameters:
@@ -96,8 +97,10 @@ def test_blend_fit_with_resizing_matches_oracle(hsc):
     assert any(c.morph.shape != hsc["morph_%d" % k].shape for k, c in enumerate(sc.components))
     chi = np.array(blend.loss) - sc.log_norm
     chi_ref = np.array(sc.loss) - sc.log_norm
-    assert_allclose(chi[:25], chi_ref[:25], rtol=5e-4)
-    assert abs(chi[-1] - chi_ref[-1]) < 5e-3 * abs(chi_ref[-1])
+    # measured: 9e-5 over the first 25 iterations, 1.9e-4 at most (iteration 29, after
+    # the restarts), 8e-6 at the end
+    assert_allclose(chi, chi_ref, rtol=5e-4)
+    assert abs(chi[-1] - chi_ref[-1]) < 3e-5 * abs(chi_ref[-1])
 
 
 def test_blend_fit_callback_host_stepped(hsc):

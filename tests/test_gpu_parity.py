@@ -301,17 +301,31 @@ def test_first_step_exact_structure(amd, hsc, path):
 
 
 @pytest.mark.parametrize("path", PATHS)
-def test_hsc_fit_converges_like_oracle(amd, hsc, path):
+def test_hsc_fit_follows_the_oracle_for_all_iterations(amd, hsc, path):
+    """Whole fit of the quickstart scene (BASELINE configs[0]: 100 iterations max,
+    e_rel 1e-4) against the reference-faithful oracle (float32 parameters, float64
+    optimizer state, blend.py:155-160) and against its float32-state mode, which restates
+    the device's precision.  Measured on MI355X (tools/fit_parity.py): identical iteration
+    count (76); relative chi^2 difference <= 8e-6 over the first 12 iterations, 1.2e-7 /
+    8e-7 (fused / rocFFT) at the end, and a transient of 1.4e-4 / 2.1e-4 around iteration
+    25.  The transient is not the float32 state: the two oracle modes differ from EACH
+    OTHER by 2.7e-4 there and by 1.2e-7 at the end (tests/test_oracle_golden.py::
+    test_float32_state_mode_of_the_oracle), with identical sub-iteration counts -- the scene
+    passes through a few ill-conditioned iterations in which any 1e-7 perturbation grows a
+    thousandfold and then dies out.  north_star's 1e-5 holds for the result of the fit."""
     batch = hsc_batch(amd, hsc, max_iter=100, conv_path=path)
     n_iter, logL = batch.fit(max_iter=100, e_rel=1e-4)
-    sc = hsc_scene(hsc)
-    n_ref, logL_ref = sc.fit(max_iter=100, e_rel=1e-4)
     loss = batch.loss_history()[0]
-    assert len(loss) == n_iter[0]
-    # trajectories pass through min/max branches: compare the likelihood reached
-    chi2 = lambda l: l - sc.log_norm  # noqa: E731
-    assert abs(chi2(-logL[0]) - chi2(-logL_ref)) < 2e-3 * abs(chi2(-logL_ref))
-    assert abs(int(n_iter[0]) - n_ref) <= max(3, n_ref // 10)
+    assert len(loss) == n_iter[0] and -loss[-1] == logL[0]
+    for state_dtype, whole, final in ((np.float64, 5e-4, RTOL), (np.float32, 5e-4, 2e-6)):
+        sc = hsc_scene(hsc, state_dtype=state_dtype)
+        n_ref, logL_ref = sc.fit(max_iter=100, e_rel=1e-4)
+        assert int(n_iter[0]) == n_ref  # the stopping rule fires in the same iteration
+        chi, ref = loss - sc.log_norm, np.array(sc.loss) - sc.log_norm
+        rel = np.abs(chi - ref) / np.abs(ref)
+        assert rel[:12].max() < 2e-5
+        assert rel.max() < whole
+        assert rel[-1] < final
     assert -loss[-1] > -loss[0]
 
 

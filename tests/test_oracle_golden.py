@@ -418,3 +418,25 @@ def test_multiresolution_fit_term_golden():
         fd_sed, fd_morph = g["fd_%d" % (3 * k)], g["fd_%d" % (3 * k + 1)]
         assert np.abs(g_sed - fd_sed).max() < 1e-7 * np.abs(fd_sed).max()
         assert np.abs(g_morph - fd_morph).max() < 1e-6 * np.abs(fd_morph).max()
+
+
+def test_float32_state_mode_of_the_oracle(hsc):
+    """``state_dtype=np.float32`` (oracle/pgm.py: the device's precision -- float32 moments
+    and optimizer arithmetic) against the reference-faithful float64 state on the whole
+    quickstart fit: same iteration count, same result to 1e-6, and a transient difference
+    of ~3e-4 around iteration 25 that is a property of the scene, not of either
+    implementation (the GPU tests bound the device against both modes)."""
+    import numpy as np
+    from conftest import hsc_scene
+
+    runs = {}
+    for dt in (np.float64, np.float32):
+        sc = hsc_scene(hsc, state_dtype=dt)
+        n, _ = sc.fit(max_iter=100, e_rel=1e-4)
+        assert sc.components[0].m_morph.dtype == dt and sc.components[0].v_sed.dtype == dt
+        runs[dt] = (n, np.array(sc.loss) - sc.log_norm)
+    (n64, a), (n32, b) = runs[np.float64], runs[np.float32]
+    assert n64 == n32 == 76
+    rel = np.abs(a - b) / np.abs(a)
+    assert rel[:12].max() < 2e-5 and rel.max() < 1e-3 and rel[-1] < 1e-6
+    assert rel.max() > 5e-5  # the transient exists on the CPU alone
