@@ -19,6 +19,7 @@ from .batch import BlendBatch, ComponentSpec, PointSourceSpec
 from .bbox import overlapped_slices
 from .component import CombinedComponent, FactorizedComponent
 from .constraint import PositivityConstraint, device_flags
+from .hoststep import HostParameter
 from .model import UpdateException
 from .morphology import PointSourceMorphology
 from .psf import GaussianPSF
@@ -138,8 +139,14 @@ class Blend(CombinedComponent):
         return data, weights, kernel
 
     def _specs(self, comps):
+        """Device description of every component.  Parameters whose constraint chain or
+        step rule the device cannot express (user ``Constraint`` subclasses, built-in
+        chains in another order, ``use_mask=True``, custom step callables) are listed in
+        ``self._host`` as ``(component index, HostParameter)``: the device treats them
+        as fixed and without constraint, the host updates them (hoststep.py)."""
         specs = []
-        for comp in comps:
+        self._host = []
+        for k, comp in enumerate(comps):
             spectrum, morphology = comp.children
             sed = spectrum.parameters[0]
             image = morphology.parameters[0]
@@ -158,21 +165,47 @@ class Blend(CombinedComponent):
                     const, rel, _ = _step_rule(shift.step, "shift")
                     if rel:
                         raise NotImplementedError("relative steps for a shift parameter")
+                    if max(image.shape) > 100:
+                        raise NotImplementedError(
+                            "a component with a free Fourier shift is limited to boxes of "
+                            "100 pixels a side on the device (got {})".format(image.shape))
                     shift_kw = dict(shift=np.asarray(shift), shift_step=0.0 if shift.fixed else const)
             if sed.prior is not None or image.prior is not None:
                 raise NotImplementedError("priors are not supported on the device")
-            # Parameter(fixed=True) stays in X with a zero gradient (blend.py:107-115); its
-            # step is never used and may be missing
-            s_const, s_rel, s_min = (0.0, 0.0, 0.0) if sed.fixed and sed.step is None else \
-                _step_rule(sed.step, "spectrum")
+
+            def rule(p, what):
+                """step rule of a parameter, or the callable itself if it is user code"""
+                if p.fixed and p.step is None:
+                    return (0.0, 0.0, 0.0)  # never used (blend.py:107-115)
+                try:
+                    return _step_rule(p.step, what)
+                except NotImplementedError:
+                    return p.step
+
+            sed_rule, morph_rule = rule(sed, "spectrum"), rule(image, "morphology")
+            # the spectrum kernel applies PositivityConstraint(1e-20) (spectrum.py:54-56)
             free_form = isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20
-            if not free_form and not (sed.fixed and sed.constraint is None and np.all(np.asarray(sed) > 1e-20)):
-                raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
-            m_const, m_rel, m_min = (0.0, 0.0, 0.0) if image.fixed and image.step is None else \
-                _step_rule(image.step, "morphology")
-            flags = device_flags(image.constraint)
-            flags["flags"] |= (_lib.COMPONENT_FIXED_SED if sed.fixed else 0) | (
-                _lib.COMPONENT_FIXED_MORPH if image.fixed else 0)
+            sed_on_device = not callable(sed_rule) and (
+                free_form or (sed.fixed and sed.constraint is None and np.all(np.asarray(sed) > 1e-20)))
+            try:
+                flags = device_flags(image.constraint)
+                morph_on_device = not callable(morph_rule)
+            except NotImplementedError:
+                flags = device_flags(None)
+                morph_on_device = False
+            if not (sed_on_device and morph_on_device) and shift_kw:
+                raise NotImplementedError(
+                    "user-defined constraints / steps on a component with a free Fourier shift")
+            if not sed_on_device:
+                self._host.append((k, HostParameter(sed, "sed", sed_rule)))
+                sed_rule = (0.0, 0.0, 0.0)
+            if not morph_on_device:
+                self._host.append((k, HostParameter(image, "morph", morph_rule)))
+                morph_rule = (0.0, 0.0, 0.0)
+            s_const, s_rel, s_min = sed_rule
+            m_const, m_rel, m_min = morph_rule
+            flags["flags"] |= (_lib.COMPONENT_FIXED_SED if sed.fixed or not sed_on_device else 0) | (
+                _lib.COMPONENT_FIXED_MORPH if image.fixed or not morph_on_device else 0)
             specs.append(
                 ComponentSpec(
                     np.asarray(sed), np.asarray(image), morphology.bbox.origin[-2:],
@@ -192,6 +225,20 @@ class Blend(CombinedComponent):
                 )
             )
         return specs
+
+    def _host_update(self, batch, local, grads, e_rel, prox_max_iter, opt):
+        """The host's share of iteration ``local``: AMSGrad + proximal sub-iterations of
+        the parameters in ``self._host`` from the gradients the device gathered before its
+        own update, then the new values go back to the device."""
+        g_sed, g_morph = grads
+        seds, morphs = batch.parameters()
+        for k, hp in self._host:
+            if hp.kind == "sed":
+                seds[k] = hp.update(local, g_sed[k], e_rel, prox_max_iter, **opt)
+            else:
+                morphs[k] = hp.update(local, g_morph[k], e_rel, prox_max_iter, **opt)
+            hp.store()
+        batch.set_parameters(seds, morphs)
 
     @staticmethod
     def _point_spec(sed, center, morphology):
@@ -268,9 +315,15 @@ class Blend(CombinedComponent):
                 *[[getattr(p, name) if p is not None and getattr(p, name) is not None
                    else (0.0, 0.0) for p in vec] for name in ("m", "v", "vhat")])
 
+    def _download(self, batch, comps):
+        """Device -> the Parameters (values in place, moments as float64 arrays);
+        host-updated parameters keep the host's moments."""
+        self._download_all(batch, comps)
+        for _, hp in getattr(self, "_host", ()):
+            hp.store()
+
     @staticmethod
-    def _download(batch, comps):
-        """Device -> the Parameters (values in place, moments as float64 arrays)."""
+    def _download_all(batch, comps):
         seds, morphs = batch.parameters()
         mom = batch.moments()
         centers = None
@@ -323,6 +376,10 @@ class Blend(CombinedComponent):
             raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
         free = [p for obs in self.observations for p in obs.parameters if not p.fixed]
         if free:
+            self._specs(_flatten(self.sources))
+            if self._host:
+                raise NotImplementedError(
+                    "user-defined constraints / steps together with a free psf_shift")
             return self._fit_with_psf_shift(max_iter, e_rel, min_iter, prox_max_iter, opt, callback)
 
         it = 0
@@ -338,12 +395,19 @@ class Blend(CombinedComponent):
                     # i.e. once 11, 21, ... iterations of this batch are done
                     next_hook = 11 if local == 0 else ((local - 1) // 10 + 1) * 10 + 1
                     n = min(next_hook - local, max_iter - it - local)
-                    if callback is not None:
+                    if callback is not None or self._host:
                         n = 1
+                    # plug-in seam: gradients at the parameters of this iteration for the
+                    # parameters the host updates (hoststep.py)
+                    grads = batch.gradient() if self._host else None
                     batch.step(local, n, e_rel=e_rel, min_iter=min_iter,
                                prox_max_iter=prox_max_iter, check_convergence=True)
                     active, err = batch.status()
                     done = len(batch.loss_history()[0])
+                    if self._host and err < 0 and done == local + 1:
+                        self._host_update(batch, local, grads, e_rel, prox_max_iter, opt)
+                        if not all(hp.p.is_finite for _, hp in self._host):
+                            err = 0
                     if err >= 0:
                         self.loss.extend(batch.loss_history()[0])
                         self._download(batch, comps)
@@ -657,7 +721,20 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
         def total(self):
             return self.base + self.local
 
-    runs = [_Run(b) for b in blends]
+    # blends with host-updated parameters (hoststep.py) step one iteration per device call
+    solo = set()
+    for i, b in enumerate(blends):
+        b._specs(_flatten(b.sources))
+        if b._host:
+            solo.add(i)
+    solo_results = {}
+    for i in sorted(solo):
+        blends[i].device = device
+        try:
+            solo_results[i] = blends[i].fit(max_iter, e_rel, min_iter, prox_max_iter=prox_max_iter, **opt)
+        except ArithmeticError as e:
+            solo_results[i] = e
+    runs = [_Run(b) for i, b in enumerate(blends) if i not in solo]
     while True:
         todo = [r for r in runs if r.result is None and r.total < max_iter]
         if not todo:
@@ -686,7 +763,7 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
                            check_convergence=True)
                 states = batch.states()
                 losses = batch.loss_history()
-                Blend._download(batch, flat)
+                Blend._download_all(batch, flat)
             finally:
                 batch.close()
             for r, state, loss in zip(group, states, losses):
@@ -710,8 +787,16 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
                 elif state == 2 or r.total >= max_iter:
                     r.result = True
     out, errors = [], []
-    for i, r in enumerate(runs):
-        blend = r.blend
+    batched = iter(runs)
+    for i, blend in enumerate(blends):
+        if i in solo:
+            res = solo_results[i]
+            if isinstance(res, Exception):
+                errors.append((i, res))
+                res = (len(blend.loss), float("nan"))
+            out.append(res)
+            continue
+        r = next(batched)
         if isinstance(r.result, Exception):
             errors.append((i, r.result))
             out.append((len(blend.loss), float("nan")))

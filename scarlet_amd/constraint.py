@@ -2,9 +2,11 @@
 class names and defaults (scarlet/constraint.py).
 
 Called stand-alone they act on host arrays (the monotonicity sweep goes through
-the C ABI to the GPU).  Inside ``Blend.fit`` the built-in classes are not called
-at all: the chain of every parameter is translated into ``SMI_PROX_*`` flags and
-runs fused in the device update kernel (``device_flags`` below).
+the C ABI to the GPU).  Inside ``Blend.fit`` the built-in chains are not called
+at all: the chain of a parameter is translated into ``SMI_PROX_*`` flags and runs
+fused in the device update kernel (``device_flags`` below).  A chain the device
+cannot express -- a user subclass, another order, ``use_mask=True`` -- is called
+as written, on the host, for that parameter only (``hoststep.py``).
 """
 
 import numpy as np
@@ -203,7 +205,8 @@ def device_flags(constraint):
 
     Returns ``dict(flags, neighbor_weight, min_gradient, zero, l_thresh)`` or
     raises ``NotImplementedError`` for chains the device kernel cannot express
-    (user callables, other orders) -- there is no host fallback.
+    (user callables, other orders); ``Blend`` then keeps that parameter's update on
+    the host (``hoststep.HostParameter``).
     """
     out = dict(flags=0, neighbor_weight=None, min_gradient=0.0, zero=0.0, l_thresh=0.0,
                center_floor=1e-6, sym_strength=1.0, chain_repeat=1)

@@ -1,0 +1,114 @@
+"""Plug-in seam of the fit (reference constraint.py:39-55, blend.py:135-138): parameters
+whose proximal operator or step rule is user code.
+
+``Blend.fit`` hands every parameter's constraint to ``proxmin.adaprox`` as a Python
+callable ``prox(X, step)`` and evaluates callable steps as ``step(X, it)``.  The device
+loop only knows the built-in chains (``constraint.device_flags``).  A parameter with
+anything else -- a ``Constraint`` subclass, a built-in chain in another order,
+``MonotonicityConstraint(use_mask=True)``, a custom step callable -- stays with the
+host: per iteration the device still renders, convolves and gathers the gradient of
+every parameter (``smi_batch_gradient``) and updates all parameters it can express;
+the host takes the AMSGrad step and the proximal sub-iterations of the rest with the
+user's callables and uploads the result.
+
+The arithmetic here restates the device kernels (``csrc/kernels.hip``:
+``update_spectrum``, ``update_kernel_reg``) operation by operation in float32,
+including the order of the wavefront reductions, so that a user constraint that does
+what a built-in one does gives bit-identical results to the device path.
+"""
+
+import numpy as np
+
+F32 = np.float32
+
+
+def wave_sum(x):
+    """Sum of a float32 array the way the 64-lane reductions of the kernels form it:
+    lane l adds its elements l, l + 64, ... in ascending order, then the lanes are
+    combined in a balanced binary tree (DPP quad swaps, half-row and row mirrors,
+    readlanes of the four rows)."""
+    x = np.asarray(x, dtype=F32).reshape(-1)
+    n = -(-x.size // 64) * 64
+    lanes = np.zeros(n, dtype=F32)
+    lanes[: x.size] = x
+    rows = lanes.reshape(-1, 64)
+    acc = np.zeros(64, dtype=F32)
+    for row in rows:
+        acc = acc + row
+    while acc.size > 1:
+        acc = acc[0::2] + acc[1::2]
+    return F32(acc[0])
+
+
+def _max_nan(a, floor):
+    """np.maximum (a NaN in the data propagates), as the kernels' max_nan."""
+    return np.maximum(a, F32(floor))
+
+
+class HostParameter:
+    """One ``Parameter`` of a factorized component that the host updates.
+
+    kind: "sed" (spectrum, (C,)) or "morph" (image, (h, w))
+    step: ``(constant, relative factor, minimum)`` of a built-in rule, or the user's
+        callable ``step(X, it)``
+    """
+
+    def __init__(self, parameter, kind, step):
+        self.p = parameter
+        self.kind = kind
+        self.step = step
+        for name in ("m", "v", "vhat"):
+            value = getattr(parameter, name)
+            setattr(self, name, np.zeros(parameter.shape, F32) if value is None
+                    else np.array(value, dtype=F32))
+
+    def alpha(self, it):
+        x = np.asarray(self.p, dtype=F32)
+        if callable(self.step):
+            return np.asarray(self.step(self.p, it=it), dtype=F32)
+        const, rel, minimum = self.step
+        mean = wave_sum(x) / F32(x.size)
+        if self.kind == "sed":  # update_spectrum: fmaxf(min_step_c, rel * mean)
+            floor = np.maximum(np.asarray(minimum, dtype=np.float64), const).astype(F32)
+            return np.maximum(np.broadcast_to(floor, x.shape), F32(rel) * mean)
+        # update_kernel_reg: fmaxf(morph_step, rel * (sum / N))
+        return np.maximum(F32(max(const, float(np.max(minimum)))), F32(rel) * mean)
+
+    def update(self, it, g, e_rel, prox_max_iter, b1, b2, eps):
+        """AMSGrad step (a tenth of it at ``it == 0``) and proximal sub-iterations
+        (lite/parameters.py:274-305), in place on the Parameter."""
+        p = self.p
+        x0 = np.array(p, dtype=F32)
+        g = np.zeros_like(x0) if p.fixed else np.asarray(g, dtype=F32).reshape(x0.shape)
+        b1, b2, eps, one = F32(b1), F32(b2), F32(eps), F32(1)
+        alpha = self.alpha(it)  # on the pre-update values (blend.py:135-138)
+        self.m = (one - b1) * g + b1 * self.m
+        self.v = (one - b2) * g * g + b2 * self.v
+        self.vhat = self.v.copy() if it == 0 else np.maximum(self.vhat, self.v)
+        psi = np.sqrt(np.maximum(self.vhat, eps))
+        upd = alpha * self.m / psi
+        if it == 0:
+            upd = upd / F32(10)
+        x = x0 - upd
+        prox = p.constraint
+        z = x
+        if prox is not None:
+            pmax = F32(psi.max())
+            # the spectrum kernel divides, the image kernel multiplies by the reciprocal
+            ratio = psi / pmax if self.kind == "sed" else psi * (one / pmax)
+            gamma = alpha / pmax
+            e2 = F32(e_rel) * F32(e_rel)
+            z = x.copy()
+            for _ in range(prox_max_iter):
+                zn = np.asarray(prox(z - ratio * (z - x), gamma), dtype=F32)
+                d2 = wave_sum((zn - z) * (zn - z))
+                z2 = wave_sum(z * z)
+                z = zn
+                if d2 <= e2 * z2:
+                    break
+        p[...] = z
+        return z
+
+    def store(self):
+        """Leave the moments on the Parameter like the device path does (float64)."""
+        self.p.m, self.p.v, self.p.vhat = (a.astype(np.float64) for a in (self.m, self.v, self.vhat))

@@ -892,3 +892,121 @@ def test_initialisation_of_synthetic_scenes_matches_reference():
         assert abs(logL0 - float(g[tag + "logL"])) < 1e-3 * abs(float(g[tag + "logL"])) + 0.5, t
         n, logL = blend.fit(30, e_rel=1e-4)
         assert logL > logL0
+
+
+# ---------------------------------------------------------------- plug-in seam (seam 3)
+def _fit_pair(hsc, mutate, n_it=15, **kw):
+    """(built-in blend, mutated blend) after the same fit"""
+    ref, _ = build_blend(hsc, resizing=False)
+    ref.fit(n_it, e_rel=1e-6, **kw)
+    blend, _ = build_blend(hsc, resizing=False)
+    mutate(blend)
+    blend.fit(n_it, e_rel=1e-6, **kw)
+    return ref, blend
+
+
+def test_user_constraint_subclass_reproduces_the_device_result(hsc):
+    """A Python ``Constraint`` subclass is a valid proximal operator (reference
+    constraint.py:39-55).  The fit degrades to the host-stepped iteration for that
+    parameter (device forward + gradient, host AMSGrad + prox, hoststep.py) instead of
+    raising; a subclass that re-implements the spectrum's positivity must reproduce the
+    all-device result bit for bit -- losses, every parameter, every moment."""
+    import scarlet_amd as scarlet
+
+    calls = []
+
+    class MyPositivity(scarlet.Constraint):
+        def __call__(self, X, step):
+            calls.append(np.shape(step))
+            return np.maximum(X, 1e-20)
+
+    def mutate(blend):
+        for comp in components_of(blend):
+            comp.children[0].parameters[0].constraint = MyPositivity()
+
+    ref, blend = _fit_pair(hsc, mutate)
+    assert calls and len(blend._host) == len(components_of(blend))
+    assert_allclose(blend.loss, ref.loss, rtol=0, atol=0)
+    for p, q in zip(ref.parameters, blend.parameters):
+        assert_allclose(np.asarray(q), np.asarray(p), rtol=0, atol=0)
+        if p.m is not None:
+            for name in ("m", "v", "vhat"):
+                assert_allclose(getattr(q, name), getattr(p, name), rtol=0, atol=0, err_msg=p.name)
+            assert_allclose(np.ma.filled(q.std, 0), np.ma.filled(p.std, 0), rtol=0, atol=0)
+
+
+def test_user_step_callable_and_user_morphology_chain(hsc):
+    """callable ``Parameter.step`` (reference blend.py:135-138) and a user-written chain
+    for the image: host-stepped.  The constant step callable is exact; the chain divides
+    by the maximum where the device multiplies by its reciprocal (<= 1 ulp per pixel and
+    sub-iteration), so the image fit agrees to float32 accuracy."""
+    import scarlet_amd as scarlet
+
+    # a callable that returns what relative_step returns: numpy's mean instead of the wave tree
+    def same_rule(blend):
+        for comp in components_of(blend):
+            sed = comp.children[0].parameters[0]
+            rule = sed.step
+            sed.step = lambda X, it, rule=rule: rule(X, it)
+
+    ref, blend = _fit_pair(hsc, same_rule)
+    assert len(blend._host) == len(components_of(blend))
+    assert_allclose(blend.loss, ref.loss, rtol=1e-6)
+
+    class MyChain(scarlet.Constraint):
+        def __init__(self):
+            self.parts = [scarlet.MonotonicityConstraint(neighbor_weight="angle", min_gradient=0),
+                          scarlet.PositivityConstraint(), scarlet.CenterOnConstraint(),
+                          scarlet.NormalizationConstraint("max")]
+
+        def __call__(self, X, step):
+            for c in self.parts:
+                X = c(X, step)
+            return X
+
+    def chains(blend):
+        for comp in components_of(blend):
+            comp.children[1].parameters[0].constraint = MyChain()
+
+    ref, blend = _fit_pair(hsc, chains, n_it=12)
+    assert [hp.kind for _, hp in blend._host] == ["morph"] * len(components_of(blend))
+    chi = np.array(blend.loss) - float(hsc["log_norm"])
+    chi_ref = np.array(ref.loss) - float(hsc["log_norm"])
+    assert_allclose(chi, chi_ref, rtol=2e-5)
+    for a, b in zip(components_of(ref), components_of(blend)):
+        assert np.abs(np.asarray(a.children[1].parameters[0])
+                      - np.asarray(b.children[1].parameters[0])).max() < 1e-4
+
+
+def test_use_mask_and_foreign_chain_orders_fit_host_stepped(hsc):
+    """``MonotonicityConstraint(use_mask=True)`` (reference constraint.py:228-232) and a
+    chain in an order the fused device chain does not have run through the host prox"""
+    import scarlet_amd as scarlet
+
+    def masked(blend):
+        for comp in components_of(blend)[:3]:
+            comp.children[1].parameters[0].constraint = scarlet.ConstraintChain(
+                scarlet.MonotonicityConstraint(neighbor_weight="angle", min_gradient=0, use_mask=True),
+                scarlet.PositivityConstraint(), scarlet.CenterOnConstraint(),
+                scarlet.NormalizationConstraint("max"))
+        # positivity before monotonicity: not the device order
+        components_of(blend)[3].children[1].parameters[0].constraint = scarlet.ConstraintChain(
+            scarlet.PositivityConstraint(),
+            scarlet.MonotonicityConstraint(neighbor_weight="flat", min_gradient=0.1),
+            scarlet.NormalizationConstraint("max"))
+
+    blend, _ = build_blend(hsc, resizing=True)
+    masked(blend)
+    n, logL = blend.fit(25, e_rel=1e-6)
+    assert len(blend._host) == 4 and n == 25 and np.isfinite(logL)
+    assert logL > -blend.loss[0]
+    for comp in components_of(blend)[:4]:
+        image = np.asarray(comp.children[1].parameters[0])
+        assert image.max() == 1.0 and image.min() >= 0
+    # many blends: the host-stepped one fits alone, the others in the batch
+    a, _ = build_blend(hsc, resizing=False)
+    b, _ = build_blend(hsc, resizing=False)
+    masked(b)
+    c, _ = build_blend(hsc, resizing=False)
+    out = scarlet.fit_blends([a, b, c], 8, e_rel=1e-9)
+    assert [r[0] for r in out] == [8, 8, 8] and out[0] == out[2] and out[1] != out[0]

@@ -330,3 +330,39 @@ def test_tan_wcs_matches_astropy():
         moved = h.deepcopy()
         moved.wcs.crpix -= (3, 5)
         assert np.abs(moved.world_to_pixel_values(sky) - (back - (3, 5))).max() < 1e-7
+
+
+def test_host_stepped_parameter_matches_a_float64_restatement():
+    """hoststep.HostParameter (the host's AMSGrad + prox for user constraints): the
+    float32 arithmetic agrees with a plain float64 restatement of
+    lite/parameters.py:274-305; ``wave_sum`` is the 64-lane tree"""
+    from scarlet_amd import Parameter, PositivityConstraint, hoststep, relative_step
+    from functools import partial
+
+    rng = np.random.default_rng(3)
+    x = rng.uniform(1, 5, 1681).astype(np.float32)
+    assert abs(float(hoststep.wave_sum(x)) - float(x.astype(np.float64).sum())) < 1e-3
+    tree = x[:64].copy()
+    while tree.size > 1:
+        tree = tree[0::2] + tree[1::2]
+    assert hoststep.wave_sum(x[:64]) == tree[0]
+
+    sed = Parameter(rng.uniform(1, 5, 5).astype(np.float32), name="spectrum",
+                    step=partial(relative_step, factor=1e-2, minimum=0.05),
+                    constraint=PositivityConstraint(1e-20))
+    hp = hoststep.HostParameter(sed, "sed", (0.0, 1e-2, 0.05))
+    x64 = np.asarray(sed, dtype=np.float64).copy()
+    m = v = vh = np.zeros(5)
+    for it in range(4):
+        g = rng.normal(size=5)
+        alpha = max(0.05, 1e-2 * x64.mean())
+        m = 0.1 * g + 0.9 * m
+        v = 0.001 * g * g + 0.999 * v
+        vh = v.copy() if it == 0 else np.maximum(vh, v)
+        psi = np.sqrt(np.maximum(vh, 1e-8))
+        x64 = np.maximum(x64 - alpha * m / psi / (10 if it == 0 else 1), 1e-20)
+        hp.update(it, g.astype(np.float32), 1e-3, 10, 0.9, 0.999, 1e-8)
+        assert np.allclose(np.asarray(sed), x64, rtol=1e-5)
+    hp.store()
+    # 1 - float32(0.999) differs from 0.001 by 5e-5 relative (the device's arithmetic)
+    assert sed.m.dtype == np.float64 and np.allclose(sed.v, v, rtol=2e-4)
