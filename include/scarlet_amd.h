@@ -275,6 +275,14 @@ int smi_batch_set_optimizer(smi_batch *b, float b1, float b2, float eps);
  * observation.py:147-186).  Call before smi_batch_set_observation. */
 int smi_batch_set_log_norm(smi_batch *b, int32_t include);
 
+/* Add a constant to the loss of every blend (on top of log_norm + chi^2 / 2).  The
+ * facade uses it for the part of an observation that lies outside the model frame:
+ * the reference zero-fills the model there (renderer.py:130-161, match_shape), so those
+ * pixels contribute sum w d^2 / 2 and their share of log_norm to the loss
+ * (observation.py:147-186) and, through |L|, to the stopping rule, but not to the
+ * gradient.  Call after smi_batch_set_observation (which resets it). */
+int smi_batch_add_loss_constant(smi_batch *b, const double *constant /* [n_blends] */);
+
 /* Seed the "previous loss" of the stopping rule |L - L_prev| < e_rel |L| (same sign
  * convention as smi_batch_get_loss) for a batch that continues an earlier one, e.g.
  * after scarlet.lite resized a box: LiteBlend.fit keeps counting and compares the first

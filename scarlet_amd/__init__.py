@@ -18,6 +18,7 @@ from .constraint import (  # noqa: F401
     L1Constraint,
     ThresholdConstraint,
     MonotonicityConstraint,
+    MonotonicMaskConstraint,
     SymmetryConstraint,
     CenterOnConstraint,
 )

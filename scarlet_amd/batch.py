@@ -361,6 +361,12 @@ class BlendBatch:
         loss = np.ascontiguousarray(np.broadcast_to(loss, (self.n_blends,)), dtype=np.float64)
         _lib.check(self._lib.smi_batch_set_previous_loss(self._h, _lib.ptr(loss, ctypes.c_double)))
 
+    def add_loss_constant(self, constant):
+        """Add a constant per blend to the loss (the part of an observation that lies
+        outside the model frame)."""
+        c = np.ascontiguousarray(np.broadcast_to(constant, (self.n_blends,)), dtype=np.float64)
+        _lib.check(self._lib.smi_batch_add_loss_constant(self._h, _lib.ptr(c, ctypes.c_double)))
+
     def set_sub_ranges(self, n):
         """Split every step into ``n`` ranges of blends on streams of their own (0 =
         automatic).  Results do not depend on ``n``."""

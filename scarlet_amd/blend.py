@@ -89,6 +89,7 @@ class Blend(CombinedComponent):
         weights = np.zeros(self.frame.shape, dtype=np.float32)
         kernels, covered = [None] * C, np.zeros(C, dtype=int)
         self._lowres = []
+        self._loss_constant = 0.0  # observed pixels outside the model frame
         for obs in self.observations:
             r = obs.renderer
             idx = [channels.index(c) for c in obs.channels]
@@ -116,6 +117,17 @@ class Blend(CombinedComponent):
                 for j, c in enumerate(idx):
                     data[c][tuple(model_sl[1:])] = obs.data[j][tuple(data_sl[1:])]
                     weights[c][tuple(model_sl[1:])] = obs.weights[j][tuple(data_sl[1:])]
+                # where the observation sticks out of the frame the reference's model is
+                # zero (match_shape): a constant sum w d^2 / 2 + that region's log_norm
+                outside = np.ones(obs.data.shape, dtype=bool)
+                outside[(slice(None),) + tuple(data_sl[1:])] = False
+                w_out = np.where(outside, np.asarray(obs.weights, dtype=np.float64), 0.0)
+                seen = w_out != 0
+                if seen.any():
+                    d_out = np.asarray(obs.data, dtype=np.float64)
+                    self._loss_constant += float(
+                        0.5 * np.sum(w_out * d_out * d_out)
+                        + seen.sum() / 2 * np.log(2 * np.pi) - 0.5 * np.sum(np.log(w_out[seen])))
             if isinstance(r, ConvolutionRenderer):
                 k = np.asarray(r.kernel_image(), dtype=np.float32)
                 for j, c in enumerate(idx):
@@ -276,6 +288,8 @@ class Blend(CombinedComponent):
         for obs, idx in self._lowres:
             _, handle, _ = obs.renderer._resampler()
             batch.attach_lowres(handle, idx, obs.data, obs.weights, obs.log_norm)
+        if self._loss_constant:
+            batch.add_loss_constant(self._loss_constant)
         self._upload_state(batch, comps)
         return batch
 
@@ -755,6 +769,8 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
                 max_iter=n, device=device)
             try:
                 flat = [c for cs in comps for c in cs]
+                if any(r.blend._loss_constant for r in group):
+                    batch.add_loss_constant([r.blend._loss_constant for r in group])
                 Blend._upload_state(batch, flat)
                 batch.set_optimizer(**opt)
                 if local > 0:  # the stopping rule compares with the loss before this round

@@ -160,6 +160,29 @@ class MonotonicityConstraint(Constraint):
         return result
 
 
+class MonotonicMaskConstraint(Constraint):
+    """Monotonicity by branching out from ``center``: pixels that no monotonic path
+    connects to the centre are interpolated (``operator.prox_monotonic_mask``; reference
+    constraint.py:237-259).  A 3-D ``morph`` is treated image by image.  Inside
+    ``Blend.fit`` it runs on the host (hoststep.py)."""
+
+    def __init__(self, center, center_radius=1, variance=0.0, max_iter=3):
+        self.center = center
+        self.center_radius = center_radius
+        self.variance = variance
+        self.max_iter = max_iter
+
+    def _one(self, image, step):
+        return operator.prox_monotonic_mask(
+            image, step, center=self.center, center_radius=self.center_radius,
+            variance=self.variance, max_iter=self.max_iter)[1]
+
+    def __call__(self, morph, step):
+        if np.ndim(morph) == 2:
+            return self._one(morph, step)
+        return np.array([self._one(image, step) for image in morph])
+
+
 class SymmetryConstraint(Constraint):
     """Two-fold rotation symmetry about the centre, softened by ``strength``."""
 

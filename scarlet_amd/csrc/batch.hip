@@ -870,6 +870,19 @@ int smi_batch_set_previous_loss(smi_batch *b, const double *loss) {
     return SMI_OK;
 }
 
+int smi_batch_add_loss_constant(smi_batch *b, const double *constant) {
+    SMI_REQUIRE(b && constant, "null argument");
+    SMI_REQUIRE(b->have_obs, "smi_batch_add_loss_constant follows smi_batch_set_observation");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int nb = b->d.n_blends;
+    std::vector<double> ln(nb);
+    SMI_HIP(hipMemcpy(ln.data(), b->log_norm, nb * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nb; ++i) ln[i] += constant[i];
+    SMI_HIP(hipMemcpy(b->log_norm, ln.data(), nb * sizeof(double), hipMemcpyHostToDevice));
+    return SMI_OK;
+}
+
 int smi_batch_set_log_norm(smi_batch *b, int32_t include) {
     SMI_REQUIRE(b, "null batch");
     SMI_REQUIRE(!b->have_obs, "smi_batch_set_log_norm must precede smi_batch_set_observation");

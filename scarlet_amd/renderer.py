@@ -37,12 +37,27 @@ class Renderer(Model):
             return model
         return model[self.channel_map]
 
+    def _overlap_slices(self):
+        """(data slices, model slices) of the region where an observation on the model's
+        pixel grid (translation only) and the model frame overlap: what ``match_shape``
+        crops / zero-embeds (renderer.py:130-161, 184-195)."""
+        pix = self.data_frame.convert_pixel_to(self.model_frame)
+        lo = np.round(pix.min(axis=0)).astype("int")
+        hi = np.round(pix.max(axis=0)).astype("int") + 1
+        data_box = self.model_frame.bbox[0] @ Box.from_bounds((lo[0], hi[0]), (lo[1], hi[1]))
+        return overlapped_slices(data_box, self.model_frame.bbox)
+
 
 class NullRenderer(Renderer):
     """Observation and model share the PSF: rendering is the identity."""
 
     def __init__(self, data_frame, model_frame):
         super().__init__(data_frame, model_frame)
+        if tuple(data_frame.shape[1:]) == tuple(model_frame.shape[1:]):
+            full = (slice(None),) * 3
+            self.slices = (full, full)
+        else:
+            self.slices = self._overlap_slices()
 
     def get_model(self, *parameters):
         return lambda model: model
@@ -63,11 +78,7 @@ class ConvolutionRenderer(Renderer):
         self._convolution_type = convolution_type
 
         # region of the model frame covered by the data (translation only)
-        pix = data_frame.convert_pixel_to(model_frame)
-        lo = np.round(pix.min(axis=0)).astype("int")
-        hi = np.round(pix.max(axis=0)).astype("int") + 1
-        data_box = model_frame.bbox[0] @ Box.from_bounds((lo[0], hi[0]), (lo[1], hi[1]))
-        self.slices = overlapped_slices(data_box, model_frame.bbox)
+        self.slices = self._overlap_slices()
 
         dtype = model_frame.dtype
         self.diff_kernel = fft.match_psf(

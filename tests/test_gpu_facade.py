@@ -1010,3 +1010,39 @@ def test_use_mask_and_foreign_chain_orders_fit_host_stepped(hsc):
     c, _ = build_blend(hsc, resizing=False)
     out = scarlet.fit_blends([a, b, c], 8, e_rel=1e-9)
     assert [r[0] for r in out] == [8, 8, 8] and out[0] == out[2] and out[1] != out[0]
+
+
+@pytest.mark.parametrize("null_renderer", [False, True])
+def test_observation_larger_than_the_model_frame(hsc, null_renderer):
+    """An observation that sticks out of the model frame: the reference zero-fills the
+    model there (renderer.py:130-161), so the outside pixels add a constant to the loss;
+    the device loss (smi_batch_add_loss_constant) equals the host evaluation of
+    Observation.get_log_likelihood on the same model, for both same-grid renderers."""
+    import scarlet_amd as scarlet
+
+    filters = list("grizy")
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5)
+    frame = scarlet.Frame((5, 40, 36), psf=model_psf, channels=filters)
+    obs = scarlet.Observation(hsc["images"], psf=model_psf if null_renderer
+                              else scarlet.ImagePSF(hsc["psfs"].copy()),
+                              weights=hsc["weights"], channels=filters).match(frame)
+    assert type(obs.renderer).__name__ == ("NullRenderer" if null_renderer else "ConvolutionRenderer")
+    k = 0
+    h, w = hsc["morph_%d" % k].shape
+    box = scarlet.Box((5, h, w), origin=(0, 5, 3))
+    spectrum = scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                         min_step=hsc["min_step_%d" % k])
+    morphology = scarlet.ExtendedSourceMorphology(
+        frame, (5 + h // 2, 3 + w // 2), hsc["morph_%d" % k].copy(), bbox=box[1:],
+        monotonic="angle", resizing=False)
+    blend = scarlet.Blend([scarlet.FactorizedComponent(frame, spectrum, morphology)], obs)
+    model = blend.get_model()
+    if null_renderer:
+        rendered = np.zeros(obs.data.shape, dtype=np.float32)
+        rendered[:, :40, :36] = model
+        want = -obs.log_norm - np.sum(obs.weights * (rendered - obs.data) ** 2) / 2
+    else:
+        want = obs.get_log_likelihood(model)
+    blend.fit(1, e_rel=1e-9)
+    assert blend._loss_constant > 0
+    assert abs(-blend.loss[0] - want) < 1e-6 * abs(want)
