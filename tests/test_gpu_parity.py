@@ -94,6 +94,47 @@ def test_sweep_golden_from_reference(amd):
             assert_array_equal(c(x0.copy(), 0), g["sweep_{}_{}_{}".format(mode, gr, tag)])
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sweep_and_mask_operators_independent_known_answers(amd, dtype):
+    """seam 1 against answers that do not pass through the oracle's C files: the scalar
+    Python transcription of the reference's sweep loop on the reference's own set-up
+    tables, and the hand-derived known answers of the two mask operators
+    (tests/mask_kats.py)"""
+    import mask_kats
+    from scarlet_amd import operator
+
+    g = golden("operator_tables")
+    for tag in ("7x9", "21x21"):
+        h, w = map(int, tag.split("x"))
+        off = np.array([-w - 1, -w, -w + 1, -1, 1, w - 1, w, w + 1], dtype=np.int32)
+        rng = np.random.default_rng(h * 100 + w)
+        didx = g["didx_" + tag][1:]
+        for mode, gr in MODES:
+            wts = g["w_{}_{}".format(mode, tag)]
+            x0 = rng.random((h, w)).astype(dtype)
+            want = mask_kats.sweep_transcription(x0.copy(), wts, off, didx, gr)
+            got = operator._native_sweep(x0.copy(), wts, off, didx, gr)
+            assert_array_equal(got, want)
+    for name, img, (i, j), var, thr, unc_w, orp_w, b_w in mask_kats.valid_pixel_cases(dtype):
+        unchecked = np.ones(img.shape, dtype=bool)
+        unchecked[i, j] = False
+        orphans = np.zeros(img.shape, dtype=bool)
+        bounds = np.array([i, i, j, j], dtype=np.int32)
+        operator.get_valid_monotonic_pixels(i, j, img, unchecked, orphans, var, bounds, thr)
+        assert_array_equal(unchecked, unc_w, err_msg=name)
+        assert_array_equal(orphans, orp_w, err_msg=name)
+        assert bounds.tolist() == b_w, name
+    for name, model, unc, orp, oi, oj, rec, b0, m_w, unc_w, orp_w, b_w in \
+            mask_kats.interpolation_cases(dtype):
+        model, unc, orp = model.copy(), unc.copy(), orp.copy()
+        bounds = np.array(b0, dtype=np.int32)
+        operator.linear_interpolate_invalid_pixels(oi, oj, unc, model, orp, 0.0, rec, bounds)
+        assert_array_equal(model, m_w, err_msg=name)
+        assert_array_equal(unc, unc_w, err_msg=name)
+        assert_array_equal(orp, orp_w, err_msg=name)
+        assert bounds.tolist() == b_w, name
+
+
 def test_sweep_empty_and_degenerate(amd):
     from oracle import proxops
 

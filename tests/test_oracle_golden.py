@@ -135,6 +135,62 @@ def test_operator_tables_match_reference():
             assert_array_equal(out, g["sweep_{}_{}_{}".format(mode, gr, tag)])
 
 
+def _offsets(w):
+    """operator.getOffsets (reference operator.py:512-527)"""
+    return np.array([-w - 1, -w, -w + 1, -1, 1, w - 1, w, w + 1], dtype=np.int32)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("tag", ["7x9", "21x21"])
+def test_sweep_against_a_transcription_of_the_reference_loop(dtype, tag):
+    """The sweep goldens of ``operator_tables.npz`` went through oracle/csrc/sweep.c when
+    they were made (the reference's compiled module could not be built, its Python calls
+    were routed to the oracle).  This test pins the sweep without that file: the C++ loop
+    (operators_pybind11.cc:14-36) transcribed line by line into scalar Python
+    (tests/mask_kats.py::sweep_transcription), run on the weight / order tables that the
+    reference's own pure-NumPy set-up code produced (didx_*, w_* in the golden), must give
+    bit for bit what the C restatement gives."""
+    from mask_kats import sweep_transcription
+
+    g = golden("operator_tables")
+    h, w = map(int, tag.split("x"))
+    rng = np.random.default_rng(h * 100 + w)
+    didx = g["didx_" + tag][1:]  # the peak itself is not swept (operator.py:92)
+    for mode, gr in (("flat", 0.1), ("angle", 0.0), ("nearest", 0.0), ("angle", 0.25)):
+        wts = g["w_{}_{}".format(mode, tag)]
+        x0 = (rng.random((h, w)) + 0.1 * rng.random((h, w)) * (mode == "flat")).astype(dtype)
+        want = sweep_transcription(x0.copy(), wts, _offsets(w), didx, gr)
+        got = proxops.sweep(x0.copy(), wts, _offsets(w), didx, gr)
+        assert_array_equal(got, want)
+        assert not np.array_equal(want, x0)  # the sweep clipped something
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_mask_operators_hand_derived_known_answers(dtype):
+    """oracle/csrc/mask.c against the known answers derived by hand from
+    operators_pybind11.cc:61-232 (tests/mask_kats.py)"""
+    import mask_kats
+
+    for name, img, (i, j), var, thr, unc_w, orp_w, b_w in mask_kats.valid_pixel_cases(dtype):
+        unchecked = np.ones(img.shape, dtype=bool)
+        unchecked[i, j] = False
+        orphans = np.zeros(img.shape, dtype=bool)
+        bounds = np.array([i, i, j, j], dtype=np.int32)
+        proxops.get_valid_monotonic_pixels(i, j, img, unchecked, orphans, var, bounds, thr)
+        assert_array_equal(unchecked, unc_w, err_msg=name)
+        assert_array_equal(orphans, orp_w, err_msg=name)
+        assert bounds.tolist() == b_w, name
+    for name, model, unc, orp, oi, oj, rec, b0, m_w, unc_w, orp_w, b_w in \
+            mask_kats.interpolation_cases(dtype):
+        model, unc, orp = model.copy(), unc.copy(), orp.copy()
+        bounds = np.array(b0, dtype=np.int32)
+        proxops.linear_interpolate_invalid_pixels(oi, oj, unc, model, orp, 0.0, rec, bounds)
+        assert_array_equal(model, m_w, err_msg=name)
+        assert_array_equal(unc, unc_w, err_msg=name)
+        assert_array_equal(orp, orp_w, err_msg=name)
+        assert bounds.tolist() == b_w, name
+
+
 # ---- G2: PSF matching and convolution
 def test_fft_psf_matching_golden():
     g = golden("fft_psf")
