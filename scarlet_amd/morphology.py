@@ -149,19 +149,18 @@ class ExtendedSourceMorphology(ImageMorphology):
 
     def __init__(self, frame, center, image, bbox=None, monotonic="angle", symmetric=False,
                  min_grad=0, shifting=False, resizing=True):
-        constraints = []
-        if monotonic is True:
-            monotonic = "angle"
-        elif monotonic is False:
-            monotonic = None
-        if monotonic is not None:
-            constraints.append(
-                MonotonicityConstraint(neighbor_weight=monotonic, min_gradient=min_grad)
-            )
+        # booleans are the old spelling of the monotonicity argument
+        weighting = {True: "angle", False: None}.get(monotonic, monotonic) \
+            if isinstance(monotonic, bool) else monotonic
+        shape_terms = []
+        if weighting is not None:
+            shape_terms.append(MonotonicityConstraint(neighbor_weight=weighting,
+                                                      min_gradient=min_grad))
         if symmetric:
-            constraints.append(SymmetryConstraint())
-        constraints += [PositivityConstraint(), CenterOnConstraint(),
-                        NormalizationConstraint("max")]
+            shape_terms.append(SymmetryConstraint())
+        # the order of the fused device chain (constraint._DEVICE_ORDER)
+        constraints = shape_terms + [PositivityConstraint(), CenterOnConstraint(),
+                                     NormalizationConstraint("max")]
         image = Parameter(image, name="image", step=1e-2, constraint=ConstraintChain(*constraints))
         self.pixel_center = np.round(center).astype("int")
         # with shifting the sub-pixel offset of the centre becomes a free parameter

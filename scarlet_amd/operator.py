@@ -231,25 +231,25 @@ def prox_monotonic_mask(X, step, center, center_radius=1, variance=0.0, max_iter
     pixels reachable from the (optionally re-fitted) centre without rising by more than
     ``variance`` are valid; orphans next to them are interpolated up to ``max_iter`` times;
     the rest is cleared.  Returns ``(valid, model, bounds)``."""
-    if center_radius > 0:
-        i, j = get_center(X, center, center_radius)
-    else:
-        i, j = int(np.round(center[0])), int(np.round(center[1]))
+    seed = get_center(X, center, center_radius) if center_radius > 0 else np.round(center)
+    i, j = (int(c) for c in seed)
     X = np.ascontiguousarray(X)
-    unchecked = np.ones(X.shape, dtype=bool)
-    unchecked[i, j] = False
-    orphans = np.zeros(X.shape, dtype=bool)
-    bounds = np.array([i, i, j, j], dtype=np.int32)
-    get_valid_monotonic_pixels(i, j, X, unchecked, orphans, variance, bounds, 0)
+
+    # state the two native operators share: pixels not settled yet, pixels rejected from
+    # every side so far, bounding box of the accepted region
+    pending = np.ones(X.shape, dtype=bool)
+    pending[i, j] = False
+    rejected = np.zeros(X.shape, dtype=bool)
+    box = np.array([i, i, j, j], dtype=np.int32)
+    get_valid_monotonic_pixels(i, j, X, pending, rejected, variance, box, 0)
     model = X.copy()
-    it = 0
-    while np.sum(orphans & unchecked) > 0 and it < max_iter:
-        it += 1
-        all_i, all_j = np.where(orphans)
-        linear_interpolate_invalid_pixels(all_i, all_j, unchecked, model, orphans, variance, True,
-                                          bounds)
-    valid = ~unchecked & ~orphans
-    return valid, model * valid, bounds
+    for _ in range(max_iter):
+        if not np.any(rejected & pending):
+            break
+        rows, cols = np.nonzero(rejected)
+        linear_interpolate_invalid_pixels(rows, cols, pending, model, rejected, variance, True, box)
+    valid = ~(pending | rejected)
+    return valid, np.where(valid, model, 0).astype(model.dtype), box
 
 
 def prox_sdss_symmetry(X, step):
