@@ -365,6 +365,9 @@ typedef struct smi_resampler smi_resampler;
 int smi_resampler_create(const float *A, const float *Pt, int32_t C, int32_t n_a, int32_t n_b,
                          int32_t Fy, int32_t Fx, smi_resampler **out);
 int smi_resampler_render(smi_resampler *r, const float *model, float *out);
+/* mean device time (ms) of one rendering of the model last passed to smi_resampler_render,
+ * over n_rep repetitions without host transfers (benchmark of BASELINE config 5) */
+int smi_resampler_time(smi_resampler *r, int32_t n_rep, double *ms_per_render);
 int smi_resampler_destroy(smi_resampler *r);
 
 /* The low-resolution observation as a further term of a fit (Blend._loss_func sums the

@@ -116,6 +116,8 @@ SYMBOLS = {
          ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)],
     ),
     "smi_resampler_render": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
+    "smi_resampler_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.POINTER(ctypes.c_double)]),
     "smi_resampler_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "smi_batch_attach_lowres": (
         ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i32p, c_f32p, c_f32p, ctypes.c_double]

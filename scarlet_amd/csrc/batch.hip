@@ -537,6 +537,11 @@ int smi_resampler_render(smi_resampler *r, const float *model, float *out) {
     return resampler_render(r->impl, model, out);
 }
 
+int smi_resampler_time(smi_resampler *r, int32_t n_rep, double *ms_per_render) {
+    SMI_REQUIRE(r && r->impl && ms_per_render && n_rep > 0, "bad argument");
+    return resampler_time(r->impl, n_rep, ms_per_render);
+}
+
 static constexpr int kMaxLowRes = 8;
 
 int smi_batch_attach_lowres(smi_batch *b, smi_resampler *r, const int32_t *channels,

@@ -12,82 +12,141 @@
 //   B[(y, x), b] = sum_x' model[y, x'] * P[(x, b), x']      (F_y x F_x) . (F_x x F_x n_b)
 //   out[a, b]    = sum_{(y, x)} A[a, (y, x)] * B[(y, x), b]  (n_a x F_y F_x) . (F_y F_x x n_b)
 //
-// Plain dense f32 products with f64 accumulation (the second one sums F_y F_x ~ 4e4
-// terms); the long reduction is split over workgroups and reduced in a second kernel.
+// The products run on the matrix cores: v_mfma_f32_32x32x2_f32 tiles (f32 inputs, f32
+// accumulation = an fmaf chain in k order), staged through LDS.  The reductions are long
+// (the second product sums F_y F_x ~ 4e4..2e5 terms), so K is cut into slices of a few
+// hundred terms: inside a slice the accumulation is float32, across slices the partial
+// tiles are summed in double by a second kernel -- that keeps the renderings within
+// ~1e-7 of the reference's float64 evaluation and gives a small output enough workgroups
+// to fill the chip.  The bands of an observation are one batched launch.
 #include "common.h"
 
 namespace smi {
 namespace {
 
-constexpr int kTile = 64, kTK = 16;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// C[M x N] (+)= A[M x K] . B[K x N], row major, one 64 x 64 tile per workgroup of 256
-// threads (4 x 4 outputs per thread); blockIdx.z selects the K slice [z * kslice, ...),
-// partial results go to Cpart[z][M][N] in double.
-__global__ __launch_bounds__(256) void gemm_slices_kernel(const float *A, const float *B,
-                                                          double *Cpart, int M, int N, int K,
-                                                          int kslice) {
-    __shared__ float As[kTK][kTile + 1], Bs[kTK][kTile + 1];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.y * kTile, n0 = blockIdx.x * kTile;
-    const int k_lo = blockIdx.z * kslice, k_hi = min(K, k_lo + kslice);
-    double acc[4][4] = {};
-    for (int k0 = k_lo; k0 < k_hi; k0 += kTK) {
-        for (int i = threadIdx.x; i < kTile * kTK; i += 256) {
-            const int m = i / kTK, kk = i % kTK;  // A tile: 64 rows x 16 k
-            As[kk][m] = (m0 + m < M && k0 + kk < k_hi) ? A[(int64_t)(m0 + m) * K + k0 + kk] : 0.f;
-            const int kb = i / kTile, n = i % kTile;  // B tile: 16 k x 64 columns
-            Bs[kb][n] = (n0 + n < N && k0 + kb < k_hi) ? B[(int64_t)(k0 + kb) * N + n0 + n] : 0.f;
+constexpr int kBM = 128, kBN = 128, kBK = 16;  // block tile; 4 waves as 2 x 2, 64 x 64 each
+constexpr int kPad = 4;                        // LDS row padding (floats)
+constexpr int kSliceTerms = 256;               // float32 accumulation length inside a slice
+
+// C_b[M x N] = A_b[M x K] . B_b[K x N] for b < n_batch (row major; the batch strides may
+// be 0).  blockIdx.z = batch * n_slices + slice; slice z covers K in [z kslice, ...).
+// n_slices == 1: the tile goes straight to C (float); otherwise to Cpart[b][z][M][N]
+// (double) for reduce_slices_kernel.
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t strideA,
+                                                        const float *B, int64_t strideB,
+                                                        float *C, int64_t strideC, double *Cpart,
+                                                        int M, int N, int K, int kslice,
+                                                        int n_slices) {
+    __shared__ float As[kBK][kBM + kPad], Bs[kBK][kBN + kPad];
+    const int batch = blockIdx.z / n_slices, z = blockIdx.z - batch * n_slices;
+    A += batch * strideA;
+    B += batch * strideB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int k_lo = z * kslice, k_hi = min(K, k_lo + kslice);
+
+    // global -> registers -> LDS.  A tile: 128 rows x 16 k, thread t takes k = t % 16 of
+    // the rows t / 16 + 16 q (a row's 16 floats are one 64-byte segment); B tile: 16 k x
+    // 128 columns, thread t takes column t % 128 of the rows t / 128 + 2 q.
+    const int a_k = tid & 15, a_r = tid >> 4, b_n = tid & 127, b_k = tid >> 7;
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = m0 + a_r + 16 * q, k = k0 + a_k;
+            ra[q] = (m < M && k < k_hi) ? A[(int64_t)m * K + k] : 0.f;
+            const int kb = k0 + b_k + 2 * q, n = n0 + b_n;
+            rb[q] = (kb < k_hi && n < N) ? B[(int64_t)kb * N + n] : 0.f;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += kBK) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            As[a_k][a_r + 16 * q] = ra[q];
+            Bs[b_k + 2 * q][b_n] = rb[q];
         }
         __syncthreads();
+        if (k0 + kBK < k_hi) fetch(k0 + kBK);  // in flight during the products
+        // operand layout of v_mfma_f32_32x32x2_f32: lane l holds A[i = l & 31][k = l >> 5]
+        // and B[k = l >> 5][j = l & 31]
+        const int kk = lane >> 5, ij = lane & 31;
 #pragma unroll
-        for (int kk = 0; kk < kTK; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = As[kk][ty * 4 + i];
-                b[i] = Bs[kk][tx * 4 + i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += (double)a[i] * (double)b[j];
+        for (int ks = 0; ks < kBK; ks += 2) {
+            const float a0 = As[ks + kk][wm + ij], a1 = As[ks + kk][wm + 32 + ij];
+            const float b0 = Bs[ks + kk][wn + ij], b1 = Bs[ks + kk][wn + 32 + ij];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }
-    double *Cz = Cpart + (int64_t)blockIdx.z * M * N;
+    // accumulator layout of the 32 x 32 tile: lane l, register e -> row 8 (e / 4) +
+    // 4 (l >> 5) + e % 4, column l & 31
+    double *Cz = Cpart ? Cpart + ((int64_t)batch * n_slices + z) * M * N : nullptr;
+    float *Cb = C + batch * strideC;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < M && n < N) Cz[(int64_t)m * N + n] = acc[i][j];
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+                const int n = n0 + wn + 32 * j + (lane & 31);
+                if (m < M && n < N) {
+                    if (Cz)
+                        Cz[(int64_t)m * N + n] = (double)acc[i][j][e];
+                    else
+                        Cb[(int64_t)m * N + n] = acc[i][j][e];
+                }
+            }
 }
 
-__global__ void reduce_slices_kernel(const double *Cpart, float *C, int64_t MN, int n_slices) {
+// C_b = sum over slices of Cpart[b][z] (double), b < n_batch
+__global__ void reduce_slices_kernel(const double *Cpart, float *C, int64_t strideC, int64_t MN,
+                                     int n_slices) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= MN) return;
+    const int b = blockIdx.y;
+    const double *p = Cpart + (int64_t)b * n_slices * MN + i;
     double t = 0.0;
-    for (int z = 0; z < n_slices; ++z) t += Cpart[(int64_t)z * MN + i];
-    C[i] = (float)t;
+    for (int z = 0; z < n_slices; ++z) t += p[(int64_t)z * MN];
+    C[b * strideC + i] = (float)t;
 }
 
-int gemm(const float *A, const float *B, float *C, double *scratch, size_t scratch_elems, int M,
-         int N, int K, hipStream_t s) {
-    const int tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
-    // enough K slices to occupy the chip when the output is small
-    int n_slices = std::max(1, std::min((K + 255) / 256, 2048 / std::max(tiles, 1)));
-    while ((size_t)n_slices * M * N > scratch_elems && n_slices > 1) --n_slices;
-    SMI_REQUIRE((size_t)n_slices * M * N <= scratch_elems, "resampler scratch too small");
+int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float *C,
+         int64_t strideC, int n_batch, double *scratch, size_t scratch_elems, int M, int N, int K,
+         hipStream_t s) {
+    const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN) * n_batch;
+    // slices of ~kSliceTerms terms (float32 accumulation length); fewer when the tiles
+    // alone fill the chip several times over and the partials would not fit the scratch
+    int n_slices = std::max(1, (K + kSliceTerms - 1) / kSliceTerms);
+    const size_t MN = (size_t)M * N;
+    while (n_slices > 1 && ((size_t)n_slices * n_batch * MN > scratch_elems ||
+                            (tiles >= 2048 && K <= 4 * kSliceTerms)))
+        --n_slices;
     int kslice = (K + n_slices - 1) / n_slices;
-    kslice = (kslice + kTK - 1) / kTK * kTK;
+    kslice = (kslice + kBK - 1) / kBK * kBK;
     n_slices = (K + kslice - 1) / kslice;
-    hipLaunchKernelGGL(gemm_slices_kernel, dim3((N + kTile - 1) / kTile, (M + kTile - 1) / kTile, n_slices),
-                       dim3(256), 0, s, A, B, scratch, M, N, K, kslice);
-    const int64_t MN = (int64_t)M * N;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, s,
-                       scratch, C, MN, n_slices);
+    hipLaunchKernelGGL(gemm_mfma_kernel,
+                       dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, n_slices * n_batch),
+                       dim3(256), 0, s, A, strideA, B, strideB, C, strideC,
+                       n_slices > 1 ? scratch : nullptr, M, N, K, kslice, n_slices);
+    if (n_slices > 1)
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((MN + 255) / 256), n_batch),
+                           dim3(256), 0, s, scratch, C, strideC, (int64_t)MN, n_slices);
     return SMI_OK;
 }
 
@@ -97,7 +156,7 @@ struct Resampler {
     int C = 0, n_a = 0, n_b = 0, Fy = 0, Fx = 0;
     float *A = nullptr;    // [C][n_a][Fy * Fx]
     float *Pt = nullptr;   // [Fx][Fx * n_b]  (transposed shift operator, shared by the bands)
-    float *model = nullptr, *B = nullptr, *out = nullptr;
+    float *model = nullptr, *B = nullptr, *out = nullptr;  // B: [C][Fy * Fx * n_b]
     double *scratch = nullptr;
     size_t scratch_elems = 0;
     // transposed operators for the adjoint (built when a fit attaches the resampler)
@@ -110,8 +169,13 @@ int resampler_create(const float *A, const float *Pt, int C, int n_a, int n_b, i
     auto *r = new Resampler;
     r->C = C; r->n_a = n_a; r->n_b = n_b; r->Fy = Fy; r->Fx = Fx;
     const size_t nA = (size_t)C * n_a * Fy * Fx, nP = (size_t)Fx * Fx * n_b;
-    const size_t nB = (size_t)Fy * Fx * n_b;
-    r->scratch_elems = std::max(nB, (size_t)n_a * n_b * 2048);
+    const size_t nB = (size_t)C * Fy * Fx * n_b;
+    // double partials of the sliced products: out (n_a x n_b, thousands of slices) and
+    // the model-sized results of the adjoint (F_y x F_x, ~100 slices), all bands at once
+    const size_t slices_out = ((size_t)Fy * Fx + kSliceTerms - 1) / kSliceTerms + 1;
+    const size_t slices_g = ((size_t)Fx * n_b + kSliceTerms - 1) / kSliceTerms + 1;
+    r->scratch_elems = (size_t)C * std::max((size_t)n_a * n_b * slices_out,
+                                            (size_t)Fy * Fx * slices_g);
     *out = r;
     SMI_HIP(hipMalloc((void **)&r->A, nA * sizeof(float)));
     SMI_HIP(hipMalloc((void **)&r->Pt, nP * sizeof(float)));
@@ -132,18 +196,15 @@ void resampler_destroy(Resampler *r) {
     delete r;
 }
 
-// r->model (device, padded) -> r->out, on stream s
+// r->model (device, padded) -> r->out, on stream s; all bands in one launch per product
 static int resampler_forward(Resampler *r, hipStream_t s) {
-    const size_t plane = (size_t)r->Fy * r->Fx;
-    for (int c = 0; c < r->C; ++c) {
-        int rc = gemm(r->model + c * plane, r->Pt, r->B, r->scratch, r->scratch_elems, r->Fy,
-                      r->Fx * r->n_b, r->Fx, s);
-        if (rc) return rc;
-        rc = gemm(r->A + (size_t)c * r->n_a * plane, r->B, r->out + (size_t)c * r->n_a * r->n_b,
-                  r->scratch, r->scratch_elems, r->n_a, r->n_b, (int)plane, s);
-        if (rc) return rc;
-    }
-    return SMI_OK;
+    const int64_t plane = (int64_t)r->Fy * r->Fx;
+    int rc = gemm(r->model, plane, r->Pt, 0, r->B, plane * r->n_b, r->C, r->scratch,
+                  r->scratch_elems, r->Fy, r->Fx * r->n_b, r->Fx, s);
+    if (rc) return rc;
+    return gemm(r->A, (int64_t)r->n_a * plane, r->B, plane * r->n_b, r->out,
+                (int64_t)r->n_a * r->n_b, r->C, r->scratch, r->scratch_elems, r->n_a, r->n_b,
+                (int)plane, s);
 }
 
 int resampler_render(Resampler *r, const float *model, float *out) {
@@ -155,6 +216,27 @@ int resampler_render(Resampler *r, const float *model, float *out) {
     SMI_HIP(hipDeviceSynchronize());
     SMI_HIP(hipMemcpy(out, r->out, (size_t)r->C * r->n_a * r->n_b * sizeof(float),
                       hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+
+// device time of `n_rep` renderings of the resident model (no host transfers): the
+// figure the flops roofline of BASELINE config 5 is measured on
+int resampler_time(Resampler *r, int n_rep, double *ms_per_render) {
+    hipEvent_t e0, e1;
+    SMI_HIP(hipEventCreate(&e0));
+    SMI_HIP(hipEventCreate(&e1));
+    int rc = resampler_forward(r, nullptr);  // warm-up
+    if (rc) return rc;
+    SMI_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < n_rep; ++i)
+        if ((rc = resampler_forward(r, nullptr))) return rc;
+    SMI_HIP(hipEventRecord(e1, nullptr));
+    SMI_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SMI_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_render = (double)ms / n_rep;
     return SMI_OK;
 }
 
@@ -294,15 +376,11 @@ int lowres_evaluate(LowRes *l, const float *P, int Py, int Px, int backward, hip
     hipLaunchKernelGGL(lowres_residual_kernel, dim3(1), dim3(1024), 0, s, r->out, l->data,
                        l->weights, l->resid, n, l->log_norm, l->term);
     if (!backward) return SMI_OK;
-    for (int c = 0; c < r->C; ++c) {
-        rc = gemm(r->At + (size_t)c * r->n_a * plane, l->resid + (size_t)c * r->n_a * r->n_b, r->B,
-                  r->scratch, r->scratch_elems, plane, r->n_b, r->n_a, s);
-        if (rc) return rc;
-        rc = gemm(r->B, r->P, l->gpad + (size_t)c * plane, r->scratch, r->scratch_elems, r->Fy,
-                  r->Fx, r->Fx * r->n_b, s);
-        if (rc) return rc;
-    }
-    return SMI_OK;
+    rc = gemm(r->At, (int64_t)r->n_a * plane, l->resid, (int64_t)r->n_a * r->n_b, r->B,
+              (int64_t)plane * r->n_b, r->C, r->scratch, r->scratch_elems, plane, r->n_b, r->n_a, s);
+    if (rc) return rc;
+    return gemm(r->B, (int64_t)plane * r->n_b, r->P, 0, l->gpad, plane, r->C, r->scratch,
+                r->scratch_elems, r->Fy, r->Fx, r->Fx * r->n_b, s);
 }
 
 void lowres_add_gradient(LowRes *l, float *Q, int Py, int Px, hipStream_t s) {
