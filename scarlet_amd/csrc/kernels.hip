@@ -65,7 +65,7 @@ __device__ __forceinline__ int wave_or(int v) {
 // the origin; for the rocFFT path Fy x Fx is the zero-padded FFT input and the padding
 // stays zero, for the fused path the cube is compact).
 //
-// Pixel-owner: one wavefront per pair of frame rows, lane l the columns l, l + 64 of a
+// Pixel-owner: one wavefront per four frame rows, lane l the columns l, l + 64 of a
 // 128-column strip; every pixel accumulates its components in ascending order (the
 // summation order of blend.py:30-46) in registers and is written once.  Component
 // metadata sits one component per lane and is broadcast with v_readlane; a component
@@ -75,7 +75,9 @@ __device__ __forceinline__ int wave_or(int v) {
 // fused_conv_kernel, so render waves of one range of blends run in the issue slots the
 // convolution of another range leaves idle.
 // ---------------------------------------------------------------------------
-constexpr int kRenderRows = 2, kRenderWaves = 4;
+constexpr int kRenderRows = 4, kRenderWaves = 4;
+// NB: bands per pass (the accumulators are registers: 4 rows x 2 columns x NB)
+template <int NB>
 __global__ __launch_bounds__(64 * kRenderWaves) void render_kernel(BatchView v, float *P) {
     const int b = blockIdx.y + v.blend0;
     if (v.state[b] >= 2) return;
@@ -85,32 +87,37 @@ __global__ __launch_bounds__(64 * kRenderWaves) void render_kernel(BatchView v, 
     if (y0 >= v.H) return;
     const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
     const int H = v.H, W = v.W;
+    const int y1 = min(y0 + kRenderRows, H);
     for (int x0 = 0; x0 < W; x0 += 128) {
-        for (int c0 = 0; c0 < v.C; c0 += kBandChunk) {
-            const int nc = min(kBandChunk, v.C - c0);
-            float acc[kRenderRows][2][kBandChunk];
+        const int x1 = min(x0 + 128, W);
+        for (int c0 = 0; c0 < v.C; c0 += NB) {
+            const int nc = min(NB, v.C - c0);
+            float acc[kRenderRows][2][NB];
 #pragma unroll
             for (int r = 0; r < kRenderRows; ++r)
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int j = 0; j < kBandChunk; ++j) acc[r][q][j] = 0.f;
+                    for (int j = 0; j < NB; ++j) acc[r][q][j] = 0.f;
             for (int kb = cs; kb < ce; kb += 64) {
                 const int kk = kb + lane;
                 const bool have = kk < ce;
                 const int l_oy = have ? v.c_oy[kk] : 0, l_ox = have ? v.c_ox[kk] : 0;
                 const int l_h = have ? v.c_h[kk] : 0, l_w = have ? v.c_w[kk] : 0;
                 const int l_mo = have ? (int)v.c_moff[kk] : 0;  // packed offsets fit 31 bits
-                const int kend = min(ce, kb + 64);
-                for (int k = kb; k < kend; ++k) {
-                    const int kl = k - kb;
+                // the components (one per lane) whose box meets the wave's rows and strip
+                const bool hit = have && min(y1, l_oy + l_h) > max(y0, l_oy) &&
+                                 min(x1, l_ox + l_w) > max(x0, l_ox);
+                unsigned long long todo = __ballot(hit);
+                while (todo) {  // ascending component order
+                    const int kl = __builtin_ctzll(todo);
+                    todo &= todo - 1;
                     const int oy = __builtin_amdgcn_readlane(l_oy, kl);
                     const int hh = __builtin_amdgcn_readlane(l_h, kl);
                     const int ox = __builtin_amdgcn_readlane(l_ox, kl);
                     const int w = __builtin_amdgcn_readlane(l_w, kl);
-                    const int r_lo = max(y0, oy), r_hi = min(min(y0 + kRenderRows, H), oy + hh);
-                    const int x_lo = max(x0, ox), x_hi = min(min(x0 + 128, W), ox + w);
-                    if (r_hi <= r_lo || x_hi <= x_lo) continue;  // wave-uniform
+                    const int r_lo = max(y0, oy), r_hi = min(y1, oy + hh);
+                    const int x_lo = max(x0, ox), x_hi = min(x1, ox + w);
                     const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
                     float mv[kRenderRows][2];
                     bool ok[kRenderRows][2];
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(64 * kRenderWaves) void render_kernel(BatchView v, 
                             ok[r][q] = yy >= r_lo && yy < r_hi && xx >= x_lo && xx < x_hi;
                             mv[r][q] = ok[r][q] ? mbase[(yy - oy) * w + (xx - ox)] : 0.f;
                         }
-                    const float *sed = v.sed + (int64_t)k * v.C + c0;
+                    const float *sed = v.sed + (int64_t)(kb + kl) * v.C + c0;
 #pragma unroll
-                    for (int j = 0; j < kBandChunk; ++j) {
+                    for (int j = 0; j < NB; ++j) {
                         if (j >= nc) break;
                         const float sd = sed[j];
 #pragma unroll
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(64 * kRenderWaves) void render_kernel(BatchView v, 
                 }
             }
 #pragma unroll
-            for (int j = 0; j < kBandChunk; ++j) {
+            for (int j = 0; j < NB; ++j) {
                 if (j >= nc) break;
 #pragma unroll
                 for (int r = 0; r < kRenderRows; ++r)
@@ -1367,8 +1374,16 @@ static inline int pix_blocks(const BatchView &v) {
 
 void launch_render(const BatchView &v, float *P, hipStream_t s) {
     const int rows_per_block = kRenderRows * kRenderWaves;
-    hipLaunchKernelGGL(render_kernel, dim3((v.H + rows_per_block - 1) / rows_per_block, v.nb),
-                       dim3(64 * kRenderWaves), 0, s, v, P);
+    const dim3 grid((v.H + rows_per_block - 1) / rows_per_block, v.nb), block(64 * kRenderWaves);
+    // bands per pass: all of them when they fit the registers (C <= 6), else chunks of 4
+    switch (v.C <= 6 ? v.C : 4) {
+        case 1: hipLaunchKernelGGL(render_kernel<1>, grid, block, 0, s, v, P); break;
+        case 2: hipLaunchKernelGGL(render_kernel<2>, grid, block, 0, s, v, P); break;
+        case 3: hipLaunchKernelGGL(render_kernel<3>, grid, block, 0, s, v, P); break;
+        case 4: hipLaunchKernelGGL(render_kernel<4>, grid, block, 0, s, v, P); break;
+        case 5: hipLaunchKernelGGL(render_kernel<5>, grid, block, 0, s, v, P); break;
+        default: hipLaunchKernelGGL(render_kernel<6>, grid, block, 0, s, v, P); break;
+    }
 }
 
 void launch_residual(const BatchView &v, const float *Q, float *R, hipStream_t s) {

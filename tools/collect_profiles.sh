@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collect the rocprofv3 summaries behind bench.py's roofline object on the GPU box and leave
+# them under gpurun_out/<tag>/ (copy the CSVs / JSON you want judged into profiles/).
+#   gpurun -- 'bash tools/collect_profiles.sh r02'
+# Kernel trace and counters are separate runs (gpurun refuses --pmc with trace domains other
+# than --kernel-trace; counters in passes of their own as MI355X_MICROARCH.md prescribes).
+set -u
+TAG=${1:-r02}
+R=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+
+stats() {  # name, bench arguments
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats -d "$OUT/$name" -o run --output-format csv -- \
+        python "$R/bench.py" "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
+    cp "$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats_$name.csv"
+}
+stats single_range --steps 100 --warmup 10 --no-cpu --sub-ranges 1
+stats default --steps 100 --warmup 10 --no-cpu
+stats cfg1 --config cfg1 --steps 100 --warmup 10 --no-cpu --sub-ranges 1
+stats cfg5 --config cfg5 --steps 40
+
+pmc() {  # name, counters...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/pmc_$name" -o run --output-format csv -- \
+        python "$R/bench.py" --steps 20 --warmup 2 --no-cpu --sub-ranges 1 > /dev/null 2> "$OUT/pmc_$name.err"
+}
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
+pmc valu SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES
+pmc busy SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY
+pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU
+
+python "$R/tools/hbm_counters.py" "$OUT" "$TAG" 1024
