@@ -275,6 +275,15 @@ int smi_batch_set_optimizer(smi_batch *b, float b1, float b2, float eps);
  * observation.py:147-186).  Call before smi_batch_set_observation. */
 int smi_batch_set_log_norm(smi_batch *b, int32_t include);
 
+/* A further observation of every blend on the model's pixel grid: Blend._loss_func sums
+ * the log-likelihoods of all observations (blend.py:264-271), so two observations that
+ * share model channels are two terms of the loss and of the gradient image.  data, weights:
+ * [n_blends][C][H][W] over the MODEL's channels (zero weight where this observation has
+ * none); kernel: like smi_batch_set_kernel (same stamp shape / band layout as the batch's).
+ * Needs the fused convolution path; call after smi_batch_set_observation / _set_kernel. */
+int smi_batch_add_observation(smi_batch *b, const float *data, const float *weights,
+                              const float *kernel);
+
 /* Add a constant to the loss of every blend (on top of log_norm + chi^2 / 2).  The
  * facade uses it for the part of an observation that lies outside the model frame:
  * the reference zero-fills the model there (renderer.py:130-161, match_shape), so those

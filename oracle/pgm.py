@@ -103,6 +103,33 @@ class Component:
         )
 
 
+class SameGridObservation:
+    """A further observation on the model's pixel grid for ``Scene(extra_observations=)``:
+    one more term of ``Blend._loss_func``'s sum over observations (blend.py:264-271) --
+    e.g. a second exposure of bands the first observation already covers.  ``data`` /
+    ``weights`` (C, H, W) over the model channels, ``kernel`` (Ck, P, P) or None."""
+
+    def __init__(self, data, weights, kernel):
+        self.data, self.weights, self.kernel = data, weights, kernel
+
+    def render(self, model):
+        return model if self.kernel is None else fftconv.convolve(model, self.kernel, axes=(1, 2))
+
+    @property
+    def log_norm(self):
+        seen = self.weights != 0
+        return seen.sum() / 2 * np.log(2 * np.pi) - 0.5 * np.sum(np.log(self.weights[seen]))
+
+    def neg_log_likelihood(self, model):
+        resid = self.render(model) - self.data
+        return self.log_norm + 0.5 * np.sum(self.weights * resid**2), self.weights * resid
+
+    def adjoint(self, upstream, n_model_channels):
+        if self.kernel is None:
+            return upstream
+        return fftconv.convolve_adjoint(upstream, self.kernel, axes=(1, 2))
+
+
 def integrated_gaussian(X, sigma):
     """Pixel-integrated 1-D Gaussian ``GaussianPSF._f`` (psf.py:128-142)."""
     from scipy.special import erfc

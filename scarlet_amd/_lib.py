@@ -150,6 +150,7 @@ SYMBOLS = {
     "smi_batch_get_fista_state": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f64p]),
     "smi_batch_set_fista_state": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f64p]),
     "smi_batch_set_log_norm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "smi_batch_add_observation": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p]),
     "smi_batch_add_loss_constant": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "smi_batch_set_previous_loss": (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
     "smi_batch_set_sub_ranges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),

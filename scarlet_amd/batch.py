@@ -361,6 +361,18 @@ class BlendBatch:
         loss = np.ascontiguousarray(np.broadcast_to(loss, (self.n_blends,)), dtype=np.float64)
         _lib.check(self._lib.smi_batch_set_previous_loss(self._h, _lib.ptr(loss, ctypes.c_double)))
 
+    def add_observation(self, data, weights, kernel):
+        """A further observation of every blend on the model's pixel grid (one more term
+        of the loss and of the gradient image, blend.py:264-271): ``data`` / ``weights``
+        (n_blends, C, H, W) over the model's channels, ``kernel`` with the stamp shape
+        the batch was created with."""
+        data, weights, kernel = _lib.f32(data), _lib.f32(weights), _lib.f32(kernel)
+        assert data.shape == weights.shape == (self.n_blends, self.C, self.H, self.W)
+        assert kernel.shape == self._kernel_shape, "kernel stamp shape is fixed at construction"
+        _lib.check(self._lib.smi_batch_add_observation(
+            self._h, _lib.ptr(data, ctypes.c_float), _lib.ptr(weights, ctypes.c_float),
+            _lib.ptr(kernel, ctypes.c_float)))
+
     def add_loss_constant(self, constant):
         """Add a constant per blend to the loss (the part of an observation that lies
         outside the model frame)."""

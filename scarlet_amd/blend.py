@@ -77,33 +77,45 @@ class Blend(CombinedComponent):
         """(data, weights, kernel) of the scene as ONE cube over the model channels.
 
         Several observations on the model's pixel grid (e.g. different instruments
-        covering different channels) are merged: every model channel must be
-        observed exactly once; per-channel difference kernels are zero-padded to a
-        common stamp, a NullRenderer observation contributes a delta kernel.  The
-        summed log-likelihood of the reference's loop over observations
-        (blend.py:265-271) is the log-likelihood of the merged cube."""
+        covering different channels) are merged: per-channel difference kernels are
+        zero-padded to a common stamp, a NullRenderer observation contributes a delta
+        kernel.  The summed log-likelihood of the reference's loop over observations
+        (blend.py:265-271) is the log-likelihood of the merged cube.  Observations that
+        share a model channel with an earlier one cannot be merged: they go into further
+        cubes of the same layout, ``self._extra_layers`` (one more term of the loss and
+        of the gradient each, ``smi_batch_add_observation``)."""
         C = self.frame.C
         spatial = tuple(self.frame.shape[1:])
         channels = list(self.frame.channels)
-        data = np.zeros(self.frame.shape, dtype=np.float32)
-        weights = np.zeros(self.frame.shape, dtype=np.float32)
-        kernels, covered = [None] * C, np.zeros(C, dtype=int)
+        layers = []  # dict(data, weights, kernels[C], taken[C])
         self._lowres = []
         self._loss_constant = 0.0  # observed pixels outside the model frame
+
+        def layer_for(idx):
+            for layer in layers:
+                if not layer["taken"][idx].any():
+                    return layer
+            layers.append(dict(data=np.zeros(self.frame.shape, dtype=np.float32),
+                               weights=np.zeros(self.frame.shape, dtype=np.float32),
+                               kernels=[None] * C, taken=np.zeros(C, dtype=bool)))
+            return layers[-1]
+
         for obs in self.observations:
             r = obs.renderer
             idx = [channels.index(c) for c in obs.channels]
-            covered[idx] += 1
             if type(r) is ResolutionRenderer:
-                # coarser pixel grid: its own term of the loss (smi_batch_attach_lowres);
-                # in the merged cube its channels carry zero weight
+                # coarser pixel grid: its own term of the loss (smi_batch_attach_lowres)
                 self._lowres.append((obs, idx))
                 continue
             if type(r) not in (NullRenderer, ConvolutionRenderer):
                 raise NotImplementedError(
-                    "renderer {} cannot run on the device".format(type(r).__name__))
+                    "renderer {} cannot run on the device (a user-defined renderer needs "
+                    "automatic differentiation)".format(type(r).__name__))
             if any(not p.fixed for p in obs.parameters):
                 raise NotImplementedError("free renderer parameters with several observations")
+            layer = layer_for(idx)
+            layer["taken"][idx] = True
+            data, weights = layer["data"], layer["weights"]
             if tuple(obs.shape[1:]) == spatial:
                 data[idx] = obs.data
                 weights[idx] = obs.weights
@@ -131,24 +143,36 @@ class Blend(CombinedComponent):
             if isinstance(r, ConvolutionRenderer):
                 k = np.asarray(r.kernel_image(), dtype=np.float32)
                 for j, c in enumerate(idx):
-                    kernels[c] = k[j if k.shape[0] > 1 else 0]
-        if np.any(covered != 1):
-            raise NotImplementedError("every model channel must be observed exactly once")
-        if all(k is None for k in kernels):
-            return data, weights, None
-        ph = max(k.shape[0] for k in kernels if k is not None)
-        pw = max(k.shape[1] for k in kernels if k is not None)
-        ph, pw = ph | 1, pw | 1  # odd, so that the stamps share their centre
-        kernel = np.zeros((C, ph, pw), dtype=np.float32)
-        for c, k in enumerate(kernels):
-            if k is None:
-                kernel[c, ph // 2, pw // 2] = 1
-            else:
-                oy, ox = ph // 2 - k.shape[0] // 2, pw // 2 - k.shape[1] // 2
-                kernel[c, oy:oy + k.shape[0], ox:ox + k.shape[1]] = k
-        if all(np.array_equal(kernel[0], kernel[c]) for c in range(1, C)):
-            kernel = kernel[:1]
-        return data, weights, kernel
+                    layer["kernels"][c] = k[j if k.shape[0] > 1 else 0]
+        if not layers:
+            layers.append(dict(data=np.zeros(self.frame.shape, dtype=np.float32),
+                               weights=np.zeros(self.frame.shape, dtype=np.float32),
+                               kernels=[None] * C, taken=np.zeros(C, dtype=bool)))
+        stamps = [k for layer in layers for k in layer["kernels"] if k is not None]
+        self._extra_layers = []
+        if not stamps:
+            if len(layers) > 1:
+                raise NotImplementedError("several NullRenderer observations of one channel")
+            return layers[0]["data"], layers[0]["weights"], None
+        ph = max(k.shape[0] for k in stamps) | 1  # odd, so that the stamps share their centre
+        pw = max(k.shape[1] for k in stamps) | 1
+
+        def stamp_cube(kernels):
+            kernel = np.zeros((C, ph, pw), dtype=np.float32)
+            for c, k in enumerate(kernels):
+                if k is None:
+                    kernel[c, ph // 2, pw // 2] = 1
+                else:
+                    oy, ox = ph // 2 - k.shape[0] // 2, pw // 2 - k.shape[1] // 2
+                    kernel[c, oy:oy + k.shape[0], ox:ox + k.shape[1]] = k
+            return kernel
+
+        cubes = [stamp_cube(layer["kernels"]) for layer in layers]
+        if len(layers) == 1 and all(np.array_equal(cubes[0][0], cubes[0][c]) for c in range(1, C)):
+            cubes[0] = cubes[0][:1]
+        self._extra_layers = [(layer["data"], layer["weights"], cube)
+                              for layer, cube in zip(layers[1:], cubes[1:])]
+        return layers[0]["data"], layers[0]["weights"], cubes[0]
 
     def _specs(self, comps):
         """Device description of every component.  Parameters whose constraint chain or
@@ -288,6 +312,8 @@ class Blend(CombinedComponent):
         for obs, idx in self._lowres:
             _, handle, _ = obs.renderer._resampler()
             batch.attach_lowres(handle, idx, obs.data, obs.weights, obs.log_norm)
+        for extra_data, extra_weights, extra_kernel in self._extra_layers:
+            batch.add_observation(extra_data[None], extra_weights[None], extra_kernel)
         if self._loss_constant:
             batch.add_loss_constant(self._loss_constant)
         self._upload_state(batch, comps)
@@ -727,9 +753,10 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
             # of the whole loss history after a restart (blend.py:101, 198)
             self.blend, self.base, self.local, self.result = blend, 0, 0, None
             self.obs = blend._observation()
-            if blend._lowres:
+            if blend._lowres or blend._extra_layers:
                 raise NotImplementedError(
-                    "fit_blends: blends with a ResolutionRenderer observation fit one by one")
+                    "fit_blends: blends with a ResolutionRenderer observation or with several "
+                    "observations of one channel fit one by one")
 
         @property
         def total(self):

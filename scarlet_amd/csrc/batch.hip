@@ -236,6 +236,15 @@ struct smi_batch {
     // of one range's update kernel overlaps the next iteration's convolution of the others
     int n_sub = 0;  // 0 = automatic
     std::vector<int32_t> h_comp_start;
+    // further observations of the batch on the model's pixel grid (smi_batch_add_observation):
+    // own data, weights and kernel spectrum; their loss partials follow layer 0's in
+    // loss_partial ([nb][(1 + n_layers) C]), their gradient images are added to Q via Q2
+    struct ObsLayer {
+        float *data = nullptr, *weights = nullptr;
+        float2 *Kt = nullptr;
+    };
+    std::vector<ObsLayer> layers;
+    float *Q2 = nullptr;
     // work items of the register-resident update kernels (common.h, BatchView::work)
     int32_t *work_items = nullptr;
     std::vector<int32_t> h_work_start;  // [kNumUpdateClasses][n_blends + 1]
@@ -302,7 +311,7 @@ void refresh_view(smi_batch *b) {
     v.have_prev = b->have_prev;
     v.scratch = b->scratch;
     v.loss_partial = b->loss_partial;
-    v.n_partial = b->fused ? b->d.C : (b->d.H * b->d.W + 255) / 256;
+    v.n_partial = b->fused ? b->d.C * (1 + (int)b->layers.size()) : (b->d.H * b->d.W + 255) / 256;
     v.plans = b->d_plans;
     v.max_levels = b->max_levels;
     v.fast_plans = 1;
@@ -773,6 +782,10 @@ int smi_batch_destroy(smi_batch *b) {
     for (auto e : b->sub_events) (void)hipEventDestroy(e);
     for (auto st : b->sub_streams) (void)hipStreamDestroy(st);
     for (auto *l : b->lowres) lowres_destroy(l);
+    for (auto &l : b->layers)
+        for (void *p : {(void *)l.data, (void *)l.weights, (void *)l.Kt})
+            if (p) (void)hipFree(p);
+    if (b->Q2) (void)hipFree(b->Q2);
     if (b->extra_terms) (void)hipFree(b->extra_terms);
     delete b;
     return SMI_OK;
@@ -1013,6 +1026,75 @@ int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
         SMI_HIP(hipStreamSynchronize(b->stream));
     }
     b->have_kernel = true;
+    return SMI_OK;
+}
+
+// Q += Q2 (gradient images of further observations)
+__global__ void add_images_kernel(float *Q, const float *Q2, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Q[i] += Q2[i];
+}
+
+// the further same-grid observations: loss partials (and with `backward` their gradient
+// images, added to Q) for the model cube in b->P
+static int layers_evaluate(smi_batch *b, const BatchView &v, int backward, hipStream_t s) {
+    const int C = b->d.C;
+    for (size_t l = 0; l < b->layers.size(); ++l) {
+        BatchView vl = v;
+        vl.data = b->layers[l].data;
+        vl.weights = b->layers[l].weights;
+        vl.loss_partial = v.loss_partial + (l + 1) * C;
+        const int rc = launch_fused_conv(vl, b->Fy, b->Fx, b->P, b->layers[l].Kt, b->d.kernel_bands,
+                                         b->d.kernel_per_blend, b->Q2, backward ? 0 : 1, nullptr, s);
+        if (rc) return rc;
+        if (backward) {
+            const int64_t n = (int64_t)b->d.n_blends * C * b->d.H * b->d.W;
+            hipLaunchKernelGGL(add_images_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                               b->Q, b->Q2, n);
+        }
+    }
+    return SMI_OK;
+}
+
+int smi_batch_add_observation(smi_batch *b, const float *data, const float *weights,
+                              const float *kernel) {
+    SMI_REQUIRE(b && data && weights && kernel, "null argument");
+    SMI_REQUIRE(b->have_obs && b->have_kernel, "add the first observation and its kernel first");
+    SMI_REQUIRE(b->fused, "further observations need the fused convolution path");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int nb = b->d.n_blends, C = b->d.C;
+    const size_t n = (size_t)nb * C * b->d.H * b->d.W;
+    smi_batch::ObsLayer layer;
+    int rc;
+    if ((rc = upload(&layer.data, data, n))) return rc;
+    if ((rc = upload(&layer.weights, weights, n))) return rc;
+    // kernel spectrum: the routine of smi_batch_set_kernel, into a buffer of its own
+    float2 *first = b->Kt;
+    b->Kt = nullptr;
+    rc = smi_batch_set_kernel(b, kernel);
+    layer.Kt = b->Kt;
+    b->Kt = first;
+    if (rc) return rc;
+    // log_norm of the layer joins the blend's (observation.py:172-186)
+    if (b->include_log_norm) {
+        double *d_ln = nullptr;
+        SMI_HIP(dev_alloc(&d_ln, (size_t)nb));
+        launch_log_norm(layer.weights, d_ln, nb, (int64_t)C * b->d.H * b->d.W, b->stream);
+        std::vector<double> ln(nb);
+        SMI_HIP(hipMemcpyAsync(ln.data(), d_ln, nb * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        SMI_HIP(hipStreamSynchronize(b->stream));
+        (void)hipFree(d_ln);
+        if ((rc = smi_batch_add_loss_constant(b, ln.data()))) return rc;
+    }
+    b->layers.push_back(layer);
+    if (!b->Q2) SMI_HIP(dev_alloc(&b->Q2, n));
+    if (b->loss_partial) SMI_HIP(hipFree(b->loss_partial));
+    b->loss_partial = nullptr;
+    SMI_HIP(dev_alloc(&b->loss_partial, (size_t)nb * C * (1 + b->layers.size())));
+    const int keep = b->view.max_box_pixels;
+    refresh_view(b);
+    b->view.max_box_pixels = keep;
     return SMI_OK;
 }
 
@@ -1406,6 +1488,7 @@ int smi_batch_forward(smi_batch *b, float *model, float *rendered, double *logL)
         if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
                                     b->d.kernel_per_blend, b->Q, 1, nullptr, b->stream)))
             return rc;
+        if ((rc = layers_evaluate(b, v, 0, b->stream))) return rc;
     } else if ((rc = convolve(b, v, 0))) {
         return rc;
     }
@@ -1448,6 +1531,7 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
         if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
                                     b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
             return rc;
+        if ((rc = layers_evaluate(b, v, 1, b->stream))) return rc;
     } else {
         launch_render(v, b->P, b->stream);
         if ((rc = lowres_evaluate_all(b, 1))) return rc;
@@ -1473,7 +1557,8 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
 
 // number of blend ranges a step is split into
 static int sub_ranges(const smi_batch *b) {
-    const bool plain = b->fused && b->n_point == 0 && b->n_shift == 0 && b->lowres.empty();
+    const bool plain = b->fused && b->n_point == 0 && b->n_shift == 0 && b->lowres.empty() &&
+                       b->layers.empty();
     if (!plain) return 1;
     const int nb = b->d.n_blends;
     // measured on MI355X (bench.py --blends N --sub-ranges n, 100 iterations): 128 blends 450 k
@@ -1602,6 +1687,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
             if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
                                         b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
                 return rc;
+            if ((rc = layers_evaluate(b, v, 1, b->stream))) return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
             launch_finalize(v, it, e_rel, min_iter, check, b->stream);
             if (ev) SMI_HIP(hipEventRecord(ev[3], b->stream));

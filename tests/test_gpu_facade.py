@@ -1046,3 +1046,70 @@ def test_observation_larger_than_the_model_frame(hsc, null_renderer):
     blend.fit(1, e_rel=1e-9)
     assert blend._loss_constant > 0
     assert abs(-blend.loss[0] - want) < 1e-6 * abs(want)
+
+
+def test_two_observations_of_the_same_channels(hsc):
+    """``Blend._loss_func`` sums over any number of observations (blend.py:264-271).  Two
+    same-grid observations that share model channels -- a second exposure of g, r, i with
+    another PSF and noise next to the five-band one -- are two terms of the loss and of the
+    gradient image (``smi_batch_add_observation``); the fit follows the oracle with the
+    same extra term."""
+    import scarlet_amd as scarlet
+    from oracle import pgm
+
+    filters = list("grizy")
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5)
+    frame = scarlet.Frame(hsc["images"].shape, psf=model_psf, channels=filters)
+    obs1 = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                               weights=hsc["weights"], channels=filters).match(frame)
+    rng = np.random.default_rng(11)
+    images2 = (hsc["images"][:3] * 0.9 + rng.normal(0, 0.05, hsc["images"][:3].shape)).astype(np.float32)
+    weights2 = (hsc["weights"][:3] * rng.uniform(0.3, 0.6, hsc["weights"][:3].shape)).astype(np.float32)
+    weights2[:, :5] = 0  # masked rows
+    psfs2 = scarlet.GaussianPSF(sigma=(1.6, 1.7, 1.8), boxsize=31).get_model().astype(np.float32)
+    obs2 = scarlet.Observation(images2, psf=scarlet.ImagePSF(psfs2), weights=weights2,
+                               channels=filters[:3]).match(frame)
+
+    def sources():
+        out = []
+        for k in range(int(hsc["n_comp"])):
+            h, w = hsc["morph_%d" % k].shape
+            oy, ox = hsc["origin_%d" % k]
+            box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+            out.append(scarlet.FactorizedComponent(
+                frame,
+                scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                          min_step=hsc["min_step_%d" % k]),
+                scarlet.ExtendedSourceMorphology(frame, (oy + h // 2, ox + w // 2),
+                                                 hsc["morph_%d" % k].copy(), bbox=box[1:],
+                                                 resizing=False)))
+        return out
+
+    blend = scarlet.Blend(sources(), [obs1, obs2])
+    n, logL = blend.fit(15, e_rel=1e-9)
+    assert len(blend._extra_layers) == 1 and n == 15
+
+    sc = hsc_scene(hsc)
+    for c in sc.components:
+        c.source = None
+    data2 = np.zeros(hsc["images"].shape, dtype=np.float32)
+    w2 = np.zeros(hsc["images"].shape, dtype=np.float32)
+    data2[:3], w2[:3] = images2, weights2
+    k2 = np.asarray(obs2.renderer.kernel_image(), dtype=np.float32)
+    ph = max(k2.shape[1], hsc["diff_kernel"].shape[1]) | 1
+    kernel2 = np.zeros((5, ph, ph), dtype=np.float32)
+    kernel2[:, ph // 2, ph // 2] = 1  # unobserved channels: weight zero, any kernel
+    o = ph // 2 - k2.shape[1] // 2
+    kernel2[:3, o:o + k2.shape[1], o:o + k2.shape[2]] = k2
+    sc.extra_observations = [pgm.SameGridObservation(data2, w2, kernel2)]
+    n_ref, logL_ref = sc.fit(15, e_rel=1e-9)
+    assert n_ref == 15
+    off = sc.log_norm + sc.extra_observations[0].log_norm
+    chi, chi_ref = np.array(blend.loss) - off, np.array(sc.loss) - off
+    assert_allclose(chi[0], chi_ref[0], rtol=RTOL)
+    assert_allclose(chi, chi_ref, rtol=2e-4)
+    assert chi[-1] < chi[0]
+    # and the single-observation fit is something else
+    alone = scarlet.Blend(sources(), obs1)
+    alone.fit(3, e_rel=1e-9)
+    assert abs(alone.loss[0] - blend.loss[0]) > 1e-3 * abs(blend.loss[0])
