@@ -264,12 +264,6 @@ struct Conv {
 };
 
 
-// element (row r of the chunk, column x) of the pair-packed scratch
-__device__ __forceinline__ float &zref(float2 *Z, int SX, int r, int x) {
-    float2 &e = Z[(r >> 1) * SX + x];
-    return (r & 1) ? e.y : e.x;
-}
-
 extern __shared__ __attribute__((aligned(16))) float2 lds_conv[];
 
 // model: the model cube [nb][C][H][W] (render_kernel)
@@ -368,47 +362,57 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int y0 = ch * 2 * kPairs;
         // data / weights of the chunk are fetched before the inverse row transforms so
-        // that their HBM latency hides behind them
-        constexpr int kRows = 2 * kPairs / (kThreads / 64);
+        // that their HBM latency hides behind them.  Wave w owns the row pairs w and
+        // w + 16 of the chunk: both rows of a pair at the lane's columns are one 8-byte
+        // element of the pair-packed scratch
+        constexpr int kWaves = kThreads / 64;
+        constexpr int kPairsW = kPairs / kWaves;  // pairs per wave
         constexpr int kXPre = kXIter > 2 ? 2 : kXIter;  // columns >= 128 are loaded late
-        float dpre[kRows][kXPre], wpre[kRows][kXPre];
+        static_assert(kPairs % kWaves == 0, "pairs per wave");
+        const int64_t band = ((int64_t)b * v.C + c) * H * W;
+        float dpre[kPairsW][2][kXPre], wpre[kPairsW][2][kXPre];
 #pragma unroll
-        for (int j = 0; j < kRows; ++j) {
-            const int y = y0 + wave + j * (kThreads / 64);
+        for (int j = 0; j < kPairsW; ++j)
 #pragma unroll
-            for (int q = 0; q < kXPre; ++q) {
-                const int x = lane + 64 * q;
-                dpre[j][q] = 0.f;
-                wpre[j][q] = 0.f;
-                if (x < W && y < H) {
-                    const int64_t iD = (((int64_t)b * v.C + c) * H + y) * W + x;
-                    dpre[j][q] = v.data[iD];
-                    wpre[j][q] = v.weights[iD];
+            for (int rr = 0; rr < 2; ++rr) {
+                const int y = y0 + 2 * (wave + j * kWaves) + rr;
+#pragma unroll
+                for (int q = 0; q < kXPre; ++q) {
+                    const int x = lane + 64 * q;
+                    dpre[j][rr][q] = 0.f;
+                    wpre[j][rr][q] = 0.f;
+                    if (x < W && y < H) {
+                        dpre[j][rr][q] = v.data[band + (int64_t)y * W + x];
+                        wpre[j][rr][q] = v.weights[band + (int64_t)y * W + x];
+                    }
                 }
             }
-        }
         cv.rows_inverse(ch);
 #pragma unroll
-        for (int j = 0; j < kRows; ++j) {
-            const int r = wave + j * (kThreads / 64);
-            const int y = y0 + r;
+        for (int j = 0; j < kPairsW; ++j) {
+            const int pair = wave + j * kWaves;
 #pragma unroll
             for (int q = 0; q < kXIter; ++q) {
                 const int x = lane + 64 * q;
                 if (x >= C::FX) continue;
-                float &slot = zref(cv.Z, C::SX, r, x);
-                float res = 0.f;
-                if (x < W && y < H) {
-                    const float m = slot;
-                    const int64_t iD = (((int64_t)b * v.C + c) * H + y) * W + x;
-                    if (mode == 1) out[iD] = m;
-                    const float dv = q < kXPre ? dpre[j][q < kXPre ? q : 0] : v.data[iD];
-                    const float wv = q < kXPre ? wpre[j][q < kXPre ? q : 0] : v.weights[iD];
-                    const float diff = m - dv;
-                    res = wv * diff;
-                    loss += (double)(res * diff);
+                float2 &slot = cv.Z[pair * C::SX + x];
+                const float2 m2 = slot;
+                float res[2] = {0.f, 0.f};
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int y = y0 + 2 * pair + rr;
+                    if (x < W && y < H) {
+                        const float m = rr ? m2.y : m2.x;
+                        const int64_t iD = band + (int64_t)y * W + x;
+                        if (mode == 1) out[iD] = m;
+                        const float dv = q < kXPre ? dpre[j][rr][q < kXPre ? q : 0] : v.data[iD];
+                        const float wv = q < kXPre ? wpre[j][rr][q < kXPre ? q : 0] : v.weights[iD];
+                        const float diff = m - dv;
+                        res[rr] = wv * diff;
+                        loss += (double)(res[rr] * diff);
+                    }
                 }
-                slot = res;
+                slot = make_float2(res[0], res[1]);
             }
         }
         __syncthreads();
@@ -429,13 +433,18 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int y0 = ch * 2 * kPairs;
         cv.rows_inverse(ch);
-        for (int r = wave; r < 2 * kPairs; r += kThreads / 64) {
-            const int y = y0 + r;
+        for (int pair = wave; pair < kPairs; pair += kThreads / 64) {
+            const int y = y0 + 2 * pair;
             if (y >= H) break;
+            float *row = out + ((int64_t)b * v.C + c) * H * W + (int64_t)y * W;
 #pragma unroll
             for (int q = 0; q < kXIter; ++q) {
                 const int x = lane + 64 * q;
-                if (x < W) out[(((int64_t)b * v.C + c) * H + y) * W + x] = zref(cv.Z, C::SX, r, x);
+                if (x < W) {
+                    const float2 g = cv.Z[pair * C::SX + x];  // both rows of the pair
+                    row[x] = g.x;
+                    if (y + 1 < H) row[W + x] = g.y;
+                }
             }
         }
         __syncthreads();
