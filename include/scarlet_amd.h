@@ -130,6 +130,11 @@ enum {
      * sub-iteration, gamma = alpha / max(psi) (type="relative", the reference's default,
      * constraint.py:117-145; lite/parameters.py:296-299) */
     SMI_PROX_L_RELATIVE = 1024,
+    /* MonotonicityConstraint(use_mask=True) (constraint.py:228-232): pixels that a
+     * strictly decreasing, positive 4-neighbour path connects to the centre
+     * (get_valid_monotonic_pixels, operators_pybind11.cc:61-125, variance 0) keep their
+     * value from before the sweep; needs SMI_PROX_MONOTONIC */
+    SMI_PROX_MONO_MASK = 2048,
     /* not a constraint: the component is a PointSource (source.py:92-128) whose
      * morphology is the model PSF evaluated at a free sub-pixel centre
      * (PointSourceMorphology, morphology.py:476-513; GaussianPSF, psf.py:80-142) */

@@ -27,6 +27,7 @@ PROX_L0 = 128
 PROX_FIT_CENTER = 256  # MonotonicityConstraint(fit_center_radius=1): 9 consecutive plans
 PROX_BG_THRESH = 512   # scarlet.lite background threshold (replaces positivity)
 PROX_L_RELATIVE = 1024  # L0/L1 threshold x step of the proximal sub-iteration
+PROX_MONO_MASK = 2048  # MonotonicityConstraint(use_mask=True)
 SCHEME_AMSGRAD, SCHEME_FISTA = 0, 1
 COMPONENT_POINT_SOURCE = 1 << 16  # PointSource: morphology = model PSF at a free centre
 COMPONENT_SHIFTING = 1 << 17  # image morphology moved by a free Fourier shift

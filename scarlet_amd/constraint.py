@@ -256,13 +256,13 @@ def device_flags(constraint):
             )
         rank = r
         if isinstance(c, MonotonicityConstraint):
-            if c.use_mask:
-                raise NotImplementedError("use_mask=True is not supported inside the device loop")
             if c.fit_center_radius > 1:
                 raise NotImplementedError("fit_center_radius > 1 is not supported on the device")
             out["flags"] |= _lib.PROX_MONOTONIC
             if c.fit_center:
                 out["flags"] |= _lib.PROX_FIT_CENTER
+            if c.use_mask:
+                out["flags"] |= _lib.PROX_MONO_MASK
             out["neighbor_weight"] = c.neighbor_weight
             out["min_gradient"] = float(c.min_gradient)
         elif isinstance(c, SymmetryConstraint):

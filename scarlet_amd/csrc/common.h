@@ -143,6 +143,7 @@ struct BatchView {
     int32_t max_box_pixels;
     int32_t max_levels;  // over all plans
     int32_t fast_plans;  // every plan has the slot layout
+    int32_t mono_mask;   // some component carries SMI_PROX_MONO_MASK (general update kernel)
     float b1, b2, eps;   // AMSGrad constants (defaults 0.9, 0.999, 1e-8: lite/parameters.py:194)
     // point sources: per component {offset y, x, m y, x, v y, x, vhat y, x} with
     // offset = centre - mean(box bounds) (morphology.py:503-507), and the PSF sigma
