@@ -331,17 +331,11 @@ def main():
     stream = torch.cuda.Stream(device=local_rank)
     batch.set_stream(stream.cuda_stream)
     batch.set_sub_ranges(args.sub_ranges)
-    seds0, morphs0 = batch.parameters()
-    zs = np.zeros_like(seds0)
-    zm = [np.zeros_like(m) for m in morphs0]
+    batch.save_state()  # parameters and optimizer state of iteration 0, kept on the device
 
     def fresh():
-        """parameters and optimizer state of iteration 0"""
-        batch.set_parameters(seds0, morphs0)
-        batch.set_moments(zs, zs, zs, zm, zm, zm)
-        if args.loop == "lite-fista":
-            batch.set_fista_state(seds0, morphs0, np.ones((len(seds0), 2)))
-        batch.reset()
+        """back to iteration 0 (device-to-device: the GPU does not idle before the timed region)"""
+        batch.restore_state()
 
     def run(it0, n):
         batch.step(it0, n, e_rel=e_rel, prox_max_iter=prox_max_iter, check_convergence=False)

@@ -355,6 +355,14 @@ int smi_batch_get_loss(smi_batch *b, double *out, int32_t capacity, int32_t *n_i
 /* Re-arm all blends (active, loss history cleared); parameters are kept. */
 int smi_batch_reset(smi_batch *b);
 
+/* Keep / bring back a device-side copy of everything a step changes (parameters, m / v /
+ * vhat, FISTA and point-source state): the warm restart of Blend.fit (X, M, V, Vhat carried
+ * into a new adaprox call, blend.py:155-170) without a round trip over the host.
+ * smi_batch_restore_state also re-arms the blends like smi_batch_reset.  Both are
+ * asynchronous on the batch stream. */
+int smi_batch_save_state(smi_batch *b);
+int smi_batch_restore_state(smi_batch *b);
+
 /* Mean device time in milliseconds of the dominant kernel family per iteration,
  * measured with hipEvents on the batch stream during the last smi_batch_step call
  * when timing was enabled with smi_batch_enable_timing(b, 1); with several ranges of

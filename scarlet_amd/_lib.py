@@ -176,6 +176,8 @@ SYMBOLS = {
     ),
     "smi_batch_get_loss": (ctypes.c_int, [ctypes.c_void_p, c_f64p, ctypes.c_int32, c_i32p]),
     "smi_batch_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "smi_batch_save_state": (ctypes.c_int, [ctypes.c_void_p]),
+    "smi_batch_restore_state": (ctypes.c_int, [ctypes.c_void_p]),
     "smi_batch_enable_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "smi_batch_get_timing": (ctypes.c_int, [ctypes.c_void_p, c_f64p, ctypes.c_int32]),
     "smi_batch_fft_shape": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),

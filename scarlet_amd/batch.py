@@ -415,6 +415,15 @@ class BlendBatch:
     def reset(self):
         _lib.check(self._lib.smi_batch_reset(self._h))
 
+    def save_state(self):
+        """Device-side copy of parameters and optimizer state (see ``restore_state``)."""
+        _lib.check(self._lib.smi_batch_save_state(self._h))
+
+    def restore_state(self):
+        """Back to the saved parameters and optimizer state, blends re-armed, loss
+        histories cleared; no host round trip."""
+        _lib.check(self._lib.smi_batch_restore_state(self._h))
+
     # -- parameters and optimizer state ---------------------------------------
     def parameters(self):
         """(seds (n_components, C), list of morphologies)."""

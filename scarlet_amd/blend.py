@@ -177,7 +177,7 @@ class Blend(CombinedComponent):
     def _specs(self, comps):
         """Device description of every component.  Parameters whose constraint chain or
         step rule the device cannot express (user ``Constraint`` subclasses, built-in
-        chains in another order, ``use_mask=True``, custom step callables) are listed in
+        chains in another order, custom step callables) are listed in
         ``self._host`` as ``(component index, HostParameter)``: the device treats them
         as fixed and without constraint, the host updates them (hoststep.py)."""
         specs = []

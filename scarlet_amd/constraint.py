@@ -5,7 +5,7 @@ Called stand-alone they act on host arrays (the monotonicity sweep goes through
 the C ABI to the GPU).  Inside ``Blend.fit`` the built-in chains are not called
 at all: the chain of a parameter is translated into ``SMI_PROX_*`` flags and runs
 fused in the device update kernel (``device_flags`` below).  A chain the device
-cannot express -- a user subclass, another order, ``use_mask=True`` -- is called
+cannot express -- a user subclass, another order -- is called
 as written, on the host, for that parameter only (``hoststep.py``).
 """
 

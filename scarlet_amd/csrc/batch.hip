@@ -220,8 +220,13 @@ struct smi_batch {
     float *c_center_floor = nullptr, *c_bg_level = nullptr, *c_fista_step = nullptr;
     float *c_sym_strength = nullptr;
     int32_t *c_chain_repeat = nullptr;
+    int32_t mono_mask = 0;  // a component carries SMI_PROX_MONO_MASK
     float *c_pos_floor = nullptr;
     double *fista_t = nullptr;
+    // smi_batch_save_state: device copies of everything a step changes
+    // {sed, morph, morph_param, m/v/vhat x2, fista_t, pt} and their sizes in bytes
+    void *saved[11] = {};
+    size_t saved_bytes[11] = {};
     int scheme = SMI_SCHEME_AMSGRAD;
     bool include_log_norm = true;
     bool lite_flags = false;  // some component uses FIT_CENTER / BG_THRESH
@@ -249,7 +254,7 @@ struct smi_batch {
     int32_t *work_items = nullptr;
     std::vector<int32_t> h_work_start;  // [kNumUpdateClasses][n_blends + 1]
     std::vector<hipStream_t> sub_streams;
-    std::vector<hipEvent_t> sub_events;  // [0] fork, [1 + s] join of range s
+    std::vector<hipEvent_t> sub_events;  // [0] fork, [s] join of range s >= 1
     // per blend
     int32_t *state = nullptr, *zero_state = nullptr, *n_loss = nullptr, *status_out = nullptr;
     double *loss_hist = nullptr, *last_loss = nullptr, *loss_partial = nullptr;
@@ -315,6 +320,7 @@ void refresh_view(smi_batch *b) {
     v.plans = b->d_plans;
     v.max_levels = b->max_levels;
     v.fast_plans = 1;
+    v.mono_mask = b->mono_mask;
     v.b1 = b->b1;
     v.b2 = b->b2;
     v.eps = b->eps;
@@ -785,6 +791,8 @@ int smi_batch_destroy(smi_batch *b) {
     for (auto &l : b->layers)
         for (void *p : {(void *)l.data, (void *)l.weights, (void *)l.Kt})
             if (p) (void)hipFree(p);
+    for (void *p : b->saved)
+        if (p) (void)hipFree(p);
     if (b->Q2) (void)hipFree(b->Q2);
     if (b->extra_terms) (void)hipFree(b->extra_terms);
     delete b;
@@ -1178,6 +1186,12 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     std::vector<float> full_strength(n, 1.f);
     UP(c_sym_strength, c->sym_strength ? c->sym_strength : full_strength.data(), n);
     UP(c_pos_floor, c->pos_floor ? c->pos_floor : zeros_n.data(), n);
+    b->mono_mask = 0;
+    for (int k = 0; k < n; ++k)
+        if (c->prox_flags[k] & SMI_PROX_MONO_MASK) {
+            SMI_REQUIRE(c->prox_flags[k] & SMI_PROX_MONOTONIC, "SMI_PROX_MONO_MASK needs SMI_PROX_MONOTONIC");
+            b->mono_mask = 1;
+        }
     bool repeats = false;
     for (int k = 0; k < n && c->chain_repeat; ++k) {
         SMI_REQUIRE(c->chain_repeat[k] >= 1, "chain_repeat must be >= 1");
@@ -1220,7 +1234,7 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         b->scratch = nullptr;
     }
     // x / psi / z of the generic update kernel fit the LDS up to ~100^2 pixels per box
-    if (4 * (size_t)((max_pix + 3) & ~3) * sizeof(float) + 4096 > 160 * 1024)
+    if ((4 + (b->mono_mask ? 1.25 : 0)) * ((max_pix + 3) & ~3) * sizeof(float) + 4096 > 160 * 1024)
         SMI_HIP(dev_alloc(&b->scratch, 3 * (size_t)b->n_morph));
     if (b->g_sed) SMI_HIP(hipFree(b->g_sed));
     if (b->g_morph) SMI_HIP(hipFree(b->g_morph));
@@ -1561,10 +1575,12 @@ static int sub_ranges(const smi_batch *b) {
                        b->layers.empty();
     if (!plain) return 1;
     const int nb = b->d.n_blends;
-    // measured on MI355X (bench.py --blends N --sub-ranges n, 100 iterations): 128 blends 450 k
-    // blend-it/s in one range, 508 k in two, 337 k in three; 256 blends 599 / 628 / 487 k (4);
-    // 1024 blends 705 / 751 / 748 k -- two ranges from a config-3 shard (128 blends) on
-    int n = b->n_sub > 0 ? b->n_sub : (nb >= 128 ? 2 : 1);
+    // measured on MI355X (bench.py --blends N --sub-ranges n --steps 20, k blend-it/s for
+    // n = 2 / 3 / 4): 128 blends 506 / 508 / 335, 256 blends 658 / 673 / 498, 512 blends
+    // 760 / 785 / 662, 1024 blends 824 / 829 / 781.  Range 0 runs on the batch stream, so
+    // three ranges sit on three of HIP's four hardware queues; a fourth shares one (with
+    // GPU_MAX_HW_QUEUES=8 four ranges give 517 / 842 k at 128 / 1024 blends, six fewer).
+    int n = b->n_sub > 0 ? b->n_sub : (nb >= 128 ? 3 : 1);
     return std::max(1, std::min(n, nb));
 }
 
@@ -1572,12 +1588,15 @@ static int sub_ranges(const smi_batch *b) {
 static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter, float e_rel,
                            int32_t min_iter, int32_t prox_max_iter, int check) {
     int rc;
-    while ((int)b->sub_streams.size() < n_sub) {
+    // range 0 stays on the batch stream, the others get streams of their own.  HIP maps
+    // streams onto 4 hardware queues round-robin (GPU_MAX_HW_QUEUES); streams that share a
+    // queue run one after the other, so more than 4 ranges do not overlap any further.
+    while ((int)b->sub_streams.size() < n_sub - 1) {
         hipStream_t st;
         SMI_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         b->sub_streams.push_back(st);
     }
-    while ((int)b->sub_events.size() < n_sub + 1) {
+    while ((int)b->sub_events.size() < n_sub) {
         hipEvent_t e;
         SMI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         b->sub_events.push_back(e);
@@ -1601,13 +1620,13 @@ static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter,
         views[s].n_comp = b->h_comp_start[hi] - b->h_comp_start[lo];
     }
     SMI_HIP(hipEventRecord(b->sub_events[0], b->stream));
-    for (int s = 0; s < n_sub; ++s)
-        SMI_HIP(hipStreamWaitEvent(b->sub_streams[s], b->sub_events[0], 0));
+    for (int s = 1; s < n_sub; ++s)
+        SMI_HIP(hipStreamWaitEvent(b->sub_streams[s - 1], b->sub_events[0], 0));
     for (int i = 0; i < n_iter; ++i) {
         const int it = it0 + i;
         for (int s = 0; s < n_sub; ++s) {
             const BatchView &v = views[s];
-            hipStream_t st = b->sub_streams[s];
+            hipStream_t st = s == 0 ? b->stream : b->sub_streams[s - 1];
             // phase times are those of range 0 (its kernels overlap the other ranges')
             hipEvent_t *ev = timing && s == 0 ? &b->events[(size_t)i * 6] : nullptr;
             if (ev) SMI_HIP(hipEventRecord(ev[0], st));
@@ -1626,9 +1645,9 @@ static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter,
             if (ev) SMI_HIP(hipEventRecord(ev[5], st));
         }
     }
-    for (int s = 0; s < n_sub; ++s) {
-        SMI_HIP(hipEventRecord(b->sub_events[1 + s], b->sub_streams[s]));
-        SMI_HIP(hipStreamWaitEvent(b->stream, b->sub_events[1 + s], 0));
+    for (int s = 1; s < n_sub; ++s) {
+        SMI_HIP(hipEventRecord(b->sub_events[s], b->sub_streams[s - 1]));
+        SMI_HIP(hipStreamWaitEvent(b->stream, b->sub_events[s], 0));
     }
     SMI_HIP(hipGetLastError());
     return SMI_OK;
@@ -1809,6 +1828,60 @@ int smi_batch_reset(smi_batch *b) {
     SMI_HIP(hipMemset(b->n_loss, 0, nb * sizeof(int32_t)));
     SMI_HIP(hipMemset(b->last_loss, 0, nb * sizeof(double)));
     SMI_HIP(hipMemset(b->have_prev, 0, nb * sizeof(int32_t)));
+    return SMI_OK;
+}
+
+namespace {
+// the arrays a step changes, in the order of smi_batch::saved
+void mutable_state(smi_batch *b, void **ptr, size_t *bytes) {
+    const size_t n = (size_t)b->d.n_components, nC = n * b->d.C, nm = (size_t)b->n_morph;
+    void *p[11] = {b->sed, b->morph, b->morph_param, b->mom[0], b->mom[1], b->mom[2], b->mom[3],
+                   b->mom[4], b->mom[5], b->fista_t, b->pt};
+    const size_t s[11] = {nC * 4, nm * 4, nm * 4, nC * 4, nC * 4, nC * 4, nm * 4, nm * 4, nm * 4,
+                          n * 2 * sizeof(double), n * 8 * sizeof(double)};
+    for (int i = 0; i < 11; ++i) {
+        ptr[i] = p[i];
+        bytes[i] = p[i] ? s[i] : 0;
+    }
+}
+}  // namespace
+
+int smi_batch_save_state(smi_batch *b) {
+    SMI_REQUIRE(b && b->have_components, "components not set");
+    SMI_HIP(hipSetDevice(b->device));
+    void *ptr[11];
+    size_t bytes[11];
+    mutable_state(b, ptr, bytes);
+    for (int i = 0; i < 11; ++i) {
+        if (b->saved[i] && b->saved_bytes[i] != bytes[i]) {
+            SMI_HIP(hipFree(b->saved[i]));
+            b->saved[i] = nullptr;
+        }
+        b->saved_bytes[i] = bytes[i];
+        if (!bytes[i]) continue;
+        if (!b->saved[i]) SMI_HIP(hipMalloc(&b->saved[i], bytes[i]));
+        SMI_HIP(hipMemcpyAsync(b->saved[i], ptr[i], bytes[i], hipMemcpyDeviceToDevice, b->stream));
+    }
+    return SMI_OK;
+}
+
+int smi_batch_restore_state(smi_batch *b) {
+    SMI_REQUIRE(b && b->have_components, "components not set");
+    SMI_HIP(hipSetDevice(b->device));
+    void *ptr[11];
+    size_t bytes[11];
+    mutable_state(b, ptr, bytes);
+    for (int i = 0; i < 11; ++i) {
+        SMI_REQUIRE(bytes[i] == b->saved_bytes[i] && (!bytes[i] || b->saved[i]),
+                    "no saved state for these components (smi_batch_save_state)");
+        if (bytes[i])
+            SMI_HIP(hipMemcpyAsync(ptr[i], b->saved[i], bytes[i], hipMemcpyDeviceToDevice, b->stream));
+    }
+    const int nb = b->d.n_blends;
+    SMI_HIP(hipMemsetAsync(b->state, 0, nb * sizeof(int32_t), b->stream));
+    SMI_HIP(hipMemsetAsync(b->n_loss, 0, nb * sizeof(int32_t), b->stream));
+    SMI_HIP(hipMemsetAsync(b->last_loss, 0, nb * sizeof(double), b->stream));
+    SMI_HIP(hipMemsetAsync(b->have_prev, 0, nb * sizeof(int32_t), b->stream));
     return SMI_OK;
 }
 

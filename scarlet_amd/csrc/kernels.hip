@@ -551,6 +551,41 @@ __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCt
     }
 }
 
+// MonotonicityConstraint(use_mask=True) (constraint.py:228-232 -> operator.py:131-176 with
+// center_radius = 0, variance = 0, max_iter = 0): the pixels that get_valid_monotonic_pixels
+// (operators_pybind11.cc:61-125) accepts -- reachable from `start` over 4-neighbour steps
+// onto a strictly smaller, positive value -- keep the value they had before the sweep.
+// The accepted set is the closure of that relation, so it is relaxed in parallel until
+// nothing changes (as mask.hip does); `ws` receives the image, `fl` the accepted flags.
+__device__ __forceinline__ void monotonic_mask(const float *us, float *ws, uint8_t *fl,
+                                               const CompCtx &c, int start) {
+    const int N = c.N, w = c.w, h = c.h, lane = c.lane;
+    for (int i = lane; i < N; i += 64) {
+        ws[i] = us[i];
+        fl[i] = i == start;
+    }
+    wave_lds_fence();
+    for (;;) {
+        int changed = 0;
+        for (int i = lane; i < N; i += 64) {
+            if (fl[i]) continue;
+            const float val = ws[i];
+            if (!(val > 0.f)) continue;
+            const int y = i / w, x = i - y * w;
+            const bool accept = (y > 0 && fl[i - w] && val < ws[i - w]) ||
+                                (y < h - 1 && fl[i + w] && val < ws[i + w]) ||
+                                (x > 0 && fl[i - 1] && val < ws[i - 1]) ||
+                                (x < w - 1 && fl[i + 1] && val < ws[i + 1]);
+            if (accept) {
+                fl[i] = 1;
+                changed = 1;
+            }
+        }
+        wave_lds_fence();
+        if (!wave_or(changed)) break;
+    }
+}
+
 // -- generic variant: everything in LDS, plans with any number of terms -----
 __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G, int it,
                                                     float e_rel, int prox_max_iter,
@@ -569,6 +604,9 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     float *zs = rs + (v.scratch ? c.N : npad);
     float *us = v.scratch ? lds_dyn : zs + npad;  // candidate (and g_morph before that)
     int32_t *lvl = reinterpret_cast<int32_t *>(us + npad);  // level_start of the plan
+    // SMI_PROX_MONO_MASK: image before the sweep and the flags of the accepted pixels
+    float *ws = reinterpret_cast<float *>(lvl + ((v.max_levels + 2 + 3) & ~3));
+    uint8_t *fl = reinterpret_cast<uint8_t *>(ws + npad);
 
     float g_sed = gather_gradient(v, c, G, us);
     __syncthreads();
@@ -658,14 +696,25 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         // the convergence pass below
         float div = 1.f;
         for (int rep = 0; rep < repeat; ++rep) {
+            int start = ctr;
             if (fit_center) {
-                pl = v.plans[plan_id + fit_center_index(us, c)];
+                const int j = fit_center_index(us, c);
+                start = ctr + (j / 3 - 1) * c.w + (j % 3 - 1);
+                pl = v.plans[plan_id + j];
                 for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
                 __syncthreads();
             }
+            const bool masked = monotonic && (flags & SMI_PROX_MONO_MASK);
+            if (masked) monotonic_mask(us, ws, fl, c, start);
             if (monotonic)
                 sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
                                            pl.nbr, pl.wt, one_minus_g, lane);
+            if (masked) {
+                __syncthreads();
+                for (int i = lane; i < N; i += 64)
+                    if (fl[i]) us[i] = ws[i];
+                __syncthreads();
+            }
             chain_symmetry_threshold(us, c, flags, lthresh, sed_new, bg_level,
                                      (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[c.k] : 1.f);
             float mx = -INFINITY, sm = 0.f;
@@ -1415,7 +1464,10 @@ void launch_cmul(float2 *S, const float2 *K, int32_t nb, int32_t C, int64_t plan
 
 static size_t update_lds_bytes(const BatchView &v) {
     const size_t npad = (v.max_box_pixels + 3) & ~3;
-    return (v.scratch ? 1 : 4) * npad * sizeof(float) + (size_t)(v.max_levels + 2) * sizeof(int32_t);
+    size_t bytes = (v.scratch ? 1 : 4) * npad * sizeof(float);
+    if (v.mono_mask)  // image before the sweep + flags of the accepted pixels
+        return bytes + (size_t)((v.max_levels + 2 + 3) & ~3) * sizeof(int32_t) + npad * 5;
+    return bytes + (size_t)(v.max_levels + 2) * sizeof(int32_t);
 }
 
 template <int NPL>
@@ -1441,7 +1493,8 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
                   int32_t grad_only, hipStream_t s) {
     if (v.n_comp == 0) return SMI_OK;
     // chains that repeat take the general kernel (the register-resident ones apply it once)
-    if (!grad_only && v.fast_plans && v.max_box_pixels <= 64 * 59 && !v.c_chain_repeat) {
+    if (!grad_only && v.fast_plans && v.max_box_pixels <= 64 * 59 && !v.c_chain_repeat &&
+        !v.mono_mask) {
         // one launch per size class that has components in this range of blends, the
         // largest boxes (longest sweeps) first
         for (int cls = kNumUpdateClasses - 1; cls >= 0; --cls) {

@@ -5,7 +5,7 @@ whose proximal operator or step rule is user code.
 callable ``prox(X, step)`` and evaluates callable steps as ``step(X, it)``.  The device
 loop only knows the built-in chains (``constraint.device_flags``).  A parameter with
 anything else -- a ``Constraint`` subclass, a built-in chain in another order,
-``MonotonicityConstraint(use_mask=True)``, a custom step callable -- stays with the
+``MonotonicMaskConstraint``, a custom step callable -- stays with the
 host: per iteration the device still renders, convolves and gathers the gradient of
 every parameter (``smi_batch_gradient``) and updates all parameters it can express;
 the host takes the AMSGrad step and the proximal sub-iterations of the rest with the

@@ -978,27 +978,55 @@ def test_user_step_callable_and_user_morphology_chain(hsc):
                       - np.asarray(b.children[1].parameters[0])).max() < 1e-4
 
 
-def test_use_mask_and_foreign_chain_orders_fit_host_stepped(hsc):
-    """``MonotonicityConstraint(use_mask=True)`` (reference constraint.py:228-232) and a
-    chain in an order the fused device chain does not have run through the host prox"""
+def test_use_mask_on_the_device_and_foreign_chain_orders_host_stepped(hsc):
+    """``MonotonicityConstraint(use_mask=True)`` (reference constraint.py:228-232) runs in the
+    device chain (SMI_PROX_MONO_MASK): the fit equals the one where the same chain is hidden
+    in a user ``Constraint`` and therefore stepped on the host through
+    ``operator.prox_monotonic_mask``.  A chain in an order the fused device chain does not
+    have runs through the host prox."""
     import scarlet_amd as scarlet
 
-    def masked(blend):
-        for comp in components_of(blend)[:3]:
-            comp.children[1].parameters[0].constraint = scarlet.ConstraintChain(
-                scarlet.MonotonicityConstraint(neighbor_weight="angle", min_gradient=0, use_mask=True),
-                scarlet.PositivityConstraint(), scarlet.CenterOnConstraint(),
-                scarlet.NormalizationConstraint("max"))
-        # positivity before monotonicity: not the device order
-        components_of(blend)[3].children[1].parameters[0].constraint = scarlet.ConstraintChain(
-            scarlet.PositivityConstraint(),
-            scarlet.MonotonicityConstraint(neighbor_weight="flat", min_gradient=0.1),
+    def chain(fit_center=0):
+        return scarlet.ConstraintChain(
+            scarlet.MonotonicityConstraint(neighbor_weight="angle", min_gradient=0, use_mask=True,
+                                           fit_center_radius=fit_center),
+            scarlet.PositivityConstraint(), scarlet.CenterOnConstraint(),
             scarlet.NormalizationConstraint("max"))
+
+    class Hidden(scarlet.Constraint):
+        def __init__(self, inner):
+            self.inner = inner
+
+        def __call__(self, X, step):
+            return self.inner(X, step)
+
+    def masked(blend, wrap=lambda c: c):
+        for i, comp in enumerate(components_of(blend)[:3]):
+            comp.children[1].parameters[0].constraint = wrap(chain(fit_center=i == 2))
+
+    device, _ = build_blend(hsc, resizing=False)
+    masked(device)
+    host, _ = build_blend(hsc, resizing=False)
+    masked(host, Hidden)
+    plain, _ = build_blend(hsc, resizing=False)
+    results = [b.fit(12, e_rel=1e-6) for b in (device, host, plain)]
+    assert len(device._host) == 0 and len(host._host) == 3
+    assert [r[0] for r in results] == [12, 12, 12]
+    assert_allclose(device.loss, host.loss, rtol=2e-5)  # the user chain divides by the maximum (DESIGN 8.6)
+    assert not np.allclose(device.loss, plain.loss, rtol=1e-6)  # the mask does something
+    for a, b in zip(components_of(device), components_of(host)):
+        assert_allclose(np.asarray(a.children[1].parameters[0]),
+                        np.asarray(b.children[1].parameters[0]), atol=1e-4)
 
     blend, _ = build_blend(hsc, resizing=True)
     masked(blend)
+    # positivity before monotonicity: not the device order
+    components_of(blend)[3].children[1].parameters[0].constraint = scarlet.ConstraintChain(
+        scarlet.PositivityConstraint(),
+        scarlet.MonotonicityConstraint(neighbor_weight="flat", min_gradient=0.1),
+        scarlet.NormalizationConstraint("max"))
     n, logL = blend.fit(25, e_rel=1e-6)
-    assert len(blend._host) == 4 and n == 25 and np.isfinite(logL)
+    assert len(blend._host) == 1 and n == 25 and np.isfinite(logL)
     assert logL > -blend.loss[0]
     for comp in components_of(blend)[:4]:
         image = np.asarray(comp.children[1].parameters[0])
@@ -1006,7 +1034,7 @@ def test_use_mask_and_foreign_chain_orders_fit_host_stepped(hsc):
     # many blends: the host-stepped one fits alone, the others in the batch
     a, _ = build_blend(hsc, resizing=False)
     b, _ = build_blend(hsc, resizing=False)
-    masked(b)
+    masked(b, Hidden)
     c, _ = build_blend(hsc, resizing=False)
     out = scarlet.fit_blends([a, b, c], 8, e_rel=1e-9)
     assert [r[0] for r in out] == [8, 8, 8] and out[0] == out[2] and out[1] != out[0]

@@ -747,7 +747,7 @@ def test_sub_ranges_on_streams_do_not_change_results(amd):
     """smi_batch_set_sub_ranges: ranges of blends stepped on streams of their own give
     bit-identical losses, iteration counts and parameters for every number of ranges,
     ragged blends (different component counts, an empty one) and convergence freezing
-    included; the automatic choice is 2 ranges from 256 blends on."""
+    included; the automatic choice is 3 ranges from 128 blends on."""
     from scarlet_amd import synthetic
 
     kern = synthetic.psfs()
@@ -785,7 +785,7 @@ def test_sub_ranges_on_streams_do_not_change_results(amd):
             else:
                 for a, b_ in zip(got[4][key], want):
                     assert_array_equal(a, b_)
-    # the automatic choice at the benchmark's scale: two ranges from 256 blends on
+    # the automatic choice at the benchmark's scale: three ranges from 128 blends on
     many = synthetic.make_batch(range(3000, 3256), kernel=kern)
     hist = []
     for n_sub in (0, 1):
@@ -795,7 +795,7 @@ def test_sub_ranges_on_streams_do_not_change_results(amd):
                            np.stack([s["weights"] for s in many]), comps, kernel=kern[2],
                            max_iter=5)
         b.set_sub_ranges(n_sub)
-        assert b.sub_ranges() == (2 if n_sub == 0 else 1)
+        assert b.sub_ranges() == (3 if n_sub == 0 else 1)
         b.step(0, 4, e_rel=1e-3)
         hist.append(np.array(b.loss_history()))
         b.close()
@@ -976,6 +976,49 @@ def test_batch_fit_to_convergence_mixed_states(amd):
         assert abs(int(n_iter[b]) - n_ref) <= max(2, n_ref // 10)
         chi, chi_ref = -logL[b] - sc.log_norm, -logL_ref - sc.log_norm
         assert abs(chi - chi_ref) < 3e-3 * abs(chi_ref)
+
+
+def test_saved_state_restarts_the_fit_bit_for_bit(amd):
+    """smi_batch_save_state / smi_batch_restore_state (the warm restart of blend.py:155-170
+    kept on the device): a fit repeated from the saved state gives the same losses,
+    parameters and moments bit for bit, for image components and for point sources"""
+    from conftest import golden
+    from scarlet_amd import synthetic
+
+    kern = synthetic.psfs()
+    scenes = synthetic.make_batch(range(900, 904), kernel=kern)
+    comps = [[amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                                sed_min_step=s["noise_rms"]) for k in range(10)] for s in scenes]
+    extended = amd.BlendBatch(np.stack([s["data"] for s in scenes]),
+                              np.stack([s["weights"] for s in scenes]), comps, kernel=kern[2],
+                              max_iter=12)
+    for batch in (extended, _point_batch(amd, golden("point_source"), max_iter=12)):
+        with pytest.raises(RuntimeError, match="no saved state"):
+            batch.restore_state()
+        batch.step(0, 3, e_rel=1e-3)  # a state with non-trivial moments
+        batch.save_state()
+        seds0, morphs0 = batch.parameters()
+        runs = []
+        for _ in range(2):
+            batch.step(3, 6, e_rel=1e-3)
+            runs.append((batch.loss_history(), batch.parameters(), batch.moments(),
+                         batch.centers()))
+            batch.restore_state()
+            seds, morphs = batch.parameters()
+            assert np.array_equal(seds, seds0)
+            assert all(np.array_equal(a, b) for a, b in zip(morphs, morphs0))
+            assert all(len(l) == 0 for l in batch.loss_history())
+        (l0, p0, m0, c0), (l1, p1, m1, c1) = runs
+        assert all(len(a) == 6 and np.array_equal(a, b) for a, b in zip(l0, l1))
+        assert np.array_equal(p0[0], p1[0])
+        assert all(np.array_equal(a, b) for a, b in zip(p0[1], p1[1]))
+        for name in m0:
+            if name.endswith("sed"):
+                assert np.array_equal(m0[name], m1[name])
+            else:
+                assert all(np.array_equal(x, y) for x, y in zip(m0[name], m1[name]))
+        assert all(np.array_equal(c0[k], c1[k]) for k in c0)
+        batch.close()
 
 
 # ---------------------------------------------------------------- point sources
