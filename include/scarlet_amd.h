@@ -237,6 +237,29 @@ int smi_batch_set_observation_device(smi_batch *b, const float *d_data,
                                      const float *d_weights);
 /* kernel: [kernel_per_blend ? n_blends : 1][kernel_bands][kernel_h][kernel_w] */
 int smi_batch_set_kernel(smi_batch *b, const float *kernel);
+
+/* ConvolutionRenderer(psf_shift=...) (renderer.py:175-177, 215-228): the difference kernel
+ * is moved by a free sub-pixel Fourier shift (fft.shift, fft.py:399-428) that the fit
+ * updates like any other parameter (no constraint, AMSGrad step `step`, 1e-2 in the
+ * reference).  Call after smi_batch_set_observation and smi_batch_set_components instead
+ * of smi_batch_set_kernel.
+ *   kernel    [n_sets][kernel_bands][h0][w0]: the unshifted stamps as the renderer holds
+ *             them (h0 <= kernel_h, w0 <= kernel_w; centred in the batch's odd stamp);
+ *             n_sets = kernel_per_blend ? n_blends : 1 (a shared kernel needs n_blends = 1)
+ *   fft_shape FFT lengths (y, x) fft.shift uses for an (h0, w0) image (fft.py:116-167 with
+ *             padding 10): the periodic interpolation depends on them
+ *   shift     [n_sets][2] initial (y, x); moments [n_sets][6] = m, v, vhat (y, x each) or NULL
+ * Every smi_batch_step then evaluates d(-logL)/d(shift) = sum w (m - d) (model (*) dK/ds)
+ * at the parameters of the iteration, steps the shift and rebuilds the kernel spectrum on
+ * the device; smi_batch_gradient evaluates the gradient only.  smi_batch_set_kernel makes
+ * the kernel fixed again. */
+int smi_batch_set_kernel_shift(smi_batch *b, const float *kernel, int32_t h0, int32_t w0,
+                               const int32_t *fft_shape, const double *shift,
+                               const double *moments, double step);
+/* shift [n_sets][2], moments [n_sets][6], gradient [n_sets][2] (last evaluation), kernel
+ * [n_sets][kernel_bands][kernel_h][kernel_w] at the current shift; any may be NULL */
+int smi_batch_get_kernel_shift(smi_batch *b, double *shift, double *moments, double *gradient,
+                               float *kernel);
 int smi_batch_set_components(smi_batch *b, const smi_components *comps);
 
 /* AMSGrad moments (blend.py:153-163), same packing as sed / morph; NULL = zeros */

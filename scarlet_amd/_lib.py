@@ -176,6 +176,9 @@ SYMBOLS = {
     ),
     "smi_batch_get_loss": (ctypes.c_int, [ctypes.c_void_p, c_f64p, ctypes.c_int32, c_i32p]),
     "smi_batch_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "smi_batch_set_kernel_shift": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_int32, ctypes.c_int32,
+                                                  c_i32p, c_f64p, c_f64p, ctypes.c_double]),
+    "smi_batch_get_kernel_shift": (ctypes.c_int, [ctypes.c_void_p, c_f64p, c_f64p, c_f64p, c_f32p]),
     "smi_batch_save_state": (ctypes.c_int, [ctypes.c_void_p]),
     "smi_batch_restore_state": (ctypes.c_int, [ctypes.c_void_p]),
     "smi_batch_enable_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),

@@ -259,6 +259,48 @@ class BlendBatch:
         assert kernel.shape == self._kernel_shape, "kernel shape is fixed at construction"
         _lib.check(self._lib.smi_batch_set_kernel(self._h, _lib.ptr(kernel, ctypes.c_float)))
 
+    def set_kernel_shift(self, kernel, shift, fft_shape, step=1e-2, m=None, v=None, vhat=None):
+        """``ConvolutionRenderer(psf_shift=...)`` (renderer.py:175-177, 215-228): from now on
+        the difference kernel is ``fft.shift(kernel, shift)`` with ``shift`` a free
+        parameter of the fit (``smi_batch_set_kernel_shift``).
+
+        kernel: the unshifted stamps ``(n_sets, kernel_bands, h0, w0)`` (or without the
+            leading axis for one set), at most the stamp shape given at construction
+        shift: ``(n_sets, 2)`` or ``(2,)``; ``m``, ``v``, ``vhat`` likewise (warm start)
+        fft_shape: FFT lengths ``fft.shift`` uses for an ``(h0, w0)`` image"""
+        kernel = _lib.f32(kernel)
+        if kernel.ndim == 3:
+            kernel = kernel[None]
+        n_sets = kernel.shape[0]
+        assert kernel.shape[1] == self._kernel_shape[-3], "number of kernel bands is fixed at construction"
+        shift = np.ascontiguousarray(np.asarray(shift, dtype=np.float64).reshape(n_sets, 2))
+        moments = None
+        if m is not None or v is not None or vhat is not None:
+            moments = np.ascontiguousarray(np.stack(
+                [np.zeros((n_sets, 2)) if a is None else np.asarray(a, dtype=np.float64).reshape(n_sets, 2)
+                 for a in (m, v, vhat)], axis=1))
+        _lib.check(self._lib.smi_batch_set_kernel_shift(
+            self._h, _lib.ptr(kernel, ctypes.c_float), kernel.shape[2], kernel.shape[3],
+            _lib.ptr(_lib.i32(fft_shape), ctypes.c_int32), _lib.ptr(shift, ctypes.c_double),
+            _lib.ptr(moments, ctypes.c_double), float(step)))
+        self._kernel_sets = n_sets
+
+    def kernel_shift(self, kernel=False):
+        """State of the free kernel shift: dict of ``(n_sets, 2)`` float64 arrays ``shift``,
+        ``m``, ``v``, ``vhat``, ``gradient`` (d(-logL)/d(shift) of the last ``step`` /
+        ``gradient`` call) and, on request, ``kernel``: the stamps at the current shift."""
+        n = self._kernel_sets
+        shift, grad, mom = np.zeros((n, 2)), np.zeros((n, 2)), np.zeros((n, 3, 2))
+        stamps = np.zeros((n,) + tuple(self._kernel_shape[-3:]), dtype=np.float32) if kernel else None
+        _lib.check(self._lib.smi_batch_get_kernel_shift(
+            self._h, _lib.ptr(shift, ctypes.c_double), _lib.ptr(mom, ctypes.c_double),
+            _lib.ptr(grad, ctypes.c_double), _lib.ptr(stamps, ctypes.c_float)))
+        out = dict(shift=shift, m=mom[:, 0].copy(), v=mom[:, 1].copy(), vhat=mom[:, 2].copy(),
+                   gradient=grad)
+        if kernel:
+            out["kernel"] = stamps
+        return out
+
     def set_optimizer(self, b1=0.9, b2=0.999, eps=1e-8):
         """AMSGrad constants (``proxmin.adaprox`` keywords b1, b2, eps)."""
         _lib.check(self._lib.smi_batch_set_optimizer(self._h, b1, b2, eps))

@@ -14,7 +14,7 @@ from functools import partial
 import numpy as np
 import numpy.ma as ma
 
-from . import _lib
+from . import _lib, fft
 from .batch import BlendBatch, ComponentSpec, PointSourceSpec
 from .bbox import overlapped_slices
 from .component import CombinedComponent, FactorizedComponent
@@ -27,6 +27,10 @@ from .parameter import relative_step
 from .renderer import ConvolutionRenderer, NullRenderer, ResolutionRenderer
 
 logger = logging.getLogger("scarlet_amd.blend")
+
+
+class _HostSteppedShift(Exception):
+    """the batch cannot step the kernel shift on the device (no fused convolution)"""
 
 
 def _flatten(sources):
@@ -111,7 +115,7 @@ class Blend(CombinedComponent):
                 raise NotImplementedError(
                     "renderer {} cannot run on the device (a user-defined renderer needs "
                     "automatic differentiation)".format(type(r).__name__))
-            if any(not p.fixed for p in obs.parameters):
+            if any(not p.fixed for p in obs.parameters) and getattr(self, "_psf", None) is None:
                 raise NotImplementedError("free renderer parameters with several observations")
             layer = layer_for(idx)
             layer["taken"][idx] = True
@@ -309,6 +313,21 @@ class Blend(CombinedComponent):
         data, weights, kernel = self._observation()
         batch = BlendBatch(data[None], weights[None], [self._specs(comps)], kernel=kernel,
                            max_iter=max(capacity, 1), device=self.device)
+        if getattr(self, "_psf", None) is not None:
+            # ConvolutionRenderer(psf_shift=...): the kernel moves with a free shift that
+            # the device steps along with the components (smi_batch_set_kernel_shift)
+            shift, renderer = self._psf
+            image = np.asarray(renderer.diff_kernel.image, dtype=np.float32)
+            try:
+                batch.set_kernel_shift(
+                    image[:kernel.shape[0]], np.asarray(shift), step=self._psf_step,
+                    fft_shape=fft._get_fft_shape(image, image, padding=10, axes=(-2, -1)),
+                    m=shift.m, v=shift.v, vhat=shift.vhat)
+            except _lib.ScarletAmdError as err:
+                batch.close()
+                if "fused" in str(err):
+                    raise _HostSteppedShift()
+                raise
         for obs, idx in self._lowres:
             _, handle, _ = obs.renderer._resampler()
             batch.attach_lowres(handle, idx, obs.data, obs.weights, obs.log_norm)
@@ -361,6 +380,11 @@ class Blend(CombinedComponent):
         self._download_all(batch, comps)
         for _, hp in getattr(self, "_host", ()):
             hp.store()
+        if getattr(self, "_psf", None) is not None:
+            state = batch.kernel_shift()
+            shift = self._psf[0]
+            shift[...] = state["shift"][0]
+            shift.m, shift.v, shift.vhat = (state[n][0].copy() for n in ("m", "v", "vhat"))
 
     @staticmethod
     def _download_all(batch, comps):
@@ -415,17 +439,23 @@ class Blend(CombinedComponent):
         if alg_kwargs:
             raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
         free = [p for obs in self.observations for p in obs.parameters if not p.fixed]
+        self._psf = None
         if free:
             self._specs(_flatten(self.sources))
             if self._host:
                 raise NotImplementedError(
                     "user-defined constraints / steps together with a free psf_shift")
-            return self._fit_with_psf_shift(max_iter, e_rel, min_iter, prox_max_iter, opt, callback)
+            self._psf = self._free_psf_shift()
+        extra = () if self._psf is None else (self._psf[0],)
 
         it = 0
         while it < max_iter:
             comps = _flatten(self.sources)
-            batch = self._build_batch(comps, max_iter - it)
+            try:
+                batch = self._build_batch(comps, max_iter - it)
+            except _HostSteppedShift:
+                # frames beyond the fused convolution kernel: the shift is stepped by the host
+                return self._fit_with_psf_shift(max_iter, e_rel, min_iter, prox_max_iter, opt, callback)
             batch.set_optimizer(**opt)
             restart = False
             try:
@@ -467,7 +497,7 @@ class Blend(CombinedComponent):
                         if not hook:
                             self._download(batch, comps)
                         try:
-                            callback(*self.parameters, it=local - 1)
+                            callback(*self.parameters, *extra, it=local - 1)
                         except StopIteration:
                             break
                 self.loss.extend(batch.loss_history()[0])
@@ -481,18 +511,15 @@ class Blend(CombinedComponent):
 
         logger.info("scarlet ran for {0} iterations to logL = {1}".format(
             len(self.loss), -self.loss[-1]))
-        for p in self.parameters:
+        for p in self.parameters + extra:
             if p.v is not None:
                 p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))  # rough estimate, blend.py:189-192
         return len(self.loss), -self.loss[-1]
 
-    def _fit_with_psf_shift(self, max_iter, e_rel, min_iter, prox_max_iter, opt, callback):
-        """``ConvolutionRenderer(psf_shift=...)``: the difference kernel carries a free
-        sub-pixel shift (renderer.py:175-177, 215-228).  Host-stepped: per iteration the
-        device runs the usual step with the kernel at the current shift, and two extra
-        forward renders with the kernel's derivatives give
-        ``d(-logL)/d(shift) = sum w (m - d) (model (*) dK/ds)``; the shift then takes its
-        unconstrained AMSGrad step (step 1e-2) on the host."""
+    def _free_psf_shift(self):
+        """``(shift parameter, renderer)`` of the one observation whose
+        ``ConvolutionRenderer(psf_shift=...)`` carries the free sub-pixel shift of the
+        difference kernel (renderer.py:175-177, 215-228)."""
         if len(self.observations) != 1:
             raise NotImplementedError("psf_shift with several observations")
         obs = self.observations[0]
@@ -504,9 +531,24 @@ class Blend(CombinedComponent):
             raise NotImplementedError("psf_shift needs an observation on the model frame")
         if shift.prior is not None or shift.constraint is not None:
             raise NotImplementedError("priors / constraints on psf_shift")
-        alpha, rel, _ = _step_rule(shift.step, "psf_shift")
+        self._psf_step, rel, _ = _step_rule(shift.step, "psf_shift")
         if rel:
             raise NotImplementedError("relative steps for psf_shift")
+        return shift, renderer
+
+    def _fit_with_psf_shift(self, max_iter, e_rel, min_iter, prox_max_iter, opt, callback):
+        """``ConvolutionRenderer(psf_shift=...)``: the difference kernel carries a free
+        sub-pixel shift (renderer.py:175-177, 215-228), for frames beyond the fused convolution
+        kernel (the others step the shift on the device, ``smi_batch_set_kernel_shift``).
+        Host-stepped: per iteration the
+        device runs the usual step with the kernel at the current shift, and two extra
+        forward renders with the kernel's derivatives give
+        ``d(-logL)/d(shift) = sum w (m - d) (model (*) dK/ds)``; the shift then takes its
+        unconstrained AMSGrad step (step 1e-2) on the host."""
+        shift, renderer = self._free_psf_shift()
+        obs = self.observations[0]
+        alpha = self._psf_step
+        self._psf = None  # _specs / _download: no device-side shift in this mode
         C = self.frame.C
         data = np.ascontiguousarray(obs.data, dtype=np.float32)
         weights = np.ascontiguousarray(obs.weights, dtype=np.float32)

@@ -223,10 +223,14 @@ struct smi_batch {
     int32_t mono_mask = 0;  // a component carries SMI_PROX_MONO_MASK
     float *c_pos_floor = nullptr;
     double *fista_t = nullptr;
+    // free shift of the difference kernel (smi_batch_set_kernel_shift); ks.stamp == nullptr: none
+    smi::KernelShiftView ks{};
+    float *ks_resid = nullptr;  // rendered cube / weighted residual [nb][C][H][W]
+    double2 *ks_tmp = nullptr;  // scratch of launch_stamp_spectrum
     // smi_batch_save_state: device copies of everything a step changes
-    // {sed, morph, morph_param, m/v/vhat x2, fista_t, pt} and their sizes in bytes
-    void *saved[11] = {};
-    size_t saved_bytes[11] = {};
+    // {sed, morph, morph_param, m/v/vhat x2, fista_t, pt, kernel shift} and their sizes in bytes
+    void *saved[12] = {};
+    size_t saved_bytes[12] = {};
     int scheme = SMI_SCHEME_AMSGRAD;
     bool include_log_norm = true;
     bool lite_flags = false;  // some component uses FIT_CENTER / BG_THRESH
@@ -750,6 +754,9 @@ int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out) {
     return rc;
 }
 
+static void release_kernel_shift(smi_batch *b);
+static int refresh_shifted_kernel(smi_batch *b, int respect_state);
+
 int smi_batch_destroy(smi_batch *b) {
     if (!b) return SMI_OK;
     (void)hipSetDevice(b->device);
@@ -793,6 +800,7 @@ int smi_batch_destroy(smi_batch *b) {
             if (p) (void)hipFree(p);
     for (void *p : b->saved)
         if (p) (void)hipFree(p);
+    release_kernel_shift(b);
     if (b->Q2) (void)hipFree(b->Q2);
     if (b->extra_terms) (void)hipFree(b->extra_terms);
     delete b;
@@ -970,11 +978,121 @@ int smi_batch_set_observation_device(smi_batch *b, const float *d_data, const fl
     return SMI_OK;
 }
 
+// ---- ConvolutionRenderer(psf_shift=...): free shift of the difference kernel ----------
+static void release_kernel_shift(smi_batch *b) {
+    for (void *p : {(void *)b->ks.stamp, (void *)b->ks.shifted, (void *)b->ks.partial,
+                    (void *)b->ks.state, (void *)b->ks_resid, (void *)b->ks_tmp})
+        if (p) (void)hipFree(p);
+    b->ks = smi::KernelShiftView{};
+    b->ks_resid = nullptr;
+    b->ks_tmp = nullptr;
+}
+
+// stamps at the current shift -> spectrum the fused kernel reads
+static int refresh_shifted_kernel(smi_batch *b, int respect_state) {
+    int rc;
+    if ((rc = launch_psf_shift_forward(b->view, b->ks, respect_state, b->stream))) return rc;
+    const double sc = 0.5 / ((double)b->Fy * (double)b->Fx);
+    return launch_stamp_spectrum(b->ks.shifted, b->ks_tmp, b->Kt, b->ks.n_sets * b->ks.bands,
+                                 b->ks.ph, b->ks.pw, b->Fy, b->Fx, sc, b->stream);
+}
+
+// gradient of -logL w.r.t. the kernel shift at the model cube in b->P (and, unless
+// grad_only, the AMSGrad step of the shift; the spectrum is refreshed after the iteration's
+// convolution, which still belongs to the old shift)
+static int kernel_shift_backward(smi_batch *b, const BatchView &v, int it, int grad_only) {
+    int rc;
+    if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
+                                b->d.kernel_per_blend, b->ks_resid, 1, nullptr, b->stream)))
+        return rc;
+    return launch_psf_shift_backward(v, b->ks, b->ks_resid, b->P, it, grad_only, b->stream);
+}
+
+int smi_batch_set_kernel_shift(smi_batch *b, const float *kernel, int32_t h0, int32_t w0,
+                               const int32_t *fft_shape, const double *shift,
+                               const double *moments, double step) {
+    SMI_REQUIRE(b && kernel && fft_shape && shift, "null argument");
+    SMI_REQUIRE(b->fused, "a free kernel shift needs the fused convolution path");
+    SMI_REQUIRE(b->have_components && b->have_obs, "set the observation and the components first");
+    SMI_REQUIRE(b->layers.empty() && b->lowres.empty(), "a free kernel shift with several observations");
+    SMI_REQUIRE(b->d.kernel_per_blend || b->d.n_blends == 1,
+                "a free kernel shift belongs to one blend: use per-blend kernels");
+    const int ph = b->d.kernel_h, pw = b->d.kernel_w;
+    SMI_REQUIRE(h0 > 0 && w0 > 0 && h0 <= ph && w0 <= pw, "stamp larger than the batch's kernel stamp");
+    SMI_REQUIRE(fft_shape[0] >= h0 && fft_shape[1] >= w0 && fft_shape[0] <= 512 && fft_shape[1] <= 512,
+                "bad FFT shape of the shift");
+    SMI_REQUIRE(step >= 0, "negative step");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    release_kernel_shift(b);
+    smi::KernelShiftView &ks = b->ks;
+    ks.n_sets = b->d.kernel_per_blend ? b->d.n_blends : 1;
+    ks.bands = b->d.kernel_bands;
+    ks.per_blend = b->d.kernel_per_blend;
+    ks.h0 = h0;
+    ks.w0 = w0;
+    ks.ph = ph;
+    ks.pw = pw;
+    ks.oy = ph / 2 - h0 / 2;
+    ks.ox = pw / 2 - w0 / 2;
+    ks.Fy = fft_shape[0];
+    ks.Fx = fft_shape[1];
+    ks.slab = 8;
+    ks.n_part = (ks.bands == 1 ? b->d.C : 1) * ((b->d.H + ks.slab - 1) / ks.slab);
+    ks.step = step;
+    const size_t n_img = (size_t)ks.n_sets * ks.bands, n0 = (size_t)h0 * w0;
+    int rc;
+    float *stamp = nullptr;
+    if ((rc = upload(&stamp, kernel, n_img * n0))) return rc;
+    ks.stamp = stamp;
+    SMI_HIP(dev_alloc(&ks.shifted, n_img * ph * pw));
+    SMI_HIP(hipMemset(ks.shifted, 0, n_img * ph * pw * sizeof(float)));
+    SMI_HIP(dev_alloc(&ks.partial, n_img * ks.n_part * n0));
+    std::vector<double> st((size_t)ks.n_sets * 10, 0.0);
+    for (int s = 0; s < ks.n_sets; ++s) {
+        st[(size_t)s * 10] = shift[2 * s];
+        st[(size_t)s * 10 + 1] = shift[2 * s + 1];
+        for (int i = 0; moments && i < 6; ++i) st[(size_t)s * 10 + 2 + i] = moments[6 * s + i];
+    }
+    if ((rc = upload(&ks.state, st.data(), st.size()))) return rc;
+    SMI_HIP(dev_alloc(&b->ks_resid, (size_t)b->d.n_blends * b->d.C * b->d.H * b->d.W));
+    SMI_HIP(dev_alloc(&b->ks_tmp, n_img * ph * b->Fxh));
+    if (!b->Kt) SMI_HIP(dev_alloc(&b->Kt, n_img * b->Fy * b->Fxh));
+    if ((rc = refresh_shifted_kernel(b, 0))) return rc;
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipGetLastError());
+    b->have_kernel = true;
+    return SMI_OK;
+}
+
+int smi_batch_get_kernel_shift(smi_batch *b, double *shift, double *moments, double *gradient,
+                               float *kernel) {
+    SMI_REQUIRE(b && b->ks.stamp, "the batch has no free kernel shift");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int n = b->ks.n_sets;
+    std::vector<double> st((size_t)n * 10);
+    SMI_HIP(hipMemcpy(st.data(), b->ks.state, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int s = 0; s < n; ++s) {
+        for (int a = 0; a < 2; ++a) {
+            if (shift) shift[2 * s + a] = st[(size_t)s * 10 + a];
+            if (gradient) gradient[2 * s + a] = st[(size_t)s * 10 + 8 + a];
+        }
+        for (int i = 0; moments && i < 6; ++i) moments[6 * s + i] = st[(size_t)s * 10 + 2 + i];
+    }
+    if (kernel)
+        SMI_HIP(hipMemcpy(kernel, b->ks.shifted,
+                          (size_t)n * b->ks.bands * b->ks.ph * b->ks.pw * sizeof(float),
+                          hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+
 int smi_batch_set_kernel(smi_batch *b, const float *kernel) {
     SMI_REQUIRE(b && kernel, "null argument");
     SMI_REQUIRE(!b->null_renderer, "batch was created without a kernel (NullRenderer)");
     SMI_HIP(hipSetDevice(b->device));
     SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
+    release_kernel_shift(b);  // a fixed kernel from now on
     const int n_img = (b->d.kernel_per_blend ? b->d.n_blends : 1) * b->d.kernel_bands;
     const int ph = b->d.kernel_h, pw = b->d.kernel_w;
     SMI_REQUIRE(ph <= b->Fy && pw <= b->Fx, "kernel larger than the FFT shape");
@@ -1069,6 +1187,7 @@ int smi_batch_add_observation(smi_batch *b, const float *data, const float *weig
     SMI_REQUIRE(b && data && weights && kernel, "null argument");
     SMI_REQUIRE(b->have_obs && b->have_kernel, "add the first observation and its kernel first");
     SMI_REQUIRE(b->fused, "further observations need the fused convolution path");
+    SMI_REQUIRE(!b->ks.stamp, "a free kernel shift with several observations");
     SMI_HIP(hipSetDevice(b->device));
     SMI_HIP(hipStreamSynchronize(b->stream));
     const int nb = b->d.n_blends, C = b->d.C;
@@ -1542,6 +1661,7 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     if (b->fused) {
         launch_render(v, b->P, b->stream);
         if ((rc = lowres_evaluate_all(b, 1))) return rc;
+        if (b->ks.stamp && (rc = kernel_shift_backward(b, v, 0, 1))) return rc;
         if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
                                     b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
             return rc;
@@ -1572,7 +1692,7 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
 // number of blend ranges a step is split into
 static int sub_ranges(const smi_batch *b) {
     const bool plain = b->fused && b->n_point == 0 && b->n_shift == 0 && b->lowres.empty() &&
-                       b->layers.empty();
+                       b->layers.empty() && !b->ks.stamp;
     if (!plain) return 1;
     const int nb = b->d.n_blends;
     // measured on MI355X (bench.py --blends N --sub-ranges n --steps 20, k blend-it/s for
@@ -1701,6 +1821,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
         if (b->fused) {
             launch_render(v, b->P, b->stream);
             if ((rc = lowres_evaluate_all(b, 1))) return rc;
+            if (b->ks.stamp && (rc = kernel_shift_backward(b, v, it, 0))) return rc;
             // conv + residual/loss + conv^T in one LDS-resident kernel
             if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
             if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
@@ -1731,6 +1852,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
                                        b->stream)))
             return rc;
         if ((rc = launch_shift_forward(v, 1, b->stream))) return rc;
+        if (b->ks.stamp && (rc = refresh_shifted_kernel(b, 1))) return rc;
         if (check) launch_advance(v, b->stream);
         if (ev) SMI_HIP(hipEventRecord(ev[5], b->stream));
     }
@@ -1835,11 +1957,12 @@ namespace {
 // the arrays a step changes, in the order of smi_batch::saved
 void mutable_state(smi_batch *b, void **ptr, size_t *bytes) {
     const size_t n = (size_t)b->d.n_components, nC = n * b->d.C, nm = (size_t)b->n_morph;
-    void *p[11] = {b->sed, b->morph, b->morph_param, b->mom[0], b->mom[1], b->mom[2], b->mom[3],
-                   b->mom[4], b->mom[5], b->fista_t, b->pt};
-    const size_t s[11] = {nC * 4, nm * 4, nm * 4, nC * 4, nC * 4, nC * 4, nm * 4, nm * 4, nm * 4,
-                          n * 2 * sizeof(double), n * 8 * sizeof(double)};
-    for (int i = 0; i < 11; ++i) {
+    void *p[12] = {b->sed, b->morph, b->morph_param, b->mom[0], b->mom[1], b->mom[2], b->mom[3],
+                   b->mom[4], b->mom[5], b->fista_t, b->pt, b->ks.state};
+    const size_t s[12] = {nC * 4, nm * 4, nm * 4, nC * 4, nC * 4, nC * 4, nm * 4, nm * 4, nm * 4,
+                          n * 2 * sizeof(double), n * 8 * sizeof(double),
+                          (size_t)b->ks.n_sets * 10 * sizeof(double)};
+    for (int i = 0; i < 12; ++i) {
         ptr[i] = p[i];
         bytes[i] = p[i] ? s[i] : 0;
     }
@@ -1849,10 +1972,10 @@ void mutable_state(smi_batch *b, void **ptr, size_t *bytes) {
 int smi_batch_save_state(smi_batch *b) {
     SMI_REQUIRE(b && b->have_components, "components not set");
     SMI_HIP(hipSetDevice(b->device));
-    void *ptr[11];
-    size_t bytes[11];
+    void *ptr[12];
+    size_t bytes[12];
     mutable_state(b, ptr, bytes);
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < 12; ++i) {
         if (b->saved[i] && b->saved_bytes[i] != bytes[i]) {
             SMI_HIP(hipFree(b->saved[i]));
             b->saved[i] = nullptr;
@@ -1868,10 +1991,10 @@ int smi_batch_save_state(smi_batch *b) {
 int smi_batch_restore_state(smi_batch *b) {
     SMI_REQUIRE(b && b->have_components, "components not set");
     SMI_HIP(hipSetDevice(b->device));
-    void *ptr[11];
-    size_t bytes[11];
+    void *ptr[12];
+    size_t bytes[12];
     mutable_state(b, ptr, bytes);
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < 12; ++i) {
         SMI_REQUIRE(bytes[i] == b->saved_bytes[i] && (!bytes[i] || b->saved[i]),
                     "no saved state for these components (smi_batch_save_state)");
         if (bytes[i])
@@ -1882,7 +2005,7 @@ int smi_batch_restore_state(smi_batch *b) {
     SMI_HIP(hipMemsetAsync(b->n_loss, 0, nb * sizeof(int32_t), b->stream));
     SMI_HIP(hipMemsetAsync(b->last_loss, 0, nb * sizeof(double), b->stream));
     SMI_HIP(hipMemsetAsync(b->have_prev, 0, nb * sizeof(int32_t), b->stream));
-    return SMI_OK;
+    return b->ks.stamp ? refresh_shifted_kernel(b, 0) : SMI_OK;
 }
 
 int smi_batch_enable_timing(smi_batch *b, int32_t on) {

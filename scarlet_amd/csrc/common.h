@@ -204,6 +204,31 @@ int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e
 int launch_shift_backward(const BatchView &v, const float *G, int32_t it, double *g_shift_out,
                           int32_t grad_only, hipStream_t s);
 int launch_shift_forward(const BatchView &v, int32_t respect_state, hipStream_t s);
+
+// ConvolutionRenderer(psf_shift=...) (renderer.py:175-177, 215-228): the difference kernel
+// carries a free sub-pixel Fourier shift, one per kernel set (the batch's kernel, or one
+// per blend), shared by the bands of the set
+struct KernelShiftView {
+    int32_t n_sets, bands, per_blend;
+    int32_t h0, w0;    // stamp as the renderer holds it
+    int32_t ph, pw;    // device stamp (odd sides), the renderer's sits at (oy, ox)
+    int32_t oy, ox;
+    int32_t Fy, Fx;    // FFT lengths of fft.shift for an (h0, w0) image (fft.py:116-167, padding 10)
+    int32_t n_part;    // partial sums per stamp pixel of the kernel gradient
+    int32_t slab;      // frame rows per partial sum
+    double step;
+    const float *stamp;  // [n_sets bands][h0][w0] unshifted
+    float *shifted;      // [n_sets bands][ph][pw] kernel at the current shift
+    double *partial;     // [n_sets bands][n_part][h0 w0]
+    double *state;       // [n_sets][10]: shift, m, v, vhat, last gradient, (y, x) each
+};
+// R: rendered cube [nb][C][H][W] on entry, w (rendered - data) on return; M: the model
+// cube.  Gradient of -logL w.r.t. the shift into state[8..9]; unless grad_only the shift
+// takes its AMSGrad step (the kernel itself is refreshed by launch_psf_shift_forward).
+int launch_psf_shift_backward(const BatchView &v, const KernelShiftView &ks, float *R,
+                              const float *M, int32_t it, int32_t grad_only, hipStream_t s);
+int launch_psf_shift_forward(const BatchView &v, const KernelShiftView &ks, int32_t respect_state,
+                             hipStream_t s);
 // seam 1, monotonic mask operators (mask.hip)
 template <typename T>
 int mask_valid_host_buffers(int32_t i, int32_t j, const T *image, int32_t rows, int32_t cols,
