@@ -10,7 +10,7 @@ import torch  # noqa: F401  (loads the HIP runtime first)
 
 from scarlet_amd import BlendBatch, ComponentSpec, synthetic, _lib
 
-nb = 1024
+nb = int(sys.argv[sys.argv.index("--blends") + 1]) if "--blends" in sys.argv else 1024
 no_sweep = "--no-sweep" in sys.argv
 flags = _lib.PROX_EXTENDED_SOURCE & ~(_lib.PROX_MONOTONIC if no_sweep else 0)
 scenes = synthetic.make_batch(range(1234, 1234 + nb))
