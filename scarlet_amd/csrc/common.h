@@ -90,6 +90,9 @@ struct alignas(16) SweepSlotEntry {
 // standard boxes (21 + 10 k pixels a side, morphology.py / initialization.py:173-177)
 // 21^2 .. 61^2 map onto one class each.
 constexpr int kNumUpdateClasses = 5;
+// up to this many components a range with several size classes is updated in one launch
+// (update_kernel_mixed): about one wave per SIMD
+constexpr int kMixedUpdateLimit = 1024;
 constexpr int kUpdateNpl[kNumUpdateClasses] = {7, 16, 27, 42, 59};
 inline int update_class(int n_pix) {
     for (int c = 0; c < kNumUpdateClasses; ++c)

@@ -1042,15 +1042,13 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
 // (`work` lists them class by class, common.h), so the per-pixel loops carry no bounds
 // for the first kFull slots and a small box never runs through a large box's loops.
 template <int NPL, int MODE>
-__global__ __launch_bounds__(64) SMI_WAVES void update_kernel_reg(BatchView v, const float *G,
-                                                                  int it, float e_rel,
-                                                                  int prox_max_iter) {
+__device__ __forceinline__ void update_component(const BatchView &v, const float *G, int it,
+                                                 float e_rel, int prox_max_iter, int k) {
     constexpr bool LITE = MODE != 0;
     constexpr bool fista = MODE == 2;
     // every box of this size class has more than 64 * kFull pixels (common.h)
     constexpr int kFull = NPL == 7 ? 0 : NPL == 16 ? 7 : NPL == 27 ? 16 : NPL == 42 ? 27 : 42;
     const int lane = threadIdx.x;
-    const int k = v.work[blockIdx.x + v.work0];
     const CompCtx c = comp_ctx(v, k, lane);
     if (v.state[c.b] >= 2) return;
     const int N = c.N;
@@ -1303,6 +1301,36 @@ __global__ __launch_bounds__(64) SMI_WAVES void update_kernel_reg(BatchView v, c
     if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
 }
 
+template <int NPL, int MODE>
+__global__ __launch_bounds__(64) SMI_WAVES void update_kernel_reg(BatchView v, const float *G,
+                                                                  int it, float e_rel,
+                                                                  int prox_max_iter) {
+    update_component<NPL, MODE>(v, G, it, e_rel, prox_max_iter, v.work[blockIdx.x + v.work0]);
+}
+
+// Few components of several size classes (a single blend with boxes of 21^2 .. 61^2 pixels):
+// a launch per class would run the classes one after the other, each one a latency-bound
+// wave per component.  Here one launch holds every component of the range and each
+// wavefront takes the code of its own class; the registers are those of the largest class,
+// which costs nothing while the SIMDs hold one wave or less.
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void update_kernel_mixed(
+    BatchView v, const float *G, int it, float e_rel, int prox_max_iter) {
+    const int k = v.comp0 + blockIdx.x;
+    if (v.c_flags[k] & SMI_COMPONENT_POINT_SOURCE) return;
+    const int n = v.c_h[k] * v.c_w[k];  // uniform over the wavefront
+    if (n <= 64 * kUpdateNpl[0])
+        update_component<kUpdateNpl[0], MODE>(v, G, it, e_rel, prox_max_iter, k);
+    else if (n <= 64 * kUpdateNpl[1])
+        update_component<kUpdateNpl[1], MODE>(v, G, it, e_rel, prox_max_iter, k);
+    else if (n <= 64 * kUpdateNpl[2])
+        update_component<kUpdateNpl[2], MODE>(v, G, it, e_rel, prox_max_iter, k);
+    else if (n <= 64 * kUpdateNpl[3])
+        update_component<kUpdateNpl[3], MODE>(v, G, it, e_rel, prox_max_iter, k);
+    else
+        update_component<kUpdateNpl[4], MODE>(v, G, it, e_rel, prox_max_iter, k);
+}
+
 // log_norm of Observation (observation.py:172-186): D/2 ln(2 pi) + sum ln(1/sqrt(w))
 __global__ __launch_bounds__(256) void log_norm_kernel(const float *weights, double *out,
                                                        int64_t n) {
@@ -1495,6 +1523,25 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
     // chains that repeat take the general kernel (the register-resident ones apply it once)
     if (!grad_only && v.fast_plans && v.max_box_pixels <= 64 * 59 && !v.c_chain_repeat &&
         !v.mono_mask) {
+        // latency regime with several size classes: one launch for all of them
+        int classes = 0;
+        for (int cls = 0; cls < kNumUpdateClasses; ++cls) {
+            const int32_t *start = v.work_start + (size_t)cls * (v.nb_total + 1);
+            classes += start[v.blend0 + v.nb] > start[v.blend0];
+        }
+        if (classes > 1 && v.n_comp <= kMixedUpdateLimit) {
+            const size_t lds = (size_t)(64 * kUpdateNpl[kNumUpdateClasses - 1] + 4) * sizeof(float);
+            if (v.scheme == SMI_SCHEME_FISTA)
+                hipLaunchKernelGGL(update_kernel_mixed<2>, dim3(v.n_comp), dim3(64), lds, s, v, G, it,
+                                   e_rel, prox_max_iter);
+            else if (v.lite)
+                hipLaunchKernelGGL(update_kernel_mixed<1>, dim3(v.n_comp), dim3(64), lds, s, v, G, it,
+                                   e_rel, prox_max_iter);
+            else
+                hipLaunchKernelGGL(update_kernel_mixed<0>, dim3(v.n_comp), dim3(64), lds, s, v, G, it,
+                                   e_rel, prox_max_iter);
+            return SMI_OK;
+        }
         // one launch per size class that has components in this range of blends, the
         // largest boxes (longest sweeps) first
         for (int cls = kNumUpdateClasses - 1; cls >= 0; --cls) {
