@@ -91,8 +91,8 @@ struct alignas(16) SweepSlotEntry {
 // 21^2 .. 61^2 map onto one class each.
 constexpr int kNumUpdateClasses = 5;
 // up to this many components a range with several size classes is updated in one launch
-// (update_kernel_mixed): about one wave per SIMD
-constexpr int kMixedUpdateLimit = 1024;
+// (update_kernel_mixed; measurements there)
+constexpr int kMixedUpdateLimit = 3072;
 constexpr int kUpdateNpl[kNumUpdateClasses] = {7, 16, 27, 42, 59};
 inline int update_class(int n_pix) {
     for (int c = 0; c < kNumUpdateClasses; ++c)

@@ -1308,11 +1308,15 @@ __global__ __launch_bounds__(64) SMI_WAVES void update_kernel_reg(BatchView v, c
     update_component<NPL, MODE>(v, G, it, e_rel, prox_max_iter, v.work[blockIdx.x + v.work0]);
 }
 
-// Few components of several size classes (a single blend with boxes of 21^2 .. 61^2 pixels):
-// a launch per class would run the classes one after the other, each one a latency-bound
-// wave per component.  Here one launch holds every component of the range and each
-// wavefront takes the code of its own class; the registers are those of the largest class,
-// which costs nothing while the SIMDs hold one wave or less.
+// Components of several size classes (a blend with boxes of 21^2 .. 61^2 pixels): a launch
+// per class runs the classes one after the other, each of them bounded below by the serial
+// chain of one wave (gather, up to ten sub-iterations of 30 .. 90 sweep steps).  Here one
+// launch holds every component of the range and each wavefront takes the code of its own
+// class, so the chains of the classes overlap; the registers are those of the largest class
+// (two waves per SIMD).  Measured on batches of the quickstart blend (k blend-it/s, launch
+// per class -> this kernel): 16 blends 50 -> 103, 128: 340 -> 567, 512: 857 -> 1003, 768:
+// 1027 -> 1062, 1024: 1159 -> 1145 (three ranges of 3413 components: the occupancy of the
+// small classes starts to count), hence kMixedUpdateLimit.
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void update_kernel_mixed(
     BatchView v, const float *G, int it, float e_rel, int prox_max_iter) {
