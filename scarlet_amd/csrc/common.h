@@ -271,6 +271,9 @@ bool fused_conv_choose(int ny, int nx, int *Fy, int *Fx);
 int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float *model, const float2 *Kt,
                       int k_bands, int k_per_blend, float *out, int mode, long long *dbg,
                       hipStream_t s);
+int launch_fused_conv_short(const BatchView &v, int Fy, int Fx, const float *model,
+                            const float2 *Kt, int k_bands, int k_per_blend, float *out, int mode,
+                            long long *dbg, hipStream_t s);
 int launch_stamp_spectrum(const float *d_kern, double2 *d_tmp, float2 *Kt, int n_img, int ph,
                           int pw, int Fy, int Fx, double scale, hipStream_t s);
 int launch_permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int n_img, int Fy, int Fx,

@@ -36,7 +36,10 @@ using fftk::st;
 
 namespace {
 
-#ifndef SMI_CONV_THREADS  // experiment knobs: workgroup size and row pairs per chunk
+// Workgroup size and row pairs per chunk.  This file is compiled twice: as it is
+// (1024 threads) and through fused_conv_short.hip with 512 threads for transforms with
+// short rows (SMI_CONV_SHORT_ROWS: only launch_fused_conv_short is emitted there).
+#ifndef SMI_CONV_THREADS
 #define SMI_CONV_THREADS 1024
 #define SMI_CONV_PAIRS 32
 #endif
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
 #undef SMI_STAMP
 }
 
+#ifndef SMI_CONV_SHORT_ROWS
 // natural-order spectrum (rocFFT, [img][ky][kx]) -> [img][pos_y(ky)][kx], scaled
 template <int FY1>
 __global__ void permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int NKX, float scale) {
@@ -510,6 +514,8 @@ __global__ void stamp_dft_y(const double2 *A, float2 *Kt, int ph, int NKX, doubl
         make_float2((float)(re * scale), (float)(im * scale));
 }
 
+#endif  // SMI_CONV_SHORT_ROWS
+
 template <int FY1, int FX1>
 int launch_impl(const BatchView &v, const float *model, const float2 *Kt, int k_bands,
                 int k_per_blend, float *out, int mode, long long *dbg, hipStream_t s) {
@@ -525,6 +531,7 @@ int launch_impl(const BatchView &v, const float *model, const float2 *Kt, int k_
 
 }  // namespace
 
+#ifndef SMI_CONV_SHORT_ROWS
 // supported (FY, FX): multiples of 16 with first radix in {4,5,6,8,10}; LDS must fit
 bool fused_conv_supported(int Fy, int Fx) {
     auto ok = [](int f) { return f == 64 || f == 80 || f == 96 || f == 128 || f == 160; };
@@ -541,6 +548,8 @@ int fused_conv_length(int n) {
         if (f >= n) return f;
     return 0;
 }
+
+#endif
 
 #define SMI_FUSED_DISPATCH(FN, ...)                                             \
     switch (Fy / 16 * 100 + Fx / 16) {                                          \
@@ -572,6 +581,15 @@ int fused_conv_length(int n) {
         default: break;                                                         \
     }
 
+#ifdef SMI_CONV_SHORT_ROWS
+int launch_fused_conv_short(const BatchView &v, int Fy, int Fx, const float *model,
+                            const float2 *Kt, int k_bands, int k_per_blend, float *out, int mode,
+                            long long *dbg, hipStream_t s) {
+    SMI_FUSED_DISPATCH(launch_impl, v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s)
+    set_error("fused convolution: FFT shape not instantiated");
+    return SMI_ERR_INVALID;
+}
+#else
 // every (Fy, Fx) in {64,80,96,128,160}^2 is instantiated; the LDS bound decides
 bool fused_conv_instantiated(int Fy, int Fx) { return fused_conv_supported(Fy, Fx); }
 
@@ -593,6 +611,13 @@ bool fused_conv_choose(int ny, int nx, int *Fy, int *Fx) {
 int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float *model, const float2 *Kt,
                       int k_bands, int k_per_blend, float *out, int mode, long long *dbg,
                       hipStream_t s) {
+    // rows of up to 96 elements: the row passes of a chunk have 32 x 16 and 32 x Fx/16 work
+    // items, which leave most of 1024 threads idle behind the barriers; 512 threads are
+    // faster there (ms per 512 blends x 5 bands, 1024 -> 512 threads: 64^2 0.123 -> 0.084,
+    // 80^2 0.155 -> 0.120, 96^2 0.242 -> 0.195, 128 x 64 0.187 -> 0.142; but 64 x 128
+    // 0.176 -> 0.210, 128^2 0.294 -> 0.336, 160^2 0.414 -> 0.485; tools/conv_sizes.py)
+    if (Fx <= 96)
+        return launch_fused_conv_short(v, Fy, Fx, model, Kt, k_bands, k_per_blend, out, mode, dbg, s);
     SMI_FUSED_DISPATCH(launch_impl, v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s)
     set_error("fused convolution: FFT shape not instantiated");
     return SMI_ERR_INVALID;
@@ -634,5 +659,7 @@ int launch_permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int n_img, in
     }
     return SMI_OK;
 }
+
+#endif  // SMI_CONV_SHORT_ROWS
 
 }  // namespace smi
