@@ -21,6 +21,7 @@
 // so no transposition pass is ever needed; the kernel spectrum K^ is stored in the
 // same order.  Rows are transformed two at a time (row 2j + i row 2j+1) and
 // separated by Hermitian symmetry; zero padding is never stored for the columns.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -611,12 +612,14 @@ bool fused_conv_choose(int ny, int nx, int *Fy, int *Fx) {
 int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float *model, const float2 *Kt,
                       int k_bands, int k_per_blend, float *out, int mode, long long *dbg,
                       hipStream_t s) {
-    // rows of up to 96 elements: the row passes of a chunk have 32 x 16 and 32 x Fx/16 work
-    // items, which leave most of 1024 threads idle behind the barriers; 512 threads are
-    // faster there (ms per 512 blends x 5 bands, 1024 -> 512 threads: 64^2 0.123 -> 0.084,
-    // 80^2 0.155 -> 0.120, 96^2 0.242 -> 0.195, 128 x 64 0.187 -> 0.142; but 64 x 128
-    // 0.176 -> 0.210, 128^2 0.294 -> 0.336, 160^2 0.414 -> 0.485; tools/conv_sizes.py)
-    if (Fx <= 96)
+    // short rows: the row passes of a chunk have 32 x 16 and 32 x Fx/16 work items, which
+    // leave most of 1024 threads idle behind the barriers; 512 threads are faster there
+    // (tools/conv_sizes.py, ms per 512 blends x 5 bands, 1024 -> 512 threads: 64^2 0.123 ->
+    // 0.084, 80^2 0.155 -> 0.120, 96^2 0.242 -> 0.195, 160 x 64 0.212 -> 0.155, 160 x 80
+    // 0.250 -> 0.203; but 128 x 96 0.255 -> 0.301, 160 x 96 0.279 -> 0.328, 64 x 128 0.176 ->
+    // 0.210, 128^2 0.294 -> 0.336, 160^2 0.414 -> 0.485)
+    static const char *force = getenv("SMI_CONV_WORKGROUP");  // development aid: "512" / "1024"
+    if (force ? force[0] == '5' : (Fx <= 80 || (Fx == 96 && Fy <= 96)))
         return launch_fused_conv_short(v, Fy, Fx, model, Kt, k_bands, k_per_blend, out, mode, dbg, s);
     SMI_FUSED_DISPATCH(launch_impl, v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s)
     set_error("fused convolution: FFT shape not instantiated");

@@ -15,7 +15,10 @@ yy, xx = np.mgrid[:p, :p] - p // 2
 kernel = np.exp(-(yy**2 + xx**2) / 8.0).astype(np.float32)[None]
 kernel /= kernel.sum()
 out = []
-for H, W in [(40, 40), (56, 56), (72, 72), (100, 100), (128, 128), (40, 100), (100, 40), (56, 128)]:
+shapes = [(40, 40), (56, 56), (72, 72), (100, 100), (128, 128), (40, 100), (100, 40), (56, 128)]
+if "--more" in sys.argv:
+    shapes = [(128, 40), (128, 56), (128, 72), (72, 40), (40, 72), (56, 72), (72, 56), (72, 100), (100, 72)]
+for H, W in shapes:
     data = rng.normal(0, 1, (nb, C, H, W)).astype(np.float32)
     weights = np.ones_like(data)
     morph = np.ones((11, 11), np.float32)
@@ -27,4 +30,4 @@ for H, W in [(40, 40), (56, 56), (72, 72), (100, 100), (128, 128), (40, 100), (1
     b.step(5, 20)
     out.append("%dx%d->F%s %.4f" % (H, W, "x".join(map(str, b.fft_shape)), b.timing()["conv"]))
     b.close()
-print(os.path.basename(os.environ.get("SCARLET_AMD_LIB", "default")), " ".join(out))
+print(os.environ.get("SMI_CONV_WORKGROUP", "auto"), " ".join(out))
