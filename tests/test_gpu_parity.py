@@ -807,6 +807,36 @@ def test_sub_ranges_on_streams_do_not_change_results(amd):
     small.close()
 
 
+def test_mixed_and_per_class_update_launches_agree(amd, hsc):
+    """Components of several box-size classes: up to kMixedUpdateLimit (3072) components per
+    range go through update_kernel_mixed (one launch, every wavefront runs the code of its
+    class), larger ranges through one update_kernel_reg launch per class.  Both must give
+    every blend the same bits: 320 copies of the quickstart blend (3200 components, boxes
+    21^2 .. 61^2) in one range against a batch of three copies."""
+    def run(nb):
+        n = int(hsc["n_comp"])
+        comps = [amd.ComponentSpec(hsc["sed_%d" % k], hsc["morph_%d" % k], hsc["origin_%d" % k],
+                                   sed_min_step=hsc["min_step_%d" % k]) for k in range(n)]
+        b = amd.BlendBatch(np.repeat(hsc["images"][None], nb, 0), np.repeat(hsc["weights"][None], nb, 0),
+                           [comps] * nb, kernel=hsc["diff_kernel"], max_iter=16)
+        b.set_sub_ranges(1)
+        b.step(0, 12, e_rel=1e-3)
+        out = b.loss_history(), b.parameters(), b.moments()
+        b.close()
+        return out
+
+    big, small = run(320), run(3)
+    n = int(hsc["n_comp"])
+    for i in (0, 171, 319):
+        assert_array_equal(big[0][i], small[0][0])
+        assert_array_equal(big[1][0][i * n:(i + 1) * n], small[1][0][:n])
+        for a, b_ in zip(big[1][1][i * n:(i + 1) * n], small[1][1][:n]):
+            assert_array_equal(a, b_)
+        for key in ("m_morph", "v_morph", "vhat_morph"):
+            for a, b_ in zip(big[2][key][i * n:(i + 1) * n], small[2][key][:n]):
+                assert_array_equal(a, b_)
+
+
 def test_tiny_frames_and_single_band(amd):
     """frames much smaller than a chunk of the fused kernel, one band, boxes larger than
     the frame"""
