@@ -259,7 +259,42 @@ __global__ __launch_bounds__(256) void cmul_kernel(float2 *S, const float2 *K, i
 }
 
 // ---------------------------------------------------------------------------
-// Monotonic sweep on an LDS-resident image, one wavefront, level by level.
+// The threads of one component in the general update kernel: one wavefront, or four for
+// boxes beyond the register-resident kernels (the element-wise passes and the sweep levels
+// of a 100^2 box keep four waves busy).  With one wavefront every reduction is the plain
+// 64-lane tree of the other kernels.
+// ---------------------------------------------------------------------------
+template <int T>
+struct Team {
+    static_assert(T == 64 || T == 256, "team size");
+    static __device__ __forceinline__ void sync() { __syncthreads(); }
+    static __device__ __forceinline__ float sum(float v) {
+        v = wave_sum(v);
+        if (T == 64) return v;
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        return t;
+    }
+    static __device__ __forceinline__ float max(float v) {
+        v = wave_max(v);
+        if (T == 64) return v;
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        const float t = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        return t;
+    }
+    static __device__ __forceinline__ int any(int v) {
+        return T == 64 ? wave_or(v) : __syncthreads_or(v);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Monotonic sweep on an LDS-resident image, level by level.
 // Separate multiply and add (no FMA contraction): bit-identical to the
 // reference's sequential loop (operators_pybind11.cc:14-36).
 // ---------------------------------------------------------------------------
@@ -276,14 +311,14 @@ __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, 
 template <>
 __device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
 
-template <typename T, typename W>
+template <typename T, typename W, int THREADS = 64>
 __device__ __forceinline__ void sweep_levels(T *img, const int32_t *level_start, int n_levels,
                                              int E, const int32_t *pix, const int32_t *cnt,
                                              const int32_t *nbr, const W *wt,
                                              T one_minus_g, int lane) {
     for (int l = 0; l < n_levels; ++l) {
         const int s = level_start[l], e = level_start[l + 1];
-        for (int q = s + lane; q < e; q += 64) {
+        for (int q = s + lane; q < e; q += THREADS) {
             const int p = pix[q];
             const int n = cnt[q];
             T ref = 0;
@@ -293,6 +328,64 @@ __device__ __forceinline__ void sweep_levels(T *img, const int32_t *level_start,
             if (lim < img[p]) img[p] = lim;
         }
         __syncthreads();
+    }
+}
+
+// The same sweep with the plan entries of the next level requested before the current
+// level is applied: the entries come from global memory (L2), and a level is only a few
+// dependent instructions long, so without this every level waits for a load round trip
+// (a 150^2 box has about 440 levels).  One entry per thread and level in registers;
+// further entries of a level wider than the team are loaded in place.
+template <int THREADS>
+__device__ __forceinline__ void sweep_levels_prefetch(float *img, const int32_t *level_start,
+                                                      int n_levels, int E, int max_terms,
+                                                      const int32_t *pix, const int32_t *cnt,
+                                                      const int32_t *nbr, const float *wt,
+                                                      float one_minus_g, int lane) {
+    constexpr int kTerms = 8;  // offsets of operators_pybind11.cc:14-36
+    struct Entry {
+        int p, n;
+        int nb[kTerms];
+        float w[kTerms];
+    };
+    auto load = [&](int q, Entry &e) {
+        e.p = pix[q];
+        e.n = cnt[q];
+#pragma unroll
+        for (int j = 0; j < kTerms; ++j)
+            if (j < max_terms) {
+                e.nb[j] = nbr[(int64_t)j * E + q];
+                e.w[j] = wt[(int64_t)j * E + q];
+            }
+    };
+    auto apply = [&](const Entry &e) {
+        float ref = 0.f;
+#pragma unroll
+        for (int j = 0; j < kTerms; ++j)
+            if (j < e.n) ref = __fadd_rn(ref, __fmul_rn(img[e.nb[j]], e.w[j]));
+        const float lim = __fmul_rn(ref, one_minus_g);
+        if (lim < img[e.p]) img[e.p] = lim;
+    };
+    if (n_levels <= 0) return;
+    int s = level_start[0], e = level_start[1];
+    Entry cur{}, nxt{};
+    bool have = s + lane < e;
+    if (have) load(s + lane, cur);
+    for (int l = 0; l < n_levels; ++l) {
+        const int e_next = l + 1 < n_levels ? level_start[l + 2] : e;
+        const bool have_next = l + 1 < n_levels && e + lane < e_next;
+        if (have_next) load(e + lane, nxt);
+        if (have) apply(cur);
+        for (int q = s + lane + THREADS; q < e; q += THREADS) {
+            Entry more{};
+            load(q, more);
+            apply(more);
+        }
+        __syncthreads();
+        cur = nxt;
+        have = have_next;
+        s = e;
+        e = e_next;
     }
 }
 
@@ -335,11 +428,12 @@ __device__ __forceinline__ CompCtx comp_ctx(const BatchView &v) {
 
 // slice G into the box (zero outside the frame, blend.py:30-46); us[i] = sum_c sed G,
 // return (in lane c) sum_yx G[c] morph  (lite/models.py:206-216)
+template <int T>
 __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompCtx &c,
                                                  const float *G, float *us) {
     float g_sed = 0.f;
     if (c.pre) {
-        for (int i = c.lane; i < c.N; i += 64) us[i] = v.g_morph_buf[c.moff + i];
+        for (int i = c.lane; i < c.N; i += T) us[i] = v.g_morph_buf[c.moff + i];
         return c.lane < c.C ? v.g_sed_buf[(int64_t)c.k * c.C + c.lane] : 0.f;
     }
     const float inv_w = 1.0f / (float)c.w;
@@ -354,12 +448,12 @@ __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompC
 #define SMI_GU 3
 #endif
         constexpr int kGU = SMI_GU;
-        for (int i0 = c.lane; i0 < c.N; i0 += 64 * kGU) {
+        for (int i0 = c.lane; i0 < c.N; i0 += T * kGU) {
             float gv[kGU][kBandChunk], mv[kGU];
             bool in_box[kGU];
 #pragma unroll
             for (int u = 0; u < kGU; ++u) {
-                const int i = i0 + 64 * u;
+                const int i = i0 + T * u;
                 // exact for i < 2^20: the float quotient is off by < 1e-6 relative
                 const int y = (int)(((float)i + 0.5f) * inv_w);
                 const int x = i - y * c.w;
@@ -375,7 +469,7 @@ __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompC
             }
 #pragma unroll
             for (int u = 0; u < kGU; ++u) {
-                const int i = i0 + 64 * u;
+                const int i = i0 + T * u;
                 if (!in_box[u]) continue;
                 float gm = c0 == 0 ? 0.f : us[i];
 #pragma unroll
@@ -390,7 +484,7 @@ __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompC
 #pragma unroll
         for (int j = 0; j < kBandChunk; ++j)
             if (j < nc) {
-                const float t = wave_sum(acc[j]);
+                const float t = Team<T>::sum(acc[j]);
                 if (c.lane == c0 + j) g_sed = t;
             }
     }
@@ -398,11 +492,12 @@ __device__ __forceinline__ float gather_gradient(const BatchView &v, const CompC
 }
 
 // Parameter(fixed=True): the optimizer sees a zero gradient (blend.py:107-115)
+template <int T>
 __device__ __forceinline__ float hold_fixed(const BatchView &v, const CompCtx &c, float g_sed,
                                             float *us) {
     const int flags = v.c_flags[c.k];
     if (flags & SMI_COMPONENT_FIXED_MORPH)
-        for (int i = c.lane; i < c.N; i += 64) us[i] = 0.f;
+        for (int i = c.lane; i < c.N; i += T) us[i] = 0.f;
     return (flags & SMI_COMPONENT_FIXED_SED) ? 0.f : g_sed;
 }
 
@@ -492,9 +587,18 @@ __device__ __forceinline__ int fit_center_index(const float *us, const CompCtx &
 __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
+// the same between the passes of a component's threads: a barrier once they are several waves
+template <int T>
+__device__ __forceinline__ void team_fence() {
+    if (T == 64)
+        wave_lds_fence();
+    else
+        __syncthreads();
+}
 
 // the element-wise members of the chain that act on the LDS image `us` before the
 // final positivity / centre / normalisation pass (constraint.py:262-273, 117-145)
+template <int T = 64>
 __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCtx &c, int flags,
                                                          float lthresh, const float *sed_new,
                                                          const float *bg_level,
@@ -503,20 +607,20 @@ __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCt
     if (flags & SMI_PROX_BG_THRESH) {
         // lite/models.py:222-228: zero where the model stays below the background
         // level in every band (spectrum already updated)
-        for (int i = lane; i < N; i += 64) {
+        for (int i = lane; i < N; i += T) {
             const float u = us[i];
             bool below = true;
             for (int b = 0; b < c.C; ++b) below = below && (sed_new[b] * u < bg_level[b]);
             if (below) us[i] = 0.f;
         }
-        wave_lds_fence();  // a wave only touches its own image
+        team_fence<T>();  // a team only touches its own image
     }
     if (flags & SMI_PROX_SYMMETRY) {
         // prox_soft_symmetry (operator.py:274-293), x <- s/2 (x + rot180 x) + (1 - s) x: even axes are
         // padded by one trailing zero before the 180-degree rotation
         const int hp = h + !(h & 1), wp = w + !(w & 1);
         const float s = strength, keep = 1.f - strength;
-        for (int i = lane; i < N; i += 64) {
+        for (int i = lane; i < N; i += T) {
             const int y = i / w, x = i - y * w;
             const int py = hp - 1 - y, px = wp - 1 - x;
             const bool has = py < h && px < w;
@@ -538,10 +642,10 @@ __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCt
                 us[j] = 0.5f * s * (xj + xi) + keep * xj;
             }
         }
-        wave_lds_fence();  // a wave only touches its own image
+        team_fence<T>();  // a team only touches its own image
     }
     if (flags & (SMI_PROX_L1 | SMI_PROX_L0)) {
-        for (int i = lane; i < N; i += 64) {
+        for (int i = lane; i < N; i += T) {
             const float u = us[i];
             if (flags & SMI_PROX_L1)
                 us[i] = copysignf(fmaxf(fabsf(u) - lthresh, 0.f), u);
@@ -557,17 +661,18 @@ __device__ __forceinline__ void chain_symmetry_threshold(float *us, const CompCt
 // onto a strictly smaller, positive value -- keep the value they had before the sweep.
 // The accepted set is the closure of that relation, so it is relaxed in parallel until
 // nothing changes (as mask.hip does); `ws` receives the image, `fl` the accepted flags.
+template <int T>
 __device__ __forceinline__ void monotonic_mask(const float *us, float *ws, uint8_t *fl,
                                                const CompCtx &c, int start) {
     const int N = c.N, w = c.w, h = c.h, lane = c.lane;
-    for (int i = lane; i < N; i += 64) {
+    for (int i = lane; i < N; i += T) {
         ws[i] = us[i];
         fl[i] = i == start;
     }
-    wave_lds_fence();
+    team_fence<T>();
     for (;;) {
         int changed = 0;
-        for (int i = lane; i < N; i += 64) {
+        for (int i = lane; i < N; i += T) {
             if (fl[i]) continue;
             const float val = ws[i];
             if (!(val > 0.f)) continue;
@@ -581,16 +686,18 @@ __device__ __forceinline__ void monotonic_mask(const float *us, float *ws, uint8
                 changed = 1;
             }
         }
-        wave_lds_fence();
-        if (!wave_or(changed)) break;
+        team_fence<T>();
+        if (!Team<T>::any(changed)) break;
     }
 }
 
 // -- generic variant: everything in LDS, plans with any number of terms -----
-__global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G, int it,
-                                                    float e_rel, int prox_max_iter,
-                                                    float *g_sed_out, float *g_morph_out,
-                                                    int grad_only) {
+// T threads per component (Team): 64, or 256 for boxes of more than 64 x 64 pixels
+template <int T>
+__global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, int it,
+                                                   float e_rel, int prox_max_iter,
+                                                   float *g_sed_out, float *g_morph_out,
+                                                   int grad_only) {
     const CompCtx c = comp_ctx(v);
     if (!grad_only && v.state[c.b] >= 2) return;
     if (!grad_only && v.n_point && (v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
@@ -608,32 +715,35 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     float *ws = reinterpret_cast<float *>(lvl + ((v.max_levels + 2 + 3) & ~3));
     uint8_t *fl = reinterpret_cast<uint8_t *>(ws + npad);
 
-    float g_sed = gather_gradient(v, c, G, us);
+    float g_sed = gather_gradient<T>(v, c, G, us);
     __syncthreads();
     if (grad_only) {
         if (lane < c.C) g_sed_out[(int64_t)c.k * c.C + lane] = g_sed;
-        for (int i = lane; i < N; i += 64) g_morph_out[c.moff + i] = us[i];
+        for (int i = lane; i < N; i += T) g_morph_out[c.moff + i] = us[i];
         return;
     }
-    g_sed = hold_fixed(v, c, g_sed, us);
+    g_sed = hold_fixed<T>(v, c, g_sed, us);
     __syncthreads();
     const float e2 = e_rel * e_rel;
     __shared__ float sed_new[64];
     const bool fista = v.scheme == SMI_SCHEME_FISTA;
     if (fista) prox_max_iter = 1;  // FistaParameter applies the prox once
     float msum = 0.f, msum2 = 0.f;
-    for (int i = lane; i < N; i += 64) {
+    for (int i = lane; i < N; i += T) {
         const float mval = c.morph[i];
         msum += mval;
         msum2 += mval * mval;
     }
-    msum = wave_sum(msum);
-    msum2 = wave_sum(msum2);
+    msum = Team<T>::sum(msum);
+    msum2 = Team<T>::sum(msum2);
     // sum of the squared *old* spectrum: FISTA step of the morphology (lite/models.py:249-254)
     const float so = lane < c.C ? c.sed[lane] : 0.f;
-    const float ssum2 = wave_sum(so * so);
+    const float ssum2 = Team<T>::sum(so * so);
     const float t_old = fista ? (float)v.fista_t[2 * (int64_t)c.k + 1] : 1.f;
-    int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, sed_new);
+    // the spectrum belongs to the first wavefront (one band per lane)
+    int bad = 0;
+    if (T == 64 || threadIdx.x < 64)
+        bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, sed_new);
 
     const int flags = v.c_flags[c.k];
     const int plan_id = v.c_plan[c.k];
@@ -641,7 +751,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     float pmax = 0.f;
     if (fista) {
         const float step = v.c_fista_step[c.k] / ssum2;
-        for (int i = lane; i < N; i += 64) {
+        for (int i = lane; i < N; i += T) {
             const float y = v.m_morph[c.moff + i] - step * us[i];
             xs[i] = y;
             zs[i] = y;
@@ -649,7 +759,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         }
         pmax = 1.f;
     } else {
-        for (int i = lane; i < N; i += 64) {
+        for (int i = lane; i < N; i += T) {
             const float g = us[i];
             const float m = (1.f - v.b1) * g + v.b1 * v.m_morph[c.moff + i];
             const float vv = (1.f - v.b2) * g * g + v.b2 * v.v_morph[c.moff + i];
@@ -666,7 +776,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
             rs[i] = psi;
             pmax = fmaxf(pmax, psi);
         }
-        pmax = wave_max(pmax);
+        pmax = Team<T>::max(pmax);
     }
 
     const bool monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
@@ -674,7 +784,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     SweepPlanDev pl;
     if (monotonic && !fit_center) {
         pl = v.plans[plan_id];
-        for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
+        for (int i = lane; i <= pl.n_levels; i += T) lvl[i] = pl.level_start[i];
     }
     const float one_minus_g = 1.f - v.c_min_grad[c.k];
     const int ctr = (c.h / 2) * c.w + (c.w / 2);
@@ -686,10 +796,10 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
     const float *bg_level = v.c_bg_level ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;
     const int repeat = v.c_chain_repeat ? v.c_chain_repeat[c.k] : 1;
     __syncthreads();
-    for (int i = lane; i < N; i += 64) rs[i] = rs[i] / pmax;
+    for (int i = lane; i < N; i += T) rs[i] = rs[i] / pmax;
 
     for (int tau = 0; tau < prox_max_iter; ++tau) {
-        for (int i = lane; i < N; i += 64) us[i] = zs[i] - rs[i] * (zs[i] - xs[i]);
+        for (int i = lane; i < N; i += T) us[i] = zs[i] - rs[i] * (zs[i] - xs[i]);
         __syncthreads();
         // ConstraintChain (constraint.py:76-80) in the order of morphology.py:644-670,
         // `repeat` times over (constraint.py:60-80); the last normalisation is folded into
@@ -701,24 +811,24 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
                 const int j = fit_center_index(us, c);
                 start = ctr + (j / 3 - 1) * c.w + (j % 3 - 1);
                 pl = v.plans[plan_id + j];
-                for (int i = lane; i <= pl.n_levels; i += 64) lvl[i] = pl.level_start[i];
+                for (int i = lane; i <= pl.n_levels; i += T) lvl[i] = pl.level_start[i];
                 __syncthreads();
             }
             const bool masked = monotonic && (flags & SMI_PROX_MONO_MASK);
-            if (masked) monotonic_mask(us, ws, fl, c, start);
+            if (masked) monotonic_mask<T>(us, ws, fl, c, start);
             if (monotonic)
-                sweep_levels<float, float>(us, lvl, pl.n_levels, pl.n_entries, pl.pix, pl.cnt,
-                                           pl.nbr, pl.wt, one_minus_g, lane);
+                sweep_levels_prefetch<T>(us, lvl, pl.n_levels, pl.n_entries, pl.max_terms, pl.pix,
+                                         pl.cnt, pl.nbr, pl.wt, one_minus_g, lane);
             if (masked) {
                 __syncthreads();
-                for (int i = lane; i < N; i += 64)
+                for (int i = lane; i < N; i += T)
                     if (fl[i]) us[i] = ws[i];
                 __syncthreads();
             }
-            chain_symmetry_threshold(us, c, flags, lthresh, sed_new, bg_level,
+            chain_symmetry_threshold<T>(us, c, flags, lthresh, sed_new, bg_level,
                                      (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[c.k] : 1.f);
             float mx = -INFINITY, sm = 0.f;
-            for (int i = lane; i < N; i += 64) {
+            for (int i = lane; i < N; i += T) {
                 float u = us[i];
                 if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
                 if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
@@ -727,24 +837,24 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
                 sm += u;
             }
             div = 1.f;
-            if (flags & SMI_PROX_NORM_MAX) div = wave_max(mx);
-            if (flags & SMI_PROX_NORM_SUM) div = wave_sum(sm);
+            if (flags & SMI_PROX_NORM_MAX) div = Team<T>::max(mx);
+            if (flags & SMI_PROX_NORM_SUM) div = Team<T>::sum(sm);
             if (rep + 1 < repeat) {
                 if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
-                    for (int i = lane; i < N; i += 64) us[i] = us[i] / div;
+                    for (int i = lane; i < N; i += T) us[i] = us[i] / div;
                 __syncthreads();
             }
         }
         float d2 = 0.f, z2 = 0.f;
-        for (int i = lane; i < N; i += 64) {
+        for (int i = lane; i < N; i += T) {
             const float u = (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM)) ? us[i] / div : us[i];
             const float z = zs[i];
             d2 += (u - z) * (u - z);
             z2 += z * z;
             zs[i] = u;
         }
-        d2 = wave_sum(d2);
-        z2 = wave_sum(z2);
+        d2 = Team<T>::sum(d2);
+        z2 = Team<T>::sum(z2);
         __syncthreads();
         if (d2 <= e2 * z2) break;
     }
@@ -754,7 +864,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         omega = 1.f + (t_old - 1.f) / tn;
         if (lane == 0) v.fista_t[2 * (int64_t)c.k + 1] = (double)tn;
     }
-    for (int i = lane; i < N; i += 64) {
+    for (int i = lane; i < N; i += T) {
         const float z = zs[i];
         if (fista) {
             const float xo = c.morph[i];
@@ -763,7 +873,7 @@ __global__ __launch_bounds__(64) void update_kernel(BatchView v, const float *G,
         c.morph_out[i] = z;
         bad |= !isfinite(z);
     }
-    if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
+    if (Team<T>::any(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
 }
 
 // -- point sources ---------------------------------------------------------------
@@ -817,7 +927,7 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
     };
 
     if (mode != 2) {
-        const float g_sed = gather_gradient(v, c, G, us);
+        const float g_sed = gather_gradient<64>(v, c, G, us);
         __syncthreads();
         profiles(true);
         const double Sy = wave_sum(fy[lane]), Sx = wave_sum(fx[lane]);
@@ -1564,10 +1674,19 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
     }
     const size_t lds = update_lds_bytes(v);
     SMI_REQUIRE(lds <= 160 * 1024, "component box too large for the LDS-resident update");
+    // four waves per component once the boxes are beyond the register-resident kernels
+    if (v.max_box_pixels > 64 * 64) {
+        static size_t configured[kMaxDevices] = {};
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(update_kernel<256>), lds, configured))
+            return rc;
+        hipLaunchKernelGGL(update_kernel<256>, dim3(v.n_comp), dim3(256), lds, s, v, G, it, e_rel,
+                           prox_max_iter, g_sed_out, g_morph_out, grad_only);
+        return SMI_OK;
+    }
     static size_t configured[kMaxDevices] = {};
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(update_kernel), lds, configured))
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(update_kernel<64>), lds, configured))
         return rc;
-    hipLaunchKernelGGL(update_kernel, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
+    hipLaunchKernelGGL(update_kernel<64>, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
                        prox_max_iter, g_sed_out, g_morph_out, grad_only);
     return SMI_OK;
 }
