@@ -267,24 +267,28 @@ __global__ __launch_bounds__(256) void cmul_kernel(float2 *S, const float2 *K, i
 template <int T>
 struct Team {
     static_assert(T == 64 || T == 256, "team size");
-    static __device__ __forceinline__ void sync() { __syncthreads(); }
+    static constexpr int kWaves = T / 64;
     static __device__ __forceinline__ float sum(float v) {
         v = wave_sum(v);
         if (T == 64) return v;
-        __shared__ float red[4];
+        __shared__ float red[kWaves];
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
         __syncthreads();
-        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < kWaves; i += 4) t += (red[i] + red[i + 1]) + (red[i + 2] + red[i + 3]);
         __syncthreads();
         return t;
     }
     static __device__ __forceinline__ float max(float v) {
         v = wave_max(v);
         if (T == 64) return v;
-        __shared__ float red[4];
+        __shared__ float red[kWaves];
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
         __syncthreads();
-        const float t = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float t = red[0];
+#pragma unroll
+        for (int i = 1; i < kWaves; ++i) t = fmaxf(t, red[i]);
         __syncthreads();
         return t;
     }
@@ -692,6 +696,8 @@ __device__ __forceinline__ void monotonic_mask(const float *us, float *ws, uint8
 }
 
 // -- generic variant: everything in LDS, plans with any number of terms -----
+__device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slots, int n_slots,
+                                            float one_minus_g, int lane);
 // T threads per component (Team): 64, or 256 for boxes of more than 64 x 64 pixels
 template <int T>
 __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, int it,
@@ -710,7 +716,8 @@ __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, 
     float *rs = xs + (v.scratch ? c.N : npad);
     float *zs = rs + (v.scratch ? c.N : npad);
     float *us = v.scratch ? lds_dyn : zs + npad;  // candidate (and g_morph before that)
-    int32_t *lvl = reinterpret_cast<int32_t *>(us + npad);  // level_start of the plan
+    // (+ 4: the spare zero cell the slot plans send their idle lanes to)
+    int32_t *lvl = reinterpret_cast<int32_t *>(us + npad + 4);  // level_start of the plan
     // SMI_PROX_MONO_MASK: image before the sweep and the flags of the accepted pixels
     float *ws = reinterpret_cast<float *>(lvl + ((v.max_levels + 2 + 3) & ~3));
     uint8_t *fl = reinterpret_cast<uint8_t *>(ws + npad);
@@ -816,9 +823,21 @@ __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, 
             }
             const bool masked = monotonic && (flags & SMI_PROX_MONO_MASK);
             if (masked) monotonic_mask<T>(us, ws, fl, c, start);
-            if (monotonic)
-                sweep_levels_prefetch<T>(us, lvl, pl.n_levels, pl.n_entries, pl.max_terms, pl.pix,
-                                         pl.cnt, pl.nbr, pl.wt, one_minus_g, lane);
+            if (monotonic) {
+                if (pl.slots) {
+                    // plans of at most four terms (every weighting of the reference but
+                    // "flat" away from the axes): the packed slot plan of the register-
+                    // resident kernels, swept by the first wavefront without barriers
+                    if (T == 64 || threadIdx.x < 64) {
+                        if (lane == 0) us[(N + 3) & ~3] = 0.f;
+                        sweep_slots(us, pl.slots, pl.n_slots, one_minus_g, lane);
+                    }
+                    __syncthreads();
+                } else {
+                    sweep_levels_prefetch<T>(us, lvl, pl.n_levels, pl.n_entries, pl.max_terms,
+                                             pl.pix, pl.cnt, pl.nbr, pl.wt, one_minus_g, lane);
+                }
+            }
             if (masked) {
                 __syncthreads();
                 for (int i = lane; i < N; i += T)
@@ -1606,7 +1625,7 @@ void launch_cmul(float2 *S, const float2 *K, int32_t nb, int32_t C, int64_t plan
 
 static size_t update_lds_bytes(const BatchView &v) {
     const size_t npad = (v.max_box_pixels + 3) & ~3;
-    size_t bytes = (v.scratch ? 1 : 4) * npad * sizeof(float);
+    size_t bytes = ((v.scratch ? 1 : 4) * npad + 4) * sizeof(float);
     if (v.mono_mask)  // image before the sweep + flags of the accepted pixels
         return bytes + (size_t)((v.max_levels + 2 + 3) & ~3) * sizeof(int32_t) + npad * 5;
     return bytes + (size_t)(v.max_levels + 2) * sizeof(int32_t);
@@ -1675,6 +1694,7 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
     const size_t lds = update_lds_bytes(v);
     SMI_REQUIRE(lds <= 160 * 1024, "component box too large for the LDS-resident update");
     // four waves per component once the boxes are beyond the register-resident kernels
+    // (multi-resolution tutorial fit, ms per iteration with 1 / 4 / 16 waves: 2.89 / 2.20 / 2.37)
     if (v.max_box_pixels > 64 * 64) {
         static size_t configured[kMaxDevices] = {};
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(update_kernel<256>), lds, configured))
