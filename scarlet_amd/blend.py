@@ -210,8 +210,8 @@ class Blend(CombinedComponent):
                             "a component with a free Fourier shift is limited to boxes of "
                             "100 pixels a side on the device (got {})".format(image.shape))
                     shift_kw = dict(shift=np.asarray(shift), shift_step=0.0 if shift.fixed else const)
-            if sed.prior is not None or image.prior is not None:
-                raise NotImplementedError("priors are not supported on the device")
+            if shift_kw and (sed.prior is not None or image.prior is not None):
+                raise NotImplementedError("priors on a component with a free Fourier shift")
 
             def rule(p, what):
                 """step rule of a parameter, or the callable itself if it is user code"""
@@ -225,11 +225,13 @@ class Blend(CombinedComponent):
             sed_rule, morph_rule = rule(sed, "spectrum"), rule(image, "morphology")
             # the spectrum kernel applies PositivityConstraint(1e-20) (spectrum.py:54-56)
             free_form = isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20
-            sed_on_device = not callable(sed_rule) and (
+            # a prior is user code: its gradient joins the likelihood's on the host
+            # (blend.py:120-131), so the parameter is stepped there
+            sed_on_device = not callable(sed_rule) and sed.prior is None and (
                 free_form or (sed.fixed and sed.constraint is None and np.all(np.asarray(sed) > 1e-20)))
             try:
                 flags = device_flags(image.constraint)
-                morph_on_device = not callable(morph_rule)
+                morph_on_device = not callable(morph_rule) and image.prior is None
             except NotImplementedError:
                 flags = device_flags(None)
                 morph_on_device = False

@@ -4,7 +4,7 @@ whose proximal operator or step rule is user code.
 ``Blend.fit`` hands every parameter's constraint to ``proxmin.adaprox`` as a Python
 callable ``prox(X, step)`` and evaluates callable steps as ``step(X, it)``.  The device
 loop only knows the built-in chains (``constraint.device_flags``).  A parameter with
-anything else -- a ``Constraint`` subclass, a built-in chain in another order,
+anything else -- a ``Prior``, a ``Constraint`` subclass, a built-in chain in another order,
 ``MonotonicMaskConstraint``, a custom step callable -- stays with the
 host: per iteration the device still renders, convolves and gathers the gradient of
 every parameter (``smi_batch_gradient``) and updates all parameters it can express;
@@ -80,6 +80,10 @@ class HostParameter:
         p = self.p
         x0 = np.array(p, dtype=F32)
         g = np.zeros_like(x0) if p.fixed else np.asarray(g, dtype=F32).reshape(x0.shape)
+        if p.prior is not None and not p.fixed:
+            # the reference adds what the prior returns for the current value to the
+            # likelihood's gradient (blend.py:120-131: ``x.prior(x)``, not ``prior.grad``)
+            g = g + np.asarray(p.prior(np.asarray(p).view(np.ndarray)), dtype=F32)
         b1, b2, eps, one = F32(b1), F32(b2), F32(eps), F32(1)
         alpha = self.alpha(it)  # on the pre-update values (blend.py:135-138)
         self.m = (one - b1) * g + b1 * self.m

@@ -961,6 +961,44 @@ def test_user_constraint_subclass_reproduces_the_device_result(hsc):
             assert_allclose(np.ma.filled(q.std, 0), np.ma.filled(p.std, 0), rtol=0, atol=0)
 
 
+def test_priors_join_the_gradient_on_the_host(hsc):
+    """``Parameter.prior`` (reference parameter.py:42-71; blend.py:120-131 adds ``x.prior(x)``
+    to the likelihood's gradient): parameters with a prior are stepped on the host.  A prior
+    that returns zeros reproduces the all-device fit bit for bit; one that pulls the image
+    towards zero lowers the fitted flux and the likelihood."""
+    import scarlet_amd as scarlet
+
+    class Flat(scarlet.Prior):
+        def __call__(self, x):
+            return np.zeros_like(x)
+
+        def grad(self, x):
+            return np.zeros_like(x)
+
+    class Pull(Flat):
+        def __call__(self, x):
+            return 50.0 * x
+
+    def flat(blend):
+        for comp in components_of(blend):
+            comp.children[0].parameters[0].prior = Flat()
+
+    ref, blend = _fit_pair(hsc, flat)
+    assert len(blend._host) == len(components_of(blend))
+    assert_allclose(blend.loss, ref.loss, rtol=0, atol=0)
+    for p, q in zip(ref.parameters, blend.parameters):
+        assert_allclose(np.asarray(q), np.asarray(p), rtol=0, atol=0)
+
+    def pull(blend):
+        components_of(blend)[0].children[0].parameters[0].prior = Pull()
+
+    _, pulled = _fit_pair(hsc, pull)
+    assert len(pulled._host) == 1
+    a = np.asarray(components_of(ref)[0].children[0].parameters[0])
+    b = np.asarray(components_of(pulled)[0].children[0].parameters[0])
+    assert np.all(b < a) and pulled.loss[-1] > ref.loss[-1]
+
+
 def test_user_step_callable_and_user_morphology_chain(hsc):
     """callable ``Parameter.step`` (reference blend.py:135-138) and a user-written chain
     for the image: host-stepped.  The constant step callable is exact; the chain divides

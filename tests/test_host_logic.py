@@ -366,3 +366,28 @@ def test_host_stepped_parameter_matches_a_float64_restatement():
     hp.store()
     # 1 - float32(0.999) differs from 0.001 by 5e-5 relative (the device's arithmetic)
     assert sed.m.dtype == np.float64 and np.allclose(sed.v, v, rtol=2e-4)
+
+    # a prior adds what it returns for the current value to the gradient (blend.py:120-131)
+    from scarlet_amd import Prior
+
+    class Pull(Prior):
+        def __call__(self, x):
+            return 0.3 * (x - 2.0)
+
+        def grad(self, x):
+            return 0.3 * np.ones_like(x)
+
+    prior = Parameter(rng.uniform(1, 5, 5).astype(np.float32), name="spectrum", step=0.05,
+                      prior=Pull(), constraint=PositivityConstraint(1e-20))
+    hp = hoststep.HostParameter(prior, "sed", (0.05, 0.0, 0.0))
+    x64 = np.asarray(prior, dtype=np.float64).copy()
+    m = v = vh = np.zeros(5)
+    for it in range(3):
+        g = rng.normal(size=5)
+        gp = g + 0.3 * (x64 - 2.0)
+        m = 0.1 * gp + 0.9 * m
+        v = 0.001 * gp * gp + 0.999 * v
+        vh = v.copy() if it == 0 else np.maximum(vh, v)
+        x64 = np.maximum(x64 - 0.05 * m / np.sqrt(np.maximum(vh, 1e-8)) / (10 if it == 0 else 1), 1e-20)
+        hp.update(it, g.astype(np.float32), 1e-3, 10, 0.9, 0.999, 1e-8)
+        assert np.allclose(np.asarray(prior), x64, rtol=1e-5)
