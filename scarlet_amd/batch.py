@@ -309,6 +309,14 @@ class BlendBatch:
         """Launch on the given HIP stream (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
         _lib.check(self._lib.smi_batch_set_stream(self._h, ctypes.c_void_p(stream_handle)))
 
+    def set_observation(self, data, weights):
+        """Replace data and weights (same shape; the normalisation term of the loss follows
+        the new weights)."""
+        data, weights = _lib.f32(data), _lib.f32(weights)
+        assert data.shape == weights.shape == (self.n_blends, self.C, self.H, self.W)
+        _lib.check(self._lib.smi_batch_set_observation(
+            self._h, _lib.ptr(data, ctypes.c_float), _lib.ptr(weights, ctypes.c_float)))
+
     def set_observation_device(self, data_ptr, weights_ptr):
         """Adopt device-resident data/weights (e.g. ``tensor.data_ptr()``)."""
         _lib.check(

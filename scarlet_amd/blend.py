@@ -429,8 +429,10 @@ class Blend(CombinedComponent):
         reference, blend.py:168,301-302) switches to host-stepped mode: one
         iteration per device call, parameters downloaded before every call of the
         callback; ``StopIteration`` raised by it ends the fit cleanly."""
-        if noise_factor:
-            raise NotImplementedError("noise_factor > 0 is not supported")
+        if noise_factor and (len(self.observations) != 1 or
+                             tuple(self.observations[0].shape) != tuple(self.frame.shape) or
+                             type(self.observations[0].renderer) is ResolutionRenderer):
+            raise NotImplementedError("noise_factor > 0 needs one observation on the model frame")
         scheme = alg_kwargs.pop("scheme", "amsgrad")
         prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
         callback = alg_kwargs.pop("callback", None)
@@ -467,8 +469,10 @@ class Blend(CombinedComponent):
                     # i.e. once 11, 21, ... iterations of this batch are done
                     next_hook = 11 if local == 0 else ((local - 1) // 10 + 1) * 10 + 1
                     n = min(next_hook - local, max_iter - it - local)
-                    if callback is not None or self._host:
+                    if callback is not None or self._host or noise_factor:
                         n = 1
+                    if noise_factor:
+                        self._draw_noise(batch, noise_factor)
                     # plug-in seam: gradients at the parameters of this iteration for the
                     # parameters the host updates (hoststep.py)
                     grads = batch.gradient() if self._host else None
@@ -517,6 +521,22 @@ class Blend(CombinedComponent):
             if p.v is not None:
                 p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))  # rough estimate, blend.py:189-192
         return len(self.loss), -self.loss[-1]
+
+    def _draw_noise(self, batch, noise_factor):
+        """``noise_factor > 0`` (observation.py:165-168): every evaluation of the likelihood
+        sees the data plus a fresh noise draw and weights / (noise_factor + 1); the
+        normalisation stays that of the original weights."""
+        obs = self.observations[0]
+        data, weights = obs.data, obs.weights
+        try:
+            obs.data, obs.weights = obs.noisy(noise_factor)
+            noisy_data, noisy_weights, _ = self._observation()
+        finally:
+            obs.data, obs.weights = data, weights
+        batch.set_observation(noisy_data[None], noisy_weights[None])
+        # the device derives log_norm from the weights it holds: take the scaling out again
+        n_seen = int(np.count_nonzero(noisy_weights))
+        batch.add_loss_constant(-0.5 * n_seen * np.log(noise_factor + 1.0))
 
     def _free_psf_shift(self):
         """``(shift parameter, renderer)`` of the one observation whose

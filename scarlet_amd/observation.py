@@ -107,10 +107,18 @@ class Observation(Frame):
 
     def get_log_likelihood(self, model, *parameters, noise_factor=0):
         """``-log_norm - sum w (render(model) - data)^2 / 2``."""
-        if noise_factor > 0:
-            raise NotImplementedError("noise_factor > 0 (random noise injection) is not supported")
         model_ = self.render(model, *parameters)
-        return -self.log_norm - np.sum(self.weights * (model_ - self.data) ** 2) / 2
+        data_, weights_ = self.noisy(noise_factor) if noise_factor > 0 else (self.data, self.weights)
+        return -self.log_norm - np.sum(weights_ * (model_ - data_) ** 2) / 2
+
+    def noisy(self, noise_factor):
+        """``(data, weights)`` of one evaluation with ``noise_factor > 0``
+        (observation.py:165-168): a fresh draw of the pixel noise from NumPy's global
+        generator is added to the data, the weights are divided by ``noise_factor + 1``."""
+        noise = np.random.normal(loc=0, scale=self.noise_rms)
+        # pixels without weight have no noise level; they do not enter the likelihood
+        noise = np.where(ma.getmaskarray(self.noise_rms), 0, np.asarray(noise))
+        return self.data + noise.astype(self.data.dtype), self.weights / (noise_factor + 1)
 
     @property
     def log_norm(self):

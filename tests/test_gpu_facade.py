@@ -999,6 +999,34 @@ def test_priors_join_the_gradient_on_the_host(hsc):
     assert np.all(b < a) and pulled.loss[-1] > ref.loss[-1]
 
 
+def test_noise_factor_draws_fresh_noise_every_iteration(hsc):
+    """``Blend.fit(noise_factor=f)`` (reference observation.py:165-168, blend.py:100,
+    268-270): every evaluation sees data + a draw of the pixel noise from NumPy's global
+    generator and weights / (f + 1), the normalisation term stays that of the original
+    weights.  With the generator seeded, the first losses equal the host evaluation of the
+    same formula on the same draws."""
+    blend, obs = build_blend(hsc, resizing=False)
+    rendered = obs.render(blend.get_model())
+    f = 1.0
+    np.random.seed(11)
+    want = []
+    for _ in range(2):  # the second draw belongs to iteration 1, whose model we do not know
+        noise = np.asarray(np.random.normal(loc=0, scale=obs.noise_rms))
+        want.append(obs.log_norm + 0.5 * np.sum(
+            obs.weights.astype(np.float64) / (f + 1) * (rendered - obs.data - noise) ** 2))
+    np.random.seed(11)
+    assert_allclose(-obs.get_log_likelihood(blend.get_model(), noise_factor=f), want[0], rtol=1e-6)
+    np.random.seed(11)
+    n, logL = blend.fit(4, e_rel=1e-9, noise_factor=f)
+    assert n == 4 and np.isfinite(logL)
+    assert_allclose(blend.loss[0], want[0], rtol=1e-6)
+    quiet, _ = build_blend(hsc, resizing=False)
+    quiet.fit(4, e_rel=1e-9)
+    assert abs(blend.loss[0] - quiet.loss[0]) > 1e-3 * abs(quiet.loss[0])
+    # the observation itself is untouched
+    np.testing.assert_array_equal(obs.data, hsc["images"])
+
+
 def test_user_step_callable_and_user_morphology_chain(hsc):
     """callable ``Parameter.step`` (reference blend.py:135-138) and a user-written chain
     for the image: host-stepped.  The constant step callable is exact; the chain divides
