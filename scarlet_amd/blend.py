@@ -191,6 +191,8 @@ class Blend(CombinedComponent):
             sed = spectrum.parameters[0]
             image = morphology.parameters[0]
             if isinstance(morphology, PointSourceMorphology):
+                if self._scheme_args()[0] != "amsgrad":
+                    raise NotImplementedError("point sources with another scheme than amsgrad")
                 specs.append(self._point_spec(sed, image, morphology))
                 continue
             shift_kw = {}
@@ -227,11 +229,14 @@ class Blend(CombinedComponent):
             free_form = isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20
             # a prior is user code: its gradient joins the likelihood's on the host
             # (blend.py:120-131), so the parameter is stepped there
-            sed_on_device = not callable(sed_rule) and sed.prior is None and (
+            device_scheme = getattr(self, "_scheme", ("amsgrad", 0.25))[0] == "amsgrad"
+            if shift_kw and not device_scheme:
+                raise NotImplementedError("free Fourier shifts with another scheme than amsgrad")
+            sed_on_device = device_scheme and not callable(sed_rule) and sed.prior is None and (
                 free_form or (sed.fixed and sed.constraint is None and np.all(np.asarray(sed) > 1e-20)))
             try:
                 flags = device_flags(image.constraint)
-                morph_on_device = not callable(morph_rule) and image.prior is None
+                morph_on_device = device_scheme and not callable(morph_rule) and image.prior is None
             except NotImplementedError:
                 flags = device_flags(None)
                 morph_on_device = False
@@ -239,10 +244,10 @@ class Blend(CombinedComponent):
                 raise NotImplementedError(
                     "user-defined constraints / steps on a component with a free Fourier shift")
             if not sed_on_device:
-                self._host.append((k, HostParameter(sed, "sed", sed_rule)))
+                self._host.append((k, HostParameter(sed, "sed", sed_rule, *self._scheme_args())))
                 sed_rule = (0.0, 0.0, 0.0)
             if not morph_on_device:
-                self._host.append((k, HostParameter(image, "morph", morph_rule)))
+                self._host.append((k, HostParameter(image, "morph", morph_rule, *self._scheme_args())))
                 morph_rule = (0.0, 0.0, 0.0)
             s_const, s_rel, s_min = sed_rule
             m_const, m_rel, m_min = morph_rule
@@ -267,6 +272,9 @@ class Blend(CombinedComponent):
                 )
             )
         return specs
+
+    def _scheme_args(self):
+        return getattr(self, "_scheme", ("amsgrad", 0.25))
 
     def _host_update(self, batch, local, grads, e_rel, prox_max_iter, opt):
         """The host's share of iteration ``local``: AMSGrad + proximal sub-iterations of
@@ -436,13 +444,16 @@ class Blend(CombinedComponent):
         scheme = alg_kwargs.pop("scheme", "amsgrad")
         prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
         callback = alg_kwargs.pop("callback", None)
-        if scheme != "amsgrad":
-            raise NotImplementedError("only scheme='amsgrad' runs on the device")
+        # the device loop is AMSGrad (the reference's default); any other scheme of
+        # proxmin.adaprox steps every parameter on the host from the device's gradients
+        self._scheme = (scheme, alg_kwargs.pop("p", 0.25))
         opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
                    eps=alg_kwargs.pop("eps", 1e-8))
         if alg_kwargs:
             raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
         free = [p for obs in self.observations for p in obs.parameters if not p.fixed]
+        if free and scheme != "amsgrad":
+            raise NotImplementedError("a free psf_shift with scheme={!r}".format(scheme))
         self._psf = None
         if free:
             self._specs(_flatten(self.sources))
@@ -803,7 +814,8 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
         raise NotImplementedError("callback= needs the host-stepped mode of Blend.fit")
     scheme = alg_kwargs.pop("scheme", "amsgrad")
     if scheme != "amsgrad":
-        raise NotImplementedError("only scheme='amsgrad' runs on the device")
+        raise NotImplementedError("fit_blends batches the device's AMSGrad loop; use Blend.fit "
+                                  "for scheme={!r} (host-stepped)".format(scheme))
     prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
     opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
                eps=alg_kwargs.pop("eps", 1e-8))
@@ -816,6 +828,7 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
             # `base + local` is the reference's `it`: 0 at the start of fit(), the length
             # of the whole loss history after a restart (blend.py:101, 198)
             self.blend, self.base, self.local, self.result = blend, 0, 0, None
+            blend._scheme = ("amsgrad", 0.25)  # the batched device loop
             self.obs = blend._observation()
             if blend._lowres or blend._extra_layers:
                 raise NotImplementedError(

@@ -20,6 +20,7 @@ what a built-in one does gives bit-identical results to the device path.
 import numpy as np
 
 F32 = np.float32
+SCHEMES = ("adam", "nadam", "amsgrad", "padam", "adamx", "radam")
 
 
 def wave_sum(x):
@@ -53,10 +54,14 @@ class HostParameter:
         callable ``step(X, it)``
     """
 
-    def __init__(self, parameter, kind, step):
+    def __init__(self, parameter, kind, step, scheme="amsgrad", p=0.25):
         self.p = parameter
         self.kind = kind
         self.step = step
+        if scheme not in SCHEMES:
+            raise ValueError("scheme must be one of {}".format(SCHEMES))
+        self.scheme = scheme
+        self.padam_p = p
         for name in ("m", "v", "vhat"):
             value = getattr(parameter, name)
             setattr(self, name, np.zeros(parameter.shape, F32) if value is None
@@ -88,9 +93,8 @@ class HostParameter:
         alpha = self.alpha(it)  # on the pre-update values (blend.py:135-138)
         self.m = (one - b1) * g + b1 * self.m
         self.v = (one - b2) * g * g + b2 * self.v
-        self.vhat = self.v.copy() if it == 0 else np.maximum(self.vhat, self.v)
-        psi = np.sqrt(np.maximum(self.vhat, eps))
-        upd = alpha * self.m / psi
+        phi, psi = self.phi_psi(it, g, b1, b2, eps)
+        upd = alpha * phi / psi
         if it == 0:
             upd = upd / F32(10)
         x = x0 - upd
@@ -112,6 +116,37 @@ class HostParameter:
                     break
         p[...] = z
         return z
+
+    def phi_psi(self, it, g, b1, b2, eps):
+        """Direction ``phi`` and metric ``psi`` of the step ``x -= alpha phi / psi`` from the
+        moments already updated with ``g`` (``proxmin.adaprox(scheme=...)``, blend.py:144;
+        the reference lists the schemes at lite/parameters.py:158-165).  "amsgrad" is the
+        device kernels' arithmetic.  proxmin is not available here: the other schemes
+        follow the papers the reference cites (lite/parameters.py:187-193) -- parity
+        unpinned."""
+        one, t = F32(1), it + 1
+        if self.scheme in ("amsgrad", "adamx", "padam"):
+            # AdamX rescales vhat by ((1 - b1_t) / (1 - b1_{t-1}))^2, which is 1 for the
+            # constant b1 of Blend.fit (Phuong & Phong 2019)
+            self.vhat = self.v.copy() if it == 0 else np.maximum(self.vhat, self.v)
+            vh = np.maximum(self.vhat, eps)
+            if self.scheme == "padam":  # Chen & Gu 2018: vhat^p instead of the square root
+                return self.m, np.power(vh, F32(self.padam_p))
+            return self.m, np.sqrt(vh)
+        c1, c2 = one - F32(b1) ** t, one - F32(b2) ** t  # bias corrections
+        if self.scheme == "adam":  # Kingma & Ba 2015
+            return self.m / c1, np.sqrt(self.v / c2) + eps
+        if self.scheme == "nadam":  # Dozat 2016: Nesterov look-ahead on the first moment
+            return (b1 * self.m + (one - b1) * g) / c1, np.sqrt(self.v / c2) + eps
+        # RAdam (Liu et al. 2019): variance rectification once rho_t > 4, else plain momentum
+        rho_inf = 2.0 / (1.0 - float(b2)) - 1.0
+        rho = rho_inf - 2.0 * t * float(b2) ** t / (1.0 - float(b2) ** t)
+        if rho > 4:
+            r = np.sqrt((rho - 4) * (rho - 2) * rho_inf / ((rho_inf - 4) * (rho_inf - 2) * rho))
+            psi = np.maximum(np.sqrt(self.v / c2) / F32(r), np.sqrt(eps))
+        else:
+            psi = np.ones_like(self.v)
+        return self.m / c1, psi
 
     def store(self):
         """Leave the moments on the Parameter like the device path does (float64)."""

@@ -1027,6 +1027,27 @@ def test_noise_factor_draws_fresh_noise_every_iteration(hsc):
     np.testing.assert_array_equal(obs.data, hsc["images"])
 
 
+def test_other_adaprox_schemes_step_on_the_host(hsc):
+    """``Blend.fit(scheme=...)`` (reference blend.py:144 forwards any scheme of
+    proxmin.adaprox): the device loop is AMSGrad; every other scheme takes the device's
+    gradients and steps all parameters on the host.  AdamX with the constant b1 of
+    Blend.fit is AMSGrad and must reproduce the device fit; Adam fits the scene too."""
+    ref, adamx = _fit_pair(hsc, lambda blend: None, n_it=10)
+    adamx, _ = build_blend(hsc, resizing=False)
+    adamx.fit(10, e_rel=1e-6, scheme="adamx")
+    assert len(adamx._host) == 2 * len(components_of(adamx))
+    assert_allclose(adamx.loss, ref.loss, rtol=2e-5)
+    adam, _ = build_blend(hsc, resizing=False)
+    n, logL = adam.fit(30, e_rel=1e-6, scheme="adam")
+    assert n == 30 and logL > -adam.loss[0] and adam.loss[-1] < 0.2 * adam.loss[0]
+    for p in adam.parameters:
+        if not p.fixed and p.m is not None:
+            assert p.std is not None
+    # the next fit of the same blend is the device loop again
+    adam.fit(3, e_rel=1e-6)
+    assert adam._host == []
+
+
 def test_user_step_callable_and_user_morphology_chain(hsc):
     """callable ``Parameter.step`` (reference blend.py:135-138) and a user-written chain
     for the image: host-stepped.  The constant step callable is exact; the chain divides

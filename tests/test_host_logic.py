@@ -391,3 +391,50 @@ def test_host_stepped_parameter_matches_a_float64_restatement():
         x64 = np.maximum(x64 - 0.05 * m / np.sqrt(np.maximum(vh, 1e-8)) / (10 if it == 0 else 1), 1e-20)
         hp.update(it, g.astype(np.float32), 1e-3, 10, 0.9, 0.999, 1e-8)
         assert np.allclose(np.asarray(prior), x64, rtol=1e-5)
+
+
+def test_adaprox_schemes_of_the_host_step():
+    """``Blend.fit(scheme=...)`` other than AMSGrad steps on the host (hoststep.phi_psi).
+    Adam against a float64 restatement of Kingma & Ba; AdamX with a constant b1 and PAdam
+    with p = 1/2 are AMSGrad; RAdam takes plain momentum steps while rho_t <= 4."""
+    from scarlet_amd import Parameter, hoststep
+
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(1, 2, 7).astype(np.float32)
+    grads = rng.normal(size=(8, 7)).astype(np.float32)
+
+    def run(scheme, **kw):
+        x = Parameter(x0.copy(), name="x", step=0.05)
+        hp = hoststep.HostParameter(x, "sed", (0.05, 0.0, 0.0), scheme, **kw)
+        trace = []
+        for it, g in enumerate(grads):
+            hp.update(it, g, 1e-3, 10, 0.9, 0.999, 1e-8)
+            trace.append(np.array(x))
+        return np.array(trace)
+
+    with pytest.raises(ValueError):
+        hoststep.HostParameter(Parameter(x0.copy(), name="x", step=0.05), "sed", (0.05, 0, 0), "sgd")
+    ams = run("amsgrad")
+    assert np.array_equal(run("adamx"), ams)
+    assert np.allclose(run("padam", p=0.5), ams, rtol=1e-6)
+    assert not np.allclose(run("padam"), ams, rtol=1e-3)
+
+    x, m, v = x0.astype(np.float64), np.zeros(7), np.zeros(7)
+    adam = run("adam")
+    for it, g in enumerate(grads.astype(np.float64)):
+        m = 0.1 * g + 0.9 * m
+        v = 0.001 * g * g + 0.999 * v
+        t = it + 1
+        step = 0.05 * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-8)
+        x = x - step / (10 if it == 0 else 1)
+        assert np.allclose(adam[it], x, rtol=2e-4)
+
+    # rho_t ~ t for small t at b2 = 0.999: psi = 1, phi = bias-corrected momentum up to t = 4
+    radam = run("radam")
+    x, m = x0.astype(np.float64), np.zeros(7)
+    for it, g in enumerate(grads[:3].astype(np.float64)):
+        m = 0.1 * g + 0.9 * m
+        x = x - 0.05 * m / (1 - 0.9 ** (it + 1)) / (10 if it == 0 else 1)
+        assert np.allclose(radam[it], x, rtol=1e-5)
+    assert np.all(np.isfinite(run("nadam"))) and not np.allclose(run("nadam"), adam)
+
