@@ -204,8 +204,8 @@ def test_fit_forwards_adam_constants(hsc):
     default, _ = build_blend(hsc, resizing=False)
     default.fit(8, e_rel=1e-9)
     assert abs(default.loss[-1] - blend.loss[-1]) > 1e-3 * abs(blend.loss[-1] - sc.log_norm)
-    with pytest.raises(NotImplementedError):
-        blend.fit(2, scheme="adam")
+    with pytest.raises(ValueError):
+        blend.fit(2, scheme="sgd")  # not a scheme of proxmin.adaprox
     with pytest.raises(NotImplementedError):
         blend.fit(2, no_such_option=1)
 
