@@ -1,6 +1,6 @@
 """Random BATCHES of blends with mixed features, GPU against the oracle: ragged numbers of
 components, L0 / L1 members of the chain, centre floors, point sources, free Fourier
-shifts, several sub-ranges on streams, a few iterations of the loop.  Development aid.
+shifts, boxes beyond 64 x 64 pixels, several sub-ranges on streams, a few iterations of the loop.  Development aid.
 
     python tools/fuzz_batches.py [n_batches] [seed]
 """
@@ -30,7 +30,9 @@ for n in range(n_batches):
     sig = rng.uniform(0.8, 2.0, C)
     kernel = np.stack([np.exp(-(yy**2 + xx**2) / (2 * s**2)) for s in sig]).astype(np.float32)
     kernel /= kernel.sum(axis=(1, 2))[:, None, None]
-    feature = str(rng.choice(["plain", "sparse", "points", "shifts"]))
+    feature = str(rng.choice(["plain", "sparse", "points", "shifts", "big"]))
+    if feature == "big":  # boxes beyond 64 x 64: general update kernel with four waves
+        H, W, nb = int(rng.integers(100, 150)), int(rng.integers(100, 150)), int(rng.integers(1, 3))
     data = rng.normal(0, 1, (nb, C, H, W)).astype(np.float32)
     weights = rng.uniform(0.5, 2.0, (nb, C, H, W)).astype(np.float32)
     specs, scenes = [], []
@@ -47,6 +49,8 @@ for n in range(n_batches):
             h = w = int(rng.choice([11, 15, 21, 31]))
             if feature != "shifts":
                 h, w = int(rng.integers(5, 45)), int(rng.integers(5, 45))
+            if feature == "big" and k < 2:
+                h, w = int(rng.integers(65, 100)), int(rng.integers(65, 100))
             oy = int(rng.integers(-3, max(H - h + 3, -2)))
             ox = int(rng.integers(-3, max(W - w + 3, -2)))
             y, x = np.mgrid[:h, :w]
