@@ -1,6 +1,6 @@
 """Benchmark: PGM iterations/sec over batched blends (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg1|cfg5] [--weak]
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg1|cfg4|cfg5] [--weak]
 
 A step = one proximal-gradient iteration (render -> FFT convolution -> weighted
 residual/loss -> adjoint convolution -> gradient gather -> AMSGrad -> prox chain)
@@ -20,6 +20,9 @@ Workloads (BASELINE.json configs):
   cfg1            configs[0]'s scene (tests/golden/hsc_cosmos_35.npz: 5x58x48, 10
                   components in boxes 21^2..61^2, per-band 43^2 difference kernel)
                   replicated into a batch.
+  cfg4            configs[3]'s scene (tests/golden/point_source.npz = psf_unmatched_sim:
+                  6x40x59, per-band 31^2 difference kernel, 3 PointSources + 2 ExtendedSources
+                  in 71^2 / 81^2 boxes) replicated into a batch.
   cfg5            configs[4]: the multi-resolution operator (tools/bench_cfg5.py).
 
 ``python bench.py --gpus N`` without a torchrun environment starts its own N ranks
@@ -92,6 +95,11 @@ def _oracle_fit(args):
         from conftest import golden, hsc_scene
 
         sc = hsc_scene(golden("hsc_cosmos_35"))
+    elif kind == "cfg4":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import golden, point_scene
+
+        sc = point_scene(golden("point_source"))
     else:
         from scarlet_amd import synthetic
 
@@ -239,6 +247,26 @@ def build_cfg1(n):
     return np.ascontiguousarray(data), np.ascontiguousarray(weights), [one] * n, g["diff_kernel"]
 
 
+def build_cfg4(n):
+    """`n` copies of the point-source tutorial blend on psf_unmatched_sim (sources as the
+    reference initialised them; golden fixture): per-band difference kernel, three stars
+    with free centres, two extended sources in boxes beyond the register-resident classes."""
+    from scarlet_amd import ComponentSpec, PointSourceSpec
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "point_source.npz"))
+    one = []
+    for k in range(int(g["n_src"])):
+        if g["is_star"][k]:
+            one.append(PointSourceSpec(g["sed_%d" % k], g["center_%d" % k], 0.9,
+                                       sed_min_step=g["min_step_%d" % k]))
+        else:
+            one.append(ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
+                                     sed_min_step=g["min_step_%d" % k]))
+    data = np.broadcast_to(g["images"], (n,) + g["images"].shape)
+    weights = np.full(data.shape, 0.25, dtype=np.float32)
+    return np.ascontiguousarray(data), weights, [one] * n, g["diff_kernel"]
+
+
 def counters(kernel):
     """Counter-derived figures of the dominant kernel from the committed rocprofv3 PMC
     summaries (profiles/hbm_traffic.json, written by tools/hbm_counters.py)."""
@@ -268,7 +296,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg1", "cfg5"])
+    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg1", "cfg4", "cfg5"])
     ap.add_argument("--blends", type=int, default=1024,
                     help="blends of the whole job (per GPU with --weak)")
     ap.add_argument("--weak", action="store_true", help="--blends per GPU instead of in total")
@@ -318,6 +346,8 @@ def main():
     lite = args.loop != "blend"
     if args.config == "cfg1":
         data, weights, comps, kernel = build_cfg1(nb)
+    elif args.config == "cfg4":
+        data, weights, comps, kernel = build_cfg4(nb)
     else:
         data, weights, comps, kernel = build_cfg3(lo, hi, local_rank, args.loop if lite else None)
     K, Wm = args.steps, args.warmup
@@ -392,7 +422,10 @@ def main():
         ms_iter = elapsed / K * 1e3
         # the fused path has no kernel between the loss and the update (conv_adj = 0)
         fused = (not args.null_renderer) and phases["conv_adj"] < 0.05 * phases["conv"]
-        if fused:
+        if fused and phases["update"] > phases["conv"]:
+            # the update phase is the larger share (cfg1 / cfg4 batches: few, large boxes)
+            k_name, k_bytes, k_ms = "update kernels (update phase of the iteration)", by["update"], phases["update"]
+        elif fused:
             k_name, k_bytes, k_ms = "fused_conv_kernel", by["conv"], phases["conv"]
         elif args.null_renderer:
             k_name, k_bytes, k_ms = "update_kernel_reg", by["update"], phases["update"]
@@ -418,7 +451,8 @@ def main():
                                   if traffic else None),
             "valu_busy": cnt.get("valu_busy"),
             "flops_frac": (round(fft_flops(C, Fy, Fx) * nb / (k_ms * 1e-3) / 1e12
-                                 / F32_VECTOR_PEAK_TFLOPS, 5) if fused else None),
+                                 / F32_VECTOR_PEAK_TFLOPS, 5)
+                           if k_name == "fused_conv_kernel" else None),
             "measured": "HIP events on the batch stream, iterations %d..%d replayed in one "
                         "range of %d blends per launch (the timed region runs %d range(s) "
                         "concurrently)" % (it0 + (K if args.steady else 0),
@@ -446,6 +480,10 @@ def main():
         if args.config == "cfg1":
             what = ("configs[0] scene (hsc_cosmos_35: 5x58x48, 10 components, boxes 21^2..61^2, "
                     "per-band 43x43 kernel) replicated: %d blends in total" % n_total)
+        elif args.config == "cfg4":
+            what = ("configs[3] scene (psf_unmatched_sim: 6x40x59, per-band 31x31 kernel, 3 "
+                    "PointSources + 2 ExtendedSources in 71^2 / 81^2 boxes) replicated: %d blends "
+                    "in total" % n_total)
         else:
             what = ("configs[2]: %d independent 5-band 128x128 blends in total%s, 10 "
                     "ExtendedSource components (41x41) each" % (

@@ -85,23 +85,31 @@ struct alignas(16) SweepSlotEntry {
 };
 
 // Size classes of the register-resident update kernel: a box of N pixels runs in the
-// instantiation with the smallest NPL >= N / 64 (lane l owns pixels l, l + 64, ...), so
-// every box of class c has more than 64 * kUpdateNpl[c - 1] pixels.  The reference's
-// standard boxes (21 + 10 k pixels a side, morphology.py / initialization.py:173-177)
-// 21^2 .. 61^2 map onto one class each.
-constexpr int kNumUpdateClasses = 5;
+// instantiation with the smallest T * NPL >= N (thread t of the component's T threads owns
+// pixels t, t + T, ...), so every box of a class has more than T * NPL_prev pixels.  One
+// wavefront per component for the reference's standard boxes (21 + 10 k pixels a side,
+// morphology.py / initialization.py:173-177: 21^2 .. 61^2 map onto one class each), four
+// wavefronts for larger boxes up to 122^2 (the state of a 71^2 or 81^2 box does not fit the
+// registers of one wavefront; the image in LDS and the sweep stay those of one wavefront).
+constexpr int kNumSmallClasses = 5;
+constexpr int kNumUpdateClasses = 9;
 // up to this many components a range with several size classes is updated in one launch
 // (update_kernel_mixed; measurements there)
 constexpr int kMixedUpdateLimit = 3072;
-constexpr int kUpdateNpl[kNumUpdateClasses] = {7, 16, 27, 42, 59};
+constexpr int kUpdateNpl[kNumUpdateClasses] = {7, 16, 27, 42, 59, 16, 27, 42, 59};
+constexpr int kUpdateTeam[kNumUpdateClasses] = {64, 64, 64, 64, 64, 256, 256, 256, 256};
+constexpr int kMaxRegisterBox = 256 * 59;
 inline int update_class(int n_pix) {
     for (int c = 0; c < kNumUpdateClasses; ++c)
-        if (n_pix <= 64 * kUpdateNpl[c]) return c;
+        if (n_pix <= kUpdateTeam[c] * kUpdateNpl[c]) return c;
     return -1;
 }
-// LDS floats of one component's image in that kernel: all 64 * NPL pixel slots of the
+// LDS floats of one component's image in that kernel: all T * NPL pixel slots of the
 // class (slots beyond the box hold zeros, so the loops need no bounds) + the spare cell
-inline int update_image_stride(int n_pix) { return 64 * kUpdateNpl[update_class(n_pix)] + 4; }
+inline int update_image_stride(int n_pix) {
+    const int c = update_class(n_pix);
+    return kUpdateTeam[c] * kUpdateNpl[c] + 4;
+}
 
 struct SweepPlanDev {
     int32_t h = 0, w = 0, n_entries = 0, max_terms = 0, n_levels = 0;

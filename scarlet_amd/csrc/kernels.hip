@@ -1170,12 +1170,12 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
 // One wavefront per component; the components of a launch all belong to one size class
 // (`work` lists them class by class, common.h), so the per-pixel loops carry no bounds
 // for the first kFull slots and a small box never runs through a large box's loops.
-template <int NPL, int MODE>
+template <int NPL, int MODE, int T = 64>
 __device__ __forceinline__ void update_component(const BatchView &v, const float *G, int it,
                                                  float e_rel, int prox_max_iter, int k) {
     constexpr bool LITE = MODE != 0;
     constexpr bool fista = MODE == 2;
-    // every box of this size class has more than 64 * kFull pixels (common.h)
+    // every box of this size class has more than T * kFull pixels (common.h)
     constexpr int kFull = NPL == 7 ? 0 : NPL == 16 ? 7 : NPL == 27 ? 16 : NPL == 42 ? 27 : 42;
     const int lane = threadIdx.x;
     const CompCtx c = comp_ctx(v, k, lane);
@@ -1196,13 +1196,13 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
     {
         const rsrc_t r_morph = make_rsrc(c.morph, nbytes);
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) zs[j] = buf_load(r_morph, (uint32_t)(lane + 64 * j) * 4u);
+        for (int j = 0; j < NPL; ++j) zs[j] = buf_load(r_morph, (uint32_t)(lane + T * j) * 4u);
     }
     float g_sed = 0.f;
     if (c.pre) {
         const rsrc_t r_g = make_rsrc(v.g_morph_buf + c.moff, nbytes);
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) xs[j] = buf_load(r_g, (uint32_t)(lane + 64 * j) * 4u);
+        for (int j = 0; j < NPL; ++j) xs[j] = buf_load(r_g, (uint32_t)(lane + T * j) * 4u);
         g_sed = lane < c.C ? v.g_sed_buf[(int64_t)k * c.C + lane] : 0.f;
     } else {
         // byte offset of each of the lane's pixels inside a band plane of G (or out of
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
         const float inv_w = 1.0f / (float)c.w;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            const int i = lane + 64 * j;
+            const int i = lane + T * j;
             // exact for i < 2^20: the float quotient is off by < 1e-6 relative
             const int y = (int)(((float)i + 0.5f) * inv_w);
             const int x = i - y * c.w;
@@ -1226,7 +1226,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
             const rsrc_t r_g = make_rsrc(G + ((int64_t)c.b * c.C + cb) * plane, (uint32_t)plane * 4u);
             float g[NPL];
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) g[j] = buf_load(r_g, goff[lane + 64 * j]);
+            for (int j = 0; j < NPL; ++j) g[j] = buf_load(r_g, goff[lane + T * j]);
             const float s = c.sed[cb];
             float acc = 0.f;
 #pragma unroll
@@ -1234,7 +1234,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
                 xs[j] = fmaf(s, g[j], xs[j]);
                 acc = fmaf(g[j], zs[j], acc);
             }
-            const float t = wave_sum(acc);
+            const float t = Team<T>::sum(acc);
             if (lane == cb) g_sed = t;
         }
     }
@@ -1254,19 +1254,22 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
     float ssum2 = 1.f, t_old = 1.f;
     if (fista) {
         // sums over the *old* parameters: FISTA steps (lite/parameters.py:138)
-        msum2 = wave_sum(msum2);
+        msum2 = Team<T>::sum(msum2);
         const float so = lane < c.C ? c.sed[lane] : 0.f;
-        ssum2 = wave_sum(so * so);
+        ssum2 = Team<T>::sum(so * so);
         t_old = (float)v.fista_t[2 * (int64_t)k + 1];
     }
-    int bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, sed_new);
-    const float alpha = fmaxf(v.c_morph_step[k], v.c_morph_rel[k] * (wave_sum(msum) / (float)N));
+    // the spectrum belongs to the first wavefront (one band per lane)
+    int bad = 0;
+    if (T == 64 || threadIdx.x < 64)
+        bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, sed_new);
+    const float alpha = fmaxf(v.c_morph_step[k], v.c_morph_rel[k] * (Team<T>::sum(msum) / (float)N));
     float pmax = 0.f;
     const rsrc_t r_m = make_rsrc(v.m_morph + c.moff, nbytes);
     if (fista) {
         const float step = v.c_fista_step[k] / ssum2;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) rs[j] = buf_load(r_m, (uint32_t)(lane + 64 * j) * 4u);
+        for (int j = 0; j < NPL; ++j) rs[j] = buf_load(r_m, (uint32_t)(lane + T * j) * 4u);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             xs[j] = rs[j] - step * xs[j];
@@ -1284,7 +1287,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
         float cm[CH], cv[CH], cvh[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const uint32_t off = (uint32_t)(lane + 64 * u) * 4u;
+            const uint32_t off = (uint32_t)(lane + T * u) * 4u;
             cm[u] = buf_load(r_m, off);
             cv[u] = buf_load(r_v, off);
             cvh[u] = buf_load(r_vh, off);
@@ -1296,7 +1299,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
             for (int u = 0; u < CH; ++u) {
                 nm[u] = nv[u] = nvh[u] = 0.f;
                 if (j0 + CH + u < NPL) {
-                    const uint32_t off = (uint32_t)(lane + 64 * (j0 + CH + u)) * 4u;
+                    const uint32_t off = (uint32_t)(lane + T * (j0 + CH + u)) * 4u;
                     nm[u] = buf_load(r_m, off);
                     nv[u] = buf_load(r_v, off);
                     nvh[u] = buf_load(r_vh, off);
@@ -1306,7 +1309,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
             for (int u = 0; u < CH; ++u) {
                 const int j = j0 + u;
                 if (j < NPL) {
-                    const uint32_t off = (uint32_t)(lane + 64 * j) * 4u;
+                    const uint32_t off = (uint32_t)(lane + T * j) * 4u;
                     const float g = xs[j];
                     const float m = (1.f - b1) * g + b1 * cm[u];
                     const float vv = (1.f - b2) * g * g + b2 * cv[u];
@@ -1320,7 +1323,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
                     xs[j] = zs[j] - upd;
                     zs[j] = xs[j];
                     // slots beyond the box: x = z = 0 (loads returned 0), psi must not count
-                    const bool in_box = j < kFull || lane + 64 * j < N;
+                    const bool in_box = j < kFull || lane + T * j < N;
                     rs[j] = in_box ? psi : 0.f;
                     pmax = fmaxf(pmax, rs[j]);
                 }
@@ -1334,7 +1337,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
             // keep the scheduler from hoisting every group's loads to the top (registers)
             __builtin_amdgcn_sched_barrier(0);
         }
-        pmax = wave_max(pmax);
+        pmax = Team<T>::max(pmax);
     }
     const float rpmax = 1.f / pmax;
 #pragma unroll
@@ -1356,26 +1359,30 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
     const float pfloor = v.c_pos_floor[k];  // PositivityConstraint(zero)
     const float *bg_level =
         (LITE && v.c_bg_level) ? v.c_bg_level + (int64_t)k * c.C : nullptr;
-    wave_lds_fence();  // the offsets parked in `us` have been consumed
+    team_fence<T>();  // the offsets parked in `us` have been consumed
 
     for (int tau = 0; tau < prox_max_iter; ++tau) {
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) us[lane + 64 * j] = zs[j] - rs[j] * (zs[j] - xs[j]);
-        wave_lds_fence();
+        for (int j = 0; j < NPL; ++j) us[lane + T * j] = zs[j] - rs[j] * (zs[j] - xs[j]);
+        team_fence<T>();
         if (fit_center) {
             const int centre = __builtin_amdgcn_readfirstlane(fit_center_index(us, c));
             const SweepPlanDev &pl = v.plans[plan_id + centre];
             slots = pl.slots;
             n_slots = pl.n_slots;
         }
-        if (monotonic) sweep_slots(us, slots, n_slots, one_minus_g, lane);
-        chain_symmetry_threshold(us, c, LITE ? flags : (flags & ~SMI_PROX_BG_THRESH), lthresh,
+        if (monotonic) {
+            // one wavefront sweeps (the steps are sequential and at most 64 pixels wide)
+            if (T == 64 || threadIdx.x < 64) sweep_slots(us, slots, n_slots, one_minus_g, lane);
+            if (T > 64) __syncthreads();
+        }
+        chain_symmetry_threshold<T>(us, c, LITE ? flags : (flags & ~SMI_PROX_BG_THRESH), lthresh,
                                  sed_new, bg_level,
                                  (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[k] : 1.f);
         float mx = -INFINITY, sm = 0.f;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            const int i = lane + 64 * j;
+            const int i = lane + T * j;
             float u = us[i];
             if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
             if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
@@ -1383,8 +1390,8 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
             sm += (j < kFull || i < N) ? u : 0.f;
         }
         float div = 1.f;
-        if (flags & SMI_PROX_NORM_MAX) div = wave_max(mx);
-        if (flags & SMI_PROX_NORM_SUM) div = wave_sum(sm);
+        if (flags & SMI_PROX_NORM_MAX) div = Team<T>::max(mx);
+        if (flags & SMI_PROX_NORM_SUM) div = Team<T>::sum(sm);
         // one correctly rounded reciprocal per sub-iteration instead of N divisions; the
         // maximum itself still maps to exactly 1 (x / x), everything else is within
         // 1 ulp of the quotient
@@ -1392,7 +1399,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
         float d2 = 0.f, z2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            const int i = lane + 64 * j;
+            const int i = lane + T * j;
             float u = us[i];  // second read instead of NPL more registers
             if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
             if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
@@ -1403,8 +1410,8 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
             z2 += zs[j] * zs[j];
             zs[j] = u;
         }
-        d2 = wave_sum(d2);
-        z2 = wave_sum(z2);
+        d2 = Team<T>::sum(d2);
+        z2 = Team<T>::sum(z2);
         if (d2 <= e2 * z2) break;
     }
     float omega = 0.f;
@@ -1417,24 +1424,24 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
     if (fista) {
         float xo[NPL];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) xo[j] = buf_load(r_out, (uint32_t)(lane + 64 * j) * 4u);
+        for (int j = 0; j < NPL; ++j) xo[j] = buf_load(r_out, (uint32_t)(lane + T * j) * 4u);
 #pragma unroll
         for (int j = 0; j < NPL; ++j)
-            buf_store(r_m, (uint32_t)(lane + 64 * j) * 4u, xo[j] + omega * (zs[j] - xo[j]));
+            buf_store(r_m, (uint32_t)(lane + T * j) * 4u, xo[j] + omega * (zs[j] - xo[j]));
     }
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
-        buf_store(r_out, (uint32_t)(lane + 64 * j) * 4u, zs[j]);
+        buf_store(r_out, (uint32_t)(lane + T * j) * 4u, zs[j]);
         bad |= !isfinite(zs[j]);
     }
-    if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
+    if (Team<T>::any(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
 }
 
-template <int NPL, int MODE>
-__global__ __launch_bounds__(64) SMI_WAVES void update_kernel_reg(BatchView v, const float *G,
-                                                                  int it, float e_rel,
-                                                                  int prox_max_iter) {
-    update_component<NPL, MODE>(v, G, it, e_rel, prox_max_iter, v.work[blockIdx.x + v.work0]);
+template <int NPL, int MODE, int T>
+__global__ __launch_bounds__(T) SMI_WAVES void update_kernel_reg(BatchView v, const float *G,
+                                                                 int it, float e_rel,
+                                                                 int prox_max_iter) {
+    update_component<NPL, MODE, T>(v, G, it, e_rel, prox_max_iter, v.work[blockIdx.x + v.work0]);
 }
 
 // Components of several size classes (a blend with boxes of 21^2 .. 61^2 pixels): a launch
@@ -1631,21 +1638,21 @@ static size_t update_lds_bytes(const BatchView &v) {
     return bytes + (size_t)(v.max_levels + 2) * sizeof(int32_t);
 }
 
-template <int NPL>
+template <int NPL, int T>
 static void launch_update_reg(const BatchView &v, const float *G, int32_t it, float e_rel,
                               int32_t prox_max_iter, int32_t item0, int32_t n_items,
                               hipStream_t s) {
     BatchView vi = v;
     vi.work0 = item0;
-    const size_t lds = (size_t)(64 * NPL + 4) * sizeof(float);
+    const size_t lds = (size_t)(T * NPL + 4) * sizeof(float);
     if (v.scheme == SMI_SCHEME_FISTA)
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 2>), dim3(n_items), dim3(64), lds, s, vi, G,
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 2, T>), dim3(n_items), dim3(T), lds, s, vi, G,
                            it, e_rel, prox_max_iter);
     else if (v.lite)
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 1>), dim3(n_items), dim3(64), lds, s, vi, G,
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 1, T>), dim3(n_items), dim3(T), lds, s, vi, G,
                            it, e_rel, prox_max_iter);
     else
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 0>), dim3(n_items), dim3(64), lds, s, vi, G,
+        hipLaunchKernelGGL((update_kernel_reg<NPL, 0, T>), dim3(n_items), dim3(T), lds, s, vi, G,
                            it, e_rel, prox_max_iter);
 }
 
@@ -1654,15 +1661,17 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
                   int32_t grad_only, hipStream_t s) {
     if (v.n_comp == 0) return SMI_OK;
     // chains that repeat take the general kernel (the register-resident ones apply it once)
-    if (!grad_only && v.fast_plans && v.max_box_pixels <= 64 * 59 && !v.c_chain_repeat &&
+    if (!grad_only && v.fast_plans && v.max_box_pixels <= kMaxRegisterBox && !v.c_chain_repeat &&
         !v.mono_mask) {
         // latency regime with several size classes: one launch for all of them
-        int classes = 0;
+        int classes = 0, large = 0;
         for (int cls = 0; cls < kNumUpdateClasses; ++cls) {
             const int32_t *start = v.work_start + (size_t)cls * (v.nb_total + 1);
-            classes += start[v.blend0 + v.nb] > start[v.blend0];
+            const int present = start[v.blend0 + v.nb] > start[v.blend0];
+            classes += present;
+            large += present && cls >= kNumSmallClasses;
         }
-        if (classes > 1 && v.n_comp <= kMixedUpdateLimit) {
+        if (classes > 1 && !large && v.n_comp <= kMixedUpdateLimit) {
             const size_t lds = (size_t)(64 * kUpdateNpl[kNumUpdateClasses - 1] + 4) * sizeof(float);
             if (v.scheme == SMI_SCHEME_FISTA)
                 hipLaunchKernelGGL(update_kernel_mixed<2>, dim3(v.n_comp), dim3(64), lds, s, v, G, it,
@@ -1681,13 +1690,13 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
             const int32_t *start = v.work_start + (size_t)cls * (v.nb_total + 1);
             const int lo = start[v.blend0], hi = start[v.blend0 + v.nb];
             if (hi <= lo) continue;
+#define SMI_CLASS(i) \
+    case i: launch_update_reg<kUpdateNpl[i], kUpdateTeam[i]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
             switch (cls) {
-                case 0: launch_update_reg<kUpdateNpl[0]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
-                case 1: launch_update_reg<kUpdateNpl[1]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
-                case 2: launch_update_reg<kUpdateNpl[2]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
-                case 3: launch_update_reg<kUpdateNpl[3]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
-                default: launch_update_reg<kUpdateNpl[4]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
+                SMI_CLASS(0) SMI_CLASS(1) SMI_CLASS(2) SMI_CLASS(3) SMI_CLASS(4)
+                SMI_CLASS(5) SMI_CLASS(6) SMI_CLASS(7) SMI_CLASS(8)
             }
+#undef SMI_CLASS
         }
         return SMI_OK;
     }

@@ -20,6 +20,7 @@ stats() {  # name, bench arguments
 stats single_range --steps 100 --warmup 10 --no-cpu --sub-ranges 1
 stats default --steps 100 --warmup 10 --no-cpu
 stats cfg1 --config cfg1 --steps 100 --warmup 10 --no-cpu --sub-ranges 1
+stats cfg4 --config cfg4 --steps 100 --warmup 10 --no-cpu
 stats cfg5 --config cfg5 --steps 40
 stats driver --steps 20 --warmup 5   # the command the driver runs at round end
 
