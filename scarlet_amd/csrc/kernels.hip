@@ -698,13 +698,17 @@ __device__ __forceinline__ void monotonic_mask(const float *us, float *ws, uint8
 // -- generic variant: everything in LDS, plans with any number of terms -----
 __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slots, int n_slots,
                                             float one_minus_g, int lane);
-// T threads per component (Team): 64, or 256 for boxes of more than 64 x 64 pixels
+// T threads per component (Team): 64, or 256 for boxes of more than 64 x 59 pixels
 template <int T>
 __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, int it,
                                                    float e_rel, int prox_max_iter,
                                                    float *g_sed_out, float *g_morph_out,
                                                    int grad_only) {
     const CompCtx c = comp_ctx(v);
+    // the team is a property of the box, not of the batch: a component gets the same bits
+    // whatever else is fitted with it (two launches when a batch holds both kinds)
+    // (the same boundary as the register-resident classes: 64 x 59 pixels)
+    if ((c.N > 64 * kUpdateNpl[kNumSmallClasses - 1]) != (T == 256)) return;
     if (!grad_only && v.state[c.b] >= 2) return;
     if (!grad_only && v.n_point && (v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
     const int lane = c.lane, N = c.N;
@@ -1702,15 +1706,15 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
     }
     const size_t lds = update_lds_bytes(v);
     SMI_REQUIRE(lds <= 160 * 1024, "component box too large for the LDS-resident update");
-    // four waves per component once the boxes are beyond the register-resident kernels
-    // (multi-resolution tutorial fit, ms per iteration with 1 / 4 / 16 waves: 2.89 / 2.20 / 2.37)
-    if (v.max_box_pixels > 64 * 64) {
+    // four waves per component for boxes beyond 64 x 59 pixels (multi-resolution tutorial
+    // fit, ms per iteration with 1 / 4 / 16 waves: 2.89 / 2.20 / 2.37); every workgroup of
+    // the other launch returns at once
+    if (v.max_box_pixels > 64 * kUpdateNpl[kNumSmallClasses - 1]) {
         static size_t configured[kMaxDevices] = {};
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(update_kernel<256>), lds, configured))
             return rc;
         hipLaunchKernelGGL(update_kernel<256>, dim3(v.n_comp), dim3(256), lds, s, v, G, it, e_rel,
                            prox_max_iter, g_sed_out, g_morph_out, grad_only);
-        return SMI_OK;
     }
     static size_t configured[kMaxDevices] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(update_kernel<64>), lds, configured))
