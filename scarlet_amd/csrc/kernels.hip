@@ -807,7 +807,10 @@ __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, 
     const float *bg_level = v.c_bg_level ? v.c_bg_level + (int64_t)c.k * c.C : nullptr;
     const int repeat = v.c_chain_repeat ? v.c_chain_repeat[c.k] : 1;
     __syncthreads();
-    for (int i = lane; i < N; i += T) rs[i] = rs[i] / pmax;
+    {
+        const float rpmax = 1.f / pmax;  // like the register-resident kernels
+        for (int i = lane; i < N; i += T) rs[i] = rs[i] * rpmax;
+    }
 
     for (int tau = 0; tau < prox_max_iter; ++tau) {
         for (int i = lane; i < N; i += T) us[i] = zs[i] - rs[i] * (zs[i] - xs[i]);
@@ -868,9 +871,14 @@ __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, 
                 __syncthreads();
             }
         }
+        // the last normalisation like the register-resident kernels (one reciprocal, the
+        // maximum itself maps to exactly 1): a component gets the same bits in either kernel
+        const float rdiv = 1.f / div;
         float d2 = 0.f, z2 = 0.f;
         for (int i = lane; i < N; i += T) {
-            const float u = (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM)) ? us[i] / div : us[i];
+            float u = us[i];
+            if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
+                u = (u == div && (flags & SMI_PROX_NORM_MAX)) ? 1.f : u * rdiv;
             const float z = zs[i];
             d2 += (u - z) * (u - z);
             z2 += z * z;

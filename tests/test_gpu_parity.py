@@ -837,6 +837,38 @@ def test_mixed_and_per_class_update_launches_agree(amd, hsc):
                 assert_array_equal(a, b_)
 
 
+def test_a_component_does_not_notice_its_batch_mates(amd, hsc):
+    """A blend's bits do not depend on what else is in the batch: with a ConstraintChain(repeat)
+    component somewhere in the batch every component goes through the general update kernel
+    instead of the register-resident ones; the quickstart blend next to such a blend must
+    come out exactly as it does alone."""
+    n = int(hsc["n_comp"])
+
+    def comps(repeat):
+        return [amd.ComponentSpec(hsc["sed_%d" % k], hsc["morph_%d" % k], hsc["origin_%d" % k],
+                                  sed_min_step=hsc["min_step_%d" % k],
+                                  chain_repeat=2 if (repeat and k == 0) else 1) for k in range(n)]
+
+    def run(specs):
+        nb = len(specs)
+        b = amd.BlendBatch(np.repeat(hsc["images"][None], nb, 0), np.repeat(hsc["weights"][None], nb, 0),
+                           specs, kernel=hsc["diff_kernel"], max_iter=12)
+        b.step(0, 10, e_rel=1e-3)
+        out = b.loss_history(), b.parameters(), b.moments()
+        b.close()
+        return out
+
+    alone, mixed = run([comps(False)]), run([comps(False), comps(True)])
+    assert_array_equal(alone[0][0], mixed[0][0])
+    assert_array_equal(alone[1][0], mixed[1][0][:n])
+    for a, b_ in zip(alone[1][1], mixed[1][1][:n]):
+        assert_array_equal(a, b_)
+    for key in ("m_morph", "v_morph", "vhat_morph"):
+        for a, b_ in zip(alone[2][key], mixed[2][key][:n]):
+            assert_array_equal(a, b_)
+    assert not np.array_equal(mixed[0][0], mixed[0][1])  # the repeated chain does something
+
+
 def test_tiny_frames_and_single_band(amd):
     """frames much smaller than a chunk of the fused kernel, one band, boxes larger than
     the frame"""
