@@ -438,3 +438,26 @@ def test_adaprox_schemes_of_the_host_step():
         assert np.allclose(radam[it], x, rtol=1e-5)
     assert np.all(np.isfinite(run("nadam"))) and not np.allclose(run("nadam"), adam)
 
+
+def test_bench_prices_the_bytes_of_survey_8d():
+    """bench.algorithmic_bytes is SURVEY.md 8d's accounting: the nominated figures of config
+    2 / 3 (F = 180^2: B0 1 194 880 B, B0 + B_fft 6 669 760 B) and config 1 (2 778 560 B), and
+    the per-kernel split adds up to the whole plus the gather of the gradient image."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg3 = bench.algorithmic_bytes(5, 128, 128, [41 * 41] * 10, 180, 180, 1)
+    assert cfg3["null"] == 1194880 and cfg3["whole"] == 6669760
+    boxes = [41 * 41] * 5 + [61 * 61] * 2 + [31 * 31] + [21 * 21] * 2
+    cfg1 = bench.algorithmic_bytes(5, 58, 48, boxes, 108, 96, 5)
+    assert cfg1["null"] == 679040 and cfg1["whole"] == 2778560
+    for by, bx in ((cfg3, [41 * 41] * 10), (cfg1, boxes)):
+        gather = 4 * 5 * sum(bx)
+        assert by["conv"] + by["update"] == by["whole"] + gather
+    run = bench.algorithmic_bytes(5, 128, 128, [41 * 41] * 10, 160, 160, 1)
+    assert run["conv"] == 5051760 and run["update"] == 808280  # what the bench line prices
+
