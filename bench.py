@@ -334,6 +334,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > torch.cuda.device_count() and not share:
+        # launched by torchrun on a box with fewer GPUs than ranks: same arrangement
+        share, backend = True, "gloo"
     if share:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
