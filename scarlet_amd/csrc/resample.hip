@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBM = 128, kBN = 128, kBK = 16;  // block tile; 4 waves as 2 x 2, 64 x 64 each
 constexpr int kPad = 4;                        // LDS row padding (floats)
-constexpr int kSliceTerms = 256;               // float32 accumulation length inside a slice
+constexpr int kSliceTerms = 320;               // float32 accumulation length inside a slice
 
 // C_b[M x N] = A_b[M x K] . B_b[K x N] for b < n_batch (row major; the batch strides may
 // be 0).  blockIdx.z = batch * n_slices + slice; slice z covers K in [z kslice, ...).
