@@ -150,6 +150,11 @@ struct Conv {
     using C = Cfg<FY1, FX1>;
     float2 *T, *Z, *twy, *twx;
     int tid;
+    // Which rows use the fused radix-16 / separation pass (blocks_forward, blocks_inverse)
+    // and which the separate separation pass below: measured per row length (tools/conv_sizes.py,
+    // ms per 512 blends x 5 bands, separate -> fused: 160^2 0.411 -> 0.397, 80^2 0.120 -> 0.110,
+    // 96^2 0.195 -> 0.184, 80 x 160 0.240 -> 0.229; but 64^2 0.085 -> 0.090, 128^2 0.293 -> 0.300).
+    static constexpr bool kFusedBlocks = FX1 == 5 || FX1 == 6 || FX1 == 10;
     // Hermitian separation / recombination: work item (pair j, frequency kx) = tid + 1024 r
     // has the same j = tid % kPairs and kx = tid / kPairs + (kThreads / kPairs) r in every
     // call, so the LDS offsets of its operands are computed once per kernel: the scratch
@@ -214,9 +219,134 @@ struct Conv {
         lds_barrier();
     }
 
+    // The radix-16 pass of the row transforms is fused with the Hermitian separation /
+    // recombination of the row pairs.  Block k1 of a row holds the frequencies k1 + FX1 k2
+    // (k2 = 0 .. 15); the mirror frequency FX - k sits in block FX1 - k1 at 15 - k2 (block 0
+    // mirrors onto itself at (16 - k2) % 16, block FX1 / 2 of an even FX1 at 15 - k2).  Work
+    // item (row pair j = lane % 32, slot): the slots are ordered 1, FX1 - 1, 2, FX1 - 2, ...,
+    // 0, FX1 / 2, so that the two slots of a wavefront are a block and its mirror block:
+    // after its transform a lane gets the mirror values from lane ^ 32 and separates the
+    // eight frequencies <= FX / 2 of its block.
+    static_assert(kPairs == 32, "a wavefront = two slots of 32 row pairs");
+    static constexpr int kDouble = (FX1 - 1) / 2;  // blocks 1 .. kDouble have a distinct mirror block
+    static __device__ __forceinline__ int slot_block(int slot) {
+        if (slot < 2 * kDouble) return (slot & 1) ? FX1 - (slot / 2 + 1) : slot / 2 + 1;
+        return slot == 2 * kDouble ? 0 : FX1 / 2;
+    }
+    static __device__ __forceinline__ cf from_partner(cf v) {
+        return cf{__shfl_xor(v.x, 32, 64), __shfl_xor(v.y, 32, 64)};
+    }
+    // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^)
+    static __device__ __forceinline__ void put(float2 *t, bool ok, cf za, cf zb) {
+        if (ok) {
+            t[0] = make_float2(za.x + zb.x, za.y - zb.y);
+            t[1] = make_float2(za.y + zb.y, zb.x - za.x);
+        }
+    }
+    static __device__ __forceinline__ void get(const float2 *t, bool ok, cf &plus, cf &minus) {
+        float2 xa = make_float2(0.f, 0.f), xb = xa;
+        if (ok) {
+            xa = t[0];
+            xb = t[1];
+        }
+        plus = cf{xa.x - xb.y, xa.y + xb.x};   // Xa + i Xb
+        minus = cf{xa.x + xb.y, xb.x - xa.y};  // conj(Xa) + i conj(Xb)
+    }
+
+    // forward: radix-16 pass of the chunk's rows in Z and separation into
+    // T[kx][y0 + 2j], T[kx][y0 + 2j + 1]
+    __device__ __forceinline__ void blocks_forward(int ch) {
+        for (int b = tid; b < kPairs * FX1; b += kThreads) {
+            const int j = b & 31, slot = b >> 5, k1 = slot_block(slot);
+            const float2 *z = Z + j * C::SX + kF2 * k1;
+            const bool ok = ch * 2 * kPairs + 2 * j + 1 < C::FY;
+            float2 *t = T + sk(2 * j) + ch * kChunkStep + k1 * C::SY;
+            cf va[kF2];
+#pragma unroll
+            for (int i = 0; i < kF2; ++i) va[i] = ld(z[i]);
+            fftk::Dft<kF2, false>::run(va);
+            if (slot < 2 * kDouble) {  // uniform over the wavefront
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2 += 2) {
+                    // two frequencies at a time (registers: the scheduler would otherwise
+                    // start all sixteen exchanges at once)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const cf m0 = from_partner(va[15 - k2]), m1 = from_partner(va[14 - k2]);
+                    put(t + FX1 * k2 * C::SY, ok, va[k2], m0);
+                    put(t + FX1 * (k2 + 1) * C::SY, ok, va[k2 + 1], m1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (k1 == 0) {
+                // (two branches: a select between va[a] and va[b] would be compiled into a
+                // select of the index, i.e. a dynamically indexed register array)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2)
+                    put(t + FX1 * k2 * C::SY, ok, va[k2], va[(16 - k2) & 15]);
+                put(t + FX1 * 8 * C::SY, ok, va[8], va[8]);
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) put(t + FX1 * k2 * C::SY, ok, va[k2], va[15 - k2]);
+            }
+        }
+        lds_barrier();
+    }
+
+    // inverse: Z[pair] <- radix-16 pass of (Xa + i Xb) rebuilt from T
+    __device__ __forceinline__ void blocks_inverse(int ch) {
+        for (int b = tid; b < kPairs * FX1; b += kThreads) {
+            const int j = b & 31, slot = b >> 5, k1 = slot_block(slot);
+            float2 *z = Z + j * C::SX + kF2 * k1;
+            const bool ok = ch * 2 * kPairs + 2 * j + 1 < C::FY;
+            const float2 *t = T + sk(2 * j) + ch * kChunkStep;
+            cf va[kF2], spare;
+            if (slot < 2 * kDouble) {
+                const int kb = FX1 - k1;  // the mirror block's columns give the upper half
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    get(t + (k1 + FX1 * k2) * C::SY, ok, va[k2], spare);
+                    get(t + (kb + FX1 * k2) * C::SY, ok, spare, va[15 - k2]);
+                }
+            } else if (k1 == 0) {
+                get(t, ok, va[0], spare);
+                get(t + FX1 * 8 * C::SY, ok, va[8], spare);
+#pragma unroll
+                for (int k2 = 1; k2 < 8; ++k2) get(t + FX1 * k2 * C::SY, ok, va[k2], va[16 - k2]);
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2)
+                    get(t + (k1 + FX1 * k2) * C::SY, ok, va[k2], va[15 - k2]);
+            }
+            fftk::Dft<kF2, true>::run(va);
+#pragma unroll
+            for (int i = 0; i < kF2; ++i) z[i] = st(va[i]);
+        }
+        lds_barrier();
+    }
+
+    // forward row transforms of the chunk in Z (pairs of real rows as re/im) into T
+    __device__ __forceinline__ void rows_forward(int ch, int W, long long *stamp = nullptr) {
+        if (!kFusedBlocks) return rows_forward_separate(ch, W, stamp);
+        for (int b = tid; b < kPairs * kF2; b += kThreads)
+            pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
+        lds_barrier();
+        if (stamp) stamp[0] = clock64();
+        blocks_forward(ch);
+        if (stamp) stamp[1] = clock64();
+    }
+
+    // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
+    __device__ __forceinline__ void rows_inverse(int ch) {
+        if (!kFusedBlocks) return rows_inverse_separate(ch);
+        blocks_inverse(ch);
+        for (int b = tid; b < kPairs * kF2; b += kThreads)
+            pass_stride<FX1, true>(Z + (b % kPairs) * C::SX, b / kPairs, twx, C::FX);
+        lds_barrier();
+    }
+
+    // -- the same with the separation as a pass of its own --
     // forward row transforms of the chunk in Z (pairs of real rows as re/im) and
     // Hermitian separation into T[kx][y0 + 2j], T[kx][y0 + 2j + 1]
-    __device__ __forceinline__ void rows_forward(int ch, int W, long long *stamp = nullptr) {
+    __device__ __forceinline__ void rows_forward_separate(int ch, int W, long long *stamp = nullptr) {
         for (int b = tid; b < kPairs * kF2; b += kThreads)
             pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
         lds_barrier();
@@ -241,7 +371,7 @@ struct Conv {
     }
 
     // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
-    __device__ __forceinline__ void rows_inverse(int ch) {
+    __device__ __forceinline__ void rows_inverse_separate(int ch) {
         const int y = ch * 2 * kPairs + 2 * (tid % kPairs);
         const bool row_ok = y + 1 < C::FY;
 #pragma unroll
@@ -308,7 +438,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FX, &s, &co);
         cv.twx[j] = make_float2(co, -s);
     }
-    cv.init_separation();
+    if (!Conv<FY1, FX1>::kFusedBlocks) cv.init_separation();
     const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
                                C::FY * C::NKX;
     const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
