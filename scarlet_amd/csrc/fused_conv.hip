@@ -243,12 +243,12 @@ struct Conv {
             t[1] = make_float2(za.y + zb.y, zb.x - za.x);
         }
     }
-    static __device__ __forceinline__ void get(const float2 *t, bool ok, cf &plus, cf &minus) {
-        float2 xa = make_float2(0.f, 0.f), xb = xa;
-        if (ok) {
-            xa = t[0];
-            xb = t[1];
-        }
+    // (no row guard: a row pair beyond FY reads other elements of the LDS array and leaves
+    // values in its own rows of Z that nothing consumes -- the pairs never mix, the residual
+    // and the stores look at rows < H only, put() is guarded; a branch or a select per load
+    // would expose every LDS latency)
+    static __device__ __forceinline__ void get(const float2 *t, cf &plus, cf &minus) {
+        const float2 xa = t[0], xb = t[1];
         plus = cf{xa.x - xb.y, xa.y + xb.x};   // Xa + i Xb
         minus = cf{xa.x + xb.y, xb.x - xa.y};  // conj(Xa) + i conj(Xb)
     }
@@ -296,25 +296,24 @@ struct Conv {
         for (int b = tid; b < kPairs * FX1; b += kThreads) {
             const int j = b & 31, slot = b >> 5, k1 = slot_block(slot);
             float2 *z = Z + j * C::SX + kF2 * k1;
-            const bool ok = ch * 2 * kPairs + 2 * j + 1 < C::FY;
             const float2 *t = T + sk(2 * j) + ch * kChunkStep;
             cf va[kF2], spare;
             if (slot < 2 * kDouble) {
                 const int kb = FX1 - k1;  // the mirror block's columns give the upper half
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
-                    get(t + (k1 + FX1 * k2) * C::SY, ok, va[k2], spare);
-                    get(t + (kb + FX1 * k2) * C::SY, ok, spare, va[15 - k2]);
+                    get(t + (k1 + FX1 * k2) * C::SY, va[k2], spare);
+                    get(t + (kb + FX1 * k2) * C::SY, spare, va[15 - k2]);
                 }
             } else if (k1 == 0) {
-                get(t, ok, va[0], spare);
-                get(t + FX1 * 8 * C::SY, ok, va[8], spare);
+                get(t, va[0], spare);
+                get(t + FX1 * 8 * C::SY, va[8], spare);
 #pragma unroll
-                for (int k2 = 1; k2 < 8; ++k2) get(t + FX1 * k2 * C::SY, ok, va[k2], va[16 - k2]);
+                for (int k2 = 1; k2 < 8; ++k2) get(t + FX1 * k2 * C::SY, va[k2], va[16 - k2]);
             } else {
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2)
-                    get(t + (k1 + FX1 * k2) * C::SY, ok, va[k2], va[15 - k2]);
+                    get(t + (k1 + FX1 * k2) * C::SY, va[k2], va[15 - k2]);
             }
             fftk::Dft<kF2, true>::run(va);
 #pragma unroll
@@ -335,9 +334,10 @@ struct Conv {
     }
 
     // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
-    __device__ __forceinline__ void rows_inverse(int ch) {
+    __device__ __forceinline__ void rows_inverse(int ch, long long *stamp = nullptr) {
         if (!kFusedBlocks) return rows_inverse_separate(ch);
         blocks_inverse(ch);
+        if (stamp) stamp[0] = clock64();
         for (int b = tid; b < kPairs * kF2; b += kThreads)
             pass_stride<FX1, true>(Z + (b % kPairs) * C::SX, b / kPairs, twx, C::FX);
         lds_barrier();
@@ -521,7 +521,9 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                     }
                 }
             }
-        cv.rows_inverse(ch);
+        if (ch == 0) SMI_STAMP(10);
+        cv.rows_inverse(ch, (dbg && tid == 0 && blockIdx.x == 0 && ch == 0) ? dbg + 15 : nullptr);
+        if (ch == 0) SMI_STAMP(11);
 #pragma unroll
         for (int j = 0; j < kPairsW; ++j) {
             const int pair = wave + j * kWaves;
@@ -549,8 +551,11 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                 slot = make_float2(res[0], res[1]);
             }
         }
+        if (ch == 0) SMI_STAMP(12);
         __syncthreads();
+        if (ch == 0) SMI_STAMP(13);
         cv.rows_forward(ch, W);
+        if (ch == 0) SMI_STAMP(14);
     }
     {
         double *part = reinterpret_cast<double *>(cv.Z);  // Z is free between stages

@@ -21,3 +21,5 @@ for i, n in enumerate(names):
     print("%-22s %8d cycles" % (n, t[i + 1] - t[i]))
 print("total", t[5] - t[0])
 print("chunk0 rows_forward: stride pass", t[6]-t[8], "block pass", t[7]-t[6], "separation", t[9]-t[7])
+print("stage C chunk 0: prefetch issue", t[10]-t[2], "rows_inverse", t[11]-t[10], "residual", t[12]-t[11], "barrier", t[13]-t[12], "rows_forward", t[14]-t[13])
+print("stage C chunk 0 rows_inverse: blocks", t[15]-t[10], "stride", t[11]-t[15])
