@@ -150,39 +150,8 @@ struct Conv {
     using C = Cfg<FY1, FX1>;
     float2 *T, *Z, *twy, *twx;
     int tid;
-    // Which rows use the fused radix-16 / separation pass (blocks_forward, blocks_inverse)
-    // and which the separate separation pass below: measured per row length (tools/conv_sizes.py,
-    // ms per 512 blends x 5 bands, separate -> fused: 160^2 0.411 -> 0.397, 80^2 0.120 -> 0.110,
-    // 96^2 0.195 -> 0.184, 80 x 160 0.240 -> 0.229; but 64^2 0.085 -> 0.090, 128^2 0.293 -> 0.300).
-    static constexpr bool kFusedBlocks = FX1 == 5 || FX1 == 6 || FX1 == 10;
-    // Hermitian separation / recombination: work item (pair j, frequency kx) = tid + 1024 r
-    // has the same j = tid % kPairs and kx = tid / kPairs + (kThreads / kPairs) r in every
-    // call, so the LDS offsets of its operands are computed once per kernel: the scratch
-    // elements of +kx and -kx (digit-swapped positions) and the column element of row 2j of
-    // chunk 0 (chunk ch lies kChunkStep elements further down the column).
-    static constexpr int kSepIter = (C::NKX * kPairs + kThreads - 1) / kThreads;
     static constexpr int kChunkStep = 2 * kPairs + 2 * kPairs / kF2;  // sk(y + 64) - sk(y)
-    static_assert(kThreads % kPairs == 0 && (2 * kPairs) % kF2 == 0, "separation mapping");
-    int sep_za[kSepIter], sep_zb[kSepIter];  // element offsets into Z
-
-    __device__ __forceinline__ void init_separation() {
-        const int j = tid % kPairs;
-#pragma unroll
-        for (int r = 0; r < kSepIter; ++r) {
-            const int kx = sep_kx(r);
-            const int kxc = kx < C::NKX ? kx : 0;
-            sep_za[r] = j * C::SX + pos<FX1>(kxc);
-            sep_zb[r] = j * C::SX + pos<FX1>((C::FX - kxc) % C::FX);
-        }
-    }
-    __device__ __forceinline__ int sep_kx(int r) const {
-        return tid / kPairs + (kThreads / kPairs) * r;
-    }
-    // element offset into T of (kx, row 2j of chunk ch), or -1 beyond the last column
-    __device__ __forceinline__ int sep_t(int r, int ch) const {
-        const int kx = sep_kx(r);
-        return kx < C::NKX ? kx * C::SY + sk(2 * (tid % kPairs)) + ch * kChunkStep : -1;
-    }
+    static_assert((2 * kPairs) % kF2 == 0, "chunk rows");
 
     // column transforms fused with the spectral product:
     //   T <- IFFT_y( FFT_y(T) * K )   for every column kx, K in digit-swapped order.
@@ -324,7 +293,6 @@ struct Conv {
 
     // forward row transforms of the chunk in Z (pairs of real rows as re/im) into T
     __device__ __forceinline__ void rows_forward(int ch, int W, long long *stamp = nullptr) {
-        if (!kFusedBlocks) return rows_forward_separate(ch, W, stamp);
         for (int b = tid; b < kPairs * kF2; b += kThreads)
             pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
         lds_barrier();
@@ -335,62 +303,8 @@ struct Conv {
 
     // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
     __device__ __forceinline__ void rows_inverse(int ch, long long *stamp = nullptr) {
-        if (!kFusedBlocks) return rows_inverse_separate(ch);
         blocks_inverse(ch);
         if (stamp) stamp[0] = clock64();
-        for (int b = tid; b < kPairs * kF2; b += kThreads)
-            pass_stride<FX1, true>(Z + (b % kPairs) * C::SX, b / kPairs, twx, C::FX);
-        lds_barrier();
-    }
-
-    // -- the same with the separation as a pass of its own --
-    // forward row transforms of the chunk in Z (pairs of real rows as re/im) and
-    // Hermitian separation into T[kx][y0 + 2j], T[kx][y0 + 2j + 1]
-    __device__ __forceinline__ void rows_forward_separate(int ch, int W, long long *stamp = nullptr) {
-        for (int b = tid; b < kPairs * kF2; b += kThreads)
-            pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
-        lds_barrier();
-        if (stamp) stamp[0] = clock64();
-        for (int b = tid; b < kPairs * FX1; b += kThreads)
-            pass_block<false>(Z + (b % kPairs) * C::SX, b / kPairs);
-        lds_barrier();
-        if (stamp) stamp[1] = clock64();
-        const int y = ch * 2 * kPairs + 2 * (tid % kPairs);
-        const bool row_ok = y + 1 < C::FY;
-#pragma unroll
-        for (int r = 0; r < kSepIter; ++r)
-            if (row_ok && sep_t(r, ch) >= 0) {
-                const float2 za = Z[sep_za[r]];
-                const float2 zb = Z[sep_zb[r]];
-                // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^)
-                float2 *t = T + sep_t(r, ch);
-                t[0] = make_float2(za.x + zb.x, za.y - zb.y);
-                t[1] = make_float2(za.y + zb.y, zb.x - za.x);
-            }
-        lds_barrier();
-    }
-
-    // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
-    __device__ __forceinline__ void rows_inverse_separate(int ch) {
-        const int y = ch * 2 * kPairs + 2 * (tid % kPairs);
-        const bool row_ok = y + 1 < C::FY;
-#pragma unroll
-        for (int r = 0; r < kSepIter; ++r)
-            if (sep_kx(r) < C::NKX) {
-                float2 xa = make_float2(0.f, 0.f), xb = xa;
-                if (row_ok) {
-                    const float2 *t = T + sep_t(r, ch);
-                    xa = t[0];
-                    xb = t[1];
-                }
-                Z[sep_za[r]] = make_float2(xa.x - xb.y, xa.y + xb.x);  // Xa + i Xb
-                if (sep_kx(r) != 0 && 2 * sep_kx(r) != C::FX)          // conj(Xa) + i conj(Xb)
-                    Z[sep_zb[r]] = make_float2(xa.x + xb.y, xb.x - xa.y);
-            }
-        lds_barrier();
-        for (int b = tid; b < kPairs * FX1; b += kThreads)
-            pass_block<true>(Z + (b % kPairs) * C::SX, b / kPairs);
-        lds_barrier();
         for (int b = tid; b < kPairs * kF2; b += kThreads)
             pass_stride<FX1, true>(Z + (b % kPairs) * C::SX, b / kPairs, twx, C::FX);
         lds_barrier();
@@ -438,7 +352,6 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FX, &s, &co);
         cv.twx[j] = make_float2(co, -s);
     }
-    if (!Conv<FY1, FX1>::kFusedBlocks) cv.init_separation();
     const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
                                C::FY * C::NKX;
     const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
