@@ -660,14 +660,14 @@ bool fused_conv_choose(int ny, int nx, int *Fy, int *Fx) {
 int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float *model, const float2 *Kt,
                       int k_bands, int k_per_blend, float *out, int mode, long long *dbg,
                       hipStream_t s) {
-    // short rows: the row passes of a chunk have 32 x 16 and 32 x Fx/16 work items, which
+    // small transforms: the row passes of a chunk have 32 x 16 and 32 x Fx/16 work items, which
     // leave most of 1024 threads idle behind the barriers; 512 threads are faster there
-    // (tools/conv_sizes.py, ms per 512 blends x 5 bands, 1024 -> 512 threads: 64^2 0.123 ->
-    // 0.084, 80^2 0.155 -> 0.120, 96^2 0.242 -> 0.195, 160 x 64 0.212 -> 0.155, 160 x 80
-    // 0.250 -> 0.203; but 128 x 96 0.255 -> 0.301, 160 x 96 0.279 -> 0.328, 64 x 128 0.176 ->
-    // 0.210, 128^2 0.294 -> 0.336, 160^2 0.414 -> 0.485)
+    // (tools/conv_sizes.py, ms per 512 blends x 5 bands, 1024 -> 512 threads: 64^2 0.127 ->
+    // 0.086, 80^2 0.145 -> 0.107, 96^2 0.233 -> 0.178, 64 x 128 0.175 -> 0.134, 160 x 64 0.211
+    // -> 0.152, 160 x 80 0.234 -> 0.181; but 96 x 128 0.267 -> 0.285, 128 x 96 0.249 -> 0.278,
+    // 80 x 160 0.228 -> 0.259, 160 x 96 0.266 -> 0.298, 128^2 0.283 -> 0.302, 160^2 0.383 -> 0.431)
     static const char *force = getenv("SMI_CONV_WORKGROUP");  // development aid: "512" / "1024"
-    if (force ? force[0] == '5' : (Fx <= 80 || (Fx == 96 && Fy <= 96)))
+    if (force ? force[0] == '5' : (Fx <= 80 || Fy * Fx <= 96 * 96))
         return launch_fused_conv_short(v, Fy, Fx, model, Kt, k_bands, k_per_blend, out, mode, dbg, s);
     SMI_FUSED_DISPATCH(launch_impl, v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s)
     set_error("fused convolution: FFT shape not instantiated");
