@@ -145,6 +145,18 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// One band plane [H][W] of the model cube / data / weights through a buffer descriptor:
+// rows beyond H are beyond the descriptor's range and read 0, columns beyond W get an
+// out-of-range offset -- guarded loads without a branch or a 64-bit address per element.
+using plane_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ plane_t band_plane(const float *p, int n_elements) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, n_elements * 4, 0x00020000);
+}
+__device__ __forceinline__ float plane_load(plane_t r, int y, int x, int W) {
+    const uint32_t off = x < W ? (uint32_t)(y * W + x) * 4u : 0x80000000u;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
 template <int FY1, int FX1>
 struct Conv {
     using C = Cfg<FY1, FX1>;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         constexpr int kWaves = kThreads / 64;
         constexpr int kRows = 2 * kPairs / kWaves;
         static_assert(2 * kPairs % kWaves == 0 && kRows % 2 == 0, "rows per wave");
-        const float *mband = model + ((int64_t)b * v.C + c) * H * W;
+        const plane_t r_model = band_plane(model + ((int64_t)b * v.C + c) * H * W, H * W);
         float mrow[kRows][kXIter];
         auto fetch = [&](int y0) {
 #pragma unroll
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
 #pragma unroll
                 for (int q = 0; q < kXIter; ++q) {
                     const int x = lane + 64 * q;
-                    mrow[j][q] = (x < W && y < H) ? mband[(int64_t)y * W + x] : 0.f;
+                    mrow[j][q] = plane_load(r_model, y, x, W);
                 }
             }
         };
@@ -417,6 +429,8 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         constexpr int kXPre = kXIter > 2 ? 2 : kXIter;  // columns >= 128 are loaded late
         static_assert(kPairs % kWaves == 0, "pairs per wave");
         const int64_t band = ((int64_t)b * v.C + c) * H * W;
+        const plane_t r_data = band_plane(v.data + band, H * W);
+        const plane_t r_weights = band_plane(v.weights + band, H * W);
         float dpre[kPairsW][2][kXPre], wpre[kPairsW][2][kXPre];
 #pragma unroll
         for (int j = 0; j < kPairsW; ++j)
@@ -426,12 +440,8 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
 #pragma unroll
                 for (int q = 0; q < kXPre; ++q) {
                     const int x = lane + 64 * q;
-                    dpre[j][rr][q] = 0.f;
-                    wpre[j][rr][q] = 0.f;
-                    if (x < W && y < H) {
-                        dpre[j][rr][q] = v.data[band + (int64_t)y * W + x];
-                        wpre[j][rr][q] = v.weights[band + (int64_t)y * W + x];
-                    }
+                    dpre[j][rr][q] = plane_load(r_data, y, x, W);
+                    wpre[j][rr][q] = plane_load(r_weights, y, x, W);
                 }
             }
         if (ch == 0) SMI_STAMP(10);
@@ -454,8 +464,8 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                         const float m = rr ? m2.y : m2.x;
                         const int64_t iD = band + (int64_t)y * W + x;
                         if (mode == 1) out[iD] = m;
-                        const float dv = q < kXPre ? dpre[j][rr][q < kXPre ? q : 0] : v.data[iD];
-                        const float wv = q < kXPre ? wpre[j][rr][q < kXPre ? q : 0] : v.weights[iD];
+                        const float dv = q < kXPre ? dpre[j][rr][q < kXPre ? q : 0] : plane_load(r_data, y, x, W);
+                        const float wv = q < kXPre ? wpre[j][rr][q < kXPre ? q : 0] : plane_load(r_weights, y, x, W);
                         const float diff = m - dv;
                         res[rr] = wv * diff;
                         loss += (double)(res[rr] * diff);
