@@ -152,6 +152,10 @@ using plane_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ plane_t band_plane(const float *p, int n_elements) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, n_elements * 4, 0x00020000);
 }
+__device__ __forceinline__ void plane_store(plane_t r, int y, int x, int W, float value) {
+    const uint32_t off = x < W ? (uint32_t)(y * W + x) * 4u : 0x80000000u;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, value), r, off, 0, 0);
+}
 __device__ __forceinline__ float plane_load(plane_t r, int y, int x, int W) {
     const uint32_t off = x < W ? (uint32_t)(y * W + x) * 4u : 0x80000000u;
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
@@ -495,18 +499,17 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int y0 = ch * 2 * kPairs;
         cv.rows_inverse(ch);
+        // (stores beyond row H - 1 or column W - 1 are dropped by the descriptor's range check)
+        const plane_t r_out = band_plane(out + ((int64_t)b * v.C + c) * H * W, H * W);
         for (int pair = wave; pair < kPairs; pair += kThreads / 64) {
             const int y = y0 + 2 * pair;
-            if (y >= H) break;
-            float *row = out + ((int64_t)b * v.C + c) * H * W + (int64_t)y * W;
 #pragma unroll
             for (int q = 0; q < kXIter; ++q) {
                 const int x = lane + 64 * q;
-                if (x < W) {
-                    const float2 g = cv.Z[pair * C::SX + x];  // both rows of the pair
-                    row[x] = g.x;
-                    if (y + 1 < H) row[W + x] = g.y;
-                }
+                if (x >= C::FX) continue;
+                const float2 g = cv.Z[pair * C::SX + x];  // both rows of the pair
+                plane_store(r_out, y, x, W, g.x);
+                plane_store(r_out, y + 1, x, W, g.y);
             }
         }
         __syncthreads();
