@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                 plane_store(r_out, y + 1, x, W, g.y);
             }
         }
-        __syncthreads();
+        lds_barrier();  // the scratch is free again; the stores may still be in flight
     }
     SMI_STAMP(5);
 #undef SMI_STAMP
