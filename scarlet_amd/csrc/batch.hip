@@ -828,27 +828,24 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
     if ((rc = upload(&dp.cnt, hp.cnt.data(), hp.cnt.size()))) return rc;
     if ((rc = upload(&dp.nbr, hp.nbr.data(), hp.nbr.size()))) return rc;
     if ((rc = upload(&dp.wt, wt.data(), wt.size()))) return rc;
-    if (hp.max_terms <= 4 && h * w <= 16380) {
+    if (hp.max_terms <= 4 && h * w <= 16376) {
         // slot layout of the fast update kernel: every level padded to 64-lane steps
-        const uint32_t spare = (uint32_t)(((h * w + 3) & ~3) * 4);
-        SweepSlotEntry idle{};
-        idle.p_n0 = spare | (spare << 16);
-        idle.n1_n2 = spare | (spare << 16);
-        idle.n3 = spare;
+        const SweepSlotEntry idle{};  // zeros: the spare cell at address 0, weights 0
         std::vector<SweepSlotEntry> slots;
+        std::vector<uint32_t> used;  // lanes in use per step
         for (int l = 0; l < dp.n_levels; ++l) {
             const int s0 = hp.level_start[l], s1 = hp.level_start[l + 1];
             for (int base = s0; base < s1; base += 64) {
+                used.push_back((uint32_t)std::min(64, s1 - base));
                 for (int lane = 0; lane < 64; ++lane) {
                     SweepSlotEntry e = idle;
                     const int q = base + lane;
                     if (q < s1) {
-                        const uint32_t p = (uint32_t)hp.pix[q] * 4;
+                        const uint32_t p = 16 + (uint32_t)hp.pix[q] * 4;
                         const int n = hp.cnt[q];
                         uint32_t nb4[4] = {p, p, p, p};
-                        for (int j = 0; j < 4; ++j) e.w[j] = 0.f;
                         for (int j = 0; j < n; ++j) {
-                            nb4[j] = (uint32_t)hp.nbr[(size_t)j * hp.n_entries + q] * 4;
+                            nb4[j] = 16 + (uint32_t)hp.nbr[(size_t)j * hp.n_entries + q] * 4;
                             e.w[j] = (float)hp.wt[(size_t)j * hp.n_entries + q];
                         }
                         e.p_n0 = p | (nb4[0] << 16);
@@ -866,6 +863,9 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
             for (int lane = 0; lane < 64; ++lane) slots.push_back(idle);
         dp.n_slots = (int32_t)(slots.size() / 64);
         for (int extra = 0; extra < 3 * 64; ++extra) slots.push_back(idle);
+        used.resize(slots.size() / 64 + 3, 0);
+        for (size_t step = 0; step < slots.size() / 64; ++step)
+            for (int lane = 0; lane < 64; ++lane) slots[step * 64 + lane].lanes_ahead = used[step + 3];
         if ((rc = upload(&dp.slots, slots.data(), slots.size()))) return rc;
     }
     b->plans.push_back(dp);

@@ -76,11 +76,14 @@ bool build_sweep_plan(int32_t n_pix, const double *weights, const int32_t *offse
                       SweepPlanHost *out);
 
 // One lane's work in one 64-wide step of the sweep (fast path: <= 4 terms, images of
-// at most 16380 pixels): LDS byte addresses, two per word -- p | n0 << 16, n1 | n2 << 16,
-// n3 -- and the four weights.  Missing terms: own address, weight 0.  Idle lanes:
-// all five addresses = the spare zero cell behind the image, weights 0.
+// at most 16376 pixels): LDS byte addresses 16 + 4 * pixel, two per word -- p | n0 << 16,
+// n1 | n2 << 16, n3 -- and the four weights.  Missing terms: own address, weight 0.  The
+// pixels of a step sit in its first lanes; the other lanes are idle: all zeros, i.e. all
+// five addresses = the spare cell at address 0 in front of the image, weights 0 (what a
+// buffer load returns for an out-of-range offset: the sweep does not fetch idle entries).
+// `lanes_ahead` = number of lanes in use three steps on, the same in every entry of a step.
 struct alignas(16) SweepSlotEntry {
-    uint32_t p_n0, n1_n2, n3, pad;
+    uint32_t p_n0, n1_n2, n3, lanes_ahead;
     float w[4];
 };
 
@@ -104,8 +107,9 @@ inline int update_class(int n_pix) {
         if (n_pix <= kUpdateTeam[c] * kUpdateNpl[c]) return c;
     return -1;
 }
-// LDS floats of one component's image in that kernel: all T * NPL pixel slots of the
-// class (slots beyond the box hold zeros, so the loops need no bounds) + the spare cell
+// LDS floats of one component's image in that kernel: the spare cell of the sweep, then all
+// T * NPL pixel slots of the class (slots beyond the box hold zeros, so the loops need no
+// bounds)
 inline int update_image_stride(int n_pix) {
     const int c = update_class(n_pix);
     return kUpdateTeam[c] * kUpdateNpl[c] + 4;

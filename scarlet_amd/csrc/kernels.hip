@@ -6,6 +6,7 @@
 // coalesced along x); one wavefront per component for the parameter update, with
 // the morphology, the metric and the proximal iterate resident in LDS.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -719,9 +720,10 @@ __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, 
     float *xs = v.scratch ? v.scratch + 3 * c.moff : lds_dyn;
     float *rs = xs + (v.scratch ? c.N : npad);
     float *zs = rs + (v.scratch ? c.N : npad);
-    float *us = v.scratch ? lds_dyn : zs + npad;  // candidate (and g_morph before that)
-    // (+ 4: the spare zero cell the slot plans send their idle lanes to)
-    int32_t *lvl = reinterpret_cast<int32_t *>(us + npad + 4);  // level_start of the plan
+    // candidate (and g_morph before that); + 4: the spare cell in front of the image that
+    // the slot plans send their idle lanes to
+    float *us = (v.scratch ? lds_dyn : zs + npad) + 4;
+    int32_t *lvl = reinterpret_cast<int32_t *>(us + npad);  // level_start of the plan
     // SMI_PROX_MONO_MASK: image before the sweep and the flags of the accepted pixels
     float *ws = reinterpret_cast<float *>(lvl + ((v.max_levels + 2 + 3) & ~3));
     uint8_t *fl = reinterpret_cast<uint8_t *>(ws + npad);
@@ -836,7 +838,6 @@ __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, 
                     // "flat" away from the axes): the packed slot plan of the register-
                     // resident kernels, swept by the first wavefront without barriers
                     if (T == 64 || threadIdx.x < 64) {
-                        if (lane == 0) us[(N + 3) & ~3] = 0.f;
                         sweep_slots(us, pl.slots, pl.n_slots, one_minus_g, lane);
                     }
                     __syncthreads();
@@ -1100,9 +1101,10 @@ __device__ __forceinline__ void sweep_fence() {
 #endif
 }
 
-__device__ __forceinline__ void sweep_step(float *us, const u32x3 a, const u32x4 wb,
+// `base` = the component's LDS image - 16 bytes: plan addresses are 16 + 4 * pixel, address 0
+// is the spare cell in front of the image.
+__device__ __forceinline__ void sweep_step(char *base, const u32x4 a, const u32x4 wb,
                                            float one_minus_g) {
-    char *base = reinterpret_cast<char *>(us);
     float *pp = reinterpret_cast<float *>(base + (a.x & 0xffff));
     const float cur = *pp;
     const float u0 = *reinterpret_cast<float *>(base + (a.x >> 16));
@@ -1119,9 +1121,19 @@ __device__ __forceinline__ void sweep_step(float *us, const u32x3 a, const u32x4
 
 // `slots` must be wave-uniform: the plan is read through a buffer descriptor (lane l at
 // byte 32 l of every 2-KB step, the step offset in a scalar register), which takes the
-// address arithmetic of the prefetch out of the vector unit.
+// address arithmetic of the prefetch out of the vector unit.  The 16 bytes in front of
+// `us` must belong to the component (spare cell).
+//
+// The plan stream -- 2 KB per step and component out of L2, up to ten times per iteration --
+// is what the sweep of a full batch is most sensitive to (a second 2 KB per step: + 71 %;
+// ten more VALU operations per step: + 4 %).  A level of a 41 x 41 box has 28 pixels on
+// average, in the first lanes of its step, so only those lanes fetch: the others get an
+// out-of-range offset, for which the buffer load returns zeros without touching memory --
+// an entry of zeros is an idle entry (every address = the spare cell, weights 0).  The lane
+// count of step s + 3 rides in the fourth dword of step s's entries.
 __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slots, int n_slots,
                                             float one_minus_g, int lane) {
+    char *base = reinterpret_cast<char *>(us) - 16;
     // uniformity made explicit, or the compiler wraps every load in a waterfall loop
     const uint64_t sp = reinterpret_cast<uint64_t>(slots);
     // (the builtin returns a signed int: go through uint32_t, or the low half sign-extends)
@@ -1131,11 +1143,9 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
     n_slots = __builtin_amdgcn_readfirstlane(n_slots);
     const rsrc_t r = make_rsrc(reinterpret_cast<const void *>(sp_u), (uint32_t)(n_slots + 3) * 2048u);
     const uint32_t vo = (uint32_t)lane * 32u;
-    // three dwords: a fourth, dead one would be handed to another temporary while the load
-    // is still in flight and force an early wait
-    auto meta = [&](int step) { return __builtin_amdgcn_raw_buffer_load_b96(r, vo, step * 2048, 0); };
-    auto wts = [&](int step) {
-        return __builtin_amdgcn_raw_buffer_load_b128(r, vo + 16u, step * 2048, 0);
+    auto meta = [&](int step, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, step * 2048, 0); };
+    auto wts = [&](int step, uint32_t off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, off + 16u, step * 2048, 0);
     };
     // four steps per iteration, each plan entry requested three steps before it is used
     // (register ping-pong, no rotation moves).  The plan is padded to a multiple of four
@@ -1143,31 +1153,39 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
     // check inside an iteration.
     // issued in the order of the steady state (entry, weights, step by step): the wait
     // counter at the loop head is the minimum over both ways into the loop
-    u32x3 a0 = meta(0);
-    u32x4 w0 = wts(0);
+    u32x4 a0 = meta(0, vo);
+    u32x4 w0 = wts(0, vo);
     __builtin_amdgcn_sched_barrier(0);
-    u32x3 a1 = meta(1);
-    u32x4 w1 = wts(1);
+    u32x4 a1 = meta(1, vo);
+    u32x4 w1 = wts(1, vo);
     __builtin_amdgcn_sched_barrier(0);
-    u32x3 a2 = meta(2);
-    u32x4 w2 = wts(2);
+    u32x4 a2 = meta(2, vo);
+    u32x4 w2 = wts(2, vo);
     __builtin_amdgcn_sched_barrier(0);
+    auto lanes = [&](const u32x4 &e) {  // offset of this lane's entry three steps on, or none
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
+        return (uint32_t)lane < n ? vo : kOutOfRange;
+    };
     for (int s = 0; s < n_slots; s += 4) {
-        const u32x3 a3 = meta(s + 3);
-        const u32x4 w3 = wts(s + 3);
-        sweep_step(us, a0, w0, one_minus_g);
+        uint32_t off = lanes(a0);
+        const u32x4 a3 = meta(s + 3, off);
+        const u32x4 w3 = wts(s + 3, off);
+        sweep_step(base, a0, w0, one_minus_g);
         sweep_fence();
-        a0 = meta(s + 4);
-        w0 = wts(s + 4);
-        sweep_step(us, a1, w1, one_minus_g);
+        off = lanes(a1);
+        a0 = meta(s + 4, off);
+        w0 = wts(s + 4, off);
+        sweep_step(base, a1, w1, one_minus_g);
         sweep_fence();
-        a1 = meta(s + 5);
-        w1 = wts(s + 5);
-        sweep_step(us, a2, w2, one_minus_g);
+        off = lanes(a2);
+        a1 = meta(s + 5, off);
+        w1 = wts(s + 5, off);
+        sweep_step(base, a2, w2, one_minus_g);
         sweep_fence();
-        a2 = meta(s + 6);
-        w2 = wts(s + 6);
-        sweep_step(us, a3, w3, one_minus_g);
+        off = lanes(a3);
+        a2 = meta(s + 6, off);
+        w2 = wts(s + 6, off);
+        sweep_step(base, a3, w3, one_minus_g);
         sweep_fence();
     }
 }
@@ -1179,29 +1197,47 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
 #endif
 // MODE 0: Blend.fit, 1: lite with AdaproxParameter, 2: lite with FistaParameter
 //
-// One wavefront per component; the components of a launch all belong to one size class
-// (`work` lists them class by class, common.h), so the per-pixel loops carry no bounds
-// for the first kFull slots and a small box never runs through a large box's loops.
-template <int NPL, int MODE, int T = 64>
-__device__ __forceinline__ void update_component(const BatchView &v, const float *G, int it,
-                                                 float e_rel, int prox_max_iter, int k) {
+// The update of one component, in phases (UpdState holds what lives across them; it is
+// always inlined into registers).
+// The components of a launch all belong to one size class (`work` lists them class by
+// class, common.h), so the per-pixel loops carry no bounds for the first kFull slots and a
+// small box never runs through a large box's loops.
+template <int NPL>
+struct UpdState {
+    CompCtx c;
+    int k, flags, plan_id, bad, ctr, n_slots;
+    float xs[NPL], rs[NPL], zs[NPL];
+    float alpha, pmax, t_old;
+    bool monotonic, fit_center;
+    const SweepSlotEntry *slots;
+    float one_minus_g, lthresh, cfloor, pfloor;
+    const float *bg_level;
+    float *us, *sed_new;
+};
+
+// every box of this size class has more than T * kFull pixels (common.h)
+template <int NPL>
+struct UpdFull {
+    static constexpr int value = NPL == 7 ? 0 : NPL == 16 ? 7 : NPL == 27 ? 16 : NPL == 42 ? 27 : 42;
+};
+
+// gradient gather, spectrum update, AMSGrad (or FISTA) step of the image, set-up of the
+// proximal sub-iterations
+template <int NPL, int MODE, int T>
+__device__ __forceinline__ void upd_step(const BatchView &v, const float *G, int it, float e2,
+                                         int prox_max_iter, UpdState<NPL> &S) {
     constexpr bool LITE = MODE != 0;
     constexpr bool fista = MODE == 2;
-    // every box of this size class has more than T * kFull pixels (common.h)
-    constexpr int kFull = NPL == 7 ? 0 : NPL == 16 ? 7 : NPL == 27 ? 16 : NPL == 42 ? 27 : 42;
-    const int lane = threadIdx.x;
-    const CompCtx c = comp_ctx(v, k, lane);
-    if (v.state[c.b] >= 2) return;
-    const int N = c.N;
-    float *us = lds_dyn;
-    __shared__ float sed_new[64];
-    const float e2 = e_rel * e_rel;
-    if (fista) prox_max_iter = 1;  // FistaParameter applies the prox once
-
-    const int flags = v.c_flags[k];
-    const int plan_id = v.c_plan[k];
+    constexpr int kFull = UpdFull<NPL>::value;
+    const CompCtx &c = S.c;
+    const int lane = c.lane, k = S.k, N = c.N;
+    float *us = S.us;
+    float(&xs)[NPL] = S.xs;
+    float(&rs)[NPL] = S.rs;
+    float(&zs)[NPL] = S.zs;
+    const int flags = S.flags = v.c_flags[k];
+    const int plan_id = S.plan_id = v.c_plan[k];
     const uint32_t nbytes = (uint32_t)N * 4u;
-    float xs[NPL], rs[NPL], zs[NPL];
 
     // ---- gradient: xs = sum_c sed_c G_c[box], g_sed (lane c) = sum_yx G_c morph
     // (lite/models.py:206-216; slice of G into the box, zero outside the frame: blend.py:30-46)
@@ -1263,18 +1299,19 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
         msum += zs[j];
         msum2 = fmaf(zs[j], zs[j], msum2);
     }
-    float ssum2 = 1.f, t_old = 1.f;
+    float ssum2 = 1.f;
+    S.t_old = 1.f;
     if (fista) {
         // sums over the *old* parameters: FISTA steps (lite/parameters.py:138)
         msum2 = Team<T>::sum(msum2);
         const float so = lane < c.C ? c.sed[lane] : 0.f;
         ssum2 = Team<T>::sum(so * so);
-        t_old = (float)v.fista_t[2 * (int64_t)k + 1];
+        S.t_old = (float)v.fista_t[2 * (int64_t)k + 1];
     }
     // the spectrum belongs to the first wavefront (one band per lane)
-    int bad = 0;
+    S.bad = 0;
     if (T == 64 || threadIdx.x < 64)
-        bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, sed_new);
+        S.bad = update_spectrum(v, c, g_sed, it, e2, prox_max_iter, msum2, S.sed_new);
     const float alpha = fmaxf(v.c_morph_step[k], v.c_morph_rel[k] * (Team<T>::sum(msum) / (float)N));
     float pmax = 0.f;
     const rsrc_t r_m = make_rsrc(v.m_morph + c.moff, nbytes);
@@ -1354,106 +1391,171 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
     const float rpmax = 1.f / pmax;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) rs[j] = rs[j] * rpmax;
+    S.alpha = alpha;
+    S.pmax = pmax;
 
-    const bool monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
-    const bool fit_center = LITE && monotonic && (flags & SMI_PROX_FIT_CENTER);
-    const SweepSlotEntry *slots = nullptr;
-    int n_slots = 0;
-    if (monotonic && !fit_center) {
-        slots = v.plans[plan_id].slots;
-        n_slots = v.plans[plan_id].n_slots;
+    S.monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
+    S.fit_center = LITE && S.monotonic && (flags & SMI_PROX_FIT_CENTER);
+    S.slots = nullptr;
+    S.n_slots = 0;
+    if (S.monotonic && !S.fit_center) {
+        S.slots = v.plans[plan_id].slots;
+        S.n_slots = v.plans[plan_id].n_slots;
     }
-    const float one_minus_g = 1.f - v.c_min_grad[k];
-    const int ctr = (c.h / 2) * c.w + (c.w / 2);
-    const float lthresh =
-        v.c_lthresh[k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
-    const float cfloor = v.c_center_floor[k];
-    const float pfloor = v.c_pos_floor[k];  // PositivityConstraint(zero)
-    const float *bg_level =
-        (LITE && v.c_bg_level) ? v.c_bg_level + (int64_t)k * c.C : nullptr;
-    team_fence<T>();  // the offsets parked in `us` have been consumed
+    S.one_minus_g = 1.f - v.c_min_grad[k];
+    S.ctr = (c.h / 2) * c.w + (c.w / 2);
+    S.lthresh = v.c_lthresh[k] * ((flags & SMI_PROX_L_RELATIVE) ? alpha / pmax : 1.f);
+    S.cfloor = v.c_center_floor[k];
+    S.pfloor = v.c_pos_floor[k];  // PositivityConstraint(zero)
+    S.bg_level = (LITE && v.c_bg_level) ? v.c_bg_level + (int64_t)k * c.C : nullptr;
+}
 
-    for (int tau = 0; tau < prox_max_iter; ++tau) {
+// candidate of a proximal sub-iteration into the LDS image
+template <int NPL, int T>
+__device__ __forceinline__ void upd_prox_begin(UpdState<NPL> &S) {
+    const int lane = S.c.lane;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) us[lane + T * j] = zs[j] - rs[j] * (zs[j] - xs[j]);
-        team_fence<T>();
-        if (fit_center) {
-            const int centre = __builtin_amdgcn_readfirstlane(fit_center_index(us, c));
-            const SweepPlanDev &pl = v.plans[plan_id + centre];
-            slots = pl.slots;
-            n_slots = pl.n_slots;
-        }
-        if (monotonic) {
-            // one wavefront sweeps (the steps are sequential and at most 64 pixels wide)
-            if (T == 64 || threadIdx.x < 64) sweep_slots(us, slots, n_slots, one_minus_g, lane);
-            if (T > 64) __syncthreads();
-        }
-        chain_symmetry_threshold<T>(us, c, LITE ? flags : (flags & ~SMI_PROX_BG_THRESH), lthresh,
-                                 sed_new, bg_level,
-                                 (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[k] : 1.f);
-        float mx = -INFINITY, sm = 0.f;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int i = lane + T * j;
-            float u = us[i];
-            if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
-            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
-            mx = (j < kFull || i < N) ? fmaxf(mx, u) : mx;
-            sm += (j < kFull || i < N) ? u : 0.f;
-        }
-        float div = 1.f;
-        if (flags & SMI_PROX_NORM_MAX) div = Team<T>::max(mx);
-        if (flags & SMI_PROX_NORM_SUM) div = Team<T>::sum(sm);
-        // one correctly rounded reciprocal per sub-iteration instead of N divisions; the
-        // maximum itself still maps to exactly 1 (x / x), everything else is within
-        // 1 ulp of the quotient
-        const float rdiv = 1.f / div;
-        float d2 = 0.f, z2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int i = lane + T * j;
-            float u = us[i];  // second read instead of NPL more registers
-            if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
-            if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
-            if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
-                u = (u == div && (flags & SMI_PROX_NORM_MAX)) ? 1.f : u * rdiv;
-            if (!(j < kFull || i < N)) u = 0.f;  // slots beyond the box stay zero
-            d2 += (u - zs[j]) * (u - zs[j]);
-            z2 += zs[j] * zs[j];
-            zs[j] = u;
-        }
-        d2 = Team<T>::sum(d2);
-        z2 = Team<T>::sum(z2);
-        if (d2 <= e2 * z2) break;
+    for (int j = 0; j < NPL; ++j) S.us[lane + T * j] = S.zs[j] - S.rs[j] * (S.zs[j] - S.xs[j]);
+}
+
+// MonotonicityConstraint(fit_center_radius=1): the plan of this sub-iteration
+template <int NPL>
+__device__ __forceinline__ void upd_prox_plan(const BatchView &v, UpdState<NPL> &S) {
+    if (S.fit_center) {
+        const int centre = __builtin_amdgcn_readfirstlane(fit_center_index(S.us, S.c));
+        const SweepPlanDev &pl = v.plans[S.plan_id + centre];
+        S.slots = pl.slots;
+        S.n_slots = pl.n_slots;
     }
+}
+
+// rest of the chain after the sweep, convergence test; true when the sub-iterations end
+template <int NPL, int MODE, int T>
+__device__ __forceinline__ bool upd_prox_end(const BatchView &v, float e2, UpdState<NPL> &S) {
+    constexpr bool LITE = MODE != 0;
+    constexpr int kFull = UpdFull<NPL>::value;
+    const CompCtx &c = S.c;
+    const int lane = c.lane, N = c.N, flags = S.flags, ctr = S.ctr;
+    const float pfloor = S.pfloor, cfloor = S.cfloor;
+    float *us = S.us;
+    chain_symmetry_threshold<T>(us, c, LITE ? flags : (flags & ~SMI_PROX_BG_THRESH), S.lthresh,
+                                S.sed_new, S.bg_level,
+                                (flags & SMI_PROX_SYMMETRY) ? v.c_sym_strength[S.k] : 1.f);
+    float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int i = lane + T * j;
+        float u = us[i];
+        if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
+        if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
+        mx = (j < kFull || i < N) ? fmaxf(mx, u) : mx;
+        sm += (j < kFull || i < N) ? u : 0.f;
+    }
+    float div = 1.f;
+    if (flags & SMI_PROX_NORM_MAX) div = Team<T>::max(mx);
+    if (flags & SMI_PROX_NORM_SUM) div = Team<T>::sum(sm);
+    // one correctly rounded reciprocal per sub-iteration instead of N divisions; the
+    // maximum itself still maps to exactly 1 (x / x), everything else is within
+    // 1 ulp of the quotient
+    const float rdiv = 1.f / div;
+    float d2 = 0.f, z2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int i = lane + T * j;
+        float u = us[i];  // second read instead of NPL more registers
+        if (flags & SMI_PROX_POSITIVE) u = max_nan(u, pfloor);
+        if ((flags & SMI_PROX_CENTER_ON) && i == ctr) u = max_nan(u, cfloor);
+        if (flags & (SMI_PROX_NORM_MAX | SMI_PROX_NORM_SUM))
+            u = (u == div && (flags & SMI_PROX_NORM_MAX)) ? 1.f : u * rdiv;
+        if (!(j < kFull || i < N)) u = 0.f;  // slots beyond the box stay zero
+        d2 += (u - S.zs[j]) * (u - S.zs[j]);
+        z2 += S.zs[j] * S.zs[j];
+        S.zs[j] = u;
+    }
+    d2 = Team<T>::sum(d2);
+    z2 = Team<T>::sum(z2);
+    return d2 <= e2 * z2;
+}
+
+// parameters back to memory, finite check
+template <int NPL, int MODE, int T>
+__device__ __forceinline__ void upd_store(const BatchView &v, UpdState<NPL> &S) {
+    constexpr bool fista = MODE == 2;
+    const CompCtx &c = S.c;
+    const int lane = c.lane;
+    const uint32_t nbytes = (uint32_t)c.N * 4u;
     float omega = 0.f;
     if (fista) {
+        const float t_old = S.t_old;
         const float tn = 0.5f * (1.f + sqrtf(1.f + 4.f * t_old * t_old));
         omega = 1.f + (t_old - 1.f) / tn;
-        if (lane == 0) v.fista_t[2 * (int64_t)k + 1] = (double)tn;
+        if (lane == 0) v.fista_t[2 * (int64_t)S.k + 1] = (double)tn;
     }
     const rsrc_t r_out = make_rsrc(c.morph_out, nbytes);
     if (fista) {
+        const rsrc_t r_m = make_rsrc(v.m_morph + c.moff, nbytes);
         float xo[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) xo[j] = buf_load(r_out, (uint32_t)(lane + T * j) * 4u);
 #pragma unroll
         for (int j = 0; j < NPL; ++j)
-            buf_store(r_m, (uint32_t)(lane + T * j) * 4u, xo[j] + omega * (zs[j] - xo[j]));
+            buf_store(r_m, (uint32_t)(lane + T * j) * 4u, xo[j] + omega * (S.zs[j] - xo[j]));
     }
+    int bad = S.bad;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
-        buf_store(r_out, (uint32_t)(lane + T * j) * 4u, zs[j]);
-        bad |= !isfinite(zs[j]);
+        buf_store(r_out, (uint32_t)(lane + T * j) * 4u, S.zs[j]);
+        bad |= !isfinite(S.zs[j]);
     }
     if (Team<T>::any(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
+}
+
+template <int NPL, int MODE, int T = 64>
+__device__ __forceinline__ void update_component(const BatchView &v, const float *G, int it,
+                                                 float e_rel, int prox_max_iter, int k,
+                                                 float *us, float *sed_new) {
+    constexpr bool fista = MODE == 2;
+    UpdState<NPL> S;
+    S.k = k;
+    S.c = comp_ctx(v, k, threadIdx.x);
+    if (v.state[S.c.b] >= 2) return;
+    S.us = us;
+    S.sed_new = sed_new;
+    const float e2 = e_rel * e_rel;
+    if (fista) prox_max_iter = 1;  // FistaParameter applies the prox once
+    upd_step<NPL, MODE, T>(v, G, it, e2, prox_max_iter, S);
+    team_fence<T>();  // the offsets parked in `us` have been consumed
+    for (int tau = 0; tau < prox_max_iter; ++tau) {
+        upd_prox_begin<NPL, T>(S);
+        team_fence<T>();
+        upd_prox_plan<NPL>(v, S);
+        if (S.monotonic) {
+            // one wavefront sweeps (the steps are sequential and at most 64 pixels wide)
+            if (T == 64 || threadIdx.x < 64)
+                sweep_slots(S.us, S.slots, S.n_slots, S.one_minus_g, S.c.lane);
+            if (T > 64) __syncthreads();
+        }
+        if (upd_prox_end<NPL, MODE, T>(v, e2, S)) break;
+    }
+    upd_store<NPL, MODE, T>(v, S);
+}
+
+// XCD-aware placement of consecutive work items (workgroup b runs on XCD b % 8): XCD x gets
+// a contiguous share of the list, so the components of one blend -- neighbours in the work
+// list -- read the blend's gradient image through one L2 instead of eight.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return x * q + min(x, r) + (b >> 3);
 }
 
 template <int NPL, int MODE, int T>
 __global__ __launch_bounds__(T) SMI_WAVES void update_kernel_reg(BatchView v, const float *G,
                                                                  int it, float e_rel,
-                                                                 int prox_max_iter) {
-    update_component<NPL, MODE, T>(v, G, it, e_rel, prox_max_iter, v.work[blockIdx.x + v.work0]);
+                                                                 int prox_max_iter, int n_items) {
+    __shared__ float sed_new[64];
+    const int item = xcd_contiguous(blockIdx.x, n_items);
+    update_component<NPL, MODE, T>(v, G, it, e_rel, prox_max_iter, v.work[item + v.work0], lds_dyn + 4,
+                                   sed_new);
 }
 
 // Components of several size classes (a blend with boxes of 21^2 .. 61^2 pixels): a launch
@@ -1468,19 +1570,21 @@ __global__ __launch_bounds__(T) SMI_WAVES void update_kernel_reg(BatchView v, co
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void update_kernel_mixed(
     BatchView v, const float *G, int it, float e_rel, int prox_max_iter) {
+    __shared__ float sed_new[64];
     const int k = v.comp0 + blockIdx.x;
     if (v.c_flags[k] & SMI_COMPONENT_POINT_SOURCE) return;
     const int n = v.c_h[k] * v.c_w[k];  // uniform over the wavefront
+    float *us = lds_dyn + 4;  // (spare cell of the sweep in front)
     if (n <= 64 * kUpdateNpl[0])
-        update_component<kUpdateNpl[0], MODE>(v, G, it, e_rel, prox_max_iter, k);
+        update_component<kUpdateNpl[0], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else if (n <= 64 * kUpdateNpl[1])
-        update_component<kUpdateNpl[1], MODE>(v, G, it, e_rel, prox_max_iter, k);
+        update_component<kUpdateNpl[1], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else if (n <= 64 * kUpdateNpl[2])
-        update_component<kUpdateNpl[2], MODE>(v, G, it, e_rel, prox_max_iter, k);
+        update_component<kUpdateNpl[2], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else if (n <= 64 * kUpdateNpl[3])
-        update_component<kUpdateNpl[3], MODE>(v, G, it, e_rel, prox_max_iter, k);
+        update_component<kUpdateNpl[3], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else
-        update_component<kUpdateNpl[4], MODE>(v, G, it, e_rel, prox_max_iter, k);
+        update_component<kUpdateNpl[4], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
 }
 
 // log_norm of Observation (observation.py:172-186): D/2 ln(2 pi) + sum ln(1/sqrt(w))
@@ -1651,21 +1755,22 @@ static size_t update_lds_bytes(const BatchView &v) {
 }
 
 template <int NPL, int T>
-static void launch_update_reg(const BatchView &v, const float *G, int32_t it, float e_rel,
-                              int32_t prox_max_iter, int32_t item0, int32_t n_items,
-                              hipStream_t s) {
+static int launch_update_reg(const BatchView &v, const float *G, int32_t it, float e_rel,
+                             int32_t prox_max_iter, int32_t item0, int32_t n_items,
+                             hipStream_t s) {
     BatchView vi = v;
     vi.work0 = item0;
     const size_t lds = (size_t)(T * NPL + 4) * sizeof(float);
     if (v.scheme == SMI_SCHEME_FISTA)
         hipLaunchKernelGGL((update_kernel_reg<NPL, 2, T>), dim3(n_items), dim3(T), lds, s, vi, G,
-                           it, e_rel, prox_max_iter);
+                           it, e_rel, prox_max_iter, n_items);
     else if (v.lite)
         hipLaunchKernelGGL((update_kernel_reg<NPL, 1, T>), dim3(n_items), dim3(T), lds, s, vi, G,
-                           it, e_rel, prox_max_iter);
+                           it, e_rel, prox_max_iter, n_items);
     else
         hipLaunchKernelGGL((update_kernel_reg<NPL, 0, T>), dim3(n_items), dim3(T), lds, s, vi, G,
-                           it, e_rel, prox_max_iter);
+                           it, e_rel, prox_max_iter, n_items);
+    return SMI_OK;
 }
 
 int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
@@ -1703,7 +1808,7 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
             const int lo = start[v.blend0], hi = start[v.blend0 + v.nb];
             if (hi <= lo) continue;
 #define SMI_CLASS(i) \
-    case i: launch_update_reg<kUpdateNpl[i], kUpdateTeam[i]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s); break;
+    case i: if (int rc = launch_update_reg<kUpdateNpl[i], kUpdateTeam[i]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s)) return rc; break;
             switch (cls) {
                 SMI_CLASS(0) SMI_CLASS(1) SMI_CLASS(2) SMI_CLASS(3) SMI_CLASS(4)
                 SMI_CLASS(5) SMI_CLASS(6) SMI_CLASS(7) SMI_CLASS(8)
