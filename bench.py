@@ -33,10 +33,16 @@ Output: ONE JSON line on rank 0 with the contract's fields plus
   roofline     dominant kernel: algorithmic bytes per launch / mean launch duration
                (HIP events on the batch stream over the same K iterations, replayed
                in one range of blends), at the FFT shape the kernel runs; counter-derived
-               fields from profiles/ (HBM traffic, VALU busy); `bound` is what the
-               counters say binds the kernel
+               fields from profiles/ (HBM traffic, VALU busy; listed with their source in
+               `counter_fields`); `bound` is what the counters say binds the kernel (null
+               without counters); `speed_of_light`: the iteration against
+               max(compulsory bytes / 8 TB/s, butterfly flops / f32 peak); `measured_hbm`: HBM
+               bytes of the whole iteration by the PMC counters against the compulsory bytes
+  parity       first and last blend of every rank's shard against the CPU oracle over the
+               same K iterations (checker only, after the timed region)
   cpu_baseline the CPU oracle (NumPy/C port of the reference loop) timed on this host:
-               one thread, and a process pool over all usable host cores.
+               one thread, and a process pool over all usable host cores; plus the
+               reference's own forward timed beside the port's in the build container.
 """
 
 import argparse
@@ -112,6 +118,34 @@ def _oracle_fit(args):
     for it in range(n_iter):
         sc.step(it, e_rel)
     return n_iter, time.perf_counter() - t0
+
+
+def oracle_check(scenes, picks, loss, K, e_rel):
+    """Checker, outside the timed region: the loss histories the device produced for the
+    blends `picks` of this rank against the CPU oracle run on the same scenes for the same
+    K iterations.  Tolerances of tests/test_gpu_parity.py (relative, on the chi^2 part of
+    the loss): 2e-5 over the first twelve iterations, 5e-4 afterwards (the transient of the
+    whole-fit tests).  Returns the worst relative differences; raises if one is out of bounds."""
+    from oracle import pgm
+
+    worst_early, worst = 0.0, 0.0
+    for i in picks:
+        s = scenes[i]
+        sc = pgm.Scene(
+            s["data"].shape, s["data"], s["weights"], s["diff_kernel"],
+            [pgm.Component(s["seds"][k].copy(), s["morphs"][k].copy(), s["origins"][k],
+                           sed_min_step=s["noise_rms"]) for k in range(len(s["morphs"]))])
+        for it in range(K):
+            sc.step(it, e_rel)
+        a = np.asarray(loss[i][:K], dtype=np.float64) - sc.log_norm
+        b = np.asarray(sc.loss, dtype=np.float64) - sc.log_norm
+        rel = np.abs(a - b) / np.abs(b)
+        worst_early = max(worst_early, float(rel[:12].max()))
+        worst = max(worst, float(rel.max()))
+    if worst_early > 2e-5 or worst > 5e-4:
+        raise AssertionError("device fit differs from the oracle: %.3g (first 12 iterations), "
+                             "%.3g (all)" % (worst_early, worst))
+    return worst_early, worst
 
 
 def usable_cores():
@@ -231,7 +265,7 @@ def build_cfg3(lo, hi, device, lite_loop):
         ]
     data = np.stack([s["data"] for s in scenes])
     weights = np.stack([s["weights"] for s in scenes])
-    return data, weights, comps, kern[2]
+    return data, weights, comps, kern[2], scenes
 
 
 def build_cfg1(n):
@@ -347,12 +381,14 @@ def main():
     lo, hi = sdist.shard_range(n_total, rank, world)
     nb = hi - lo
     lite = args.loop != "blend"
+    scenes = None
     if args.config == "cfg1":
         data, weights, comps, kernel = build_cfg1(nb)
     elif args.config == "cfg4":
         data, weights, comps, kernel = build_cfg4(nb)
     else:
-        data, weights, comps, kernel = build_cfg3(lo, hi, local_rank, args.loop if lite else None)
+        data, weights, comps, kernel, scenes = build_cfg3(lo, hi, local_rank,
+                                                          args.loop if lite else None)
     K, Wm = args.steps, args.warmup
     batch = BlendBatch(
         data, weights, comps, kernel=None if args.null_renderer else kernel,
@@ -397,6 +433,14 @@ def main():
     # the only collective: the packed per-blend records of all ranks
     rec = sdist.gather_records(sdist.pack_records(loss, batch.states(), K))
     assert len(rec) == n_total and np.all(rec["n_iter"] == K)
+    # parity at the benchmark's own size: first and last blend of every rank's shard against
+    # the oracle, same K iterations (checker only, after the clock has stopped)
+    parity = None
+    if scenes is not None and not lite and not args.steady and not args.null_renderer and nb:
+        picks = sorted({0, nb - 1})
+        early, late = oracle_check(scenes, picks, loss, K, e_rel)
+        parity = sdist.gather_objects({"rank": rank, "blends": [lo + i for i in picks],
+                                       "first_12": early, "all": late})
 
     # Roofline pass: the SAME K iterations again with HIP events around every kernel, all
     # of the rank's blends in ONE range.  In the timed region ranges of blends run on
@@ -438,8 +482,50 @@ def main():
         achieved = k_bytes * nb / (k_ms * 1e-3) / 1e9
         cnt = counters(k_name) if args.config == "cfg3" and nb == 1024 else {}
         traffic = cnt["bytes_per_blend"] * nb if "bytes_per_blend" in cnt else None
+        # Speed of light of one iteration of this rank's shard: what cannot be avoided is the
+        # compulsory traffic B0 (data and weights once, parameters and moments once each way)
+        # at 8 TB/s, and the butterflies of the four transforms at the f32 vector peak.
+        counted = (args.config == "cfg3" and nb == 1024 and not args.null_renderer
+                   and os.path.exists(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        all_cnt = {k: counters(k) for k in ("fused_conv_kernel", "update_kernel_reg",
+                                            "render_kernel")} if counted else {}
+        hbm_ms = by["null"] * nb / (HBM_PEAK_GBS * 1e9) * 1e3
+        flop_ms = (fft_flops(C, Fy, Fx) * nb / (F32_VECTOR_PEAK_TFLOPS * 1e12) * 1e3
+                   if not args.null_renderer else 0.0)
+        sol_ms = max(hbm_ms, flop_ms)
+        measured_iter = (sum(c["bytes_per_blend"] for c in all_cnt.values())
+                         if all_cnt and all("bytes_per_blend" in c for c in all_cnt.values()) else None)
         roofline = {
-            "bound": cnt.get("bound", "hbm"),
+            # what binds the dominant kernel according to the counters; null without counters
+            "bound": cnt.get("bound"),
+            "speed_of_light": {
+                "compulsory_bytes_per_blend_iteration": by["null"],
+                "hbm_ms": round(hbm_ms, 4),
+                "butterfly_flops_per_blend_iteration": (round(fft_flops(C, Fy, Fx))
+                                                        if not args.null_renderer else 0),
+                "valu_ms": round(flop_ms, 4),
+                "sol_ms": round(sol_ms, 4),
+                "sol_frac": round(sol_ms / ms_iter, 4),
+                "note": "sol_ms = max(compulsory bytes / 8 TB/s, butterfly flops / 157.3 TFLOP/s) "
+                        "for this rank's %d blends; sol_frac = sol_ms / ms_per_step: the share of "
+                        "the chip's physical limit the iteration reaches.  `frac` below prices the "
+                        "SURVEY 8d byte model, most of whose bytes this design keeps in LDS." % nb,
+            },
+            "measured_hbm": {
+                "bytes_per_blend_iteration": measured_iter,
+                "over_compulsory": (round(measured_iter / by["null"], 3) if measured_iter else None),
+                "frac_of_peak": (round(measured_iter * nb / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                 if measured_iter else None),
+                "per_kernel": {k: c.get("bytes_per_blend") for k, c in all_cnt.items()} or None,
+                "source": ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                           "passes of tools/collect_profiles.sh on 1024-blend launches "
+                           "(committed constants, not measured in this run)" if all_cnt else None),
+            },
+            "counter_fields": {
+                "fields": ["bound", "traffic", "hbm_frac_measured", "valu_busy", "measured_hbm"],
+                "source": "profiles/hbm_traffic.json (committed PMC summary); every other field is "
+                          "measured in this run",
+            },
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -521,10 +607,25 @@ def main():
                 "mean_logL": float(np.mean(rec["logL"])),
             },
             "roofline": roofline,
+            "parity": ({"checked_blends": [b for p in parity for b in p["blends"]],
+                        "worst_rel_chi2_first_12_iterations": max(p["first_12"] for p in parity),
+                        "worst_rel_chi2_all_iterations": max(p["all"] for p in parity),
+                        "tolerance": [2e-5, 5e-4],
+                        "against": "CPU oracle (oracle/pgm.py), same scenes, iterations 0..%d; "
+                                   "checker only, after the timed region" % (K - 1)}
+                       if parity else None),
         }
         if not args.no_cpu and not lite and world == 1:  # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_blends,
                                                 args.cpu_iters or K, e_rel)
+            ref = os.path.join(ROOT, "profiles", "r03_reference_forward.json")
+            if os.path.exists(ref):
+                # SURVEY 8d(ii), measured once in the build container (the reference cannot
+                # travel to the GPU box): the port's forward beside the reference's own
+                with open(ref) as fh:
+                    line["cpu_baseline"]["reference_forward_check"] = dict(
+                        json.load(fh)["scenes"], source="profiles/r03_reference_forward.json "
+                        "(oracle/refshim/time_reference_forward.py, build container, one thread)")
         print(json.dumps(line), flush=True)
     batch.close()
     if world > 1:

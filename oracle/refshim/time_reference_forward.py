@@ -20,6 +20,7 @@ from oracle import pgm  # noqa: E402
 from oracle.refshim.load_reference import load  # noqa: E402
 
 scarlet = load()
+RESULTS = {}
 
 
 def clock(fn, n):
@@ -60,8 +61,11 @@ def report(name, images, weights, psfs, filters, comps, kernel):
 
     a, b = ref_forward(), oracle_forward()
     assert abs(a - b) < 1e-5 * abs(a), (a, b)
+    t_ref, t_or = clock(ref_forward, 40), clock(oracle_forward, 40)
     print("%-28s reference forward %.2f ms, oracle forward %.2f ms (same logL %.3f)"
-          % (name, clock(ref_forward, 20), clock(oracle_forward, 20), a))
+          % (name, t_ref, t_or, a))
+    RESULTS[name] = {"reference_forward_ms": round(t_ref, 3), "oracle_forward_ms": round(t_or, 3),
+                     "oracle_over_reference": round(t_or / t_ref, 3), "logL": a}
 
 
 g = np.load(os.path.join(REPO, "tests", "golden", "hsc_cosmos_35.npz"))
@@ -75,3 +79,15 @@ s = synthetic.make_blend(seed=1234)
 comps = [(s["seds"][k], s["morphs"][k], tuple(s["origins"][k])) for k in range(len(s["seds"]))]
 kern = synthetic.psfs()
 report("cfg 2 synthetic 5x128x128", s["data"], s["weights"], s["obs_psf"], list("grizy"), comps, kern[2])
+
+if "--json" in sys.argv:
+    import json
+    import platform
+
+    cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][:1]
+    out = {"what": "SURVEY 8d(ii): the reference's own forward (get_model + render + "
+                   "get_log_likelihood under the container-only shims) beside the oracle's "
+                   "forward, one thread, build container", "cpu": cpu, "python": platform.python_version(),
+           "numpy": np.__version__, "scenes": RESULTS}
+    with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
+        json.dump(out, fh, indent=1)

@@ -470,7 +470,15 @@ class Blend(CombinedComponent):
                 batch = self._build_batch(comps, max_iter - it)
             except _HostSteppedShift:
                 # frames beyond the fused convolution kernel: the shift is stepped by the host
-                return self._fit_with_psf_shift(max_iter, e_rel, min_iter, prox_max_iter, opt, callback)
+                if noise_factor:
+                    raise NotImplementedError(
+                        "noise_factor > 0 with a free psf_shift on a frame beyond the fused "
+                        "convolution (the host-stepped shift does not redraw the noise)")
+                try:
+                    return self._fit_with_psf_shift(max_iter, e_rel, min_iter, prox_max_iter, opt,
+                                                    callback)
+                finally:
+                    self._psf = None
             batch.set_optimizer(**opt)
             restart = False
             try:
@@ -531,6 +539,10 @@ class Blend(CombinedComponent):
         for p in self.parameters + extra:
             if p.v is not None:
                 p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))  # rough estimate, blend.py:189-192
+        # what _specs / _observation read is per call: nothing of this fit's renderer
+        # parameters or scheme may steer a later fit_blends
+        self._psf = None
+        self._scheme = ("amsgrad", 0.25)
         return len(self.loss), -self.loss[-1]
 
     def _draw_noise(self, batch, noise_factor):
@@ -770,11 +782,29 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, devices=None, **alg
         from . import dist as sdist
 
         rank, local_rank, world = sdist.env_rank()
+        if not sdist._active():
+            if world > 1:
+                raise RuntimeError("fit_blends(devices='ranks') under WORLD_SIZE={} needs an "
+                                   "initialised process group (scarlet_amd.dist."
+                                   "init_process_group)".format(world))
+            rank, world = 0, 1
         lo, hi = sdist.shard_range(len(blends), rank, world)
-        mine, errs = _fit_blends_on(blends[lo:hi], local_rank, **kw)
-        parts = sdist.gather_objects(
-            dict(lo=lo, results=mine, errors=[(lo + i, str(e)) for i, e in errs],
-                 states=[_export_state(b) for b in blends[lo:hi]]))
+        # a rank that fails must still take part in the collective, or the others hang in it:
+        # its exception travels as text and every rank raises together
+        try:
+            mine, errs = _fit_blends_on(blends[lo:hi], local_rank, **kw)
+            part = dict(lo=lo, results=mine, errors=[(lo + i, str(e)) for i, e in errs],
+                        states=[_export_state(b) for b in blends[lo:hi]], failed=None)
+            import pickle
+
+            pickle.dumps(part)
+        except Exception as e:  # noqa: BLE001 -- re-raised on every rank below
+            part = dict(lo=lo, results=[], errors=[], states=[],
+                        failed="rank {}: {}: {}".format(rank, type(e).__name__, e))
+        parts = sdist.gather_objects(part)
+        failed = [p["failed"] for p in parts if p["failed"]]
+        if failed:
+            raise RuntimeError("fit_blends(devices='ranks') failed: " + "; ".join(failed))
         out = []
         for part in parts:
             out.extend(part["results"])
@@ -842,6 +872,10 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
     # blends with host-updated parameters (hoststep.py) step one iteration per device call
     solo = set()
     for i, b in enumerate(blends):
+        b._psf, b._scheme = None, ("amsgrad", 0.25)  # nothing left over from an earlier fit()
+        if any(not p.fixed for obs in b.observations for p in obs.parameters):
+            raise NotImplementedError("fit_blends: a blend with free renderer parameters "
+                                      "(psf_shift) fits through Blend.fit")
         b._specs(_flatten(b.sources))
         if b._host:
             solo.add(i)

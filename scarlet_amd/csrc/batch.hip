@@ -876,6 +876,9 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
 
 int smi_batch_set_observation(smi_batch *b, const float *data, const float *weights) {
     SMI_REQUIRE(b && data && weights, "null argument");
+    // (log_norm is recomputed from this observation alone: the terms of observations added
+    // with smi_batch_add_observation and of smi_batch_add_loss_constant would be lost)
+    SMI_REQUIRE(b->layers.empty(), "the first observation cannot be replaced once further observations were added");
     SMI_HIP(hipSetDevice(b->device));
     SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
     const size_t n = (size_t)b->d.n_blends * b->d.C * b->d.H * b->d.W;
@@ -960,6 +963,9 @@ int smi_batch_set_fista_state(smi_batch *b, const float *z_sed, const float *z_m
 
 int smi_batch_set_observation_device(smi_batch *b, const float *d_data, const float *d_weights) {
     SMI_REQUIRE(b && d_data && d_weights, "null argument");
+    // (log_norm is recomputed from this observation alone: the terms of observations added
+    // with smi_batch_add_observation and of smi_batch_add_loss_constant would be lost)
+    SMI_REQUIRE(b->layers.empty(), "the first observation cannot be replaced once further observations were added");
     SMI_HIP(hipSetDevice(b->device));
     SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
     if (b->own_obs) {
@@ -1193,6 +1199,15 @@ int smi_batch_add_observation(smi_batch *b, const float *data, const float *weig
     const int nb = b->d.n_blends, C = b->d.C;
     const size_t n = (size_t)nb * C * b->d.H * b->d.W;
     smi_batch::ObsLayer layer;
+    // whatever fails below, the layer's buffers go with it
+    struct Guard {
+        smi_batch::ObsLayer *l;
+        ~Guard() {
+            if (!l) return;
+            for (void *p : {(void *)l->data, (void *)l->weights, (void *)l->Kt})
+                if (p) (void)hipFree(p);
+        }
+    } guard{&layer};
     int rc;
     if ((rc = upload(&layer.data, data, n))) return rc;
     if ((rc = upload(&layer.weights, weights, n))) return rc;
@@ -1205,15 +1220,20 @@ int smi_batch_add_observation(smi_batch *b, const float *data, const float *weig
     if (rc) return rc;
     // log_norm of the layer joins the blend's (observation.py:172-186)
     if (b->include_log_norm) {
-        double *d_ln = nullptr;
-        SMI_HIP(dev_alloc(&d_ln, (size_t)nb));
-        launch_log_norm(layer.weights, d_ln, nb, (int64_t)C * b->d.H * b->d.W, b->stream);
+        struct Scratch {
+            double *p = nullptr;
+            ~Scratch() {
+                if (p) (void)hipFree(p);
+            }
+        } d_ln;
+        SMI_HIP(dev_alloc(&d_ln.p, (size_t)nb));
+        launch_log_norm(layer.weights, d_ln.p, nb, (int64_t)C * b->d.H * b->d.W, b->stream);
         std::vector<double> ln(nb);
-        SMI_HIP(hipMemcpyAsync(ln.data(), d_ln, nb * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        SMI_HIP(hipMemcpyAsync(ln.data(), d_ln.p, nb * sizeof(double), hipMemcpyDeviceToHost, b->stream));
         SMI_HIP(hipStreamSynchronize(b->stream));
-        (void)hipFree(d_ln);
         if ((rc = smi_batch_add_loss_constant(b, ln.data()))) return rc;
     }
+    guard.l = nullptr;
     b->layers.push_back(layer);
     if (!b->Q2) SMI_HIP(dev_alloc(&b->Q2, n));
     if (b->loss_partial) SMI_HIP(hipFree(b->loss_partial));

@@ -73,31 +73,37 @@ def init_process_group(backend=None, device_index=None):
     return rank, local_rank, world
 
 
-def _active():
+def _active(min_world=2):
     import torch.distributed as dist
 
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world
 
 
 def _device(device=None):
+    """Where the tensors of a collective live: the rank's GPU with RCCL (backend "nccl"),
+    host memory with gloo."""
+    import torch
     import torch.distributed as dist
 
     if device is not None:
         return device
-    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+    if dist.get_backend() == "nccl":
+        return "cuda:%d" % torch.cuda.current_device()
+    return "cpu"
 
 
 # ------------------------------------------------------------------ collectives
-def all_gather_bytes(buf, device=None):
+def all_gather_bytes(buf, device=None, single_rank_too=False):
     """All-gather one byte string per rank (lengths may differ).  Returns the list of
     ``np.uint8`` arrays in rank order, on every rank.  Two collectives: the lengths,
-    then the payloads padded to the longest."""
+    then the payloads padded to the longest.  ``single_rank_too`` runs the collectives in
+    a process group of one rank as well (a test's way through RCCL on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
     buf = np.frombuffer(bytes(buf), dtype=np.uint8) if not isinstance(buf, np.ndarray) else \
         np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
-    if not _active():
+    if not _active(1 if single_rank_too else 2):
         return [buf.copy()]
     world = dist.get_world_size()
     device = _device(device)
@@ -200,10 +206,14 @@ def max_over_ranks(value, device=None):
 
 
 def barrier():
+    import torch
     import torch.distributed as dist
 
     if _active():
-        dist.barrier()
+        if dist.get_backend() == "nccl":  # name the device: the rank's communicator is bound to it
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 # ------------------------------------------------------------------ sharded fit

@@ -60,6 +60,12 @@ class HostParameter:
         self.step = step
         if scheme not in SCHEMES:
             raise ValueError("scheme must be one of {}".format(SCHEMES))
+        if scheme != "amsgrad":
+            import warnings
+
+            # proxmin (the reference's optimizer package) is not available to pin these against
+            warnings.warn("scheme={!r} follows the published algorithm, not a check against "
+                          "proxmin.adaprox: parity unpinned".format(scheme), stacklevel=3)
         self.scheme = scheme
         self.padam_p = p
         for name in ("m", "v", "vhat"):

@@ -66,6 +66,37 @@ SCRIPT = textwrap.dedent(
     assert [o["rank"] for o in objs] == [0, 1] and objs[1]["ids"] == list(range(6, 11))
     assert dist.max_over_ranks(1.0 + rank) == 2.0
     dist.barrier()
+
+    # the branch a multi-GPU job takes: backend "nccl" (RCCL) -> every tensor of the
+    # collectives on the rank's GPU.  No GPU here: the backend name is mocked and the
+    # requested device "cuda:0" is recorded and mapped onto host memory.
+    import torch
+    import torch.distributed as td
+    asked = []
+    def on_host(device):
+        if str(device).startswith("cuda"):
+            asked.append(str(device))
+            return "cpu"
+        return device
+    real = dict(zeros=torch.zeros, tensor=torch.tensor, to=torch.Tensor.to, backend=td.get_backend,
+                current=torch.cuda.current_device, barrier=td.barrier)
+    torch.zeros = lambda *a, device=None, **k: real["zeros"](*a, device=on_host(device), **k)
+    torch.tensor = lambda *a, device=None, **k: real["tensor"](*a, device=on_host(device), **k)
+    torch.Tensor.to = lambda self, device, *a, **k: real["to"](self, on_host(device), *a, **k)
+    td.get_backend = lambda *a, **k: "nccl"
+    torch.cuda.current_device = lambda: 0
+    td.barrier = lambda device_ids=None: (asked.append("barrier%%s" %% device_ids), real["barrier"]())[1]
+    try:
+        assert dist._device() == "cuda:0"
+        rec = dist.gather_records(dist.pack_records(losses, states, max_iter))
+        assert len(rec) == n_total and rec["n_iter"][7] == 1 + 7 %% max_iter
+        assert dist.max_over_ranks(5.0 - rank) == 5.0
+        dist.barrier()
+    finally:
+        torch.zeros, torch.tensor, torch.Tensor.to = real["zeros"], real["tensor"], real["to"]
+        td.get_backend, torch.cuda.current_device, td.barrier = real["backend"], real["current"], real["barrier"]
+    # buffers for the lengths of all ranks, my length, my payload and its upload, the timing scalar
+    assert asked.count("cuda:0") >= 4 + world and "barrier[0]" in asked, asked
     sys.stdout.write("rank" + str(rank) + "-ok" + chr(10))
     sys.stdout.flush()
     """

@@ -96,3 +96,63 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert "16 independent" in two["config"]["workload"]
     assert two["config"]["mean_logL"] == one["config"]["mean_logL"]
     assert one["config"]["blends_per_gpu"] == [16]
+
+
+def test_the_drivers_eight_rank_command_runs(tmp_path):
+    """The command the driver uses for the scaling record -- torchrun with 8 ranks and
+    ``bench.py --gpus 8`` -- on this one-GPU box: the ranks share the GPU over gloo (flagged in
+    the line), every rank fits its contiguous shard, rank 0 prints ONE JSON line for the whole
+    job whose fit equals the single-rank run's."""
+    from scarlet_amd import dist
+
+    args = ["--steps", "3", "--warmup", "1", "--blends", "64", "--no-cpu"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(dist.free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8"] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 1, out.stdout
+    eight = rows[0]
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    assert eight["config"]["blends_per_gpu"] == [8] * 8
+    assert "share" in eight["config"]["parallelism"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert one.returncode == 0, one.stdout[-3000:] + one.stderr[-3000:]
+    one = [json.loads(l) for l in one.stdout.splitlines() if l.startswith("{")][0]
+    assert eight["config"]["mean_logL"] == one["config"]["mean_logL"]
+    assert eight["parity"]["checked_blends"] and one["parity"]["checked_blends"]
+
+
+def test_result_gather_through_rccl(tmp_path):
+    """dist.all_gather_bytes / gather_records / max_over_ranks on backend "nccl" (= RCCL) with
+    tensors on the GPU.  RCCL refuses two ranks on one device, so on this box the process
+    group has one rank; the collectives still go through the RCCL communicator (the
+    ``single_rank_too`` switch), which is the branch a multi-GPU job takes."""
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(
+        "import os, sys\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1')\n"
+        "import torch, torch.distributed as td\n"
+        "from scarlet_amd import dist\n"
+        "os.environ['MASTER_PORT'] = str(dist.free_port())\n"
+        "torch.cuda.set_device(0)\n"
+        "td.init_process_group(backend='nccl', rank=0, world_size=1)\n"
+        "assert td.get_backend() == 'nccl' and dist._device() == 'cuda:0'\n"
+        "rec = dist.pack_records([np.arange(5.0), np.arange(2.0)], [2, 0], 6)\n"
+        "parts = dist.all_gather_bytes(rec.view(np.uint8).reshape(-1), single_rank_too=True)\n"
+        "assert len(parts) == 1 and parts[0].tobytes() == rec.tobytes()\n"
+        "assert dist.all_gather_bytes(b'', single_rank_too=True)[0].size == 0\n"
+        "t = torch.tensor([3.5], dtype=torch.float64, device=dist._device())\n"
+        "td.all_reduce(t, op=td.ReduceOp.MAX)\n"
+        "assert float(t.item()) == 3.5\n"
+        "td.barrier(device_ids=[0])\n"
+        "td.destroy_process_group()\n"
+        "print('rccl ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -743,6 +743,59 @@ def test_batch_invariance_at_benchmark_shape(amd):
             assert_array_equal(a, b_)
 
 
+def test_config3_at_its_own_size_follows_the_oracle(amd):
+    """BASELINE configs[2] at the size bench.py runs it: one batch of 1024 blends, and rank 7's
+    shard of an 8-GPU job (blends 896 .. 1023) as a batch of its own.  Twenty iterations from
+    the initial parameters; the loss histories of blends 0, 511 and 1023 against the oracle
+    (2e-5 relative on chi^2 over the first twelve iterations, 5e-4 through the transient
+    later on: the tolerances of the whole-fit tests), and the shard's blends bit for bit the
+    same as inside the full batch."""
+    from oracle import pgm
+    from scarlet_amd import synthetic
+
+    n_total, n_it = 1024, 20
+    kern = synthetic.psfs()
+    scenes = synthetic.make_batch(range(1234, 1234 + n_total), kernel=kern)
+
+    def fit(sel):
+        comps = [[amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                                    sed_min_step=s["noise_rms"]) for k in range(len(s["morphs"]))]
+                 for s in sel]
+        b = amd.BlendBatch(np.stack([s["data"] for s in sel]), np.stack([s["weights"] for s in sel]),
+                           comps, kernel=kern[2], max_iter=n_it + 1)
+        b.step(0, n_it, e_rel=1e-3, check_convergence=False)
+        active, err = b.status()
+        assert err < 0
+        out = [np.array(l) for l in b.loss_history()], b.parameters()
+        b.close()
+        return out
+
+    loss, (sed, morphs) = fit(scenes)
+    assert len(loss) == n_total and all(len(l) == n_it for l in loss)
+    for i in (0, 511, 1023):
+        s = scenes[i]
+        sc = pgm.Scene(s["data"].shape, s["data"], s["weights"], s["diff_kernel"],
+                       [pgm.Component(s["seds"][k].copy(), s["morphs"][k].copy(), s["origins"][k],
+                                      sed_min_step=s["noise_rms"]) for k in range(10)])
+        for it in range(n_it):
+            sc.step(it, 1e-3)
+        assert_loss_close(loss[i][:12], sc.loss[:12], sc.log_norm, rtol=2e-5)
+        assert_loss_close(loss[i], sc.loss, sc.log_norm, rtol=5e-4)
+        for k, c in enumerate(sc.components):
+            assert rel_err(sed[10 * i + k], c.sed) < 1e-3
+            assert np.abs(morphs[10 * i + k] - c.morph).max() < 1e-3
+    lo = 896  # dist.shard_range(1024, 7, 8)
+    from scarlet_amd import dist
+
+    assert dist.shard_range(n_total, 7, 8) == (lo, n_total)
+    loss_s, (sed_s, morphs_s) = fit(scenes[lo:])
+    for j in (0, 63, 127):
+        assert_array_equal(loss_s[j], loss[lo + j])
+        assert_array_equal(sed_s[10 * j:10 * j + 10], sed[10 * (lo + j):10 * (lo + j) + 10])
+        for a, b_ in zip(morphs_s[10 * j:10 * j + 10], morphs[10 * (lo + j):10 * (lo + j) + 10]):
+            assert_array_equal(a, b_)
+
+
 def test_sub_ranges_on_streams_do_not_change_results(amd):
     """smi_batch_set_sub_ranges: ranges of blends stepped on streams of their own give
     bit-identical losses, iteration counts and parameters for every number of ranges,

@@ -22,7 +22,7 @@ def run(args):
     if args.config == "cfg1":
         data, weights, comps, kernel = bench.build_cfg1(args.blends)
     else:
-        data, weights, comps, kernel = bench.build_cfg3(0, args.blends, 0, None)
+        data, weights, comps, kernel, _ = bench.build_cfg3(0, args.blends, 0, None)
     batch = BlendBatch(data, weights, comps, kernel=kernel, max_iter=args.steps + 1)
     batch.set_sub_ranges(args.sub_ranges)
     batch.step(0, args.steps, e_rel=1e-3, check_convergence=bool(args.check))
