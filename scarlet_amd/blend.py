@@ -478,7 +478,7 @@ class Blend(CombinedComponent):
                     return self._fit_with_psf_shift(max_iter, e_rel, min_iter, prox_max_iter, opt,
                                                     callback)
                 finally:
-                    self._psf = None
+                    self._psf, self._psf_stepped_on_device = None, False
             batch.set_optimizer(**opt)
             restart = False
             try:
@@ -541,6 +541,7 @@ class Blend(CombinedComponent):
                 p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))  # rough estimate, blend.py:189-192
         # what _specs / _observation read is per call: nothing of this fit's renderer
         # parameters or scheme may steer a later fit_blends
+        self._psf_stepped_on_device = self._psf is not None
         self._psf = None
         self._scheme = ("amsgrad", 0.25)
         return len(self.loss), -self.loss[-1]

@@ -524,7 +524,7 @@ def test_psf_shift_renderer(hsc):
     blend = scarlet.Blend(comps, obs)
     start = [np.array(p) for p in blend.parameters]
     n, logL = blend.fit(12, e_rel=1e-9)
-    assert blend._psf is not None  # the shift was stepped on the device
+    assert blend._psf_stepped_on_device and blend._psf is None  # (nothing left for later fits)
     sc = hsc_scene(hsc)
     for c in sc.components:
         c.source = None
