@@ -224,11 +224,20 @@ def set_spectra_to_match(sources, observations):
     models = np.array(models)
     n_models = len(models)
     for obs in observations:
-        rendered = np.stack([obs.render(m) for m in models], axis=0)
+        # The reference hands float64 unit-spectrum models to the renderer and solves the
+        # normal equations in double (initialization.py:493-588); their condition numbers
+        # are several hundred (250 .. 700 on the quickstart scene), so float32 convolutions
+        # of the device would show up as 1e-4 in the spectra.  This one-off solve therefore
+        # renders on the host in double where the renderer is a plain convolution.
+        precise = getattr(obs.renderer, "render_float64", None)
+        if precise is not None and not obs.parameters:
+            rendered = np.stack([precise(m) for m in models], axis=0)
+        else:
+            rendered = np.stack([obs.render(m) for m in models], axis=0).astype(np.float64)
         spectra = np.zeros((n_models, obs.C))
         for c in range(obs.C):
-            im = obs.data[c].reshape(-1)
-            w = obs.weights[c].reshape(-1)
+            im = obs.data[c].reshape(-1).astype(np.float64)
+            w = obs.weights[c].reshape(-1).astype(np.float64)
             m = rendered[:, c].reshape(n_models, -1)
             mw = m * w[None, :]
             seen = np.flatnonzero(np.sum(mw, axis=1) / np.sum(m, axis=1) / np.mean(w) > 0.1)

@@ -114,6 +114,22 @@ class ConvolutionRenderer(Renderer):
         self.transform = self.get_model(*parameters)
         return self.transform(model, *parameters)
 
+    def render_float64(self, model, *parameters):
+        """The same mapping evaluated in double precision on the host, like the reference's
+        NumPy path does when it is handed a float64 model (renderer.py:215-259 ->
+        fft.convolve): for set-up computations that amplify rounding, i.e. the normal
+        equations of ``initialization.set_spectra_to_match`` (condition numbers of several
+        hundred).  Not used by the fitting loop."""
+        model_ = np.asarray(self.map_channels(model), dtype=np.float64)
+        kernel = np.asarray(self.kernel_image(*parameters), dtype=np.float64)
+        out = fft.convolve(fft.Fourier(model_), kernel, axes=(1, 2)).image
+        data_sl, model_sl = self.slices
+        if out[model_sl].shape == tuple(self.data_frame.shape):
+            return out[model_sl]
+        matched = np.zeros(self.data_frame.shape, dtype=np.float64)
+        matched[data_sl] = out[model_sl]
+        return matched
+
 
 class ResolutionRenderer(Renderer):
     """Renders a high-resolution model into a low-resolution observation with a

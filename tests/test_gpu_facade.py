@@ -159,11 +159,13 @@ def test_quickstart_initialisation_matches_reference(hsc):
         assert morph.shape == hsc["morph_%d" % k].shape
         assert tuple(comp.children[1].bbox.origin) == tuple(hsc["origin_%d" % k])
         assert np.abs(morph - hsc["morph_%d" % k]).max() < 1e-5
-        assert np.abs(sed - hsc["sed_%d" % k]).max() < 2e-4 * np.abs(hsc["sed_%d" % k]).max()
+        # (the least squares of set_spectra_to_match is solved in double on double renders,
+        # like the reference: its normal matrices have condition numbers of 250 .. 700)
+        assert np.abs(sed - hsc["sed_%d" % k]).max() < 2e-5 * np.abs(hsc["sed_%d" % k]).max()
     model = blend.get_model()
-    assert np.abs(model - hsc["model"]).max() < 2e-4 * np.abs(hsc["model"]).max()
+    assert np.abs(model - hsc["model"]).max() < 2e-5 * np.abs(hsc["model"]).max()
     logL0 = obs.get_log_likelihood(model)
-    assert abs(logL0 - float(hsc["logL"])) < 1e-3 * abs(float(hsc["logL"]))
+    assert abs(logL0 - float(hsc["logL"])) < 1e-5 * abs(float(hsc["logL"]))
     n, logL = blend.fit(100, e_rel=1e-4)
     assert logL > logL0 and n <= 100
 
@@ -911,11 +913,11 @@ def test_initialisation_of_synthetic_scenes_matches_reference():
             assert morph.shape == ref_morph.shape, (t, k)
             assert tuple(comp.children[1].bbox.origin) == tuple(g[tag + "origin_%d" % k]), (t, k)
             assert np.abs(morph - ref_morph).max() < 1e-5, (t, k)
-            assert np.abs(sed - ref_sed).max() < 3e-4 * np.abs(ref_sed).max() + 1e-6, (t, k)
+            assert np.abs(sed - ref_sed).max() < 3e-5 * np.abs(ref_sed).max() + 1e-6, (t, k)
             step = comp.children[0].parameters[0].step
             assert_allclose(step.keywords["minimum"], g[tag + "min_step_%d" % k], rtol=1e-5)
         logL0 = obs.get_log_likelihood(blend.get_model())
-        assert abs(logL0 - float(g[tag + "logL"])) < 1e-3 * abs(float(g[tag + "logL"])) + 0.5, t
+        assert abs(logL0 - float(g[tag + "logL"])) < 2e-5 * abs(float(g[tag + "logL"])) + 0.05, t
         n, logL = blend.fit(30, e_rel=1e-4)
         assert logL > logL0
 

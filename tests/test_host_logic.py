@@ -461,3 +461,32 @@ def test_bench_prices_the_bytes_of_survey_8d():
     run = bench.algorithmic_bytes(5, 128, 128, [41 * 41] * 10, 160, 160, 1)
     assert run["conv"] == 5051760 and run["update"] == 808280  # what the bench line prices
 
+
+
+def test_set_spectra_to_match_reproduces_the_reference_on_the_host():
+    """``initialization.set_spectra_to_match`` on the quickstart scene, from the reference's
+    own initial morphologies (golden): the per-band least squares -- float64 renders of the
+    unit-spectrum components, float64 normal equations, like initialization.py:493-588 --
+    gives the reference's spectra to float32 rounding.  (Host code: it needs no GPU.)"""
+    import scarlet_amd as scarlet
+    from scarlet_amd.initialization import set_spectra_to_match
+    from conftest import golden
+
+    hsc = golden("hsc_cosmos_35")
+    filters = list("grizy")
+    frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5),
+                          channels=filters)
+    obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"]),
+                              weights=hsc["weights"], channels=filters).match(frame)
+    comps = []
+    for k in range(int(hsc["n_comp"])):
+        h, w = hsc["morph_%d" % k].shape
+        oy, ox = hsc["origin_%d" % k]
+        box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+        comps.append(scarlet.FactorizedComponent(
+            frame, scarlet.TabulatedSpectrum(frame, np.ones(5, dtype=np.float32), bbox=box[0]),
+            scarlet.ImageMorphology(frame, hsc["morph_%d" % k].astype(np.float64), bbox=box[1:])))
+    set_spectra_to_match(comps, obs)
+    for k, c in enumerate(comps):
+        sed, ref = np.asarray(c.children[0].parameters[0]), hsc["sed_%d" % k]
+        assert np.abs(sed - ref).max() < 2e-6 * np.abs(ref).max(), k
