@@ -41,7 +41,11 @@ def _flatten(sources):
             out.append(src)
         elif isinstance(src, CombinedComponent):
             if src.operation != "add":
-                raise NotImplementedError("CombinedComponent('multiply') is not supported")
+                # (the reference's own 'multiply' model is identically zero: its accumulator starts
+                # at zeros and is multiplied into, component.py:262-275 -- reproduced by
+                # CombinedComponent.get_model here; there is nothing to fit)
+                raise NotImplementedError("CombinedComponent('multiply') cannot be fitted: its "
+                                          "model is identically zero in the reference")
             out.extend(_flatten(src.children))
         else:
             raise NotImplementedError(
@@ -113,8 +117,9 @@ class Blend(CombinedComponent):
                 continue
             if type(r) not in (NullRenderer, ConvolutionRenderer):
                 raise NotImplementedError(
-                    "renderer {} cannot run on the device (a user-defined renderer needs "
-                    "automatic differentiation)".format(type(r).__name__))
+                    "renderer {} cannot run on the device; a linear user-defined renderer "
+                    "with an `adjoint` method is fitted through Blend.fit (host-rendered "
+                    "mode)".format(type(r).__name__))
             if any(not p.fixed for p in obs.parameters) and getattr(self, "_psf", None) is None:
                 raise NotImplementedError("free renderer parameters with several observations")
             layer = layer_for(idx)
@@ -451,6 +456,13 @@ class Blend(CombinedComponent):
                    eps=alg_kwargs.pop("eps", 1e-8))
         if alg_kwargs:
             raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
+        if any(type(obs.renderer) not in (NullRenderer, ConvolutionRenderer, ResolutionRenderer)
+               for obs in self.observations):
+            # plug-in seam (SURVEY 8b seam 3): user-written Renderer subclasses are host code
+            if noise_factor or callback is not None or scheme != "amsgrad":
+                raise NotImplementedError(
+                    "a user-defined renderer together with noise_factor, callback or another scheme")
+            return self._fit_with_host_renderers(max_iter, e_rel, min_iter, prox_max_iter, opt)
         free = [p for obs in self.observations for p in obs.parameters if not p.fixed]
         if free and scheme != "amsgrad":
             raise NotImplementedError("a free psf_shift with scheme={!r}".format(scheme))
@@ -675,6 +687,144 @@ class Blend(CombinedComponent):
         for p in self.parameters + (shift,):
             if p.v is not None:
                 p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
+        return len(self.loss), -self.loss[-1]
+
+    def _host_render_ops(self):
+        """Per observation ``(obs, forward, adjoint, log_norm)`` for the host-rendered mode:
+        ``forward(model cube) -> observation frame`` and its transpose, both float64.
+        Built-in renderers have theirs; a user renderer supplies ``adjoint`` (checked
+        against its forward with a random dot product -- a renderer that is not linear, or
+        whose ``adjoint`` is not its transpose, is refused)."""
+        ops = []
+        rng = np.random.default_rng(0)
+        for obs in self.observations:
+            r = obs.renderer
+            if any(not p.fixed for p in obs.parameters):
+                raise NotImplementedError("free renderer parameters in the host-rendered mode")
+            if type(r) is ResolutionRenderer:
+                raise NotImplementedError(
+                    "a ResolutionRenderer observation next to a user-defined renderer")
+            if type(r) in (NullRenderer, ConvolutionRenderer):
+                data_sl, model_sl = r.slices
+                kernel = None if type(r) is NullRenderer else np.asarray(r.kernel_image(), np.float64)
+
+                def forward(model, r=r, kernel=kernel, data_sl=data_sl, model_sl=model_sl):
+                    m = np.asarray(r.map_channels(model), dtype=np.float64)
+                    if kernel is not None:
+                        m = fft.convolve(fft.Fourier(m), kernel, axes=(1, 2)).image
+                    out = np.zeros(r.data_frame.shape, dtype=np.float64)
+                    out[data_sl] = m[model_sl]
+                    return out
+
+                def adjoint(res, r=r, kernel=kernel, data_sl=data_sl, model_sl=model_sl):
+                    idx = [list(self.frame.channels).index(c) for c in r.data_frame.channels]
+                    back = np.zeros((len(idx),) + tuple(self.frame.shape[1:]), dtype=np.float64)
+                    back[model_sl] = np.asarray(res, dtype=np.float64)[data_sl]
+                    if kernel is not None:  # transpose of a convolution: the flipped kernel
+                        back = fft.convolve(fft.Fourier(back), kernel[:, ::-1, ::-1],
+                                                 axes=(1, 2)).image
+                    g = np.zeros(self.frame.shape, dtype=np.float64)
+                    g[idx] = back
+                    return g
+            else:
+                if not callable(getattr(r, "adjoint", None)):
+                    raise NotImplementedError(
+                        "renderer {}: the reference differentiates a user-defined renderer "
+                        "automatically; here it must be linear and provide "
+                        "`adjoint(residual) -> gradient image in the model frame`".format(
+                            type(r).__name__))
+
+                def forward(model, obs=obs):
+                    return np.asarray(obs.render(model), dtype=np.float64)
+
+                def adjoint(res, r=r):
+                    return np.asarray(r.adjoint(np.asarray(res, dtype=np.float64)), dtype=np.float64)
+
+                x = rng.standard_normal(self.frame.shape)
+                y = rng.standard_normal(obs.data.shape)
+                fx = forward(x)
+                lhs, rhs = float(np.sum(fx * y)), float(np.sum(x * adjoint(y)))
+                lin = forward(2.0 * x) - 2.0 * fx
+                if (abs(lhs - rhs) > 1e-6 * (abs(lhs) + abs(rhs)) + 1e-12
+                        or np.abs(lin).max() > 1e-6 * np.abs(fx).max() + 1e-12):
+                    raise NotImplementedError(
+                        "renderer {} is not linear, or its `adjoint` is not the transpose of its "
+                        "forward map (<R x, y> = {:.6g}, <x, R^T y> = {:.6g})".format(
+                            type(r).__name__, lhs, rhs))
+            ops.append((obs, forward, adjoint, float(obs.log_norm)))
+        return ops
+
+    def _fit_with_host_renderers(self, max_iter, e_rel, min_iter, prox_max_iter, opt):
+        """The fit with user-written ``Renderer`` subclasses (observation.py:59-112 accepts
+        any; renderer.py:12-24).  They are host code, so per iteration the device renders
+        the model cube, the host maps it into every observation, forms the loss
+        ``sum_obs log_norm + 1/2 sum w (R m - d)^2`` (blend.py:259-274) and pulls the weighted
+        residuals back through the transposes, ``g = sum_obs R^T w (R m - d)``; the device
+        then takes the usual step -- gradient gather, AMSGrad, proximal sub-iterations --
+        with that gradient image: its identity-renderer likelihood is handed the stand-in
+        observation ``d' = m - g / w'`` with constant weight ``w' = 2^-20``, whose residual
+        ``w' (m - d')`` is ``g`` (the scale keeps ``d'`` dominated by ``g``, so the subtraction
+        loses nothing).  Loss history, stopping rule (blend.py:294-299) and the resize hook
+        are the host's in this mode."""
+        ops = self._host_render_ops()
+        self._psf = None
+        scale = np.float32(2.0 ** -20)
+        ones = np.full((1,) + tuple(self.frame.shape), scale, dtype=np.float32)
+        it = 0
+        stop = False
+        while it < max_iter and not stop:
+            comps = _flatten(self.sources)
+            specs = self._specs(comps)
+            if self._host:
+                raise NotImplementedError(
+                    "user-defined constraints / steps together with a user-defined renderer")
+            batch = BlendBatch(np.zeros_like(ones), ones, [specs], kernel=None,
+                               max_iter=max(max_iter - it, 1), device=self.device, log_norm=False)
+            self._upload_state(batch, comps)
+            batch.set_optimizer(**opt)
+            restart = False
+            try:
+                local = 0
+                while it + local < max_iter and not restart:
+                    model = batch.forward(rendered=False)[0][0].astype(np.float64)
+                    loss, g = 0.0, np.zeros(self.frame.shape, dtype=np.float64)
+                    for obs, forward, adjoint, log_norm in ops:
+                        res = forward(model) - obs.data
+                        wres = obs.weights * res
+                        loss += log_norm + 0.5 * float(np.sum(wres * res))
+                        g += adjoint(wres)
+                    self.loss.append(loss)
+                    batch.set_observation((model - g / float(scale)).astype(np.float32)[None], ones)
+                    batch.step(local, 1, e_rel=e_rel, min_iter=min_iter,
+                               prox_max_iter=prox_max_iter, check_convergence=False)
+                    active, err = batch.status()
+                    if err >= 0 or not np.isfinite(loss):
+                        self._download(batch, comps)
+                        raise ArithmeticError("parameters of the blend are not finite")
+                    local += 1
+                    if local > 1 and (local - 1) % 10 == 0:  # blend.py:284-292
+                        self._download(batch, comps)
+                        for src in self.sources:
+                            try:
+                                src.update()
+                            except UpdateException:
+                                restart = True
+                    n = len(self.loss)
+                    if (not restart and local - 1 > min_iter and n > 1
+                            and abs(self.loss[-2] - self.loss[-1]) < e_rel * abs(self.loss[-1])):
+                        stop = True
+                        break
+                if not restart:
+                    self._download(batch, comps)
+            finally:
+                batch.close()
+            if not restart:
+                break
+            it = len(self.loss)
+        for p in self.parameters:
+            if p.v is not None:
+                p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
+        self._scheme = ("amsgrad", 0.25)
         return len(self.loss), -self.loss[-1]
 
     # ------------------------------------------------------------------- model

@@ -1257,3 +1257,81 @@ def test_two_observations_of_the_same_channels(hsc):
     alone = scarlet.Blend(sources(), obs1)
     alone.fit(3, e_rel=1e-9)
     assert abs(alone.loss[0] - blend.loss[0]) > 1e-3 * abs(blend.loss[0])
+
+
+def test_user_defined_linear_renderer_matches_the_device_renderer(hsc):
+    """Plug-in seam (SURVEY 8b seam 3): ``Observation.match(frame, renderer=<a Renderer
+    subclass>)`` (observation.py:59-112).  A user-written Python renderer -- here the PSF
+    convolution re-implemented with NumPy FFTs, plus its transpose as ``adjoint`` -- is host
+    code: Blend.fit renders and pulls back on the host and keeps the component updates on
+    the device.  It must reproduce the fit with the built-in ConvolutionRenderer; a renderer
+    without ``adjoint``, or whose ``adjoint`` is not its transpose, is refused."""
+    import scarlet_amd as scarlet
+    from scarlet_amd import fft
+    from scarlet_amd.renderer import Renderer
+
+    class NumpyConvolution(Renderer):
+        def __init__(self, data_frame, model_frame):
+            super().__init__(data_frame, model_frame)
+            self.kernel = np.asarray(fft.match_psf(
+                fft.Fourier(data_frame.psf.get_model().astype(np.float32)),
+                fft.Fourier(model_frame.psf.get_model().astype(np.float32)), padding=10).image,
+                dtype=np.float64)
+
+        def get_model(self, *parameters):
+            return lambda model: fft.convolve(fft.Fourier(np.asarray(model, np.float64)),
+                                              self.kernel, axes=(1, 2)).image
+
+        def adjoint(self, residual):
+            return fft.convolve(fft.Fourier(residual), self.kernel[:, ::-1, ::-1], axes=(1, 2)).image
+
+    class NoAdjoint(NumpyConvolution):
+        adjoint = None
+
+    class WrongAdjoint(NumpyConvolution):
+        def adjoint(self, residual):
+            return 2.0 * NumpyConvolution.adjoint(self, residual)
+
+    filters = list("grizy")
+
+    def build(renderer_cls):
+        frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5),
+                              channels=filters)
+        obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"]),
+                                  weights=hsc["weights"], channels=filters)
+        obs.match(frame) if renderer_cls is None else obs.match(frame, renderer=renderer_cls(obs, frame))
+        comps = []
+        for k in range(int(hsc["n_comp"])):
+            h, w = hsc["morph_%d" % k].shape
+            oy, ox = hsc["origin_%d" % k]
+            box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+            comps.append(scarlet.FactorizedComponent(
+                frame,
+                scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                          min_step=hsc["min_step_%d" % k]),
+                scarlet.ExtendedSourceMorphology(frame, (oy + h // 2, ox + w // 2),
+                                                 hsc["morph_%d" % k].copy(), bbox=box[1:])))
+        return scarlet.Blend(comps, obs), obs
+
+    device, obs_d = build(None)
+    n_d, logL_d = device.fit(25, e_rel=1e-9)
+    user, obs_u = build(NumpyConvolution)
+    assert np.abs(obs_u.render(hsc["model"]) - hsc["rendered"]).max() < 1e-5 * np.abs(hsc["rendered"]).max()
+    n_u, logL_u = user.fit(25, e_rel=1e-9)
+    assert n_u == n_d == 25
+    log_norm = obs_d.log_norm
+    assert_allclose(np.array(user.loss) - log_norm, np.array(device.loss) - log_norm, rtol=2e-5)
+    # boxes after the resize hooks of iterations 11 and 21, parameters, optimizer state
+    for a, b in zip(components_of(user), components_of(device)):
+        assert a.children[1].bbox == b.children[1].bbox
+        for pa, pb in zip(a.parameters, b.parameters):
+            assert np.abs(np.asarray(pa) - np.asarray(pb)).max() < 2e-4 * max(np.abs(np.asarray(pb)).max(), 1e-3)
+            assert pa.m is not None and pa.std is not None
+    # the stopping rule of the host loop
+    short, _ = build(NumpyConvolution)
+    ref, _ = build(None)
+    assert short.fit(100, e_rel=1e-3)[0] == ref.fit(100, e_rel=1e-3)[0] < 100
+    for bad in (NoAdjoint, WrongAdjoint):
+        blend, _ = build(bad)
+        with pytest.raises(NotImplementedError):
+            blend.fit(3)

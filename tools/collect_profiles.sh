@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the rocprofv3 summaries behind bench.py's roofline object on the GPU box and leave
 # them under gpurun_out/<tag>/ (copy the CSVs / JSON you want judged into profiles/).
-#   gpurun -- 'bash tools/collect_profiles.sh r02'
+#   gpurun -- 'bash tools/collect_profiles.sh r03'
 # Kernel trace and counters are separate runs (gpurun refuses --pmc with trace domains other
 # than --kernel-trace; counters in passes of their own as MI355X_MICROARCH.md prescribes).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -23,6 +23,7 @@ stats cfg1 --config cfg1 --steps 100 --warmup 10 --no-cpu --sub-ranges 1
 stats cfg4 --config cfg4 --steps 100 --warmup 10 --no-cpu
 stats cfg5 --config cfg5 --steps 40
 stats driver --steps 20 --warmup 5   # the command the driver runs at round end
+stats shard128 --steps 20 --warmup 5 --no-cpu --blends 128   # one GPU's shard of an 8-GPU job
 
 pmc() {  # name, counters...
     local name=$1; shift
