@@ -1326,7 +1326,7 @@ def test_user_defined_linear_renderer_matches_the_device_renderer(hsc):
         assert a.children[1].bbox == b.children[1].bbox
         for pa, pb in zip(a.parameters, b.parameters):
             assert np.abs(np.asarray(pa) - np.asarray(pb)).max() < 2e-4 * max(np.abs(np.asarray(pb)).max(), 1e-3)
-            assert pa.m is not None and pa.std is not None
+            assert (pa.m is None) == (pb.m is None) and (pa.std is None) == (pb.std is None)
     # the stopping rule of the host loop
     short, _ = build(NumpyConvolution)
     ref, _ = build(None)
