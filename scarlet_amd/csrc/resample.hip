@@ -114,16 +114,25 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t 
             }
 }
 
-// C_b = sum over slices of Cpart[b][z] (double), b < n_batch
-__global__ void reduce_slices_kernel(const double *Cpart, float *C, int64_t strideC, int64_t MN,
-                                     int n_slices) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= MN) return;
+// C_b = sum over the slices of Cpart[b][z] (double, in the order of z), b < n_batch.  A
+// workgroup of four wavefronts per 64 outputs: wavefront w sums the slices w, w + 4, ...,
+// the four sums are combined in a fixed order.
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const double *Cpart, float *C,
+                                                           int64_t strideC, int64_t MN,
+                                                           int n_slices) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     const int b = blockIdx.y;
-    const double *p = Cpart + (int64_t)b * n_slices * MN + i;
     double t = 0.0;
-    for (int z = 0; z < n_slices; ++z) t += p[(int64_t)z * MN];
-    C[b * strideC + i] = (float)t;
+    if (i < MN) {
+        const double *p = Cpart + (int64_t)b * n_slices * MN + i;
+        for (int z = w; z < n_slices; z += 4) t += p[(int64_t)z * MN];
+    }
+    part[w][lane] = t;
+    __syncthreads();
+    if (w == 0 && i < MN)
+        C[b * strideC + i] = (float)((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 
 int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float *C,
@@ -145,7 +154,7 @@ int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float
                        dim3(256), 0, s, A, strideA, B, strideB, C, strideC,
                        n_slices > 1 ? scratch : nullptr, M, N, K, kslice, n_slices);
     if (n_slices > 1)
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((MN + 255) / 256), n_batch),
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((MN + 63) / 64), n_batch),
                            dim3(256), 0, s, scratch, C, strideC, (int64_t)MN, n_slices);
     return SMI_OK;
 }
