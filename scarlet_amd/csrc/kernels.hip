@@ -1802,18 +1802,54 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
             return SMI_OK;
         }
         // one launch per size class that has components in this range of blends, the
-        // largest boxes (longest sweeps) first
+        // largest boxes (longest sweeps) first.  Few components of several classes, four-
+        // wavefront classes among them (update_kernel_mixed does not cover those): every
+        // launch is one latency-bound chain per component, so the classes go to streams of
+        // their own, forked from and joined to `s` (multi-resolution tutorial scene: three
+        // launches of 0.23 + 0.13 + 0.10 ms in a row).
+        const bool side_by_side = classes > 1 && v.n_comp <= kMixedUpdateLimit;
+        struct Side {
+            hipStream_t stream[kNumUpdateClasses] = {};
+            hipEvent_t fork = nullptr, join[kNumUpdateClasses] = {};
+            int device = -1;
+        };
+        static thread_local Side side;
+        int n_side = 0;
+        if (side_by_side) {
+            int dev = 0;
+            SMI_HIP(hipGetDevice(&dev));
+            if (side.device != dev) {  // (first use on this device by this host thread)
+                side = Side();
+                side.device = dev;
+                SMI_HIP(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));
+            }
+            SMI_HIP(hipEventRecord(side.fork, s));
+        }
         for (int cls = kNumUpdateClasses - 1; cls >= 0; --cls) {
             const int32_t *start = v.work_start + (size_t)cls * (v.nb_total + 1);
             const int lo = start[v.blend0], hi = start[v.blend0 + v.nb];
             if (hi <= lo) continue;
+            hipStream_t sc = s;
+            if (side_by_side && n_side > 0) {  // the first class stays on `s`
+                if (!side.stream[n_side]) {
+                    SMI_HIP(hipStreamCreateWithFlags(&side.stream[n_side], hipStreamNonBlocking));
+                    SMI_HIP(hipEventCreateWithFlags(&side.join[n_side], hipEventDisableTiming));
+                }
+                sc = side.stream[n_side];
+                SMI_HIP(hipStreamWaitEvent(sc, side.fork, 0));
+            }
 #define SMI_CLASS(i) \
-    case i: if (int rc = launch_update_reg<kUpdateNpl[i], kUpdateTeam[i]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, s)) return rc; break;
+    case i: if (int rc = launch_update_reg<kUpdateNpl[i], kUpdateTeam[i]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, sc)) return rc; break;
             switch (cls) {
                 SMI_CLASS(0) SMI_CLASS(1) SMI_CLASS(2) SMI_CLASS(3) SMI_CLASS(4)
                 SMI_CLASS(5) SMI_CLASS(6) SMI_CLASS(7) SMI_CLASS(8)
             }
 #undef SMI_CLASS
+            if (sc != s) {
+                SMI_HIP(hipEventRecord(side.join[n_side], sc));
+                SMI_HIP(hipStreamWaitEvent(s, side.join[n_side], 0));
+            }
+            ++n_side;
         }
         return SMI_OK;
     }
