@@ -52,6 +52,10 @@ import subprocess
 import sys
 import time
 
+# before the HIP runtime starts (scarlet_amd._lib explains): eight hardware queues, so that a
+# small shard can step four ranges of blends side by side
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -351,7 +351,8 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
 
 /* Blends are independent, so a step can run ranges of blends on streams of their own:
  * while one range's update kernel drains, the others' next convolution fills the chip.
- * n = 0 (default): automatic (3 ranges from 128 blends on with the fused convolution, else 1);
+ * n = 0 (default): automatic (with the fused convolution 3 ranges from 128 blends on, 4 below
+ * 768 blends when GPU_MAX_HW_QUEUES >= 8; else 1);
  * point sources, free shifts and a low-resolution observation keep it at 1.  Results are
  * identical for every n.  The caller's stream (smi_batch_set_stream) still brackets the
  * step: the ranges start after its pending work and it waits for all of them. */

@@ -1720,7 +1720,16 @@ static int sub_ranges(const smi_batch *b) {
     // 760 / 785 / 662, 1024 blends 824 / 829 / 781.  Range 0 runs on the batch stream, so
     // three ranges sit on three of HIP's four hardware queues; a fourth shares one (with
     // GPU_MAX_HW_QUEUES=8 four ranges give 517 / 842 k at 128 / 1024 blends, six fewer).
-    int n = b->n_sub > 0 ? b->n_sub : (nb >= 128 ? 3 : 1);
+    // Round 3: a small batch is bound by the serial chain of a range (convolution ~60 us, then
+    // update ~140 us in the early iterations), not by the chip, so a fourth range adds
+    // throughput where a fourth hardware queue exists -- GPU_MAX_HW_QUEUES = 8 (k blend-it/s,
+    // 3 / 4 / 5 ranges): 128 blends 537 / 615 / 391, 256: 746 / 776 / 603, 512: 809 / 814 /
+    // 740, 1024: 919 / 857 / 826.
+    static const int queues = [] {
+        const char *e = getenv("GPU_MAX_HW_QUEUES");
+        return e ? atoi(e) : 4;
+    }();
+    int n = b->n_sub > 0 ? b->n_sub : (nb < 128 ? 1 : (queues >= 8 && nb < 768) ? 4 : 3);
     return std::max(1, std::min(n, nb));
 }
 

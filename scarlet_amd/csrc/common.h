@@ -99,6 +99,9 @@ constexpr int kNumUpdateClasses = 9;
 // up to this many components a range with several size classes is updated in one launch
 // (update_kernel_mixed; measurements there)
 constexpr int kMixedUpdateLimit = 3072;
+// up to this many components of a class in a range, their workgroups are packed with as many
+// wavefronts as a CU holds (update_kernel_reg; measurements there)
+constexpr int kUpdatePackLimit = 1024;
 constexpr int kUpdateNpl[kNumUpdateClasses] = {7, 16, 27, 42, 59, 16, 27, 42, 59};
 constexpr int kUpdateTeam[kNumUpdateClasses] = {64, 64, 64, 64, 64, 256, 256, 256, 256};
 constexpr int kMaxRegisterBox = 256 * 59;

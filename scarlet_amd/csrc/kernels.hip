@@ -6,6 +6,8 @@
 // coalesced along x); one wavefront per component for the parameter update, with
 // the morphology, the metric and the proximal iterate resident in LDS.
 #include <math.h>
+
+#include <algorithm>
 #include <stdlib.h>
 
 #include "common.h"
@@ -1517,7 +1519,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
     constexpr bool fista = MODE == 2;
     UpdState<NPL> S;
     S.k = k;
-    S.c = comp_ctx(v, k, threadIdx.x);
+    S.c = comp_ctx(v, k, T == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x);
     if (v.state[S.c.b] >= 2) return;
     S.us = us;
     S.sed_new = sed_new;
@@ -1548,14 +1550,34 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
     return x * q + min(x, r) + (b >> 3);
 }
 
+// Wavefronts per workgroup of the one-wavefront classes: with `pack` > 1 a workgroup holds
+// the components of `pack` consecutive work items, one per wavefront, nothing shared but the
+// CU.  What it is for: the hardware spreads workgroups over the chip, so a launch of a few
+// hundred one-wavefront workgroups (one GPU's shard of a multi-GPU job: 128 blends = 427
+// components per range) leaves one or two of them on EVERY CU for its whole latency-bound
+// ~0.1 ms -- and a CU that holds one cannot take a workgroup of the convolution kernel
+// (157 KB of LDS, the whole register file), so the other ranges' convolutions queue up
+// behind it.  Packed three to a SIMD the same components occupy 36 CUs and the rest of the
+// chip stays free.  Every wavefront runs exactly what it would run alone.  Measured with four
+// ranges on eight hardware queues (k blend-iterations/s, one wavefront per workgroup -> packed):
+// 128 blends 553 -> 613, 256 blends 749 -> 772, 512 blends (1280 components per range)
+// 872 -> 810: hence kUpdatePackLimit = 1024 components.
+constexpr int update_pack_max(int npl, int team) {
+    return team != 64 ? 1 : 4 * (npl <= 16 ? 4 : npl <= 27 ? 3 : 2);
+}
 template <int NPL, int MODE, int T>
-__global__ __launch_bounds__(T) SMI_WAVES void update_kernel_reg(BatchView v, const float *G,
-                                                                 int it, float e_rel,
-                                                                 int prox_max_iter, int n_items) {
-    __shared__ float sed_new[64];
-    const int item = xcd_contiguous(blockIdx.x, n_items);
-    update_component<NPL, MODE, T>(v, G, it, e_rel, prox_max_iter, v.work[item + v.work0], lds_dyn + 4,
-                                   sed_new);
+__global__ __launch_bounds__(T * update_pack_max(NPL, T)) SMI_WAVES void update_kernel_reg(
+    BatchView v, const float *G, int it, float e_rel, int prox_max_iter, int n_items) {
+    constexpr int kPack = update_pack_max(NPL, T);
+    __shared__ float sed_new[kPack][64];
+    // (wave-uniform, and said so: the work item must stay in scalar registers)
+    const int wave = T == 64 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int pack = T == 64 ? (int)(blockDim.x >> 6) : 1;
+    const int n_blocks = (n_items + pack - 1) / pack;
+    const int item = xcd_contiguous(blockIdx.x, n_blocks) * pack + wave;
+    if (item >= n_items) return;
+    update_component<NPL, MODE, T>(v, G, it, e_rel, prox_max_iter, v.work[item + v.work0],
+                                   lds_dyn + wave * (T * NPL + 4) + 4, sed_new[wave]);
 }
 
 // Components of several size classes (a blend with boxes of 21^2 .. 61^2 pixels): a launch
@@ -1760,16 +1782,30 @@ static int launch_update_reg(const BatchView &v, const float *G, int32_t it, flo
                              hipStream_t s) {
     BatchView vi = v;
     vi.work0 = item0;
-    const size_t lds = (size_t)(T * NPL + 4) * sizeof(float);
-    if (v.scheme == SMI_SCHEME_FISTA)
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 2, T>), dim3(n_items), dim3(T), lds, s, vi, G,
-                           it, e_rel, prox_max_iter, n_items);
-    else if (v.lite)
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 1, T>), dim3(n_items), dim3(T), lds, s, vi, G,
-                           it, e_rel, prox_max_iter, n_items);
-    else
-        hipLaunchKernelGGL((update_kernel_reg<NPL, 0, T>), dim3(n_items), dim3(T), lds, s, vi, G,
-                           it, e_rel, prox_max_iter, n_items);
+    // small launches are packed (update_kernel_reg); a launch that fills the chip anyway keeps
+    // one wavefront per workgroup, whose slots free up one by one.  SMI_UPDATE_PACK (development
+    // aid) overrides the number of wavefronts per workgroup.
+    static const int forced = [] {
+        const char *e = getenv("SMI_UPDATE_PACK");
+        return e ? atoi(e) : 0;
+    }();
+    int pack = n_items <= kUpdatePackLimit ? update_pack_max(NPL, T) : 1;
+    if (forced > 0) pack = std::min(forced, update_pack_max(NPL, T));
+    const size_t lds = (size_t)pack * (T * NPL + 4) * sizeof(float);
+    const dim3 grid((n_items + pack - 1) / pack), block(T * pack);
+#define SMI_LAUNCH(MODE)                                                                        \
+    {                                                                                           \
+        static size_t configured[kMaxDevices] = {};                                             \
+        auto kern = update_kernel_reg<NPL, MODE, T>;                                            \
+        if (lds > 48 * 1024)                                                                    \
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) \
+                return rc;                                                                      \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, vi, G, it, e_rel, prox_max_iter, n_items); \
+    }
+    if (v.scheme == SMI_SCHEME_FISTA) SMI_LAUNCH(2)
+    else if (v.lite) SMI_LAUNCH(1)
+    else SMI_LAUNCH(0)
+#undef SMI_LAUNCH
     return SMI_OK;
 }
 
