@@ -10,6 +10,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8   # what bench.py sets for itself (the profiler starts HIP first)
 
 stats() {  # name, bench arguments
     local name=$1; shift
@@ -24,6 +25,9 @@ stats cfg4 --config cfg4 --steps 100 --warmup 10 --no-cpu
 stats cfg5 --config cfg5 --steps 40
 stats driver --steps 20 --warmup 5   # the command the driver runs at round end
 stats shard128 --steps 20 --warmup 5 --no-cpu --blends 128   # one GPU's shard of an 8-GPU job
+stats shard128_100 --steps 100 --warmup 10 --no-cpu --blends 128
+stats shard256 --steps 20 --warmup 5 --no-cpu --blends 256
+stats shard512 --steps 20 --warmup 5 --no-cpu --blends 512
 
 pmc() {  # name, counters...
     local name=$1; shift

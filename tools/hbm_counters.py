@@ -73,7 +73,11 @@ for key in ("fused_conv_kernel", "update_kernel_reg", "render_kernel"):
     if "bytes_per_blend" in rec and "kernel_cycles" in rec:
         hbm_frac = rec["bytes_per_blend"] * nb / (rec["kernel_cycles"] / 2.4e9) / 8e12
         rec["hbm_frac_measured_at_2.4GHz"] = round(hbm_frac, 4)
-        rec["bound"] = "hbm" if hbm_frac > 0.6 else "valu-issue"
+        # HBM if the measured traffic needs most of the time at 8 TB/s; instruction issue if the
+        # SIMDs issue in most cycles; otherwise the kernel waits -- for the update kernel on the
+        # plan stream out of L2 and the LDS round trip of a sweep step
+        rec["bound"] = ("hbm" if hbm_frac > 0.6 else
+                        "valu-issue" if rec.get("issue_busy", 0) > 0.85 else "latency-l2-lds")
     out[key] = rec
 json.dump(out, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
