@@ -64,28 +64,6 @@ struct Cfg {
         sizeof(float2) * ((size_t)NKX * SY + (size_t)kPairs * SX + FY + FX);
 };
 
-// ---- one radix-F1 pass over elements a[16 n1 + n2] -----------------------------
-// forward: A[k1] = w_F^(n2 k1) DFT_F1(x)[k1] written to a[16 k1 + n2]; inputs with
-// index >= valid are taken as zero.  inverse: the inputs B[k1] are first multiplied by
-// w_F^(-n2 k1) (both directions carry their twiddles in this pass, which has the most
-// work items, so the radix-16 pass stays short), then inverse DFT_F1.
-template <int F1, bool INV>
-__device__ __forceinline__ void pass_stride(float2 *a, int n2, const float2 *tw, int valid) {
-    cf v[F1];
-#pragma unroll
-    for (int n1 = 0; n1 < F1; ++n1) {
-        const int idx = kF2 * n1 + n2;
-        v[n1] = (INV || idx < valid) ? ld(a[idx]) : cf{0.f, 0.f};
-        if (INV && n1 > 0) v[n1] = cmulc(v[n1], ld(tw[kF2 * n1 + n2]));
-    }
-    fftk::Dft<F1, INV>::run(v);
-#pragma unroll
-    for (int k1 = 0; k1 < F1; ++k1) {
-        if (!INV && k1 > 0) v[k1] = cmul(v[k1], ld(tw[kF2 * k1 + n2]));
-        a[kF2 * k1 + n2] = st(v[k1]);
-    }
-}
-
 // index of element y of a column of T
 __device__ __forceinline__ int sk(int y) { return y + (y >> 4); }
 
@@ -165,7 +143,14 @@ template <int FY1, int FX1>
 struct Conv {
     using C = Cfg<FY1, FX1>;
     float2 *T, *Z, *twy, *twx;
-    int tid;
+    int tid, bt;
+    // The row transforms alternate between stride passes (kPairs x 16 work items) and radix-16
+    // passes (kPairs x FX1).  A workgroup of 1024 threads gives each kind to one half of its
+    // wavefronts, and the two halves run separate code between the same barriers: the
+    // registers of one role (the prefetched data / weights of the stride role, the sixteen
+    // points of the radix-16 role) are not live in the other's code.
+    static constexpr bool kSplit = kThreads >= 2 * kPairs * kF2;
+    static constexpr int kBlockThreads = kSplit ? kThreads - kPairs * kF2 : kThreads;
     static constexpr int kChunkStep = 2 * kPairs + 2 * kPairs / kF2;  // sk(y + 64) - sk(y)
     static_assert((2 * kPairs) % kF2 == 0, "chunk rows");
 
@@ -241,7 +226,7 @@ struct Conv {
     // forward: radix-16 pass of the chunk's rows in Z and separation into
     // T[kx][y0 + 2j], T[kx][y0 + 2j + 1]
     __device__ __forceinline__ void blocks_forward(int ch) {
-        for (int b = tid; b < kPairs * FX1; b += kThreads) {
+        for (int b = bt; b < kPairs * FX1; b += kBlockThreads) {
             const int j = b & 31, slot = b >> 5, k1 = slot_block(slot);
             const float2 *z = Z + j * C::SX + kF2 * k1;
             const bool ok = ch * 2 * kPairs + 2 * j + 1 < C::FY;
@@ -273,12 +258,11 @@ struct Conv {
                 for (int k2 = 0; k2 < 8; ++k2) put(t + FX1 * k2 * C::SY, ok, va[k2], va[15 - k2]);
             }
         }
-        lds_barrier();
     }
 
     // inverse: Z[pair] <- radix-16 pass of (Xa + i Xb) rebuilt from T
     __device__ __forceinline__ void blocks_inverse(int ch) {
-        for (int b = tid; b < kPairs * FX1; b += kThreads) {
+        for (int b = bt; b < kPairs * FX1; b += kBlockThreads) {
             const int j = b & 31, slot = b >> 5, k1 = slot_block(slot);
             float2 *z = Z + j * C::SX + kF2 * k1;
             const float2 *t = T + sk(2 * j) + ch * kChunkStep;
@@ -304,26 +288,46 @@ struct Conv {
 #pragma unroll
             for (int i = 0; i < kF2; ++i) z[i] = st(va[i]);
         }
-        lds_barrier();
     }
 
-    // forward row transforms of the chunk in Z (pairs of real rows as re/im) into T
-    __device__ __forceinline__ void rows_forward(int ch, int W, long long *stamp = nullptr) {
-        for (int b = tid; b < kPairs * kF2; b += kThreads)
-            pass_stride<FX1, false>(Z + (b % kPairs) * C::SX, b / kPairs, twx, W);
-        lds_barrier();
-        if (stamp) stamp[0] = clock64();
-        blocks_forward(ch);
-        if (stamp) stamp[1] = clock64();
+    // ---- stride passes of the row transforms, fed from / drained into registers ----------
+    // Work item = (row pair j, residue n2): the radix-FX1 butterfly over the elements
+    // 16 n1 + n2 of the pair.  These are the passes next to global memory -- the model rows
+    // come in, data / weights meet the rendered rows, the gradient rows go out -- and the
+    // butterfly's FX1 points are exactly what a thread needs of its two rows, so the rows
+    // never pass through the scratch on their own: loads feed the forward butterfly, the
+    // inverse butterfly feeds the residual and the residual the next forward butterfly in
+    // registers (round 2 wrote the rows to Z, met a barrier and read them back: 4 of the 16
+    // LDS round trips of a band and 4 of its 14 barriers per chunk).
+    // The sixteen residues of a pair sit in sixteen neighbouring lanes: a wavefront's global
+    // accesses are 64-byte runs of four row pairs, and its scratch accesses are conflict-free
+    // because the two pairs of a half-wave are 16 apart (16 SX complex = 32 banks mod 64).
+    static constexpr int kStrideItems = kPairs * kF2;
+    static_assert(kStrideItems == 512 && (kSplit || kThreads == kStrideItems), "stride items");
+    __device__ __forceinline__ void stride_item(int &j, int &n2) const {
+        const int l = tid & 63, w = (tid >> 6) & (kStrideItems / 64 - 1), q = l >> 4;
+        n2 = l & 15;
+        j = 2 * w + (q >> 1) + 16 * (q & 1);
     }
-
-    // inverse row transforms of the chunk: Z[pair] <- IFFT_x(Xa + i Xb) rebuilt from T
-    __device__ __forceinline__ void rows_inverse(int ch, long long *stamp = nullptr) {
-        blocks_inverse(ch);
-        if (stamp) stamp[0] = clock64();
-        for (int b = tid; b < kPairs * kF2; b += kThreads)
-            pass_stride<FX1, true>(Z + (b % kPairs) * C::SX, b / kPairs, twx, C::FX);
-        lds_barrier();
+    // forward butterfly of v (v[n1] = element 16 n1 + n2 of the pair) into Z
+    __device__ __forceinline__ void stride_forward(cf *v, int j, int n2) {
+        float2 *a = Z + j * C::SX;
+        fftk::Dft<FX1, false>::run(v);
+#pragma unroll
+        for (int k1 = 0; k1 < FX1; ++k1) {
+            if (k1 > 0) v[k1] = cmul(v[k1], ld(twx[kF2 * k1 + n2]));
+            a[kF2 * k1 + n2] = st(v[k1]);
+        }
+    }
+    // inverse butterfly out of Z: v[k1] = element 16 k1 + n2 of the pair's rows
+    __device__ __forceinline__ void stride_inverse(cf *v, int j, int n2) {
+        const float2 *a = Z + j * C::SX;
+#pragma unroll
+        for (int n1 = 0; n1 < FX1; ++n1) {
+            v[n1] = ld(a[kF2 * n1 + n2]);
+            if (n1 > 0) v[n1] = cmulc(v[n1], ld(twx[kF2 * n1 + n2]));
+        }
+        fftk::Dft<FX1, true>::run(v);
     }
 };
 
@@ -349,7 +353,6 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int kXIter = (C::FX + 63) / 64;
     const int H = v.H, W = v.W;
 
     Conv<FY1, FX1> cv;
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     cv.twy = cv.Z + kPairs * C::SX;
     cv.twx = cv.twy + C::FY;
     cv.tid = tid;
+    cv.bt = Conv<FY1, FX1>::kSplit ? tid - Conv<FY1, FX1>::kStrideItems : tid;
     for (int j = tid; j < C::FY; j += kThreads) {  // j = 16 k1 + n2
         float s, co;
         sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FY, &s, &co);
@@ -372,118 +376,128 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                                C::FY * C::NKX;
     const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
     __syncthreads();
-#define SMI_STAMP(i) if (dbg && tid == 0 && blockIdx.x == 0) dbg[i] = clock64()
+// stage stamps of one workgroup (tools/stage_cycles.py): workgroup 0 runs in the first of a
+// launch's rounds, where every CU bursts its loads at the same moment; a development build
+// with -DSMI_DBG_BLOCK=<n> stamps a workgroup of the steady state instead
+#ifndef SMI_DBG_BLOCK
+#define SMI_DBG_BLOCK 0
+#endif
+#define SMI_STAMP(i) if (dbg && tid == 0 && blockIdx.x == SMI_DBG_BLOCK) dbg[i] = clock64()
     SMI_STAMP(0);
 
     // ---- A: model rows (blend.py:200-244, rendered by render_kernel) and their forward
-    // row transforms.  Wave w owns the row pairs 2w, 2w + 1 of a chunk, lane l the columns
-    // l, l + 64, ...; the rows of the next chunk are requested before this chunk's
+    // row transforms.  The rows of the next chunk are requested before this chunk's
     // transforms, so that their latency hides behind them.
-    {
-        constexpr int kWaves = kThreads / 64;
-        constexpr int kRows = 2 * kPairs / kWaves;
-        static_assert(2 * kPairs % kWaves == 0 && kRows % 2 == 0, "rows per wave");
-        const plane_t r_model = band_plane(model + ((int64_t)b * v.C + c) * H * W, H * W);
-        float mrow[kRows][kXIter];
+    int sj, sn2;
+    cv.stride_item(sj, sn2);
+    using std::integral_constant;
+    // roles(f): f(stride role, radix-16 role) on the code path of this wavefront
+    auto roles = [&](auto &&f) {
+        if constexpr (Conv<FY1, FX1>::kSplit) {
+            if (wave < Conv<FY1, FX1>::kStrideItems / 64)
+                f(integral_constant<bool, true>{}, integral_constant<bool, false>{});
+            else
+                f(integral_constant<bool, false>{}, integral_constant<bool, true>{});
+        } else {
+            f(integral_constant<bool, true>{}, integral_constant<bool, true>{});
+        }
+    };
+    const int64_t band = ((int64_t)b * v.C + c) * H * W;
+    roles([&](auto stride_role, auto block_role) {
+        constexpr bool S = decltype(stride_role)::value, B = decltype(block_role)::value;
+        const plane_t r_model = band_plane(model + band, H * W);
+        cf mrow[FX1];
         auto fetch = [&](int y0) {
 #pragma unroll
-            for (int j = 0; j < kRows; ++j) {
-                const int y = y0 + wave * kRows + j;
-#pragma unroll
-                for (int q = 0; q < kXIter; ++q) {
-                    const int x = lane + 64 * q;
-                    mrow[j][q] = plane_load(r_model, y, x, W);
-                }
+            for (int n1 = 0; n1 < FX1; ++n1) {
+                const int x = kF2 * n1 + sn2, y = y0 + 2 * sj;
+                mrow[n1] = cf{plane_load(r_model, y, x, W), plane_load(r_model, y + 1, x, W)};
             }
         };
-        fetch(0);
+        if (S) fetch(0);
+        SMI_STAMP(6);
         for (int ch = 0; ch < n_chunks; ++ch) {
-            const int y0 = ch * 2 * kPairs;
+            if (S) {
+                cf cur[FX1];
 #pragma unroll
-            for (int j = 0; j < kRows; j += 2)
-#pragma unroll
-                for (int q = 0; q < kXIter; ++q) {
-                    const int x = lane + 64 * q;
-                    // columns beyond W are never read by the row transform (pass_stride prunes them)
-                    if (x < C::SX)
-                        cv.Z[((wave * kRows + j) >> 1) * C::SX + x] =
-                            make_float2(mrow[j][q], mrow[j + 1][q]);
-                }
-            __syncthreads();
-            if (ch + 1 < n_chunks) fetch(y0 + 2 * kPairs);
+                for (int n1 = 0; n1 < FX1; ++n1) cur[n1] = mrow[n1];
+                if (ch + 1 < n_chunks) fetch((ch + 1) * 2 * kPairs);
+                cv.stride_forward(cur, sj, sn2);
+            }
+            lds_barrier();
             if (ch == 0) SMI_STAMP(8);
-            cv.rows_forward(ch, W, (dbg && tid == 0 && blockIdx.x == 0 && ch == 0) ? dbg + 6 : nullptr);
+            if (B) cv.blocks_forward(ch);
+            lds_barrier();
             if (ch == 0) SMI_STAMP(9);
         }
-    }
+    });
     SMI_STAMP(1);
     // ---- B: columns, x K^ --------------------------------------------------------
     cv.columns(K, H, false);
     SMI_STAMP(2);
     // ---- C: rendered rows -> residual, loss, forward rows of the residual ------------
+    // (observation.py:147-170)  One pass per chunk between the two radix-16 passes: inverse
+    // butterfly, w (m - d) and the loss on the thread's 2 x FX1 pixels, forward butterfly.
     double loss = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        const int y0 = ch * 2 * kPairs;
-        // data / weights of the chunk are fetched before the inverse row transforms so
-        // that their HBM latency hides behind them.  Wave w owns the row pairs w and
-        // w + 16 of the chunk: both rows of a pair at the lane's columns are one 8-byte
-        // element of the pair-packed scratch
-        constexpr int kWaves = kThreads / 64;
-        constexpr int kPairsW = kPairs / kWaves;  // pairs per wave
-        constexpr int kXPre = kXIter > 2 ? 2 : kXIter;  // columns >= 128 are loaded late
-        static_assert(kPairs % kWaves == 0, "pairs per wave");
-        const int64_t band = ((int64_t)b * v.C + c) * H * W;
+    roles([&](auto stride_role, auto block_role) {
+        constexpr bool S = decltype(stride_role)::value, B = decltype(block_role)::value;
         const plane_t r_data = band_plane(v.data + band, H * W);
         const plane_t r_weights = band_plane(v.weights + band, H * W);
-        float dpre[kPairsW][2][kXPre], wpre[kPairsW][2][kXPre];
+        const plane_t r_rendered = band_plane(out + band, H * W);
+        // data / weights of the chunk are fetched before the inverse radix-16 pass so that
+        // their HBM latency hides behind it; columns >= 16 kPre are loaded late
+        constexpr int kPre = FX1 > 8 ? 8 : FX1;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int y = ch * 2 * kPairs + 2 * sj;
+            cf dpre[kPre], wpre[kPre];
+            if (S) {
 #pragma unroll
-        for (int j = 0; j < kPairsW; ++j)
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int y = y0 + 2 * (wave + j * kWaves) + rr;
-#pragma unroll
-                for (int q = 0; q < kXPre; ++q) {
-                    const int x = lane + 64 * q;
-                    dpre[j][rr][q] = plane_load(r_data, y, x, W);
-                    wpre[j][rr][q] = plane_load(r_weights, y, x, W);
+                for (int n1 = 0; n1 < kPre; ++n1) {
+                    const int x = kF2 * n1 + sn2;
+                    dpre[n1] = cf{plane_load(r_data, y, x, W), plane_load(r_data, y + 1, x, W)};
+                    wpre[n1] = cf{plane_load(r_weights, y, x, W), plane_load(r_weights, y + 1, x, W)};
                 }
             }
-        if (ch == 0) SMI_STAMP(10);
-        cv.rows_inverse(ch, (dbg && tid == 0 && blockIdx.x == 0 && ch == 0) ? dbg + 15 : nullptr);
-        if (ch == 0) SMI_STAMP(11);
+            if (ch == 0) SMI_STAMP(10);
+            if (B) cv.blocks_inverse(ch);
+            lds_barrier();
+            if (ch == 0) SMI_STAMP(11);
+            if (S) {
+                cf m[FX1];
+                cv.stride_inverse(m, sj, sn2);
 #pragma unroll
-        for (int j = 0; j < kPairsW; ++j) {
-            const int pair = wave + j * kWaves;
-#pragma unroll
-            for (int q = 0; q < kXIter; ++q) {
-                const int x = lane + 64 * q;
-                if (x >= C::FX) continue;
-                float2 &slot = cv.Z[pair * C::SX + x];
-                const float2 m2 = slot;
-                float res[2] = {0.f, 0.f};
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int y = y0 + 2 * pair + rr;
-                    if (x < W && y < H) {
-                        const float m = rr ? m2.y : m2.x;
-                        const int64_t iD = band + (int64_t)y * W + x;
-                        if (mode == 1) out[iD] = m;
-                        const float dv = q < kXPre ? dpre[j][rr][q < kXPre ? q : 0] : plane_load(r_data, y, x, W);
-                        const float wv = q < kXPre ? wpre[j][rr][q < kXPre ? q : 0] : plane_load(r_weights, y, x, W);
-                        const float diff = m - dv;
-                        res[rr] = wv * diff;
-                        loss += (double)(res[rr] * diff);
+                for (int n1 = 0; n1 < FX1; ++n1) {
+                    const int x = kF2 * n1 + sn2;
+                    cf dv, wv;
+                    if (n1 < kPre) {
+                        dv = dpre[n1 < kPre ? n1 : 0];
+                        wv = wpre[n1 < kPre ? n1 : 0];
+                    } else {
+                        dv = cf{plane_load(r_data, y, x, W), plane_load(r_data, y + 1, x, W)};
+                        wv = cf{plane_load(r_weights, y, x, W), plane_load(r_weights, y + 1, x, W)};
                     }
+                    if (mode == 1) {
+                        plane_store(r_rendered, y, x, W, m[n1].x);
+                        plane_store(r_rendered, y + 1, x, W, m[n1].y);
+                    }
+                    // pixels outside the frame have weight 0 (the descriptor returns zeros)
+                    const bool in0 = x < W && y < H, in1 = x < W && y + 1 < H;
+                    const float d0 = m[n1].x - dv.x, d1 = m[n1].y - dv.y;
+                    const float r0 = in0 ? wv.x * d0 : 0.f, r1 = in1 ? wv.y * d1 : 0.f;
+                    // (rows beyond the frame may hold anything, NaN included: keep them out)
+                    loss += (double)(in0 ? r0 * d0 : 0.f);
+                    loss += (double)(in1 ? r1 * d1 : 0.f);
+                    m[n1] = cf{r0, r1};
                 }
-                slot = make_float2(res[0], res[1]);
+                cv.stride_forward(m, sj, sn2);
             }
+            lds_barrier();
+            if (ch == 0) SMI_STAMP(13);
+            if (B) cv.blocks_forward(ch);
+            lds_barrier();
+            if (ch == 0) SMI_STAMP(14);
         }
-        if (ch == 0) SMI_STAMP(12);
-        __syncthreads();
-        if (ch == 0) SMI_STAMP(13);
-        cv.rows_forward(ch, W);
-        if (ch == 0) SMI_STAMP(14);
-    }
+    });
     {
         double *part = reinterpret_cast<double *>(cv.Z);  // Z is free between stages
         const double t = block_sum(loss, part);
@@ -496,24 +510,28 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     cv.columns(K, H, true);
     SMI_STAMP(4);
     // ---- D: gradient image rows -----------------------------------------------------
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        const int y0 = ch * 2 * kPairs;
-        cv.rows_inverse(ch);
+    roles([&](auto stride_role, auto block_role) {
+        constexpr bool S = decltype(stride_role)::value, B = decltype(block_role)::value;
         // (stores beyond row H - 1 or column W - 1 are dropped by the descriptor's range check)
-        const plane_t r_out = band_plane(out + ((int64_t)b * v.C + c) * H * W, H * W);
-        for (int pair = wave; pair < kPairs; pair += kThreads / 64) {
-            const int y = y0 + 2 * pair;
+        const plane_t r_out = band_plane(out + band, H * W);
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            if (B) cv.blocks_inverse(ch);
+            lds_barrier();
+            if (ch == 0) SMI_STAMP(12);
+            if (S) {
+                const int y = ch * 2 * kPairs + 2 * sj;
+                cf g[FX1];
+                cv.stride_inverse(g, sj, sn2);
 #pragma unroll
-            for (int q = 0; q < kXIter; ++q) {
-                const int x = lane + 64 * q;
-                if (x >= C::FX) continue;
-                const float2 g = cv.Z[pair * C::SX + x];  // both rows of the pair
-                plane_store(r_out, y, x, W, g.x);
-                plane_store(r_out, y + 1, x, W, g.y);
+                for (int k1 = 0; k1 < FX1; ++k1) {
+                    plane_store(r_out, y, kF2 * k1 + sn2, W, g[k1].x);
+                    plane_store(r_out, y + 1, kF2 * k1 + sn2, W, g[k1].y);
+                }
             }
+            lds_barrier();  // the scratch is free again; the stores may still be in flight
+            if (ch == 0) SMI_STAMP(7);
         }
-        lds_barrier();  // the scratch is free again; the stores may still be in flight
-    }
+    });
     SMI_STAMP(5);
 #undef SMI_STAMP
 }
