@@ -73,13 +73,26 @@ __device__ __forceinline__ cf fma2(cf a, cf b, cf c) { return __builtin_elementw
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
-// a * b = a.xx * b + a.yy * (-b.y, b.x)
+// a * b = a.xx * b + a.yy * (-b.y, b.x): two packed operations.  The second one reads b with
+// its halves swapped (op_sel) and the low product negated (neg_lo); the compiler cannot
+// express a negation of one half of a packed operand and spends a third operation on it,
+// hence the inline assembly (same products, same single rounding of the fused step).
 __device__ __forceinline__ cf cmul(cf a, cf b) {
-    return fma2(a.yy * cf{-1.f, 1.f}, swp(b), a.xx * b);
+    const cf t = a.xx * b;
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(b), "v"(t));
+    return r;
 }
 // a * conj(b) = a.xx * (b.x, -b.y) + a.yy * (b.y, b.x)
 __device__ __forceinline__ cf cmulc(cf a, cf b) {
-    return fma2(a.yy, swp(b), (a.xx * cf{1.f, -1.f}) * b);
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=v"(r)
+        : "v"(a), "v"(b), "v"(t));
+    return r;
 }
 // b + w d and b - w d with w = -i (forward) or +i (inverse), scaled by s:
 // -i d = (d.y, -d.x), +i d = (-d.y, d.x)

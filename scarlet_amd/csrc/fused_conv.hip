@@ -8,19 +8,27 @@
 // the band in LDS from the first row transform to the last: per blend-iteration the
 // only HBM traffic left is the model cube, data and weights (read once) and the
 // gradient image (written once).  The model cube itself comes from render_kernel
-// (kernels.hip): rendering inside this kernel made every 64-row chunk wait, at a
-// workgroup barrier, for the wavefront whose rows intersect the most component boxes
-// (22 % of the kernel's time); plain rows are fetched one chunk ahead instead.
+// (kernels.hip).
 //
-// Layout: T[kx][y], kx in [0, FX/2]; element y of a column sits at y + y / 16 and the
-// column stride SY is 16 mod 32 complex, so that the 16 lanes that own a column and the
-// four columns of a wavefront hit different banks in every pass.
-// 1-D transforms of length F = F1 * 16 are two in-place passes (radix F1 over stride
-// 16, radix 16 over contiguous blocks); the forward transform leaves the spectrum in
-// the digit-swapped order pos(k1 + F1 k2) = 16 k1 + k2, the inverse starts from it,
-// so no transposition pass is ever needed; the kernel spectrum K^ is stored in the
-// same order.  Rows are transformed two at a time (row 2j + i row 2j+1) and
-// separated by Hermitian symmetry; zero padding is never stored for the columns.
+// Layout: ONE array T[kx][y], kx in [0, FX/2]; element y of a column sits at y + y / 16
+// and the column stride SY is 4 mod 8 complex.  1-D transforms of length F = F1 * 16 are
+// two in-place passes (radix F1 over stride 16, radix 16 over contiguous blocks); the
+// forward transform leaves the spectrum in the digit-swapped order pos(k1 + F1 k2) =
+// 16 k1 + k2, the inverse starts from it, so no transposition pass is ever needed; the
+// kernel spectrum K^ is stored in the same order.  Rows are transformed two at a time
+// (row 2j + i row 2j+1) and separated by Hermitian symmetry; zero padding is never stored
+// for the columns.
+//
+// Round 3: the row transforms run IN the rows of T.  The complex sequence z of the row
+// pair j (FX elements) lives in the 2 x (FX/2 + 1) slots that the pair's two rows own:
+// element p at T[p / 2][2j + p % 2].  Rounds 1 and 2 transformed the pairs in a scratch
+// Z of 32 pairs next to T -- all the LDS left -- so every row pass had 512 / 320 work
+// items for 1024 threads, twice per stage, each followed by a barrier.  Now all pairs of
+// the band go through a pass together (1024 / 640 work items for 128 rows), the
+// scratch, the copies into and out of it and half of the barriers are gone.  The
+// Hermitian separation after the radix-16 pass is an in-place permutation of the pair's
+// slots (every work item reads its sixteen points, the workgroup meets a barrier, every
+// work item writes its separated frequencies).
 #include <cstdlib>
 #include <type_traits>
 
@@ -37,37 +45,48 @@ using fftk::st;
 
 namespace {
 
-// Workgroup size and row pairs per chunk.  This file is compiled twice: as it is
-// (1024 threads) and through fused_conv_short.hip with 512 threads for transforms with
-// short rows (SMI_CONV_SHORT_ROWS: only launch_fused_conv_short is emitted there).
+// Workgroup size.  This file is compiled twice: as it is (1024 threads) and through
+// fused_conv_short.hip with 512 threads for small transforms (SMI_CONV_SHORT_ROWS: only
+// launch_fused_conv_short is emitted there).
 #ifndef SMI_CONV_THREADS
 #define SMI_CONV_THREADS 1024
-#define SMI_CONV_PAIRS 32
 #endif
 constexpr int kThreads = SMI_CONV_THREADS;
 constexpr int kF2 = 16;      // second radix of every 1-D transform
-constexpr int kPairs = SMI_CONV_PAIRS;   // row pairs per chunk (64 rows)
+
+constexpr int conv_column_stride(int fy) { return ((fy + fy / kF2 + 3) / 8) * 8 + 4; }
+constexpr size_t conv_lds_bytes(int fy, int fx) {
+    return sizeof(float2) * ((size_t)(fx / 2 + 1) * conv_column_stride(fy) + fy + fx) +
+           sizeof(double) * (kThreads / 64);
+}
 
 template <int FY1, int FX1>
 struct Cfg {
     static constexpr int FY = FY1 * kF2, FX = FX1 * kF2;
     static constexpr int NKX = FX / 2 + 1;
     // column stride of T (complex).  A column stores element y at y + y / 16 (one pad
-    // per radix-16 block, so that the 10 lanes that each own a block hit different
-    // banks); the stride is 16 mod 32 so that the four columns a wavefront works on
-    // alternate between the two halves of the 64 banks
-    static constexpr int SY = ((FY + FY / kF2 + 15) / 32) * 32 + 16;
-    static constexpr int SX = FX + 1;  // row-pair stride of the scratch (complex), odd
-    // + twiddle tables tw[k1 * 16 + n2] = exp(-2 pi i n2 k1 / F) for both axes
-    static_assert(SY >= FY + FY / kF2 && SY % 32 == 16, "column stride");
-    static constexpr size_t lds_bytes =
-        sizeof(float2) * ((size_t)NKX * SY + (size_t)kPairs * SX + FY + FX);
+    // per radix-16 block, so that the lanes that each own a block hit different banks).
+    // SY = 4 (mod 8): the eight columns 8 k1 + a that hold the elements 16 k1 + n2 of a
+    // row pair then start 4, 8, .. 28 (mod 32) slots apart in some order, and the four
+    // slots in between take the two rows of two neighbouring pairs -- a half-wave of a
+    // stride pass (16 residues x 2 pairs) touches every bank once.  Columns four apart
+    // start 16 (mod 32) slots apart: the two columns of a half-wave in the column stage
+    // are chosen that way.
+    static constexpr int SY = conv_column_stride(FY);
+    static_assert(SY >= FY + FY / kF2 && SY % 8 == 4, "column stride");
+    // + twiddle tables tw[k1 * 16 + n2] = exp(-2 pi i n2 k1 / F) for both axes, + the
+    // partial sums of the loss
+    static constexpr size_t lds_bytes = conv_lds_bytes(FY, FX);
 };
 
 // index of element y of a column of T
 __device__ __forceinline__ int sk(int y) { return y + (y >> 4); }
 
-// the same pass on a column of T (element 16 n1 + n2 lives at 17 n1 + n2)
+// radix-F1 pass on a column of T (element 16 n1 + n2 lives at 17 n1 + n2).
+// forward: A[k1] = w_F^(n2 k1) DFT_F1(x)[k1] written to a[16 k1 + n2]; inputs with
+// index >= valid are taken as zero.  inverse: the inputs B[k1] are first multiplied by
+// w_F^(-n2 k1) (both directions carry their twiddles in this pass, which has the most
+// work items, so the radix-16 pass stays short), then inverse DFT_F1.
 template <int F1, bool INV>
 __device__ __forceinline__ void pass_stride_col(float2 *a, int n2, const float2 *tw, int valid) {
     cf v[F1];
@@ -92,15 +111,11 @@ __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// ---- radix-16 pass over the contiguous block a[16 k1 .. 16 k1 + 15] ---------------
-template <bool INV>
-__device__ __forceinline__ void pass_block(float2 *a, int k1) {
-    cf v[kF2];
-#pragma unroll
-    for (int j = 0; j < kF2; ++j) v[j] = ld(a[kF2 * k1 + j]);
-    fftk::Dft<kF2, INV>::run(v);
-#pragma unroll
-    for (int j = 0; j < kF2; ++j) a[kF2 * k1 + j] = st(v[j]);
+// column of T (and of K^) that holds the frequency kx of the row transforms (Conv, radix-16
+// passes): frequency k1 + FX1 k2 in column 8 k1 + k2, the Nyquist frequency in column FX / 2
+__host__ __device__ __forceinline__ int column_of(int kx, int Fx) {
+    const int fx1 = Fx / kF2;
+    return 2 * kx == Fx ? kx : 8 * (kx % fx1) + kx / fx1;
 }
 
 // position of natural frequency k in the digit-swapped order of a length F1*16 transform
@@ -138,21 +153,32 @@ __device__ __forceinline__ float plane_load(plane_t r, int y, int x, int W) {
     const uint32_t off = x < W ? (uint32_t)(y * W + x) * 4u : 0x80000000u;
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
+// Both rows y, y + 1 of a pair at the columns 16 n1 + n2 of a stride-pass work item: two
+// byte offsets per work item, the column step is an immediate of the load (an offset
+// register per load would cost the butterfly its registers).  Rows beyond H read 0 (range
+// check); a column beyond W reads whatever follows the row -- the caller discards it.
+struct PairRows {
+    uint32_t o0, o1;
+};
+__device__ __forceinline__ PairRows pair_rows(int y, int n2, int W) {
+    PairRows a;
+    a.o0 = (uint32_t)(y * W + n2) * 4u;
+    a.o1 = a.o0 + (uint32_t)W * 4u;
+    // (opaque: hoisted out of a loop, offset + constant would become a register per load)
+    asm volatile("" : "+v"(a.o0), "+v"(a.o1));
+    return a;
+}
+template <int N1>
+__device__ __forceinline__ cf pair_load(plane_t r, PairRows a) {
+    return cf{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, a.o0 + 4u * kF2 * N1, 0, 0)),
+              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, a.o1 + 4u * kF2 * N1, 0, 0))};
+}
 
 template <int FY1, int FX1>
 struct Conv {
     using C = Cfg<FY1, FX1>;
-    float2 *T, *Z, *twy, *twx;
-    int tid, bt;
-    // The row transforms alternate between stride passes (kPairs x 16 work items) and radix-16
-    // passes (kPairs x FX1).  A workgroup of 1024 threads gives each kind to one half of its
-    // wavefronts, and the two halves run separate code between the same barriers: the
-    // registers of one role (the prefetched data / weights of the stride role, the sixteen
-    // points of the radix-16 role) are not live in the other's code.
-    static constexpr bool kSplit = kThreads >= 2 * kPairs * kF2;
-    static constexpr int kBlockThreads = kSplit ? kThreads - kPairs * kF2 : kThreads;
-    static constexpr int kChunkStep = 2 * kPairs + 2 * kPairs / kF2;  // sk(y + 64) - sk(y)
-    static_assert((2 * kPairs) % kF2 == 0, "chunk rows");
+    float2 *T, *twy, *twx;
+    int tid, n_pairs;
 
     // column transforms fused with the spectral product:
     //   T <- IFFT_y( FFT_y(T) * K )   for every column kx, K in digit-swapped order.
@@ -161,15 +187,17 @@ struct Conv {
     // second (lanes g < FY1; forward, x K, inverse in registers), and n2 = g of the last.
     // The three passes of a column only exchange data inside that group, so no
     // workgroup barrier separates them and the wavefronts drift through the stage
-    // independently (the barriers cost 43 % of this stage before).
+    // independently.  The two columns of a half-wave are four apart (16 slots mod 32).
     __device__ __forceinline__ void columns(const float2 *Kt, int H, bool conj) {
-        const int g = tid & (kF2 - 1);
-        for (int kx = tid >> 4; kx < C::NKX; kx += kThreads / kF2) {
+        const int g = tid & (kF2 - 1), G = tid >> 4;
+        const int col = 8 * (G >> 3) + ((G >> 1) & 3) + 4 * (G & 1);
+        for (int kx = col; kx < C::NKX; kx += kThreads / kF2) {
             float2 *a = T + kx * C::SY;
             pass_stride_col<FY1, false>(a, g, twy, H);
             wave_lds_fence();
             if (g < FY1) {
                 float2 *blk = a + (kF2 + 1) * g;
+                // (requesting K^ before the first pass was measured: slower, 12.9 -> 13.9 k cycles)
                 const float2 *kp = Kt + (int64_t)kx * C::FY + kF2 * g;
                 cf v[kF2], kv[kF2];
 #pragma unroll
@@ -189,145 +217,204 @@ struct Conv {
         lds_barrier();
     }
 
-    // The radix-16 pass of the row transforms is fused with the Hermitian separation /
-    // recombination of the row pairs.  Block k1 of a row holds the frequencies k1 + FX1 k2
-    // (k2 = 0 .. 15); the mirror frequency FX - k sits in block FX1 - k1 at 15 - k2 (block 0
-    // mirrors onto itself at (16 - k2) % 16, block FX1 / 2 of an even FX1 at 15 - k2).  Work
-    // item (row pair j = lane % 32, slot): the slots are ordered 1, FX1 - 1, 2, FX1 - 2, ...,
-    // 0, FX1 / 2, so that the two slots of a wavefront are a block and its mirror block:
-    // after its transform a lane gets the mirror values from lane ^ 32 and separates the
-    // eight frequencies <= FX / 2 of its block.
-    static_assert(kPairs == 32, "a wavefront = two slots of 32 row pairs");
-    static constexpr int kDouble = (FX1 - 1) / 2;  // blocks 1 .. kDouble have a distinct mirror block
-    static __device__ __forceinline__ int slot_block(int slot) {
-        if (slot < 2 * kDouble) return (slot & 1) ? FX1 - (slot / 2 + 1) : slot / 2 + 1;
-        return slot == 2 * kDouble ? 0 : FX1 / 2;
-    }
-    static __device__ __forceinline__ cf from_partner(cf v) {
-        return cf{__shfl_xor(v.x, 32, 64), __shfl_xor(v.y, 32, 64)};
-    }
-    // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^)
-    static __device__ __forceinline__ void put(float2 *t, bool ok, cf za, cf zb) {
-        if (ok) {
-            t[0] = make_float2(za.x + zb.x, za.y - zb.y);
-            t[1] = make_float2(za.y + zb.y, zb.x - za.x);
-        }
-    }
-    // (no row guard: a row pair beyond FY reads other elements of the LDS array and leaves
-    // values in its own rows of Z that nothing consumes -- the pairs never mix, the residual
-    // and the stores look at rows < H only, put() is guarded; a branch or a select per load
-    // would expose every LDS latency)
-    static __device__ __forceinline__ void get(const float2 *t, cf &plus, cf &minus) {
-        const float2 xa = t[0], xb = t[1];
-        plus = cf{xa.x - xb.y, xa.y + xb.x};   // Xa + i Xb
-        minus = cf{xa.x + xb.y, xb.x - xa.y};  // conj(Xa) + i conj(Xb)
-    }
-
-    // forward: radix-16 pass of the chunk's rows in Z and separation into
-    // T[kx][y0 + 2j], T[kx][y0 + 2j + 1]
-    __device__ __forceinline__ void blocks_forward(int ch) {
-        for (int b = bt; b < kPairs * FX1; b += kBlockThreads) {
-            const int j = b & 31, slot = b >> 5, k1 = slot_block(slot);
-            const float2 *z = Z + j * C::SX + kF2 * k1;
-            const bool ok = ch * 2 * kPairs + 2 * j + 1 < C::FY;
-            float2 *t = T + sk(2 * j) + ch * kChunkStep + k1 * C::SY;
-            cf va[kF2];
-#pragma unroll
-            for (int i = 0; i < kF2; ++i) va[i] = ld(z[i]);
-            fftk::Dft<kF2, false>::run(va);
-            if (slot < 2 * kDouble) {  // uniform over the wavefront
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2 += 2) {
-                    // two frequencies at a time (registers: the scheduler would otherwise
-                    // start all sixteen exchanges at once)
-                    __builtin_amdgcn_sched_barrier(0);
-                    const cf m0 = from_partner(va[15 - k2]), m1 = from_partner(va[14 - k2]);
-                    put(t + FX1 * k2 * C::SY, ok, va[k2], m0);
-                    put(t + FX1 * (k2 + 1) * C::SY, ok, va[k2 + 1], m1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else if (k1 == 0) {
-                // (two branches: a select between va[a] and va[b] would be compiled into a
-                // select of the index, i.e. a dynamically indexed register array)
-#pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2)
-                    put(t + FX1 * k2 * C::SY, ok, va[k2], va[(16 - k2) & 15]);
-                put(t + FX1 * 8 * C::SY, ok, va[8], va[8]);
-            } else {
-#pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2) put(t + FX1 * k2 * C::SY, ok, va[k2], va[15 - k2]);
-            }
-        }
-    }
-
-    // inverse: Z[pair] <- radix-16 pass of (Xa + i Xb) rebuilt from T
-    __device__ __forceinline__ void blocks_inverse(int ch) {
-        for (int b = bt; b < kPairs * FX1; b += kBlockThreads) {
-            const int j = b & 31, slot = b >> 5, k1 = slot_block(slot);
-            float2 *z = Z + j * C::SX + kF2 * k1;
-            const float2 *t = T + sk(2 * j) + ch * kChunkStep;
-            cf va[kF2], spare;
-            if (slot < 2 * kDouble) {
-                const int kb = FX1 - k1;  // the mirror block's columns give the upper half
-#pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2) {
-                    get(t + (k1 + FX1 * k2) * C::SY, va[k2], spare);
-                    get(t + (kb + FX1 * k2) * C::SY, spare, va[15 - k2]);
-                }
-            } else if (k1 == 0) {
-                get(t, va[0], spare);
-                get(t + FX1 * 8 * C::SY, va[8], spare);
-#pragma unroll
-                for (int k2 = 1; k2 < 8; ++k2) get(t + FX1 * k2 * C::SY, va[k2], va[16 - k2]);
-            } else {
-#pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2)
-                    get(t + (k1 + FX1 * k2) * C::SY, va[k2], va[15 - k2]);
-            }
-            fftk::Dft<kF2, true>::run(va);
-#pragma unroll
-            for (int i = 0; i < kF2; ++i) z[i] = st(va[i]);
-        }
-    }
-
-    // ---- stride passes of the row transforms, fed from / drained into registers ----------
+    // ---- stride passes of the row transforms -------------------------------------------
     // Work item = (row pair j, residue n2): the radix-FX1 butterfly over the elements
     // 16 n1 + n2 of the pair.  These are the passes next to global memory -- the model rows
     // come in, data / weights meet the rendered rows, the gradient rows go out -- and the
     // butterfly's FX1 points are exactly what a thread needs of its two rows, so the rows
-    // never pass through the scratch on their own: loads feed the forward butterfly, the
-    // inverse butterfly feeds the residual and the residual the next forward butterfly in
-    // registers (round 2 wrote the rows to Z, met a barrier and read them back: 4 of the 16
-    // LDS round trips of a band and 4 of its 14 barriers per chunk).
-    // The sixteen residues of a pair sit in sixteen neighbouring lanes: a wavefront's global
-    // accesses are 64-byte runs of four row pairs, and its scratch accesses are conflict-free
-    // because the two pairs of a half-wave are 16 apart (16 SX complex = 32 banks mod 64).
-    static constexpr int kStrideItems = kPairs * kF2;
-    static_assert(kStrideItems == 512 && (kSplit || kThreads == kStrideItems), "stride items");
-    __device__ __forceinline__ void stride_item(int &j, int &n2) const {
-        const int l = tid & 63, w = (tid >> 6) & (kStrideItems / 64 - 1), q = l >> 4;
-        n2 = l & 15;
-        j = 2 * w + (q >> 1) + 16 * (q & 1);
+    // themselves never touch the LDS: loads feed the forward butterfly, the inverse butterfly
+    // feeds the residual and the residual the next forward butterfly in registers.
+    // Item -> lanes: the sixteen residues of a pair in sixteen neighbouring lanes (a wave's
+    // global accesses are 64-byte runs of four row pairs), then the pairs.
+    struct StrideItem {
+        int j, n2, zb;  // zb: slot of element n2 of the pair; element 16 k1 + n2 is 8 SY k1 further
+        bool on;
+    };
+    __device__ __forceinline__ StrideItem stride_item(int it) const {
+        StrideItem s;
+        s.n2 = it & 15;
+        s.j = it >> 4;
+        s.on = s.j < n_pairs;
+        s.zb = (s.n2 >> 1) * C::SY + sk(2 * s.j + (s.n2 & 1));
+        return s;
     }
-    // forward butterfly of v (v[n1] = element 16 n1 + n2 of the pair) into Z
-    __device__ __forceinline__ void stride_forward(cf *v, int j, int n2) {
-        float2 *a = Z + j * C::SX;
+    __device__ __forceinline__ int stride_items() const { return n_pairs * kF2; }
+    // forward butterfly of v (v[n1] = element 16 n1 + n2 of the pair) into the pair's slots
+    __device__ __forceinline__ void stride_forward(cf *v, const StrideItem &s) {
+        float2 *a = T + s.zb;
         fftk::Dft<FX1, false>::run(v);
 #pragma unroll
         for (int k1 = 0; k1 < FX1; ++k1) {
-            if (k1 > 0) v[k1] = cmul(v[k1], ld(twx[kF2 * k1 + n2]));
-            a[kF2 * k1 + n2] = st(v[k1]);
+            if (k1 > 0) v[k1] = cmul(v[k1], ld(twx[kF2 * k1 + s.n2]));
+            a[8 * C::SY * k1] = st(v[k1]);
         }
     }
-    // inverse butterfly out of Z: v[k1] = element 16 k1 + n2 of the pair's rows
-    __device__ __forceinline__ void stride_inverse(cf *v, int j, int n2) {
-        const float2 *a = Z + j * C::SX;
+    // inverse butterfly: v[k1] = element 16 k1 + n2 of the pair's rows
+    __device__ __forceinline__ void stride_inverse(cf *v, const StrideItem &s) {
+        const float2 *a = T + s.zb;
 #pragma unroll
         for (int n1 = 0; n1 < FX1; ++n1) {
-            v[n1] = ld(a[kF2 * n1 + n2]);
-            if (n1 > 0) v[n1] = cmulc(v[n1], ld(twx[kF2 * n1 + n2]));
+            v[n1] = ld(a[8 * C::SY * n1]);
+            if (n1 > 0) v[n1] = cmulc(v[n1], ld(twx[kF2 * n1 + s.n2]));
         }
         fftk::Dft<FX1, true>::run(v);
+    }
+
+    // ---- radix-16 passes of the row transforms, fused with the Hermitian separation ------
+    // Block k1 of a pair holds the frequencies k1 + FX1 k2 (k2 = 0 .. 15); the mirror
+    // frequency FX - k sits in block FX1 - k1 at 15 - k2 (block 0 mirrors onto itself at
+    // (16 - k2) % 16, block FX1 / 2 of an even FX1 at 15 - k2).  Work item (row pair, slot);
+    // 32 pairs x 2 slots make a wavefront, and the slots are ordered 1, FX1 - 1, 2, FX1 - 2,
+    // ..., 0, FX1 / 2, so that the two slots of a wavefront are a block and its mirror
+    // block: the lanes l and l ^ 32 exchange what the other one needs.
+    // A work item separates the eight frequencies <= FX / 2 of its block (k2 < 8; block 0 the
+    // Nyquist frequency on top) -- sixteen values for the sixteen slots it read.  So the
+    // COLUMNS OF T ARE NOT IN FREQUENCY ORDER: frequency k1 + FX1 k2 lives in column
+    // 8 k1 + k2, the Nyquist frequency in column FX / 2 (column_of; K^ is stored in the same
+    // order, and the column stage does not care which frequency a column holds).  A work
+    // item then writes exactly the slots it has read, in both directions: the pass is in
+    // place without a barrier inside, and no work item touches another one's slots.
+    static constexpr int kDouble = (FX1 - 1) / 2;  // blocks 1 .. kDouble have a distinct mirror block
+    static constexpr int kSlots = FX1 + (FX1 & 1);  // slots per group of 32 pairs (even)
+    static constexpr int kGroupsPerTrip = (kThreads / 32) / kSlots;
+    static_assert(kGroupsPerTrip >= 1, "slots of a pair group in one trip");
+    static __device__ __forceinline__ int slot_block(int slot) {
+        if (slot < 2 * kDouble) return (slot & 1) ? FX1 - (slot / 2 + 1) : slot / 2 + 1;
+        return slot == 2 * kDouble ? 0 : FX1 / 2;
+    }
+    // Lanes without a work item of their own (pairs beyond the last one in the last group
+    // of 32, the pad slot of an odd FX1) repeat the work item of a neighbour -- the last
+    // pair, block 0 -- and store the same values to the same slots: no lane is masked, and
+    // the wavefronts that have no work item at all (`wave_on`, uniform) skip the pass.
+    struct BlockItem {
+        int j, slot, k1;
+        bool wave_on;
+    };
+    __device__ __forceinline__ BlockItem block_item(int group0) const {
+        BlockItem b;
+        const int grp = tid >> 5;
+        b.slot = grp % kSlots;
+        b.j = (tid & 31) + 32 * (group0 + grp / kSlots);
+        const int wgrp = __builtin_amdgcn_readfirstlane(tid >> 6) * 2;  // first group of the wavefront
+        b.wave_on = wgrp < kGroupsPerTrip * kSlots && 32 * (group0 + wgrp / kSlots) < n_pairs;
+        if (b.j >= n_pairs) b.j = n_pairs - 1;
+        b.k1 = b.slot < FX1 ? slot_block(b.slot) : 0;
+        return b;
+    }
+    __device__ __forceinline__ int block_trips() const {
+        // (one trip whenever every pair group of the tallest frame fits the workgroup)
+        if (kGroupsPerTrip >= (C::FY / 2 + 31) / 32) return 1;
+        return ((n_pairs + 31) / 32 + kGroupsPerTrip - 1) / kGroupsPerTrip;
+    }
+    static __device__ __forceinline__ cf from_partner(cf v) {
+        return cf{__shfl_xor(v.x, 32, 64), __shfl_xor(v.y, 32, 64)};
+    }
+    // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^); one packed
+    // operation each (a multiplication by +-1 is exact)
+    static __device__ __forceinline__ void sep(cf za, cf zb, cf &xa, cf &xb) {
+        xa = fftk::fma2(zb, cf{1.f, -1.f}, za);                        // (za.x + zb.x, za.y - zb.y)
+        xb = fftk::fma2(fftk::swp(za), cf{1.f, -1.f}, fftk::swp(zb));  // (za.y + zb.y, zb.x - za.x)
+    }
+    static __device__ __forceinline__ cf plus(cf xa, cf xb) {   // Xa + i Xb
+        return fftk::fma2(fftk::swp(xb), cf{-1.f, 1.f}, xa);    // (xa.x - xb.y, xa.y + xb.x)
+    }
+    static __device__ __forceinline__ cf minus(cf xa, cf xb) {  // conj(Xa) + i conj(Xb)
+        return fftk::fma2(xa, cf{1.f, -1.f}, fftk::swp(xb));    // (xa.x + xb.y, xb.x - xa.y)
+    }
+
+    // forward: radix-16 pass of every pair and separation into the pair's rows
+    __device__ __forceinline__ void blocks_forward() {
+        const int trips = block_trips();
+        for (int trip = 0; trip < trips; ++trip) {
+            const BlockItem b = block_item(trip * kGroupsPerTrip);
+            if (!b.wave_on) continue;
+            float2 *z = T + 8 * b.k1 * C::SY + sk(2 * b.j);
+            cf va[kF2], xa[8], xb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                va[2 * i] = ld(z[i * C::SY]);
+                va[2 * i + 1] = ld(z[i * C::SY + 1]);
+            }
+            fftk::Dft<kF2, false>::run(va);
+            if (b.slot < 2 * kDouble) {  // uniform over the wavefront
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) sep(va[k2], from_partner(va[15 - k2]), xa[k2], xb[k2]);
+            } else if (b.k1 == 0) {
+                // (two branches: a select between va[a] and va[b] would be compiled into a
+                // select of the index, i.e. a dynamically indexed register array)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) sep(va[k2], va[(16 - k2) & 15], xa[k2], xb[k2]);
+                cf na, nb;  // the Nyquist frequency
+                sep(va[8], va[8], na, nb);
+                float2 *t = T + (FX1 * 8) * C::SY + sk(2 * b.j);
+                t[0] = st(na);
+                t[1] = st(nb);
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) sep(va[k2], va[15 - k2], xa[k2], xb[k2]);
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                z[k2 * C::SY] = st(xa[k2]);
+                z[k2 * C::SY + 1] = st(xb[k2]);
+            }
+        }
+        lds_barrier();
+    }
+
+    // inverse: the pair's elements <- radix-16 pass of (Xa + i Xb) rebuilt from its rows;
+    // `mid` runs between the loads and the stores of a trip (global loads whose latency the
+    // rest of the pass hides)
+    template <typename F>
+    __device__ __forceinline__ void blocks_inverse(F &&mid) {
+        const int trips = block_trips();
+        for (int trip = 0; trip < trips; ++trip) {
+            const BlockItem b = block_item(trip * kGroupsPerTrip);
+            if (!b.wave_on) {
+                if (trip == 0) mid();
+                continue;
+            }
+            float2 *z = T + 8 * b.k1 * C::SY + sk(2 * b.j);
+            cf va[kF2], xa[8], xb[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                xa[k2] = ld(z[k2 * C::SY]);
+                xb[k2] = ld(z[k2 * C::SY + 1]);
+            }
+            if (b.slot < 2 * kDouble) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    va[k2] = plus(xa[k2], xb[k2]);
+                    va[15 - k2] = from_partner(minus(xa[k2], xb[k2]));
+                }
+            } else if (b.k1 == 0) {
+                const float2 *t = T + (FX1 * 8) * C::SY + sk(2 * b.j);
+                va[0] = plus(xa[0], xb[0]);
+                va[8] = plus(ld(t[0]), ld(t[1]));
+#pragma unroll
+                for (int k2 = 1; k2 < 8; ++k2) {
+                    va[k2] = plus(xa[k2], xb[k2]);
+                    va[16 - k2] = minus(xa[k2], xb[k2]);
+                }
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    va[k2] = plus(xa[k2], xb[k2]);
+                    va[15 - k2] = minus(xa[k2], xb[k2]);
+                }
+            }
+            fftk::Dft<kF2, true>::run(va);
+            // (the scheduler must not move the loads above the transform: registers)
+            __builtin_amdgcn_sched_barrier(0);
+            if (trip == 0) mid();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                z[i * C::SY] = st(va[2 * i]);
+                z[i * C::SY + 1] = st(va[2 * i + 1]);
+            }
+        }
+        lds_barrier();
     }
 };
 
@@ -351,17 +438,30 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     const int b = lid / v.C + v.blend0, c = lid % v.C;
     if (v.state[b] >= 2) return;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = v.H, W = v.W;
 
     Conv<FY1, FX1> cv;
     cv.T = lds_conv;
-    cv.Z = cv.T + C::NKX * C::SY;
-    cv.twy = cv.Z + kPairs * C::SX;
+    cv.twy = cv.T + C::NKX * C::SY;
     cv.twx = cv.twy + C::FY;
     cv.tid = tid;
-    cv.bt = Conv<FY1, FX1>::kSplit ? tid - Conv<FY1, FX1>::kStrideItems : tid;
+    cv.n_pairs = (H + 1) / 2;
+    double *loss_part = reinterpret_cast<double *>(cv.twx + C::FX);
+    const int64_t band = ((int64_t)b * v.C + c) * H * W;
+    const int n_items = cv.stride_items();
+    using Item = typename Conv<FY1, FX1>::StrideItem;
+
+    // the first model rows are requested before the twiddle tables are made
+    const plane_t r_model = band_plane(model + band, H * W);
+    cf mrow[FX1];
+    auto fetch_model = [&](const Item &s) {
+        const PairRows a = pair_rows(2 * s.j, s.n2, W);
+        fftk::static_for<0, FX1>([&](auto n1c) {
+            constexpr int n1 = decltype(n1c)::value;
+            mrow[n1] = pair_load<n1>(r_model, a);
+        });
+    };
+    fetch_model(cv.stride_item(tid));
     for (int j = tid; j < C::FY; j += kThreads) {  // j = 16 k1 + n2
         float s, co;
         sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FY, &s, &co);
@@ -374,7 +474,6 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     }
     const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
                                C::FY * C::NKX;
-    const int n_chunks = (H + 2 * kPairs - 1) / (2 * kPairs);
     __syncthreads();
 // stage stamps of one workgroup (tools/stage_cycles.py): workgroup 0 runs in the first of a
 // launch's rounds, where every CU bursts its loads at the same moment; a development build
@@ -386,123 +485,81 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     SMI_STAMP(0);
 
     // ---- A: model rows (blend.py:200-244, rendered by render_kernel) and their forward
-    // row transforms.  The rows of the next chunk are requested before this chunk's
-    // transforms, so that their latency hides behind them.
-    int sj, sn2;
-    cv.stride_item(sj, sn2);
-    using std::integral_constant;
-    // roles(f): f(stride role, radix-16 role) on the code path of this wavefront
-    auto roles = [&](auto &&f) {
-        if constexpr (Conv<FY1, FX1>::kSplit) {
-            if (wave < Conv<FY1, FX1>::kStrideItems / 64)
-                f(integral_constant<bool, true>{}, integral_constant<bool, false>{});
-            else
-                f(integral_constant<bool, false>{}, integral_constant<bool, true>{});
-        } else {
-            f(integral_constant<bool, true>{}, integral_constant<bool, true>{});
-        }
-    };
-    const int64_t band = ((int64_t)b * v.C + c) * H * W;
-    roles([&](auto stride_role, auto block_role) {
-        constexpr bool S = decltype(stride_role)::value, B = decltype(block_role)::value;
-        const plane_t r_model = band_plane(model + band, H * W);
-        cf mrow[FX1];
-        auto fetch = [&](int y0) {
+    // row transforms
+    for (int it = tid; it < n_items; it += kThreads) {
+        const Item s = cv.stride_item(it);
+        if (it != tid) fetch_model(s);
 #pragma unroll
-            for (int n1 = 0; n1 < FX1; ++n1) {
-                const int x = kF2 * n1 + sn2, y = y0 + 2 * sj;
-                mrow[n1] = cf{plane_load(r_model, y, x, W), plane_load(r_model, y + 1, x, W)};
-            }
-        };
-        if (S) fetch(0);
-        SMI_STAMP(6);
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            if (S) {
-                cf cur[FX1];
-#pragma unroll
-                for (int n1 = 0; n1 < FX1; ++n1) cur[n1] = mrow[n1];
-                if (ch + 1 < n_chunks) fetch((ch + 1) * 2 * kPairs);
-                cv.stride_forward(cur, sj, sn2);
-            }
-            lds_barrier();
-            if (ch == 0) SMI_STAMP(8);
-            if (B) cv.blocks_forward(ch);
-            lds_barrier();
-            if (ch == 0) SMI_STAMP(9);
-        }
-    });
+        for (int n1 = 0; n1 < FX1; ++n1)  // the zero padding beyond column W - 1
+            if (kF2 * n1 + s.n2 >= W) mrow[n1] = cf{0.f, 0.f};
+        cv.stride_forward(mrow, s);
+    }
+    lds_barrier();
+    SMI_STAMP(6);
+    cv.blocks_forward();
     SMI_STAMP(1);
     // ---- B: columns, x K^ --------------------------------------------------------
     cv.columns(K, H, false);
     SMI_STAMP(2);
     // ---- C: rendered rows -> residual, loss, forward rows of the residual ------------
-    // (observation.py:147-170)  One pass per chunk between the two radix-16 passes: inverse
+    // (observation.py:147-170)  One pass between the two radix-16 passes: inverse
     // butterfly, w (m - d) and the loss on the thread's 2 x FX1 pixels, forward butterfly.
     double loss = 0.0;
-    roles([&](auto stride_role, auto block_role) {
-        constexpr bool S = decltype(stride_role)::value, B = decltype(block_role)::value;
+    {
         const plane_t r_data = band_plane(v.data + band, H * W);
         const plane_t r_weights = band_plane(v.weights + band, H * W);
         const plane_t r_rendered = band_plane(out + band, H * W);
-        // data / weights of the chunk are fetched before the inverse radix-16 pass so that
-        // their HBM latency hides behind it; columns >= 16 kPre are loaded late
-        constexpr int kPre = FX1 > 8 ? 8 : FX1;
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const int y = ch * 2 * kPairs + 2 * sj;
-            cf dpre[kPre], wpre[kPre];
-            if (S) {
+        // data / weights of the first SMI_CONV_PRE columns of the butterfly are requested
+        // before the inverse radix-16 pass (their HBM latency hides behind it, the registers
+        // are live across it), the others between its loads and its stores
+#ifndef SMI_CONV_PRE
+#define SMI_CONV_PRE 0
+#endif
+        constexpr int kPre = SMI_CONV_PRE < FX1 ? SMI_CONV_PRE : FX1;
+        cf dv[FX1], wv[FX1];
+        auto fetch = [&](const Item &s, auto from, auto to) {
+            const PairRows a = pair_rows(2 * s.j, s.n2, W);
+            fftk::static_for<decltype(from)::value, decltype(to)::value>([&](auto n1c) {
+                constexpr int n1 = decltype(n1c)::value;
+                dv[n1] = pair_load<n1>(r_data, a);
+                wv[n1] = pair_load<n1>(r_weights, a);
+            });
+        };
+        using std::integral_constant;
+        const Item s0 = cv.stride_item(tid);
+        fetch(s0, integral_constant<int, 0>{}, integral_constant<int, kPre>{});
+        cv.blocks_inverse([&] { fetch(s0, integral_constant<int, kPre>{}, integral_constant<int, FX1>{}); });
+        SMI_STAMP(10);
+        for (int it = tid; it < n_items; it += kThreads) {
+            const Item s = cv.stride_item(it);
+            const int y = 2 * s.j;
+            if (it != tid) fetch(s, integral_constant<int, 0>{}, integral_constant<int, FX1>{});
+            cf m[FX1];
+            cv.stride_inverse(m, s);
 #pragma unroll
-                for (int n1 = 0; n1 < kPre; ++n1) {
-                    const int x = kF2 * n1 + sn2;
-                    dpre[n1] = cf{plane_load(r_data, y, x, W), plane_load(r_data, y + 1, x, W)};
-                    wpre[n1] = cf{plane_load(r_weights, y, x, W), plane_load(r_weights, y + 1, x, W)};
+            for (int n1 = 0; n1 < FX1; ++n1) {
+                const int x = kF2 * n1 + s.n2;
+                if (mode == 1) {
+                    plane_store(r_rendered, y, x, W, m[n1].x);
+                    plane_store(r_rendered, y + 1, x, W, m[n1].y);
                 }
+                // pixels outside the frame have weight 0 (the descriptor returns zeros)
+                const bool in0 = x < W && y < H, in1 = x < W && y + 1 < H;
+                const float d0 = m[n1].x - dv[n1].x, d1 = m[n1].y - dv[n1].y;
+                const float r0 = in0 ? wv[n1].x * d0 : 0.f, r1 = in1 ? wv[n1].y * d1 : 0.f;
+                loss += (double)(r0 * d0);
+                loss += (double)(r1 * d1);
+                m[n1] = cf{r0, r1};
             }
-            if (ch == 0) SMI_STAMP(10);
-            if (B) cv.blocks_inverse(ch);
-            lds_barrier();
-            if (ch == 0) SMI_STAMP(11);
-            if (S) {
-                cf m[FX1];
-                cv.stride_inverse(m, sj, sn2);
-#pragma unroll
-                for (int n1 = 0; n1 < FX1; ++n1) {
-                    const int x = kF2 * n1 + sn2;
-                    cf dv, wv;
-                    if (n1 < kPre) {
-                        dv = dpre[n1 < kPre ? n1 : 0];
-                        wv = wpre[n1 < kPre ? n1 : 0];
-                    } else {
-                        dv = cf{plane_load(r_data, y, x, W), plane_load(r_data, y + 1, x, W)};
-                        wv = cf{plane_load(r_weights, y, x, W), plane_load(r_weights, y + 1, x, W)};
-                    }
-                    if (mode == 1) {
-                        plane_store(r_rendered, y, x, W, m[n1].x);
-                        plane_store(r_rendered, y + 1, x, W, m[n1].y);
-                    }
-                    // pixels outside the frame have weight 0 (the descriptor returns zeros)
-                    const bool in0 = x < W && y < H, in1 = x < W && y + 1 < H;
-                    const float d0 = m[n1].x - dv.x, d1 = m[n1].y - dv.y;
-                    const float r0 = in0 ? wv.x * d0 : 0.f, r1 = in1 ? wv.y * d1 : 0.f;
-                    // (rows beyond the frame may hold anything, NaN included: keep them out)
-                    loss += (double)(in0 ? r0 * d0 : 0.f);
-                    loss += (double)(in1 ? r1 * d1 : 0.f);
-                    m[n1] = cf{r0, r1};
-                }
-                cv.stride_forward(m, sj, sn2);
-            }
-            lds_barrier();
-            if (ch == 0) SMI_STAMP(13);
-            if (B) cv.blocks_forward(ch);
-            lds_barrier();
-            if (ch == 0) SMI_STAMP(14);
+            cv.stride_forward(m, s);
         }
-    });
+        lds_barrier();
+        SMI_STAMP(11);
+        cv.blocks_forward();
+    }
     {
-        double *part = reinterpret_cast<double *>(cv.Z);  // Z is free between stages
-        const double t = block_sum(loss, part);
+        const double t = block_sum(loss, loss_part);
         if (tid == 0) v.loss_partial[(int64_t)b * v.n_partial + c] = t;
-        __syncthreads();
     }
     SMI_STAMP(3);
     if (mode == 1) return;
@@ -510,28 +567,22 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     cv.columns(K, H, true);
     SMI_STAMP(4);
     // ---- D: gradient image rows -----------------------------------------------------
-    roles([&](auto stride_role, auto block_role) {
-        constexpr bool S = decltype(stride_role)::value, B = decltype(block_role)::value;
+    {
         // (stores beyond row H - 1 or column W - 1 are dropped by the descriptor's range check)
         const plane_t r_out = band_plane(out + band, H * W);
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            if (B) cv.blocks_inverse(ch);
-            lds_barrier();
-            if (ch == 0) SMI_STAMP(12);
-            if (S) {
-                const int y = ch * 2 * kPairs + 2 * sj;
-                cf g[FX1];
-                cv.stride_inverse(g, sj, sn2);
+        cv.blocks_inverse([] {});
+        SMI_STAMP(12);
+        for (int it = tid; it < n_items; it += kThreads) {
+            const Item s = cv.stride_item(it);
+            cf g[FX1];
+            cv.stride_inverse(g, s);
 #pragma unroll
-                for (int k1 = 0; k1 < FX1; ++k1) {
-                    plane_store(r_out, y, kF2 * k1 + sn2, W, g[k1].x);
-                    plane_store(r_out, y + 1, kF2 * k1 + sn2, W, g[k1].y);
-                }
+            for (int k1 = 0; k1 < FX1; ++k1) {
+                plane_store(r_out, 2 * s.j, kF2 * k1 + s.n2, W, g[k1].x);
+                plane_store(r_out, 2 * s.j + 1, kF2 * k1 + s.n2, W, g[k1].y);
             }
-            lds_barrier();  // the scratch is free again; the stores may still be in flight
-            if (ch == 0) SMI_STAMP(7);
         }
-    });
+    }
     SMI_STAMP(5);
 #undef SMI_STAMP
 }
@@ -540,13 +591,15 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
 // natural-order spectrum (rocFFT, [img][ky][kx]) -> [img][pos_y(ky)][kx], scaled
 template <int FY1>
 __global__ void permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int NKX, float scale) {
+    const int Fx = 2 * (NKX - 1);
     constexpr int FY = FY1 * kF2;
     const int img = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= FY * NKX) return;
     const int ky = i / NKX, kx = i - ky * NKX;
     const float2 k = Khat[(int64_t)img * FY * NKX + i];
-    Kt[((int64_t)img * NKX + kx) * FY + pos<FY1>(ky)] = make_float2(k.x * scale, k.y * scale);
+    Kt[((int64_t)img * NKX + column_of(kx, Fx)) * FY + pos<FY1>(ky)] =
+        make_float2(k.x * scale, k.y * scale);
 }
 
 // Kernel spectrum for the fused path without rocFFT (whose plan creation costs ~0.6 s of
@@ -590,7 +643,7 @@ __global__ void stamp_dft_y(const double2 *A, float2 *Kt, int ph, int NKX, doubl
         re += a.x * c + a.y * s;   // a * (c - i s)
         im += a.y * c - a.x * s;
     }
-    Kt[((int64_t)img * NKX + kx) * FY + pos<FY1>(ky)] =
+    Kt[((int64_t)img * NKX + column_of(kx, 2 * (NKX - 1))) * FY + pos<FY1>(ky)] =
         make_float2((float)(re * scale), (float)(im * scale));
 }
 
@@ -616,10 +669,7 @@ int launch_impl(const BatchView &v, const float *model, const float2 *Kt, int k_
 bool fused_conv_supported(int Fy, int Fx) {
     auto ok = [](int f) { return f == 64 || f == 80 || f == 96 || f == 128 || f == 160; };
     if (!ok(Fy) || !ok(Fx)) return false;
-    const size_t sy = (size_t)((Fy + Fy / kF2 + 15) / 32) * 32 + 16;
-    const size_t lds = sizeof(float2) * ((size_t)(Fx / 2 + 1) * sy +
-                                         (size_t)kPairs * (Fx + 1) + Fy + Fx);
-    return lds <= 160 * 1024;
+    return conv_lds_bytes(Fy, Fx) <= 160 * 1024;
 }
 
 // smallest supported length >= n, or 0

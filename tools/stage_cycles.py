@@ -20,6 +20,6 @@ names = ["A rows fwd+render", "B columns", "C inv+resid+fwd", "B' columns", "D r
 for i, n in enumerate(names):
     print("%-22s %8d cycles" % (n, t[i + 1] - t[i]))
 print("total", t[5] - t[0])
-print("stage A chunk 0: first fetch issue", t[6]-t[0], "stride pass (loads -> Z)", t[8]-t[6], "radix-16 + separation", t[9]-t[8])
-print("stage C chunk 0: prefetch issue", t[10]-t[2], "radix-16 inverse", t[11]-t[10], "inverse + residual + forward stride pass", t[13]-t[11], "radix-16 + separation", t[14]-t[13])
-print("stage D chunk 0: radix-16 inverse", t[12]-t[4], "stride pass + stores", t[7]-t[12])
+print("stage A: stride pass (loads -> T)", t[6]-t[0], "radix-16 + separation", t[1]-t[6])
+print("stage C: radix-16 inverse", t[10]-t[2], "inverse + residual + forward stride pass", t[11]-t[10], "radix-16 + separation + loss", t[3]-t[11])
+print("stage D: radix-16 inverse", t[12]-t[4], "stride pass + stores", t[5]-t[12])
