@@ -506,6 +506,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     // butterfly, w (m - d) and the loss on the thread's 2 x FX1 pixels, forward butterfly.
     double loss = 0.0;
     {
+        cf loss2 = cf{0.f, 0.f};
         const plane_t r_data = band_plane(v.data + band, H * W);
         const plane_t r_weights = band_plane(v.weights + band, H * W);
         const plane_t r_rendered = band_plane(out + band, H * W);
@@ -543,15 +544,17 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                     plane_store(r_rendered, y, x, W, m[n1].x);
                     plane_store(r_rendered, y + 1, x, W, m[n1].y);
                 }
-                // pixels outside the frame have weight 0 (the descriptor returns zeros)
-                const bool in0 = x < W && y < H, in1 = x < W && y + 1 < H;
-                const float d0 = m[n1].x - dv[n1].x, d1 = m[n1].y - dv[n1].y;
-                const float r0 = in0 ? wv[n1].x * d0 : 0.f, r1 = in1 ? wv[n1].y * d1 : 0.f;
-                loss += (double)(r0 * d0);
-                loss += (double)(r1 * d1);
-                m[n1] = cf{r0, r1};
+                // rows beyond H carry weight 0 (the descriptor's range check), columns beyond
+                // W whatever follows the row: a lane select.  Packed: d = m - data, r = w d,
+                // loss += r d (per thread in float32 -- 2 FX1 terms --, across threads in double)
+                const cf w = x < W ? wv[n1] : cf{0.f, 0.f};
+                const cf d = m[n1] - dv[n1];
+                m[n1] = w * d;
+                loss2 = fftk::fma2(m[n1], d, loss2);
             }
             cv.stride_forward(m, s);
+            loss += (double)loss2.x + (double)loss2.y;
+            loss2 = cf{0.f, 0.f};
         }
         lds_barrier();
         SMI_STAMP(11);
