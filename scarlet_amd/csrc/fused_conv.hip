@@ -744,14 +744,19 @@ bool fused_conv_choose(int ny, int nx, int *Fy, int *Fx) {
 int launch_fused_conv(const BatchView &v, int Fy, int Fx, const float *model, const float2 *Kt,
                       int k_bands, int k_per_blend, float *out, int mode, long long *dbg,
                       hipStream_t s) {
-    // small transforms: the row passes of a chunk have 32 x 16 and 32 x Fx/16 work items, which
-    // leave most of 1024 threads idle behind the barriers; 512 threads are faster there
-    // (tools/conv_sizes.py, ms per 512 blends x 5 bands, 1024 -> 512 threads: 64^2 0.127 ->
-    // 0.086, 80^2 0.145 -> 0.107, 96^2 0.233 -> 0.178, 64 x 128 0.175 -> 0.134, 160 x 64 0.211
-    // -> 0.152, 160 x 80 0.234 -> 0.181; but 96 x 128 0.267 -> 0.285, 128 x 96 0.249 -> 0.278,
-    // 80 x 160 0.228 -> 0.259, 160 x 96 0.266 -> 0.298, 128^2 0.283 -> 0.302, 160^2 0.383 -> 0.431)
+    // 512 or 1024 threads per workgroup.  With the row transforms in place a band needs 44 ..
+    // 114 KB of LDS, so two or three 512-thread workgroups share a CU for most shapes -- and
+    // two workgroups that are out of step overlap each other's LDS and arithmetic phases,
+    // which the wavefronts of ONE workgroup, all in the same pass between the same barriers,
+    // do not.  tools/conv_sizes.py, ms per 512 blends x 5 bands, 512 / 1024 threads: 64^2 0.070 /
+    // 0.103, 80^2 0.087 / 0.121, 96^2 0.121 / 0.152, 128^2 0.178 / 0.212, 64 x 128 0.109 / 0.145,
+    // 128 x 64 0.101 / 0.131, 160 x 64 0.112 / 0.143, 160 x 80 0.144 / 0.174, 160 x 96 0.175 / 0.203,
+    // 96 x 128 0.154 / 0.189, 128 x 96 0.140 / 0.175, 64 x 160 0.135 / 0.173; but 80 x 160 0.206 /
+    // 0.194, 96 x 160 0.262 / 0.233, 128 x 160 0.303 / 0.268, 160 x 128 0.272 / 0.250, 160^2 0.357 /
+    // 0.310 (one workgroup per CU either way, or rows of 160 elements).
     static const char *force = getenv("SMI_CONV_WORKGROUP");  // development aid: "512" / "1024"
-    if (force ? force[0] == '5' : (Fx <= 80 || Fy * Fx <= 96 * 96))
+    const bool large = (Fx == 160 && Fy >= 80) || (Fy == 160 && Fx >= 128);
+    if (force ? force[0] == '5' : !large)
         return launch_fused_conv_short(v, Fy, Fx, model, Kt, k_bands, k_per_blend, out, mode, dbg, s);
     SMI_FUSED_DISPATCH(launch_impl, v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s)
     set_error("fused convolution: FFT shape not instantiated");

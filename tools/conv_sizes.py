@@ -18,6 +18,8 @@ out = []
 shapes = [(40, 40), (56, 56), (72, 72), (100, 100), (128, 128), (40, 100), (100, 40), (56, 128)]
 if "--more" in sys.argv:
     shapes = [(128, 40), (128, 56), (128, 72), (72, 40), (40, 72), (56, 72), (72, 56), (72, 100), (100, 72)]
+if "--wide" in sys.argv:
+    shapes = [(100, 128), (72, 128), (40, 128), (128, 100), (56, 128), (128, 128)]
 for H, W in shapes:
     data = rng.normal(0, 1, (nb, C, H, W)).astype(np.float32)
     weights = np.ones_like(data)
