@@ -26,81 +26,120 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 128, kBN = 128, kBK = 16;  // block tile; 4 waves as 2 x 2, 64 x 64 each
-constexpr int kPad = 4;                        // LDS row padding (floats)
-constexpr int kSliceTerms = 320;               // float32 accumulation length inside a slice
+constexpr int kBK = 16;          // k depth of a block tile
+constexpr int kPad = 4;          // LDS row padding (floats)
+constexpr int kSliceTerms = 320; // float32 accumulation length inside a slice
 
 // C_b[M x N] = A_b[M x K] . B_b[K x N] for b < n_batch (row major; the batch strides may
 // be 0).  blockIdx.z = batch * n_slices + slice; slice z covers K in [z kslice, ...).
 // n_slices == 1: the tile goes straight to C (float); otherwise to Cpart[b][z][M][N]
 // (double) for reduce_slices_kernel.
+//
+// Block tile 64 TM x 64 TN, four wavefronts as 2 x 2, each with TM x TN tiles of
+// v_mfma_f32_32x32x2_f32.  The operators of a rendering come in very different shapes --
+// 300 x 15 000 outputs over 300 terms, 50 x 50 outputs over 90 000 terms, 90 000 x 50 over
+// 50 -- so a dimension of up to 96 takes one MFMA tile per wavefront (round 2's single
+// 128 x 128 tile spent 85 % of the matrix-core time of a 50 x 50 product on padding), and a
+// wavefront skips the MFMA tiles that lie outside the matrix altogether (300 rows = 2.5 x 128:
+// the last 64 rows of the third tile row are not computed).  The LDS tiles are double
+// buffered: global loads of tile k + 1 are in flight during the products of tile k, their
+// LDS stores go to the other buffer, one barrier per tile.
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t strideA,
                                                         const float *B, int64_t strideB,
                                                         float *C, int64_t strideC, double *Cpart,
                                                         int M, int N, int K, int kslice,
                                                         int n_slices) {
-    __shared__ float As[kBK][kBM + kPad], Bs[kBK][kBN + kPad];
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ float As[2][kBK][BM + kPad], Bs[2][kBK][BN + kPad];
     const int batch = blockIdx.z / n_slices, z = blockIdx.z - batch * n_slices;
     A += batch * strideA;
     B += batch * strideB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     const int k_lo = z * kslice, k_hi = min(K, k_lo + kslice);
 
-    // global -> registers -> LDS.  A tile: 128 rows x 16 k, thread t takes k = t % 16 of
+    // global -> registers -> LDS.  A tile: BM rows x 16 k, thread t takes k = t % 16 of
     // the rows t / 16 + 16 q (a row's 16 floats are one 64-byte segment); B tile: 16 k x
-    // 128 columns, thread t takes column t % 128 of the rows t / 128 + 2 q.
-    const int a_k = tid & 15, a_r = tid >> 4, b_n = tid & 127, b_k = tid >> 7;
-    float ra[8], rb[8];
+    // BN columns, thread t takes column t % BN of the rows t / BN + (256 / BN) q.
+    constexpr int QA = BM / 16, QB = BN / 16, RB = 256 / BN;
+    const int a_k = tid & 15, a_r = tid >> 4, b_n = tid % BN, b_k = tid / BN;
+    float ra[QA], rb[QB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < QA; ++q) {
             const int m = m0 + a_r + 16 * q, k = k0 + a_k;
             ra[q] = (m < M && k < k_hi) ? A[(int64_t)m * K + k] : 0.f;
-            const int kb = k0 + b_k + 2 * q, n = n0 + b_n;
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int kb = k0 + b_k + RB * q, n = n0 + b_n;
             rb[q] = (kb < k_hi && n < N) ? B[(int64_t)kb * N + n] : 0.f;
         }
     };
-    f32x16 acc[2][2];
+    auto stage = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < QA; ++q) As[buf][a_k][a_r + 16 * q] = ra[q];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < QB; ++q) Bs[buf][b_k + RB * q][b_n] = rb[q];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // MFMA tiles of this wavefront that hold anything (wave-uniform)
+    bool on[TM][TN];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            on[i][j] = m0 + wm + 32 * i < M && n0 + wn + 32 * j < N;
+            any |= on[i][j];
+        }
 
     fetch(k_lo);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
     for (int k0 = k_lo; k0 < k_hi; k0 += kBK) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            As[a_k][a_r + 16 * q] = ra[q];
-            Bs[b_k + 2 * q][b_n] = rb[q];
-        }
-        __syncthreads();
-        if (k0 + kBK < k_hi) fetch(k0 + kBK);  // in flight during the products
+        const bool more = k0 + kBK < k_hi;
+        if (more) fetch(k0 + kBK);  // in flight during the products
         // operand layout of v_mfma_f32_32x32x2_f32: lane l holds A[i = l & 31][k = l >> 5]
         // and B[k = l >> 5][j = l & 31]
-        const int kk = lane >> 5, ij = lane & 31;
+        if (any) {
+            const int kk = lane >> 5, ij = lane & 31;
 #pragma unroll
-        for (int ks = 0; ks < kBK; ks += 2) {
-            const float a0 = As[ks + kk][wm + ij], a1 = As[ks + kk][wm + 32 + ij];
-            const float b0 = Bs[ks + kk][wn + ij], b1 = Bs[ks + kk][wn + 32 + ij];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int ks = 0; ks < kBK; ks += 2) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = As[buf][ks + kk][wm + 32 * i + ij];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[buf][ks + kk][wn + 32 * j + ij];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (on[i][j])
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
+        if (more) stage(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
     // accumulator layout of the 32 x 32 tile: lane l, register e -> row 8 (e / 4) +
     // 4 (l >> 5) + e % 4, column l & 31
     double *Cz = Cpart ? Cpart + ((int64_t)batch * n_slices + z) * M * N : nullptr;
     float *Cb = C + batch * strideC;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
@@ -138,7 +177,10 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const double *Cpart,
 int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float *C,
          int64_t strideC, int n_batch, double *scratch, size_t scratch_elems, int M, int N, int K,
          hipStream_t s) {
-    const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN) * n_batch;
+    // one MFMA tile per wavefront along a dimension of up to 96 (see the kernel)
+    const int tm = M <= 96 ? 1 : 2, tn = N <= 96 ? 1 : 2;
+    const int bm = 64 * tm, bn = 64 * tn;
+    const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * n_batch;
     // slices of ~kSliceTerms terms (float32 accumulation length); fewer when the tiles
     // alone fill the chip several times over and the partials would not fit the scratch
     int n_slices = std::max(1, (K + kSliceTerms - 1) / kSliceTerms);
@@ -149,10 +191,16 @@ int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float
     int kslice = (K + n_slices - 1) / n_slices;
     kslice = (kslice + kBK - 1) / kBK * kBK;
     n_slices = (K + kslice - 1) / kslice;
-    hipLaunchKernelGGL(gemm_mfma_kernel,
-                       dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, n_slices * n_batch),
-                       dim3(256), 0, s, A, strideA, B, strideB, C, strideC,
-                       n_slices > 1 ? scratch : nullptr, M, N, K, kslice, n_slices);
+    const dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm, n_slices * n_batch);
+    double *part = n_slices > 1 ? scratch : nullptr;
+#define SMI_GEMM(TM, TN)                                                                         \
+    hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN>), grid, dim3(256), 0, s, A, strideA, B, strideB, \
+                       C, strideC, part, M, N, K, kslice, n_slices)
+    if (tm == 1 && tn == 1) SMI_GEMM(1, 1);
+    else if (tm == 1) SMI_GEMM(1, 2);
+    else if (tn == 1) SMI_GEMM(2, 1);
+    else SMI_GEMM(2, 2);
+#undef SMI_GEMM
     if (n_slices > 1)
         hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((MN + 63) / 64), n_batch),
                            dim3(256), 0, s, scratch, C, strideC, (int64_t)MN, n_slices);
