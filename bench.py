@@ -534,6 +534,12 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
+            # above 1 for the fused convolution since round 3: SURVEY 8d prices four FFT passes
+            # through HBM, this kernel keeps them in LDS and moves ~1.4 MB of the 5.05 MB per
+            # blend; `speed_of_light.sol_frac` and `hbm_frac_measured` say how busy the chip is
+            "frac_note": ("algorithmic (SURVEY 8d) bytes over the measured launch time; not a "
+                          "utilisation -- most of these bytes never leave the LDS"
+                          if achieved > HBM_PEAK_GBS else None),
             "traffic": traffic,
             "kernel": k_name,
             "algorithmic_bytes_per_launch": k_bytes * nb,
