@@ -647,10 +647,14 @@ def test_many_bands_big_boxes_null_renderer(amd):
 @pytest.mark.parametrize("H,W,F", [
     (50, 85, (64, 96)), (85, 50, (96, 64)), (70, 110, (80, 128)), (110, 70, (128, 80)),
     (88, 150, (96, 160)), (150, 88, (160, 96)), (120, 120, (128, 128)), (57, 153, (64, 160)),
-    (153, 57, (160, 64)), (89, 73, (96, 80)), (60, 121, (80, 128)), (40, 40, (64, 64))])
+    (153, 57, (160, 64)), (89, 73, (96, 80)), (60, 121, (80, 128)), (40, 40, (64, 64)),
+    (149, 141, (160, 160)), (103, 139, (128, 160)), (141, 101, (160, 128))])
 def test_fused_path_every_fft_length(amd, H, W, F):
     """every LDS-resident FFT length (64, 80, 96, 128, 160 = 16 x {4,5,6,8,10}) on both
-    axes: forward, gradient and two full steps against the oracle, 15^2 kernel"""
+    axes: forward, gradient and two full steps against the oracle, 15^2 kernel.  The last three
+    run in 1024-thread workgroups (the others in 512-thread ones); 149 rows are 75 row pairs,
+    i.e. more stride-pass work items than a workgroup has threads, odd heights leave half a
+    pair, widths off the multiples of 16 a block of columns that straddles the frame"""
     rng = np.random.default_rng(H * 1000 + W)
     boxes = [((21, 21), (3, 5)), ((31, 31), (H - 35, W - 36)), ((15, 25), (H // 2, -6)),
              ((25, 15), (-7, W // 2))]
