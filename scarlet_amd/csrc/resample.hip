@@ -19,6 +19,8 @@
 // tiles are summed in double by a second kernel -- that keeps the renderings within
 // ~1e-7 of the reference's float64 evaluation and gives a small output enough workgroups
 // to fill the chip.  The bands of an observation are one batched launch.
+#include <type_traits>
+
 #include "common.h"
 
 namespace smi {
@@ -93,13 +95,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     // MFMA tiles of this wavefront that hold anything (wave-uniform)
     bool on[TM][TN];
-    bool any = false;
+    bool any = false, full = true;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             on[i][j] = m0 + wm + 32 * i < M && n0 + wn + 32 * j < N;
             any |= on[i][j];
+            full &= on[i][j];
         }
 
     fetch(k_lo);
@@ -113,20 +116,26 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t 
         // and B[k = l >> 5][j = l & 31]
         if (any) {
             const int kk = lane >> 5, ij = lane & 31;
+            auto products = [&](auto all_on) {
 #pragma unroll
-            for (int ks = 0; ks < kBK; ks += 2) {
-                float a[TM], b[TN];
+                for (int ks = 0; ks < kBK; ks += 2) {
+                    float a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = As[buf][ks + kk][wm + 32 * i + ij];
+                    for (int i = 0; i < TM; ++i) a[i] = As[buf][ks + kk][wm + 32 * i + ij];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bs[buf][ks + kk][wn + 32 * j + ij];
+                    for (int j = 0; j < TN; ++j) b[j] = Bs[buf][ks + kk][wn + 32 * j + ij];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (on[i][j])
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+                        for (int j = 0; j < TN; ++j)
+                            if (decltype(all_on)::value || on[i][j])
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            };
+            // (straight-line code for a wavefront whose tiles are all inside: a branch per
+            // MFMA keeps the scheduler from moving the LDS reads ahead of the products)
+            if (full) products(std::true_type{});
+            else products(std::false_type{});
         }
         if (more) stage(buf ^ 1);
         __syncthreads();
