@@ -211,7 +211,7 @@ struct smi_batch {
     std::vector<double> box_center;  // mean of the box bounds per component (y, x)
     std::vector<char> is_point;
     // free Fourier shifts
-    int n_shift = 0, max_box_side = 1;
+    int n_shift = 0, max_box_side = 1, max_box_w = 1;
     float *morph_param = nullptr, *c_shift_step = nullptr;
     int32_t *c_shift_fft = nullptr;
     std::vector<char> is_shift;
@@ -355,6 +355,10 @@ void refresh_view(smi_batch *b) {
     v.work0 = 0;
     v.work_start = b->h_work_start.data();
     v.nb_total = b->d.n_blends;
+    {
+        const int slots = (b->max_box_w + 14) / 16 + 1;
+        v.render_slots = slots <= 6 ? slots : 0;
+    }
     for (const auto &pl : b->plans)
         if (!pl.slots) v.fast_plans = 0;
 }
@@ -1388,12 +1392,14 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     b->n_point = 0;
     b->n_shift = 0;
     b->max_box_side = 1;
+    b->max_box_w = 1;
     b->is_shift.assign((size_t)n, 0);
     b->h_moff = moff;
     std::vector<float> shift_step(n, 1e-1f);
     std::vector<int32_t> shift_fft((size_t)n * 2, 0);
     for (int k = 0; k < n; ++k) {
         b->max_box_side = std::max(b->max_box_side, std::max(c->box_h[k], c->box_w[k]));
+        b->max_box_w = std::max(b->max_box_w, (int)c->box_w[k]);
         if (!(c->prox_flags[k] & SMI_COMPONENT_SHIFTING)) continue;
         b->n_shift++;
         b->is_shift[k] = 1;
@@ -1709,11 +1715,26 @@ int smi_batch_gradient(smi_batch *b, float *g_sed, float *g_morph) {
     return SMI_OK;
 }
 
+// nothing but factorized components under one fused convolution
+static bool plain_batch(const smi_batch *b) {
+    return b->fused && b->n_point == 0 && b->n_shift == 0 && b->lowres.empty() &&
+           b->layers.empty() && !b->ks.stamp;
+}
+
+// A plain batch needs the model only as the input rows of the convolution, and the
+// convolution kernel renders them itself (fused_conv.hip, ModelGather): no model cube, no
+// render launch per iteration.  SMI_INLINE_RENDER=0 keeps the cube (development aid).
+static bool inline_render(const smi_batch *b) {
+    static const bool allowed = [] {
+        const char *e = getenv("SMI_INLINE_RENDER");
+        return !(e && e[0] == '0');
+    }();
+    return allowed && plain_batch(b) && b->view.render_slots > 0;
+}
+
 // number of blend ranges a step is split into
 static int sub_ranges(const smi_batch *b) {
-    const bool plain = b->fused && b->n_point == 0 && b->n_shift == 0 && b->lowres.empty() &&
-                       b->layers.empty() && !b->ks.stamp;
-    if (!plain) return 1;
+    if (!plain_batch(b)) return 1;
     const int nb = b->d.n_blends;
     // measured on MI355X (bench.py --blends N --sub-ranges n --steps 20, k blend-it/s for
     // n = 2 / 3 / 4): 128 blends 506 / 508 / 335, 256 blends 658 / 673 / 498, 512 blends
@@ -1751,6 +1772,7 @@ static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter,
         b->sub_events.push_back(e);
     }
     const bool timing = b->timing;
+    const bool no_cube = inline_render(b);
     if (timing) {
         const size_t need = (size_t)n_iter * 6;
         while (b->events.size() < need) {
@@ -1779,9 +1801,9 @@ static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter,
             // phase times are those of range 0 (its kernels overlap the other ranges')
             hipEvent_t *ev = timing && s == 0 ? &b->events[(size_t)i * 6] : nullptr;
             if (ev) SMI_HIP(hipEventRecord(ev[0], st));
-            launch_render(v, b->P, st);
+            if (!no_cube) launch_render(v, b->P, st);
             if (ev) SMI_HIP(hipEventRecord(ev[1], st));
-            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
+            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, no_cube ? nullptr : b->P, b->Kt, b->d.kernel_bands,
                                         b->d.kernel_per_blend, b->Q, 0, nullptr, st)))
                 return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], st));
@@ -1830,6 +1852,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
     const int check = check_convergence != 0;
     const bool timing = b->timing;
     const int n_sub = sub_ranges(b);
+    const bool no_cube = inline_render(b);
     if (n_sub > 1) {
         if ((rc = step_sub_ranges(b, n_sub, it0, n_iter, e_rel, min_iter, prox_max_iter, check)))
             return rc;
@@ -1848,12 +1871,12 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
         hipEvent_t *ev = timing ? &b->events[(size_t)i * 6] : nullptr;
         if (ev) SMI_HIP(hipEventRecord(ev[0], b->stream));
         if (b->fused) {
-            launch_render(v, b->P, b->stream);
+            if (!no_cube) launch_render(v, b->P, b->stream);
             if ((rc = lowres_evaluate_all(b, 1))) return rc;
             if (b->ks.stamp && (rc = kernel_shift_backward(b, v, it, 0))) return rc;
             // conv + residual/loss + conv^T in one LDS-resident kernel
             if (ev) SMI_HIP(hipEventRecord(ev[1], b->stream));
-            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, b->P, b->Kt, b->d.kernel_bands,
+            if ((rc = launch_fused_conv(v, b->Fy, b->Fx, no_cube ? nullptr : b->P, b->Kt, b->d.kernel_bands,
                                         b->d.kernel_per_blend, b->Q, 0, b->dbg, b->stream)))
                 return rc;
             if ((rc = layers_evaluate(b, v, 1, b->stream))) return rc;

@@ -199,6 +199,10 @@ struct BatchView {
     // entry of every blend within a class (prefix sums), for the launch ranges.
     const int32_t *work;
     int32_t work0;
+    // fused_conv_kernel without a model cube (model == nullptr) renders its rows itself:
+    // columns of one residue class (mod 16) a box can hold, (widest box + 14) / 16 + 1; 0 =
+    // boxes too wide for that (the cube comes from render_kernel)
+    int32_t render_slots;
     const int32_t *work_start;
     int32_t nb_total;
 };

@@ -419,6 +419,102 @@ struct Conv {
 };
 
 
+// ---- model rows rendered inside the kernel (Blend.get_model, blend.py:200-244) --------------
+// Without a model cube (`model == nullptr`) a stride-pass work item builds its 2 x FX1 model
+// pixels itself: rows y, y + 1 at the columns 16 n1 + n2, every pixel the sum of sed_k[c] *
+// morph_k over the components whose box holds it, in ascending component order with one fma
+// per term -- the arithmetic of render_kernel (kernels.hip), so the rows are bit for bit what
+// the cube would have held; the cube's round trip through HBM (write, read) and a launch per
+// iteration go away.
+//
+// Component metadata sits one component per lane; the wavefront (four row pairs = eight
+// frame rows) walks through the components whose box meets its rows.  A box of width w holds
+// at most M = (w + 14) / 16 + 1 columns of one residue class, n1 = n1lo .. n1lo + M - 1 with
+// n1lo = ox / 16: every component costs 2 M loads whatever its position -- a STATIC number, so
+// that the loads of the next component are in flight while this one is accumulated (with
+// loads behind branches the compiler's wait-counter pass falls back to vmcnt(0)); lanes whose
+// column or row lies outside the box (or the frame) get an out-of-range offset, for which the
+// buffer load returns 0 without touching memory, and fma(sed, 0, acc) = acc.  Only the
+// accumulation branches (wave-uniformly) on n1lo, to keep the register indices static.
+template <int FX1, int M>
+struct ModelGather {
+    static constexpr uint32_t kNone = 0x40000000u;  // rowbase + column stays out of range
+    const BatchView &v;
+    int band_c, H, W, y, n2, ylo;
+    struct Hit {
+        int n1lo;
+        float sd;
+        bool none;
+    };
+    // pops the first component of `todo` and issues its loads into mv; with nothing left the
+    // loads are still issued (all out of range: no memory access) and the hit is `none`, so
+    // that the number of loads in flight never depends on a branch
+    __device__ __forceinline__ Hit open(unsigned long long &todo, int kb, int l_oy, int l_ox,
+                                        int l_h, int l_w, int l_mo, cf (&mv)[M]) const {
+        Hit h;
+        h.none = todo == 0;
+        const int kl = h.none ? 0 : __builtin_ctzll(todo);
+        todo &= todo - 1;  // (0 stays 0)
+        const int oy = __builtin_amdgcn_readlane(l_oy, kl), hh = __builtin_amdgcn_readlane(l_h, kl);
+        const int ox = __builtin_amdgcn_readlane(l_ox, kl), w = __builtin_amdgcn_readlane(l_w, kl);
+        const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
+        const plane_t r = band_plane(mbase, hh * w);
+        h.n1lo = (ox > 0 ? ox : 0) >> 4;
+        h.sd = v.sed[(int64_t)(kb + kl) * v.C + band_c];
+        const uint32_t hlim = h.none ? 0u : (uint32_t)min(hh, H - oy);
+        const uint32_t wlim4 = 4u * (uint32_t)min(w, W - ox);
+        const uint32_t ry = (uint32_t)(y - oy);
+        const uint32_t row0 = ry < hlim ? __umul24(ry, (uint32_t)w) * 4u : kNone;
+        const uint32_t row1 = ry + 1u < hlim ? __umul24(ry + 1u, (uint32_t)w) * 4u : kNone;
+        const uint32_t x4 = (uint32_t)(16 * h.n1lo + n2 - ox) * 4u;  // byte offset of slot 0 in its row
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            uint32_t t = x4 + 64u * m;
+            t = t < wlim4 ? t : kNone;
+            mv[m].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, row0 + t, 0, 0));
+            mv[m].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, row1 + t, 0, 0));
+        }
+        return h;
+    }
+    __device__ __forceinline__ void close(const Hit &h, const cf (&mv)[M], cf (&acc)[FX1]) const {
+        const cf sd = cf{h.sd, h.sd};
+        fftk::static_for<0, FX1>([&](auto lo) {
+            constexpr int n1lo = decltype(lo)::value;
+            if (h.n1lo == n1lo) {
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+                    if (n1lo + m < FX1) acc[n1lo + m] = fftk::fma2(mv[m], sd, acc[n1lo + m]);
+            }
+        });
+    }
+    __device__ __forceinline__ void run(int b, int lane, cf (&acc)[FX1]) const {
+#pragma unroll
+        for (int n1 = 0; n1 < FX1; ++n1) acc[n1] = cf{0.f, 0.f};
+        const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
+        for (int kb = cs; kb < ce; kb += 64) {
+            const int kk = kb + lane;
+            const bool have = kk < ce;
+            const int l_oy = have ? v.c_oy[kk] : 0, l_ox = have ? v.c_ox[kk] : 0;
+            const int l_h = have ? v.c_h[kk] : 0, l_w = have ? v.c_w[kk] : 0;
+            const int l_mo = have ? (int)v.c_moff[kk] : 0;  // packed offsets fit 31 bits
+            const bool hit = have && l_oy < ylo + 8 && l_oy + l_h > ylo && l_oy < H && l_ox < W &&
+                             l_ox + l_w > 0;
+            unsigned long long todo = __ballot(hit);
+            if (!todo) continue;
+            cf mva[M], mvb[M];
+            Hit ha = open(todo, kb, l_oy, l_ox, l_h, l_w, l_mo, mva);
+            for (;;) {
+                const Hit hb = open(todo, kb, l_oy, l_ox, l_h, l_w, l_mo, mvb);
+                close(ha, mva, acc);
+                if (hb.none) break;
+                ha = open(todo, kb, l_oy, l_ox, l_h, l_w, l_mo, mva);
+                close(hb, mvb, acc);
+                if (ha.none) break;
+            }
+        }
+    }
+};
+
 extern __shared__ __attribute__((aligned(16))) float2 lds_conv[];
 
 // model: the model cube [nb][C][H][W] (render_kernel)
@@ -452,7 +548,9 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     using Item = typename Conv<FY1, FX1>::StrideItem;
 
     // the first model rows are requested before the twiddle tables are made
-    const plane_t r_model = band_plane(model + band, H * W);
+    // (model == nullptr: the rows are rendered here, ModelGather)
+    const bool have_cube = model != nullptr;
+    const plane_t r_model = band_plane(have_cube ? model + band : v.data + band, H * W);
     cf mrow[FX1];
     auto fetch_model = [&](const Item &s) {
         const PairRows a = pair_rows(2 * s.j, s.n2, W);
@@ -461,7 +559,18 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
             mrow[n1] = pair_load<n1>(r_model, a);
         });
     };
-    fetch_model(cv.stride_item(tid));
+    auto render_rows = [&](const Item &s) {
+        // the four row pairs of this wavefront start at pair (item / 64) * 4
+        const int j0 = __builtin_amdgcn_readfirstlane(s.j - ((tid & 63) >> 4));
+        if (v.render_slots <= 4) {
+            const ModelGather<FX1, 4> g{v, c, H, W, 2 * s.j, s.n2, 2 * j0};
+            g.run(b, tid & 63, mrow);
+        } else {
+            const ModelGather<FX1, (FX1 < 6 ? FX1 : 6)> g{v, c, H, W, 2 * s.j, s.n2, 2 * j0};
+            g.run(b, tid & 63, mrow);
+        }
+    };
+    if (have_cube) fetch_model(cv.stride_item(tid));
     for (int j = tid; j < C::FY; j += kThreads) {  // j = 16 k1 + n2
         float s, co;
         sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FY, &s, &co);
@@ -486,13 +595,19 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
 
     // ---- A: model rows (blend.py:200-244, rendered by render_kernel) and their forward
     // row transforms
-    for (int it = tid; it < n_items; it += kThreads) {
+    // (rendering walks through the components with wave-wide votes: every lane of a wavefront
+    // that has an item stays in the loop)
+    for (int it = tid; (have_cube ? it : it - (tid & 63)) < n_items; it += kThreads) {
         const Item s = cv.stride_item(it);
-        if (it != tid) fetch_model(s);
+        if (have_cube) {
+            if (it != tid) fetch_model(s);
 #pragma unroll
-        for (int n1 = 0; n1 < FX1; ++n1)  // the zero padding beyond column W - 1
-            if (kF2 * n1 + s.n2 >= W) mrow[n1] = cf{0.f, 0.f};
-        cv.stride_forward(mrow, s);
+            for (int n1 = 0; n1 < FX1; ++n1)  // the zero padding beyond column W - 1
+                if (kF2 * n1 + s.n2 >= W) mrow[n1] = cf{0.f, 0.f};
+        } else {
+            render_rows(s);
+        }
+        if (s.on) cv.stride_forward(mrow, s);
     }
     lds_barrier();
     SMI_STAMP(6);
