@@ -491,8 +491,10 @@ def main():
         # at 8 TB/s, and the butterflies of the four transforms at the f32 vector peak.
         counted = (args.config == "cfg3" and nb == 1024 and not args.null_renderer
                    and os.path.exists(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        # every kernel of the iteration that the counter passes saw (no render_kernel since
+        # the convolution kernel renders its own model rows)
         all_cnt = {k: counters(k) for k in ("fused_conv_kernel", "update_kernel_reg",
-                                            "render_kernel")} if counted else {}
+                                            "render_kernel") if counters(k)} if counted else {}
         hbm_ms = by["null"] * nb / (HBM_PEAK_GBS * 1e9) * 1e3
         flop_ms = (fft_flops(C, Fy, Fx) * nb / (F32_VECTOR_PEAK_TFLOPS * 1e12) * 1e3
                    if not args.null_renderer else 0.0)

@@ -359,6 +359,14 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
 int smi_batch_set_sub_ranges(smi_batch *b, int32_t n);
 int smi_batch_get_sub_ranges(smi_batch *b, int32_t *n);
 
+/* A batch of nothing but factorized components under one fused convolution (no point
+ * sources, free shifts, further observations) needs Blend.get_model (blend.py:200-244) only
+ * as the input rows of the convolution; by default (on = 1) the convolution kernel renders
+ * those rows itself and smi_batch_step neither launches the render kernel nor moves a model
+ * cube through HBM.  on = 0 keeps the cube (render kernel per iteration).  The rows are the
+ * same bit for bit either way; boxes wider than 81 pixels always take the cube. */
+int smi_batch_set_inline_render(smi_batch *b, int32_t on);
+
 /* Blocking.  n_active: blends still iterating; error: index of the first blend
  * whose parameters became non-finite, or -1. */
 int smi_batch_status(smi_batch *b, int32_t *n_active, int32_t *first_error);

@@ -156,6 +156,7 @@ SYMBOLS = {
     "smi_batch_set_previous_loss": (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
     "smi_batch_set_sub_ranges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "smi_batch_get_sub_ranges": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
+    "smi_batch_set_inline_render": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "smi_batch_set_optimizer": (
         ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float]
     ),

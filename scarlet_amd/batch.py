@@ -434,6 +434,12 @@ class BlendBatch:
         automatic).  Results do not depend on ``n``."""
         _lib.check(self._lib.smi_batch_set_sub_ranges(self._h, int(n)))
 
+    def set_inline_render(self, on):
+        """Plain batches (factorized components under one fused convolution): let the
+        convolution kernel render its own model rows (default) or keep a model cube in HBM,
+        written by the render kernel every iteration.  Same results bit for bit."""
+        _lib.check(self._lib.smi_batch_set_inline_render(self._h, int(bool(on))))
+
     def sub_ranges(self):
         n = ctypes.c_int32()
         _lib.check(self._lib.smi_batch_get_sub_ranges(self._h, ctypes.byref(n)))

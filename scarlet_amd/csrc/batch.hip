@@ -212,6 +212,7 @@ struct smi_batch {
     std::vector<char> is_point;
     // free Fourier shifts
     int n_shift = 0, max_box_side = 1, max_box_w = 1;
+    bool inline_render = true;  // smi_batch_set_inline_render
     float *morph_param = nullptr, *c_shift_step = nullptr;
     int32_t *c_shift_fft = nullptr;
     std::vector<char> is_shift;
@@ -1729,7 +1730,7 @@ static bool inline_render(const smi_batch *b) {
         const char *e = getenv("SMI_INLINE_RENDER");
         return !(e && e[0] == '0');
     }();
-    return allowed && plain_batch(b) && b->view.render_slots > 0;
+    return allowed && b->inline_render && plain_batch(b) && b->view.render_slots > 0;
 }
 
 // number of blend ranges a step is split into
@@ -1916,6 +1917,12 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
 int smi_batch_set_sub_ranges(smi_batch *b, int32_t n) {
     SMI_REQUIRE(b && n >= 0, "bad argument");
     b->n_sub = n;
+    return SMI_OK;
+}
+
+int smi_batch_set_inline_render(smi_batch *b, int32_t on) {
+    SMI_REQUIRE(b != nullptr, "null batch");
+    b->inline_render = on != 0;
     return SMI_OK;
 }
 

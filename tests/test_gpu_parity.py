@@ -1491,3 +1491,55 @@ def test_constraint_chain_repeat(amd):
         # floored before the normalisation by the maximum: no pixel is left at zero
         assert min(float(m.min()) for m in batch.parameters()[1]) > 0.005
         batch.close()
+
+
+def _step_bits(amd, data, weights, comps, kernel, n_it, inline, sub_ranges=1):
+    batch = amd.BlendBatch(data, weights, comps, kernel=kernel, max_iter=n_it + 1, conv_path="fused")
+    batch.set_inline_render(inline)
+    batch.set_sub_ranges(sub_ranges)
+    batch.step(0, n_it, e_rel=1e-3)
+    sed, morphs = batch.parameters()
+    out = (np.concatenate(batch.loss_history()), sed.copy(),
+           np.concatenate([m.ravel() for m in morphs]))
+    batch.close()
+    return out
+
+
+@pytest.mark.parametrize("case", ["benchmark boxes", "wide boxes", "overhanging boxes",
+                                  "70 components", "too wide for the kernel"])
+def test_rows_rendered_inside_the_convolution_equal_the_model_cube(amd, case):
+    """A plain batch has no model cube: the convolution kernel renders its input rows itself
+    (Blend.get_model, blend.py:200-244, in the stride-pass layout of the row transforms).
+    The rows must be bit for bit what render_kernel writes -- same terms, same order, one fma
+    each -- so every loss and every parameter after three full iterations is identical to
+    the run that keeps the cube: 41^2 boxes (four columns of a residue class per box), 61^2 /
+    81^2 boxes (six), boxes that overhang all four edges of a frame whose sides are no
+    multiples of 16 or 2, more components than a wavefront has lanes, and a 101-pixel box,
+    which sends the batch back to the cube (nothing to compare but that it still runs)."""
+    rng = np.random.default_rng(len(case))
+    C, H, W, ks = 3, 128, 128, 15
+    if case == "benchmark boxes":
+        boxes = [((41, 41), (int(rng.integers(0, 88)), int(rng.integers(0, 88)))) for _ in range(10)]
+    elif case == "wide boxes":
+        boxes = [((61, 61), (3, 40)), ((81, 81), (30, 15)), ((21, 71), (100, 50)), ((41, 41), (60, 80))]
+    elif case == "overhanging boxes":
+        H, W = 101, 119
+        boxes = [((41, 41), (-20, -17)), ((31, 45), (85, 100)), ((25, 25), (-5, 100)),
+                 ((35, 21), (80, -10)), ((41, 41), (30, 37)), ((15, 61), (50, 70))]
+    elif case == "70 components":
+        H, W = 56, 66
+        boxes = [((9 + 2 * (k % 3), 9 + 2 * (k % 4)), (int(rng.integers(-3, 50)), int(rng.integers(-3, 60))))
+                 for k in range(70)]
+    else:
+        boxes = [((101, 101), (10, 12)), ((41, 41), (60, 80))]
+    scenes = [_random_scene(rng, C, H, W, boxes, kernel_shape=ks) for _ in range(3)]
+    kernel = scenes[0][1]
+    data = np.stack([s[2] for s in scenes])
+    weights = np.stack([s[3] for s in scenes])
+    comps = [[amd.ComponentSpec(sed * 0.8, m, o, sed_min_step=0.05) for sed, m, o in s[0]] for s in scenes]
+    ref = _step_bits(amd, data, weights, comps, kernel, 3, inline=False)
+    for sub in (1, 3):
+        got = _step_bits(amd, data, weights, comps, kernel, 3, inline=True, sub_ranges=sub)
+        for a, b in zip(got, ref):
+            assert np.all(np.isfinite(a))
+            assert_array_equal(a, b)
