@@ -441,32 +441,35 @@ struct ModelGather {
     static constexpr uint32_t kNone = 0x40000000u;  // rowbase + column stays out of range
     const BatchView &v;
     int band_c, H, W, y, n2, ylo;
-    struct Hit {
-        int n1lo;
+    // metadata of 64 components, one per lane (all that `open` needs comes from here by
+    // v_readlane: no scalar address arithmetic, no load per component)
+    struct Lanes {
+        int oy, ox, h, w, mo;
         float sd;
-        bool none;
     };
-    // pops the first component of `todo` and issues its loads into mv; with nothing left the
-    // loads are still issued (all out of range: no memory access) and the hit is `none`, so
-    // that the number of loads in flight never depends on a branch
-    __device__ __forceinline__ Hit open(unsigned long long &todo, int kb, int l_oy, int l_ox,
-                                        int l_h, int l_w, int l_mo, cf (&mv)[M]) const {
-        Hit h;
-        h.none = todo == 0;
-        const int kl = h.none ? 0 : __builtin_ctzll(todo);
+    // pops the first component of `todo` and issues its loads into mv; returns n1lo, or -1
+    // with nothing left -- the loads are still issued then (all out of range: no memory
+    // access), so that the number of loads in flight never depends on a branch
+    __device__ __forceinline__ int open(unsigned long long &todo, const Lanes &l, float &sd,
+                                        cf (&mv)[M]) const {
+        const bool none = todo == 0;
+        const int kl = none ? 0 : __builtin_ctzll(todo);
         todo &= todo - 1;  // (0 stays 0)
-        const int oy = __builtin_amdgcn_readlane(l_oy, kl), hh = __builtin_amdgcn_readlane(l_h, kl);
-        const int ox = __builtin_amdgcn_readlane(l_ox, kl), w = __builtin_amdgcn_readlane(l_w, kl);
-        const float *mbase = v.morph + __builtin_amdgcn_readlane(l_mo, kl);
+        const int oy = __builtin_amdgcn_readlane(l.oy, kl), hh = __builtin_amdgcn_readlane(l.h, kl);
+        const int ox = __builtin_amdgcn_readlane(l.ox, kl), w = __builtin_amdgcn_readlane(l.w, kl);
+        const float *mbase = v.morph + __builtin_amdgcn_readlane(l.mo, kl);
         const plane_t r = band_plane(mbase, hh * w);
-        h.n1lo = (ox > 0 ? ox : 0) >> 4;
-        h.sd = v.sed[(int64_t)(kb + kl) * v.C + band_c];
-        const uint32_t hlim = h.none ? 0u : (uint32_t)min(hh, H - oy);
+        sd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l.sd), kl));
+        const int n1lo = (ox > 0 ? ox : 0) >> 4;
+        const uint32_t hlim = none ? 0u : (uint32_t)min(hh, H - oy);
         const uint32_t wlim4 = 4u * (uint32_t)min(w, W - ox);
-        const uint32_t ry = (uint32_t)(y - oy);
-        const uint32_t row0 = ry < hlim ? __umul24(ry, (uint32_t)w) * 4u : kNone;
-        const uint32_t row1 = ry + 1u < hlim ? __umul24(ry + 1u, (uint32_t)w) * 4u : kNone;
-        const uint32_t x4 = (uint32_t)(16 * h.n1lo + n2 - ox) * 4u;  // byte offset of slot 0 in its row
+        const uint32_t ry = (uint32_t)(y - oy), w4 = 4u * (uint32_t)w;
+        uint32_t row0, row1;  // (24-bit multiplies, full rate; the compiler picks v_mul_lo_u32)
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(row0) : "v"(ry), "s"(w4));
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(row1) : "v"(ry + 1u), "s"(w4));
+        row0 = ry < hlim ? row0 : kNone;
+        row1 = ry + 1u < hlim ? row1 : kNone;
+        const uint32_t x4 = (uint32_t)(16 * n1lo + n2 - ox) * 4u;  // byte offset of slot 0 in its row
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             uint32_t t = x4 + 64u * m;
@@ -474,16 +477,19 @@ struct ModelGather {
             mv[m].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, row0 + t, 0, 0));
             mv[m].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, row1 + t, 0, 0));
         }
-        return h;
+        return none ? -1 : n1lo;
     }
-    __device__ __forceinline__ void close(const Hit &h, const cf (&mv)[M], cf (&acc)[FX1]) const {
-        const cf sd = cf{h.sd, h.sd};
+    __device__ __forceinline__ void close(int n1lo_, float sd_, const cf (&mv)[M], cf (&acc)[FX1]) const {
+        const cf sd = cf{sd_, sd_};
         fftk::static_for<0, FX1>([&](auto lo) {
             constexpr int n1lo = decltype(lo)::value;
-            if (h.n1lo == n1lo) {
+            if (n1lo_ == n1lo) {
 #pragma unroll
                 for (int m = 0; m < M; ++m)
                     if (n1lo + m < FX1) acc[n1lo + m] = fftk::fma2(mv[m], sd, acc[n1lo + m]);
+                // (keeps the cases apart: merged, they index `acc` dynamically and the
+                // array moves to scratch memory)
+                asm volatile("; n1lo = %0" ::"n"(n1lo));
             }
         });
     }
@@ -494,22 +500,27 @@ struct ModelGather {
         for (int kb = cs; kb < ce; kb += 64) {
             const int kk = kb + lane;
             const bool have = kk < ce;
-            const int l_oy = have ? v.c_oy[kk] : 0, l_ox = have ? v.c_ox[kk] : 0;
-            const int l_h = have ? v.c_h[kk] : 0, l_w = have ? v.c_w[kk] : 0;
-            const int l_mo = have ? (int)v.c_moff[kk] : 0;  // packed offsets fit 31 bits
-            const bool hit = have && l_oy < ylo + 8 && l_oy + l_h > ylo && l_oy < H && l_ox < W &&
-                             l_ox + l_w > 0;
+            Lanes l;
+            l.oy = have ? v.c_oy[kk] : 0;
+            l.ox = have ? v.c_ox[kk] : 0;
+            l.h = have ? v.c_h[kk] : 0;
+            l.w = have ? v.c_w[kk] : 0;
+            l.mo = have ? (int)v.c_moff[kk] : 0;  // packed offsets fit 31 bits
+            l.sd = have ? v.sed[kk * v.C + band_c] : 0.f;
+            const bool hit = have && l.oy < ylo + 8 && l.oy + l.h > ylo && l.oy < H && l.ox < W &&
+                             l.ox + l.w > 0;
             unsigned long long todo = __ballot(hit);
             if (!todo) continue;
             cf mva[M], mvb[M];
-            Hit ha = open(todo, kb, l_oy, l_ox, l_h, l_w, l_mo, mva);
+            float sda, sdb;
+            int na = open(todo, l, sda, mva);
             for (;;) {
-                const Hit hb = open(todo, kb, l_oy, l_ox, l_h, l_w, l_mo, mvb);
-                close(ha, mva, acc);
-                if (hb.none) break;
-                ha = open(todo, kb, l_oy, l_ox, l_h, l_w, l_mo, mva);
-                close(hb, mvb, acc);
-                if (ha.none) break;
+                const int nb = open(todo, l, sdb, mvb);
+                close(na, sda, mva, acc);
+                if (nb < 0) break;
+                na = open(todo, l, sda, mva);
+                close(nb, sdb, mvb, acc);
+                if (na < 0) break;
             }
         }
     }
