@@ -1808,10 +1808,10 @@ static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter,
                                         b->d.kernel_per_blend, b->Q, 0, nullptr, st)))
                 return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], st));
-            launch_finalize(v, it, e_rel, min_iter, check, st);
             if (ev) SMI_HIP(hipEventRecord(ev[3], st));
             if (ev) SMI_HIP(hipEventRecord(ev[4], st));
-            if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, st)))
+            // (the loss bookkeeping rides along with the updates: kernels.hip, finalize_blend)
+            if ((rc = launch_update_finalize(v, b->Q, it, e_rel, min_iter, check, prox_max_iter, st)))
                 return rc;
             if (check) launch_advance(v, st);
             if (ev) SMI_HIP(hipEventRecord(ev[5], st));
@@ -1853,7 +1853,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
     const int check = check_convergence != 0;
     const bool timing = b->timing;
     const int n_sub = sub_ranges(b);
-    const bool no_cube = inline_render(b);
+    const bool no_cube = inline_render(b), plain = plain_batch(b);
     if (n_sub > 1) {
         if ((rc = step_sub_ranges(b, n_sub, it0, n_iter, e_rel, min_iter, prox_max_iter, check)))
             return rc;
@@ -1882,7 +1882,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
                 return rc;
             if ((rc = layers_evaluate(b, v, 1, b->stream))) return rc;
             if (ev) SMI_HIP(hipEventRecord(ev[2], b->stream));
-            launch_finalize(v, it, e_rel, min_iter, check, b->stream);
+            if (!plain) launch_finalize(v, it, e_rel, min_iter, check, b->stream);
             if (ev) SMI_HIP(hipEventRecord(ev[3], b->stream));
             if (ev) SMI_HIP(hipEventRecord(ev[4], b->stream));
         } else {
@@ -1899,8 +1899,14 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
         }
         lowres_add_all(b);
         if ((rc = launch_shift_backward(v, b->Q, it, nullptr, 0, b->stream))) return rc;
-        if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0, b->stream)))
+        if (plain) {  // (the loss bookkeeping rides along with the updates)
+            if ((rc = launch_update_finalize(v, b->Q, it, e_rel, min_iter, check, prox_max_iter,
+                                             b->stream)))
+                return rc;
+        } else if ((rc = launch_update(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0,
+                                       b->stream))) {
             return rc;
+        }
         if ((rc = launch_point_sources(v, b->Q, it, e_rel, prox_max_iter, nullptr, nullptr, 0,
                                        b->stream)))
             return rc;

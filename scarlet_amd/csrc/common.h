@@ -218,6 +218,9 @@ void launch_cmul(float2 *S, const float2 *K, int32_t nb, int32_t C, int64_t plan
 int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
                   int32_t prox_max_iter, float *g_sed_out, float *g_morph_out,
                   int32_t grad_only, hipStream_t s);
+int launch_update_finalize(const BatchView &v, const float *G, int32_t it, float e_rel,
+                           int32_t min_iter, int32_t check, int32_t prox_max_iter,
+                           hipStream_t s);
 // mode 0: one optimizer step of every point source (spectrum + centre), 1: gradients only
 // (g_sed_out, g_center_out[n_comp][2]), 2: evaluate the morphologies from the centres
 int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e_rel,

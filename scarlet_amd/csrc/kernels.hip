@@ -198,16 +198,20 @@ __global__ __launch_bounds__(kPixBlock) void residual_kernel(BatchView v, const 
     }
 }
 
-// loss bookkeeping + convergence test of Blend._callback (blend.py:294-299)
-__global__ __launch_bounds__(64) void finalize_kernel(BatchView v, int it, float e_rel,
-                                                      int min_iter, int check) {
-    const int b = blockIdx.x + v.blend0;
+// loss bookkeeping + convergence test of Blend._callback (blend.py:294-299) for blend b, by
+// one wavefront.  Nothing here is read by the component updates of the same iteration (they
+// only ask whether state >= 2, which advance_kernel sets afterwards), so the workgroups that
+// run this may share a launch with them (update_kernel_reg); the non-finite flag (state 3)
+// an update may raise at the same time survives: 0 -> 1 is a compare-and-swap.
+__device__ __forceinline__ void finalize_blend(const BatchView &v, int b, int it, float e_rel,
+                                               int min_iter, int check) {
     if (v.state[b] >= 2) return;
+    const int lane = threadIdx.x & 63;
     double t = 0.0;
-    for (int i = threadIdx.x; i < v.n_partial; i += 64)
+    for (int i = lane; i < v.n_partial; i += 64)
         t += v.loss_partial[(int64_t)b * v.n_partial + i];
     t = wave_sum(t);
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         double loss = v.log_norm[b] + 0.5 * t;
         for (int i = 0; i < v.n_extra; ++i) loss += v.extra_term[i];
         const int n = v.n_loss[b];
@@ -217,8 +221,13 @@ __global__ __launch_bounds__(64) void finalize_kernel(BatchView v, int it, float
         v.last_loss[b] = loss;
         if (check && (n >= 1 || v.have_prev[b]) && it > min_iter &&
             fabs(loss - prev) < (double)e_rel * fabs(loss))
-            v.state[b] = 1;  // this iteration's update is the last one
+            atomicCAS(&v.state[b], 0, 1);  // this iteration's update is the last one
     }
+}
+
+__global__ __launch_bounds__(64) void finalize_kernel(BatchView v, int it, float e_rel,
+                                                      int min_iter, int check) {
+    finalize_blend(v, blockIdx.x + v.blend0, it, e_rel, min_iter, check);
 }
 
 __global__ void advance_kernel(int32_t *state, int nb) {
@@ -1567,13 +1576,22 @@ constexpr int update_pack_max(int npl, int team) {
 }
 template <int NPL, int MODE, int T>
 __global__ __launch_bounds__(T * update_pack_max(NPL, T)) SMI_WAVES void update_kernel_reg(
-    BatchView v, const float *G, int it, float e_rel, int prox_max_iter, int n_items) {
+    BatchView v, const float *G, int it, float e_rel, int prox_max_iter, int n_items,
+    int n_finalize, int min_iter, int check) {
     constexpr int kPack = update_pack_max(NPL, T);
     __shared__ float sed_new[kPack][64];
     // (wave-uniform, and said so: the work item must stay in scalar registers)
     const int wave = T == 64 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int pack = T == 64 ? (int)(blockDim.x >> 6) : 1;
     const int n_blocks = (n_items + pack - 1) / pack;
+    // the last n_finalize workgroups do the loss bookkeeping of the range's blends (one
+    // each): independent of the updates, so it rides along instead of being a launch of its
+    // own between the convolution and the updates (finalize_blend)
+    if ((int)blockIdx.x >= n_blocks) {
+        if (threadIdx.x < 64)
+            finalize_blend(v, (int)blockIdx.x - n_blocks + v.blend0, it, e_rel, min_iter, check);
+        return;
+    }
     const int item = xcd_contiguous(blockIdx.x, n_blocks) * pack + wave;
     if (item >= n_items) return;
     update_component<NPL, MODE, T>(v, G, it, e_rel, prox_max_iter, v.work[item + v.work0],
@@ -1776,12 +1794,22 @@ static size_t update_lds_bytes(const BatchView &v) {
     return bytes + (size_t)(v.max_levels + 2) * sizeof(int32_t);
 }
 
+// loss bookkeeping waiting for a launch to ride along with (launch_update_finalize)
+struct PendingFinalize {
+    bool on = false;
+    int32_t min_iter = 0, check = 0;
+};
+static thread_local PendingFinalize pending_finalize;
+
 template <int NPL, int T>
 static int launch_update_reg(const BatchView &v, const float *G, int32_t it, float e_rel,
                              int32_t prox_max_iter, int32_t item0, int32_t n_items,
                              hipStream_t s) {
     BatchView vi = v;
     vi.work0 = item0;
+    const PendingFinalize fin = pending_finalize;
+    pending_finalize.on = false;
+    const int n_fin = fin.on ? v.nb : 0;
     // small launches are packed (update_kernel_reg); a launch that fills the chip anyway keeps
     // one wavefront per workgroup, whose slots free up one by one.  SMI_UPDATE_PACK (development
     // aid) overrides the number of wavefronts per workgroup.
@@ -1792,7 +1820,7 @@ static int launch_update_reg(const BatchView &v, const float *G, int32_t it, flo
     int pack = n_items <= kUpdatePackLimit ? update_pack_max(NPL, T) : 1;
     if (forced > 0) pack = std::min(forced, update_pack_max(NPL, T));
     const size_t lds = (size_t)pack * (T * NPL + 4) * sizeof(float);
-    const dim3 grid((n_items + pack - 1) / pack), block(T * pack);
+    const dim3 grid((n_items + pack - 1) / pack + n_fin), block(T * pack);
 #define SMI_LAUNCH(MODE)                                                                        \
     {                                                                                           \
         static size_t configured[kMaxDevices] = {};                                             \
@@ -1800,12 +1828,38 @@ static int launch_update_reg(const BatchView &v, const float *G, int32_t it, flo
         if (lds > 48 * 1024)                                                                    \
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) \
                 return rc;                                                                      \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, vi, G, it, e_rel, prox_max_iter, n_items); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, vi, G, it, e_rel, prox_max_iter, n_items, \
+                           n_fin, fin.min_iter, fin.check);                                     \
     }
     if (v.scheme == SMI_SCHEME_FISTA) SMI_LAUNCH(2)
     else if (v.lite) SMI_LAUNCH(1)
     else SMI_LAUNCH(0)
 #undef SMI_LAUNCH
+    return SMI_OK;
+}
+
+// finalize + update of one iteration: the loss bookkeeping shares the first launch of a
+// register-resident size class; where no such launch exists (mixed / general kernels, a
+// range without components) it is the kernel of its own it used to be
+int launch_update_finalize(const BatchView &v, const float *G, int32_t it, float e_rel,
+                           int32_t min_iter, int32_t check, int32_t prox_max_iter,
+                           hipStream_t s) {
+    static const int mode = [] {  // development aid: 0 never, 1 always, default: small launches
+        const char *e = getenv("SMI_FOLD_FINALIZE");
+        return e ? atoi(e) : 2;
+    }();
+    if (mode == 0 || (mode == 2 && v.n_comp > kUpdatePackLimit)) {
+        launch_finalize(v, it, e_rel, min_iter, check, s);
+        return launch_update(v, G, it, e_rel, prox_max_iter, nullptr, nullptr, 0, s);
+    }
+    pending_finalize.on = true;
+    pending_finalize.min_iter = min_iter;
+    pending_finalize.check = check;
+    const int rc = launch_update(v, G, it, e_rel, prox_max_iter, nullptr, nullptr, 0, s);
+    const bool left = pending_finalize.on;
+    pending_finalize.on = false;
+    if (rc) return rc;
+    if (left) launch_finalize(v, it, e_rel, min_iter, check, s);
     return SMI_OK;
 }
 
