@@ -1609,8 +1609,13 @@ __global__ __launch_bounds__(T * update_pack_max(NPL, T)) SMI_WAVES void update_
 // small classes starts to count), hence kMixedUpdateLimit.
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void update_kernel_mixed(
-    BatchView v, const float *G, int it, float e_rel, int prox_max_iter) {
+    BatchView v, const float *G, int it, float e_rel, int prox_max_iter, int n_finalize,
+    int min_iter, int check) {
     __shared__ float sed_new[64];
+    if ((int)blockIdx.x >= v.n_comp) {  // loss bookkeeping riding along (update_kernel_reg)
+        finalize_blend(v, (int)blockIdx.x - v.n_comp + v.blend0, it, e_rel, min_iter, check);
+        return;
+    }
     const int k = v.comp0 + blockIdx.x;
     if (v.c_flags[k] & SMI_COMPONENT_POINT_SOURCE) return;
     const int n = v.c_h[k] * v.c_w[k];  // uniform over the wavefront
@@ -1880,15 +1885,19 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
         }
         if (classes > 1 && !large && v.n_comp <= kMixedUpdateLimit) {
             const size_t lds = (size_t)(64 * kUpdateNpl[kNumUpdateClasses - 1] + 4) * sizeof(float);
+            const PendingFinalize fin = pending_finalize;
+            pending_finalize.on = false;
+            const int n_fin = fin.on ? v.nb : 0;
+            const dim3 grid(v.n_comp + n_fin);
             if (v.scheme == SMI_SCHEME_FISTA)
-                hipLaunchKernelGGL(update_kernel_mixed<2>, dim3(v.n_comp), dim3(64), lds, s, v, G, it,
-                                   e_rel, prox_max_iter);
+                hipLaunchKernelGGL(update_kernel_mixed<2>, grid, dim3(64), lds, s, v, G, it,
+                                   e_rel, prox_max_iter, n_fin, fin.min_iter, fin.check);
             else if (v.lite)
-                hipLaunchKernelGGL(update_kernel_mixed<1>, dim3(v.n_comp), dim3(64), lds, s, v, G, it,
-                                   e_rel, prox_max_iter);
+                hipLaunchKernelGGL(update_kernel_mixed<1>, grid, dim3(64), lds, s, v, G, it,
+                                   e_rel, prox_max_iter, n_fin, fin.min_iter, fin.check);
             else
-                hipLaunchKernelGGL(update_kernel_mixed<0>, dim3(v.n_comp), dim3(64), lds, s, v, G, it,
-                                   e_rel, prox_max_iter);
+                hipLaunchKernelGGL(update_kernel_mixed<0>, grid, dim3(64), lds, s, v, G, it,
+                                   e_rel, prox_max_iter, n_fin, fin.min_iter, fin.check);
             return SMI_OK;
         }
         // one launch per size class that has components in this range of blends, the
