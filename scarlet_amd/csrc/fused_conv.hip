@@ -6,9 +6,10 @@
 // (renderer.py:247-259 / fft.py:368-396 forward, its transpose backward,
 // observation.py:147-170 in between) by ONE kernel that keeps the half-spectrum of
 // the band in LDS from the first row transform to the last: per blend-iteration the
-// only HBM traffic left is the model cube, data and weights (read once) and the
-// gradient image (written once).  The model cube itself comes from render_kernel
-// (kernels.hip).
+// only HBM traffic left is the model, data and weights (read once) and the gradient
+// image (written once).  The model comes as a cube from render_kernel (kernels.hip) or,
+// for a batch of nothing but factorized components, is rendered here row by row from the
+// components' spectra and morphologies (ModelGather below): no cube, no launch.
 //
 // Layout: ONE array T[kx][y], kx in [0, FX/2]; element y of a column sits at y + y / 16
 // and the column stride SY is 4 mod 8 complex.  1-D transforms of length F = F1 * 16 are
