@@ -1025,8 +1025,16 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
     for i, b in enumerate(blends):
         b._psf, b._scheme = None, ("amsgrad", 0.25)  # nothing left over from an earlier fit()
         if any(not p.fixed for obs in b.observations for p in obs.parameters):
-            raise NotImplementedError("fit_blends: a blend with free renderer parameters "
-                                      "(psf_shift) fits through Blend.fit")
+            solo.add(i)  # free renderer parameters (psf_shift): Blend.fit's own loop
+            continue
+        b._observation()
+        if b._lowres or b._extra_layers:
+            # a ResolutionRenderer observation / several observations of one channel are
+            # terms of ONE blend's loss on the device (smi_batch_attach_lowres,
+            # smi_batch_add_observation): such a blend is fitted by itself, like
+            # [b.fit() for b in blends] would (scarlet/testing/api.py:216-224)
+            solo.add(i)
+            continue
         b._specs(_flatten(b.sources))
         if b._host:
             solo.add(i)

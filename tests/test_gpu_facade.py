@@ -491,6 +491,71 @@ def test_fit_blends_equals_individual_fits(hsc):
     assert res[0][0] == res[1][0] == 5
 
 
+def test_fit_blends_fits_unbatchable_blends_by_themselves(hsc):
+    """``fit_blends`` stands for ``[b.fit() for b in blends]`` (scarlet/testing/api.py:216-224).
+    A blend with a second observation of the same channels (one more term of ITS loss on the
+    device) or with a free ``psf_shift`` cannot share a device batch with others; it used to
+    be refused, now it is fitted by itself inside the same call, with the results of its own
+    ``Blend.fit`` -- and the ordinary blends around it still share a batch."""
+    import scarlet_amd as scarlet
+    from scarlet_amd.renderer import ConvolutionRenderer
+
+    filters = list("grizy")
+    model_psf = scarlet.GaussianPSF(sigma=(0.8,) * 5)
+    frame = scarlet.Frame(hsc["images"].shape, psf=model_psf, channels=filters)
+
+    def sources():
+        out = []
+        for k in range(int(hsc["n_comp"])):
+            h, w = hsc["morph_%d" % k].shape
+            oy, ox = hsc["origin_%d" % k]
+            box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+            out.append(scarlet.FactorizedComponent(
+                frame,
+                scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                          min_step=hsc["min_step_%d" % k]),
+                scarlet.ExtendedSourceMorphology(frame, (oy + h // 2, ox + w // 2),
+                                                 hsc["morph_%d" % k].copy(), bbox=box[1:],
+                                                 resizing=False)))
+        return out
+
+    def plain():
+        obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                                  weights=hsc["weights"], channels=filters).match(frame)
+        return scarlet.Blend(sources(), obs)
+
+    def two_observations():
+        obs1 = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                                   weights=hsc["weights"], channels=filters).match(frame)
+        psfs2 = scarlet.GaussianPSF(sigma=(1.6, 1.7, 1.8), boxsize=31).get_model().astype(np.float32)
+        obs2 = scarlet.Observation((hsc["images"][:3] * 0.9).astype(np.float32),
+                                   psf=scarlet.ImagePSF(psfs2),
+                                   weights=(hsc["weights"][:3] * 0.5).astype(np.float32),
+                                   channels=filters[:3]).match(frame)
+        return scarlet.Blend(sources(), [obs1, obs2])
+
+    def shifted_psf():
+        obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                                  weights=hsc["weights"], channels=filters)
+        obs.match(frame, renderer=ConvolutionRenderer(obs, frame, psf_shift=np.array([0.2, -0.1])))
+        return scarlet.Blend(sources(), obs)
+
+    makers = [plain, two_observations, plain, shifted_psf]
+    alone = []
+    for make in makers:
+        b = make()
+        alone.append((b.fit(12, e_rel=1e-9), np.array(b.loss)))
+    many = [make() for make in makers]
+    out = scarlet.fit_blends(many, 12, e_rel=1e-9)
+    assert scarlet.fit_blends.errors == []
+    for b, res, (res_alone, loss_alone) in zip(many, out, alone):
+        assert res[0] == res_alone[0] == 12
+        assert_allclose(np.array(b.loss), loss_alone, rtol=1e-12)
+        assert res[1] == res_alone[1]
+    assert len(many[1]._extra_layers) == 1
+    assert out[0] == out[2] and out[1] != out[0] and out[3] != out[0]
+
+
 def test_psf_shift_renderer(hsc):
     """ConvolutionRenderer(psf_shift=...): rendering with the shifted kernel equals the
     reference's (golden), and the host-stepped fit (shift = free parameter of the
