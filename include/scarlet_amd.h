@@ -229,6 +229,16 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w,
                              const double *weights, const int32_t *offsets,
                              const int32_t *dist_idx, int32_t n_idx);
 
+/* The ring schedule the update kernels derive from such tables when they are the radial ones
+ * of operator.py:591-667 (host only, no GPU; csrc/common.h describes the schedule).  Returns
+ * 1 and fills info = {planes, n_steps, n_pad, rmax, centre, perm, lanes, 0} when the tables
+ * qualify, 0 when they do not (the kernels then keep the level plan), < 0 on bad arguments.
+ * With capacity >= lanes also wts[lanes][4] (weights by role A, B, C, D) and addr[lanes]
+ * (16 + 4 * pixel, 0 = idle); lanes = (n_pad + 6) * planes * 64, step major. */
+int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t *offsets,
+                        const int32_t *dist_idx, int32_t n_idx, int32_t info[8], float *wts,
+                        uint16_t *addr, int64_t capacity);
+
 /* data, weights: [n_blends][C][H][W] float32 (observation.py:52-57).  The _device
  * form adopts device buffers (e.g. torch tensors) without copying; they must stay
  * alive and unchanged while the batch uses them. */

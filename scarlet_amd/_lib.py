@@ -134,6 +134,11 @@ SYMBOLS = {
         [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_f64p, c_i32p, c_i32p,
          ctypes.c_int32],
     ),
+    "smi_sweep_ring_plan": (
+        ctypes.c_int,
+        [ctypes.c_int32, ctypes.c_int32, c_f64p, c_i32p, c_i32p, ctypes.c_int32, c_i32p, c_f32p,
+         ctypes.POINTER(ctypes.c_uint16), ctypes.c_int64],
+    ),
     "smi_batch_set_observation": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
     "smi_batch_set_observation_device": (
         ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]

@@ -257,6 +257,7 @@ struct smi_batch {
     float *Q2 = nullptr;
     // work items of the register-resident update kernels (common.h, BatchView::work)
     int32_t *work_items = nullptr;
+    int32_t stage_plan[kNumUpdateClasses];
     std::vector<int32_t> h_work_start;  // [kNumUpdateClasses][n_blends + 1]
     std::vector<hipStream_t> sub_streams;
     std::vector<hipEvent_t> sub_events;  // [0] fork, [s] join of range s >= 1
@@ -356,6 +357,12 @@ void refresh_view(smi_batch *b) {
     v.work0 = 0;
     v.work_start = b->h_work_start.data();
     v.nb_total = b->d.n_blends;
+    for (int cls = 0; cls < kNumUpdateClasses; ++cls) {
+        const int p = b->have_components ? b->stage_plan[cls] : -1;
+        const bool ok = p >= 0 && p < (int)b->plans.size() && b->plans[p].ring;
+        v.stage_plan[cls] = ok ? p : -1;
+        v.stage_bytes[cls] = ok ? b->plans[p].ring_bytes : 0;
+    }
     {
         const int slots = (b->max_box_w + 14) / 16 + 1;
         v.render_slots = slots <= 6 ? slots : 0;
@@ -783,6 +790,7 @@ int smi_batch_destroy(smi_batch *b) {
         (void)hipFree(pl.nbr);
         (void)hipFree(pl.wt);
         if (pl.slots) (void)hipFree(pl.slots);
+        if (pl.ring) (void)hipFree(const_cast<void *>(pl.ring));
     }
     void *bufs[] = {b->P, b->null_renderer ? nullptr : (void *)b->Q, b->S, b->Khat, b->Kt, b->work,
                     b->own_obs ? b->data : nullptr, b->own_obs ? b->weights : nullptr,
@@ -873,10 +881,50 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
             for (int lane = 0; lane < 64; ++lane) slots[step * 64 + lane].lanes_ahead = used[step + 3];
         if ((rc = upload(&dp.slots, slots.data(), slots.size()))) return rc;
     }
+    // ring schedule of the radial tables (common.h); SMI_RING_SWEEP=0 keeps the slot plan
+    // (development aid: A/B runs)
+    static const bool use_ring = [] {
+        const char *e = getenv("SMI_RING_SWEEP");
+        return !e || atoi(e) != 0;
+    }();
+    RingPlanHost rp;
+    if (use_ring && dp.slots && build_ring_plan(h, w, weights, offsets, 8, dist_idx, n_idx, &rp) &&
+        rp.planes == 1) {
+        const size_t lanes = rp.addr.size();
+        std::vector<uint8_t> buf(lanes * 18);
+        memcpy(buf.data(), rp.wts.data(), lanes * 16);
+        memcpy(buf.data() + lanes * 16, rp.addr.data(), lanes * 2);
+        uint8_t *d_ring = nullptr;
+        if ((rc = upload(&d_ring, buf.data(), buf.size()))) return rc;
+        dp.ring = d_ring;
+        dp.ring_planes = rp.planes;
+        dp.ring_pad = rp.n_pad;
+        dp.ring_rmax = rp.rmax;
+        dp.ring_centre = rp.centre;
+        dp.ring_perm = rp.perm;
+        dp.ring_bytes = (uint32_t)buf.size();
+    }
     b->plans.push_back(dp);
     if (dp.n_levels > b->max_levels) b->max_levels = dp.n_levels;
     if ((rc = upload_plans(b))) return rc;
     return (int)b->plans.size() - 1;
+}
+
+int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t *offsets,
+                        const int32_t *dist_idx, int32_t n_idx, int32_t info[8], float *wts,
+                        uint16_t *addr, int64_t capacity) {
+    SMI_REQUIRE(weights && offsets && dist_idx && info, "null argument");
+    SMI_REQUIRE(h > 0 && w > 0, "empty box");
+    RingPlanHost rp;
+    if (!build_ring_plan(h, w, weights, offsets, 8, dist_idx, n_idx, &rp)) return 0;
+    const int32_t vals[8] = {rp.planes, rp.n_steps, rp.n_pad, rp.rmax, rp.centre, (int32_t)rp.perm,
+                             (int32_t)rp.addr.size(), 0};
+    memcpy(info, vals, sizeof(vals));
+    if (wts && addr && capacity >= (int64_t)rp.addr.size()) {
+        memcpy(wts, rp.wts.data(), rp.wts.size() * sizeof(float));
+        memcpy(addr, rp.addr.data(), rp.addr.size() * sizeof(uint16_t));
+    }
+    return 1;
 }
 
 int smi_batch_set_observation(smi_batch *b, const float *data, const float *weights) {
@@ -1462,6 +1510,22 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         }
         work.push_back(-1);  // never empty
         if ((rc = upload(&b->work_items, work.data(), work.size()))) return rc;
+        // the plan most monotonic components of a class use: the one its launches stage in LDS
+        for (int cls = 0; cls < kNumUpdateClasses; ++cls) {
+            std::map<int32_t, int> uses;
+            for (int32_t k : items[cls])
+                if ((c->prox_flags[k] & SMI_PROX_MONOTONIC) && !(c->prox_flags[k] & SMI_PROX_FIT_CENTER) &&
+                    c->sweep_plan && c->sweep_plan[k] >= 0)
+                    uses[c->sweep_plan[k]]++;
+            int32_t best = -1;
+            int most = 0;
+            for (const auto &u : uses)
+                if (u.second > most && u.first < (int)b->plans.size() && b->plans[u.first].ring) {
+                    best = u.first;
+                    most = u.second;
+                }
+            b->stage_plan[cls] = best;
+        }
     }
     b->have_components = true;
     const int keep = b->view.max_box_pixels;
@@ -2099,6 +2163,37 @@ int smi_debug_fused_stamps(smi_batch *b, long long *out6) {
     SMI_HIP(hipStreamSynchronize(b->stream));
     SMI_HIP(hipMemcpy(out6, b->dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     return SMI_OK;
+}
+
+// development aid (not in the public header): shader clocks of n_rep monotonic sweeps per
+// wavefront (mode 0: slot plan, 1: ring schedule), `waves` wavefronts per workgroup, and the
+// swept images [groups * waves][h * w]
+int smi_debug_sweep_cycles(smi_batch *b, int32_t plan_id, int32_t mode, int32_t n_rep,
+                           float min_gradient, int32_t waves, int32_t groups, long long *cycles,
+                           float *images) {
+    SMI_REQUIRE(b && cycles && images, "null argument");
+    SMI_REQUIRE(plan_id >= 0 && plan_id < (int)b->plans.size(), "no such plan");
+    SMI_HIP(hipSetDevice(b->device));
+    const SweepPlanDev &pl = b->plans[plan_id];
+    const size_t nw = (size_t)waves * groups, n = (size_t)pl.h * pl.w;
+    long long *d_cycles = nullptr;
+    float *d_images = nullptr;
+    SMI_HIP(dev_alloc(&d_cycles, nw));
+    SMI_HIP(dev_alloc(&d_images, nw * n));
+    int rc = launch_sweep_timing(b->d_plans, pl, plan_id, mode, n_rep, 1.f - min_gradient, waves,
+                                 groups, d_cycles, d_images, b->stream);
+    if (rc == SMI_OK) {
+        hipError_t e = hipStreamSynchronize(b->stream);
+        if (e == hipSuccess) e = hipMemcpy(cycles, d_cycles, nw * sizeof(long long), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(images, d_images, nw * n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = SMI_ERR_HIP;
+        }
+    }
+    (void)hipFree(d_cycles);
+    (void)hipFree(d_images);
+    return rc;
 }
 
 int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w) {

@@ -118,9 +118,52 @@ inline int update_image_stride(int n_pix) {
     return kUpdateTeam[c] * kUpdateNpl[c] + 4;
 }
 
+// ---------------------------------------------------------------------------
+// Ring schedule of the radial tables (operator.py:591-667), the plan the update kernels
+// prefer.  With r = max(|Y|, |X|) the ring of a pixel around the peak and j = min(|Y|, |X|)
+// its position along the ring inside its octant, the neighbours strictly nearer the peak are
+//     A = (r-1, j-1)   B = (r-1, j)   C = (r-1, j+1) [j < r-1]   D = (r, j-1),
+// so pixel (r, j) is final after level L = 2 r + j - 1: A is final at L - 3, B at L - 2, C and
+// D at L - 1.  One lane per (octant, r mod 8 P) with P "planes" of 64 lanes: the lane walks
+// along its ring, one pixel per level, then waits for ring r + 8 P.  Its operands are its own
+// previous result (D) and the last three results of the lane of ring r - 1 (A, B, C), which
+// arrive by DPP row rotations: the sweep reads the image only for the pixel itself.  Axis
+// pixels (j = 0) take A from the octant across the axis, diagonal pixels (j = r) take B from
+// the octant across the diagonal, and either octant computes them (same operands, same order).
+// The sum runs in the order of the reference's neighbour table, a constant of the octant:
+// A, B, C ascending or descending with D at position `pd` (3 bits per octant in `perm`).
+//
+// Lane layout: lane = row * 16 + half * 8 + (r mod 8); rows = octant pairs that share an axis
+// (+x, +y, -x, -y), halves = sign along the minor axis ((-,+), (+,-), (+,-), (-,+)).
+//
+// Device stream, `n_pad` + kRingAhead steps of 64 P lanes each (n_pad = steps rounded up to
+// the unrolling of the loop, idle entries behind): float4 weights by role (A, B, C, D), then
+// uint16 LDS byte addresses 16 + 4 * pixel (0 = idle: the spare cell in front of the image).
+// ---------------------------------------------------------------------------
+constexpr int kRingUnroll = 6;   // steps per loop iteration (period of the axis / diagonal phases)
+constexpr int kRingAhead = 6;    // steps the address stream is requested ahead
+constexpr int kRingMaxPlanes = 2;
+struct RingPlanHost {
+    int32_t planes = 0;   // 1: rings up to 23, 2: up to 47
+    int32_t n_steps = 0;  // 3 rmax - 1
+    int32_t n_pad = 0;
+    int32_t rmax = 0;
+    int32_t centre = 0;   // flat index of the peak
+    uint32_t perm = 0;    // per octant (row * 2 + half): bit 0 = A, B, C ascending, bits 1-2 = pd
+    std::vector<float> wts;      // [n_pad + kRingAhead][planes][64][4]
+    std::vector<uint16_t> addr;  // [n_pad + kRingAhead][planes][64]
+};
+// false (no error set) when the tables do not have the radial structure or the box is too large
+bool build_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t *offsets,
+                     int32_t n_off, const int32_t *dist_idx, int32_t n_idx, RingPlanHost *out);
+
 struct SweepPlanDev {
     int32_t h = 0, w = 0, n_entries = 0, max_terms = 0, n_levels = 0;
     int32_t n_slots = 0;
+    // ring schedule (nullptr: the tables are not radial, or rings beyond 8 * kRingMaxPlanes - 1)
+    const void *ring = nullptr;
+    int32_t ring_planes = 0, ring_pad = 0, ring_rmax = 0, ring_centre = 0;
+    uint32_t ring_perm = 0, ring_bytes = 0;
     SweepSlotEntry *slots = nullptr;  // nullptr when the plan does not fit the fast path
     int32_t *level_start = nullptr;
     int32_t *pix = nullptr;
@@ -205,6 +248,11 @@ struct BatchView {
     int32_t render_slots;
     const int32_t *work_start;
     int32_t nb_total;
+    // register-resident update kernels with the ring plan staged in LDS (update_kernel_reg):
+    // per size class the plan most of its components use (-1: none has a ring schedule) and
+    // the bytes of its stream
+    int32_t stage_plan[kNumUpdateClasses];
+    uint32_t stage_bytes[kNumUpdateClasses];
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);
@@ -278,6 +326,9 @@ void lowres_destroy(LowRes *l);
 int lowres_evaluate(LowRes *l, const float *P, int Py, int Px, int backward, hipStream_t s);
 void lowres_add_gradient(LowRes *l, float *Q, int Py, int Px, hipStream_t s);
 int lowres_get_rendered(LowRes *l, float *out, hipStream_t s);
+int launch_sweep_timing(const SweepPlanDev *d_plans, const SweepPlanDev &host_plan, int plan_id,
+                        int mode, int n_rep, float one_minus_g, int waves, int groups,
+                        long long *cycles, float *images, hipStream_t s);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);
 void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,

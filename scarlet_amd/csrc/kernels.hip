@@ -8,6 +8,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -710,6 +711,8 @@ __device__ __forceinline__ void monotonic_mask(const float *us, float *ws, uint8
 // -- generic variant: everything in LDS, plans with any number of terms -----
 __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slots, int n_slots,
                                             float one_minus_g, int lane);
+__device__ __forceinline__ void sweep_ring(float *us, const SweepPlanDev &pl, float one_minus_g,
+                                           int lane);
 // T threads per component (Team): 64, or 256 for boxes of more than 64 x 59 pixels
 template <int T>
 __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, int it,
@@ -1104,6 +1107,18 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 #ifndef SMI_SWEEP_DRAIN
 #define SMI_SWEEP_DRAIN 0
 #endif
+#ifndef SMI_EXP_NOPLAN
+#define SMI_EXP_NOPLAN 0
+#endif
+#ifndef SMI_EXP_NODYN
+#define SMI_EXP_NODYN 0
+#endif
+#ifndef SMI_EXP_NODIAG
+#define SMI_EXP_NODIAG 0
+#endif
+#ifndef SMI_EXP_NOLDS
+#define SMI_EXP_NOLDS 0
+#endif
 __device__ __forceinline__ void sweep_fence() {
 #if SMI_SWEEP_DRAIN
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1201,6 +1216,160 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
     }
 }
 
+// -- ring schedule of the radial tables (common.h: RingPlanHost) --------------------------
+// One lane per (octant, ring mod 8): the operands of a step are the lane's own previous result
+// and the last three results of the lane of the next inner ring, fetched by DPP row rotations
+// (lane = row * 16 + half * 8 + m: the inner ring is lane - 1, or lane + 7 when m = 0; the
+// same two rotations with the roles swapped reach the octant across the axis).  The image in
+// LDS is touched once per pixel: read ahead of the step, written behind it.
+__device__ __forceinline__ float dpp_ror1(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_ror9(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x129, 0xf, 0xf, false));
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Where the plan stream of a ring sweep comes from: the plan's device buffer (buffer loads,
+// weights three and addresses six steps ahead; lanes without a pixel do not fetch weights), or
+// a copy in LDS that the workgroup staged (RingLds: one and two steps ahead).
+struct RingGlobal {
+    static constexpr int kWeightsAhead = 3, kAddrAhead = kRingAhead;
+    rsrc_t r;
+    uint32_t vo_w, vo_a;
+    __device__ __forceinline__ RingGlobal(const SweepPlanDev &pl, int n_pad, int lane) {
+        const uint64_t sp = reinterpret_cast<uint64_t>(pl.ring);
+        const uint32_t sp_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sp);
+        const uint32_t sp_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sp >> 32));
+        r = make_rsrc(reinterpret_cast<const void *>((uint64_t)sp_lo | ((uint64_t)sp_hi << 32)),
+                      (uint32_t)(n_pad + kRingAhead) * (1024u + 128u));
+        vo_w = (uint32_t)lane * 16u;
+        vo_a = (uint32_t)(n_pad + kRingAhead) * 1024u + (uint32_t)lane * 2u;
+    }
+    __device__ __forceinline__ uint32_t addr(int step) const {
+        return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, vo_a, step * 128, 0);
+    }
+    __device__ __forceinline__ f32x4 weights(int step, uint32_t a) const {
+        return __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a ? vo_w : kOutOfRange, step * 1024, 0));
+    }
+};
+struct RingLds {
+    static constexpr int kWeightsAhead = 1, kAddrAhead = 2;
+    const char *w, *a;  // this lane's entries of step 0
+    __device__ __forceinline__ RingLds(const char *plan, int n_pad, int lane) {
+        w = plan + lane * 16;
+        a = plan + (n_pad + kRingAhead) * 1024 + lane * 2;
+    }
+    __device__ __forceinline__ uint32_t addr(int step) const {
+        return *reinterpret_cast<const uint16_t *>(a + step * 128);
+    }
+    __device__ __forceinline__ f32x4 weights(int step, uint32_t) const {
+        return *reinterpret_cast<const f32x4 *>(w + step * 1024);
+    }
+};
+
+// The 16 bytes in front of `us` are the spare cell (idle lanes); n_pad, rmax, perm, centre:
+// the plan's ring_* fields, wave-uniform.
+template <class Plan>
+__device__ __forceinline__ void sweep_ring_loop(float *us, const Plan &plan, int n_pad, int rmax,
+                                                uint32_t perm, int centre_pix, float one_minus_g,
+                                                int lane) {
+    constexpr int DW = Plan::kWeightsAhead, DA = Plan::kAddrAhead;
+    static_assert(kRingUnroll == 6 && DA <= 6 && DW < DA, "register rotation of the loop");
+    char *base = reinterpret_cast<char *>(us) - 16;
+    auto lds = [&](uint32_t a) { return reinterpret_cast<float *>(base + a); };
+
+    // constants of the lane
+    const int m = lane & 7;
+    const bool inner = m >= 1;  // the lane of ring r - 1 sits right below
+    const uint32_t code = (perm >> (3 * (lane >> 3))) & 7u;
+    const bool asc = code & 1u;
+    // position of D in the sum; the first two terms commute (0 + x + y), so 0 counts as 1
+    const uint32_t pd = code >> 1;
+    const bool pd01 = pd <= 1, pd2 = pd == 2, pd3 = pd == 3;
+    // octant across the diagonal: lane + 8 for the second halves, lane - 8 for the first
+    const int diag_addr = (((lane & 8) ? lane + 8 : lane - 8) & 63) * 4;
+
+    // idle lanes read, keep and pass on the spare cell: it must hold a finite value (0 times it
+    // is added to their neighbours' sums)
+    *lds(0) = 0.f;
+    const float centre = us[centre_pix];
+    float out = centre, c1 = centre, c2 = centre, c3 = centre;
+
+    uint32_t a[6];
+    f32x4 w[6];
+#pragma unroll
+    for (int i = 0; i < DA; ++i) a[i] = plan.addr(i);
+#pragma unroll
+    for (int i = 0; i < DW; ++i) w[i] = plan.weights(i, a[i]);
+    float cur = *lds(a[0]);
+
+    // one level; I = step within the unrolled iteration (levels L = s + I + 1: axis pixels at
+    // odd L, diagonal pixels at L = 3 r - 1)
+    auto step = [&](auto Ic, int s) {
+        constexpr int I = decltype(Ic)::value;
+        w[(I + DW) % 6] = plan.weights(s + I + DW, a[(I + DW) % 6]);
+        if (DA < 6) a[(I + DA) % 6] = plan.addr(s + I + DA);
+#if SMI_EXP_NOLDS
+        const float cur_next = __uint_as_float(a[(I + 1) % 6]);
+#else
+        const float cur_next = *lds(a[(I + 1) % 6]);
+#endif
+        const float f1 = dpp_ror1(out), f9 = dpp_ror9(out);
+        c3 = c2;
+        c2 = c1;
+        c1 = inner ? f1 : f9;
+        float A = c3, B = c2;
+        if (I % 2 == 0) {  // ring (L + 1) / 2 starts on the axis
+            const int ra = (s + I + 2) >> 1;
+            const int ma = ra <= rmax ? (ra & 7) : 8;
+            A = m == ma ? (inner ? f9 : f1) : c3;
+        }
+        if (I % 3 == 1 && !SMI_EXP_NODIAG) {  // ring (L + 1) / 3 ends on the diagonal
+            const int md = ((s + I + 2) / 3) & 7;
+            const float y = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(diag_addr, __builtin_bit_cast(int, out)));
+            B = m == md ? y : c2;
+        }
+        const f32x4 &wn = w[I];
+        const float pA = __fmul_rn(A, wn.x), pB = __fmul_rn(B, wn.y);
+        const float pC = __fmul_rn(c1, wn.z), pD = __fmul_rn(out, wn.w);
+        const float e0 = asc ? pA : pC, e2 = asc ? pC : pA;
+        float ref = __fadd_rn(0.f, e0);
+        ref = __fadd_rn(ref, pd01 ? pD : pB);
+        ref = __fadd_rn(ref, pd01 ? pB : (pd2 ? pD : e2));
+        ref = __fadd_rn(ref, pd3 ? pD : e2);
+        const float lim = __fmul_rn(ref, one_minus_g);
+        out = lim < cur ? lim : cur;
+#if !SMI_EXP_NOLDS
+        *lds(a[I]) = out;
+#endif
+        if (DA == 6) a[I] = plan.addr(s + I + 6);
+        cur = cur_next;
+    };
+    for (int s = 0; s < n_pad; s += kRingUnroll) {
+        step(std::integral_constant<int, 0>(), s);
+        step(std::integral_constant<int, 1>(), s);
+        step(std::integral_constant<int, 2>(), s);
+        step(std::integral_constant<int, 3>(), s);
+        step(std::integral_constant<int, 4>(), s);
+        step(std::integral_constant<int, 5>(), s);
+    }
+}
+
+// `pl` must be wave-uniform; the plan stream comes from its device buffer.
+__device__ __forceinline__ void sweep_ring(float *us, const SweepPlanDev &pl, float one_minus_g,
+                                           int lane) {
+    const int n_pad = __builtin_amdgcn_readfirstlane(pl.ring_pad);
+    sweep_ring_loop(us, RingGlobal(pl, n_pad, lane), n_pad,
+                    __builtin_amdgcn_readfirstlane(pl.ring_rmax),
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.ring_perm),
+                    __builtin_amdgcn_readfirstlane(pl.ring_centre), one_minus_g, lane);
+}
+
 // occupancy the register allocator has to reach (waves per SIMD): three arrays of NPL
 // registers + the sweep's prefetch; without the cap the scheduler trades waves for ILP
 #ifndef SMI_WAVES
@@ -1221,6 +1390,9 @@ struct UpdState {
     float alpha, pmax, t_old;
     bool monotonic, fit_center;
     const SweepSlotEntry *slots;
+    const SweepPlanDev *ring;  // the plan when it has a ring schedule
+    const SweepPlanDev *staged;  // the plan whose ring stream the workgroup holds in LDS ...
+    const char *plan_lds;        // ... there (nullptr: none)
     float one_minus_g, lthresh, cfloor, pfloor;
     const float *bg_level;
     float *us, *sed_new;
@@ -1408,10 +1580,12 @@ __device__ __forceinline__ void upd_step(const BatchView &v, const float *G, int
     S.monotonic = (flags & SMI_PROX_MONOTONIC) && plan_id >= 0;
     S.fit_center = LITE && S.monotonic && (flags & SMI_PROX_FIT_CENTER);
     S.slots = nullptr;
+    S.ring = nullptr;
     S.n_slots = 0;
     if (S.monotonic && !S.fit_center) {
         S.slots = v.plans[plan_id].slots;
         S.n_slots = v.plans[plan_id].n_slots;
+        S.ring = v.plans[plan_id].ring ? &v.plans[plan_id] : nullptr;
     }
     S.one_minus_g = 1.f - v.c_min_grad[k];
     S.ctr = (c.h / 2) * c.w + (c.w / 2);
@@ -1437,6 +1611,7 @@ __device__ __forceinline__ void upd_prox_plan(const BatchView &v, UpdState<NPL> 
         const SweepPlanDev &pl = v.plans[S.plan_id + centre];
         S.slots = pl.slots;
         S.n_slots = pl.n_slots;
+        S.ring = pl.ring ? &pl : nullptr;
     }
 }
 
@@ -1524,11 +1699,16 @@ __device__ __forceinline__ void upd_store(const BatchView &v, UpdState<NPL> &S) 
 template <int NPL, int MODE, int T = 64>
 __device__ __forceinline__ void update_component(const BatchView &v, const float *G, int it,
                                                  float e_rel, int prox_max_iter, int k,
-                                                 float *us, float *sed_new) {
+                                                 float *us, float *sed_new,
+                                                 const SweepPlanDev *staged = nullptr,
+                                                 const char *plan_lds = nullptr, int tid = -1) {
     constexpr bool fista = MODE == 2;
     UpdState<NPL> S;
     S.k = k;
-    S.c = comp_ctx(v, k, T == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x);
+    S.staged = staged;
+    S.plan_lds = plan_lds;
+    if (tid < 0) tid = (int)threadIdx.x;
+    S.c = comp_ctx(v, k, T == 64 ? (tid & 63) : tid);
     if (v.state[S.c.b] >= 2) return;
     S.us = us;
     S.sed_new = sed_new;
@@ -1542,8 +1722,17 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
         upd_prox_plan<NPL>(v, S);
         if (S.monotonic) {
             // one wavefront sweeps (the steps are sequential and at most 64 pixels wide)
-            if (T == 64 || threadIdx.x < 64)
-                sweep_slots(S.us, S.slots, S.n_slots, S.one_minus_g, S.c.lane);
+            if (T == 64 || threadIdx.x < 64) {
+                if (S.ring && S.ring == S.staged) {
+                    const int n_pad = __builtin_amdgcn_readfirstlane(S.ring->ring_pad);
+                    sweep_ring_loop(S.us, RingLds(S.plan_lds, n_pad, S.c.lane), n_pad,
+                                    __builtin_amdgcn_readfirstlane(S.ring->ring_rmax),
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ring->ring_perm),
+                                    __builtin_amdgcn_readfirstlane(S.ring->ring_centre),
+                                    S.one_minus_g, S.c.lane);
+                } else
+                    sweep_slots(S.us, S.slots, S.n_slots, S.one_minus_g, S.c.lane);
+            }
             if (T > 64) __syncthreads();
         }
         if (upd_prox_end<NPL, MODE, T>(v, e2, S)) break;
@@ -1574,16 +1763,26 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 constexpr int update_pack_max(int npl, int team) {
     return team != 64 ? 1 : 4 * (npl <= 16 ? 4 : npl <= 27 ? 3 : 2);
 }
+// With `stage_plan` >= 0 the workgroup first copies that plan's ring stream into the LDS behind
+// its images (common.h: RingPlanHost): the sweeps of the components that use the plan -- in a
+// batch of standard sources all of them -- read the stream from there (one ds_read_b128 and
+// one ds_read_u16 per step) instead of pulling 0.6 KB per step and wavefront through the
+// vector memory pipe, which is what bounded a full batch.  With `persistent` the workgroup owns
+// a contiguous share of the work list and its wavefronts take component after component from
+// it (a counter in LDS) until it is used up -- a workgroup that holds 150 KB of LDS must not
+// idle behind its slowest component.  (One global counter per XCD, measured: 10 240 atomic
+// additions on eight addresses take 0.25 ms, longer than the updates themselves.)
 template <int NPL, int MODE, int T>
 __global__ __launch_bounds__(T * update_pack_max(NPL, T)) SMI_WAVES void update_kernel_reg(
     BatchView v, const float *G, int it, float e_rel, int prox_max_iter, int n_items,
-    int n_finalize, int min_iter, int check) {
+    int n_finalize, int min_iter, int check, int stage_plan, int persistent) {
     constexpr int kPack = update_pack_max(NPL, T);
     __shared__ float sed_new[kPack][64];
+    __shared__ int next_item;
     // (wave-uniform, and said so: the work item must stay in scalar registers)
     const int wave = T == 64 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int pack = T == 64 ? (int)(blockDim.x >> 6) : 1;
-    const int n_blocks = (n_items + pack - 1) / pack;
+    const int n_blocks = (int)gridDim.x - n_finalize;
     // the last n_finalize workgroups do the loss bookkeeping of the range's blends (one
     // each): independent of the updates, so it rides along instead of being a launch of its
     // own between the convolution and the updates (finalize_blend)
@@ -1592,10 +1791,43 @@ __global__ __launch_bounds__(T * update_pack_max(NPL, T)) SMI_WAVES void update_
             finalize_blend(v, (int)blockIdx.x - n_blocks + v.blend0, it, e_rel, min_iter, check);
         return;
     }
-    const int item = xcd_contiguous(blockIdx.x, n_blocks) * pack + wave;
-    if (item >= n_items) return;
-    update_component<NPL, MODE, T>(v, G, it, e_rel, prox_max_iter, v.work[item + v.work0],
-                                   lds_dyn + wave * (T * NPL + 4) + 4, sed_new[wave]);
+    float *us = lds_dyn + wave * (T * NPL + 4) + 4;
+    const SweepPlanDev *staged = nullptr;
+    const char *plan_lds = nullptr;
+    if (T == 64 && (stage_plan >= 0 || persistent)) {
+        if (threadIdx.x == 0) next_item = 0;
+        if (stage_plan >= 0) {
+            staged = &v.plans[stage_plan];
+            u32x4 *dst = reinterpret_cast<u32x4 *>(lds_dyn + pack * (T * NPL + 4));
+            const u32x4 *src = static_cast<const u32x4 *>(staged->ring);
+            const uint32_t n16 = staged->ring_bytes >> 4;
+            for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+            plan_lds = reinterpret_cast<const char *>(dst);
+        }
+        __syncthreads();
+    }
+    // persistent: share blockIdx.x of the list (contiguous: the components of a blend stay
+    // together, in one L2 and mostly in one CU); otherwise one item per wavefront
+    const bool loop = T == 64 && persistent;
+    const int q = n_items / n_blocks, r = n_items % n_blocks, b = (int)blockIdx.x;
+    const int lo = loop ? b * q + (b < r ? b : r) : 0;
+    const int hi = loop ? lo + q + (b < r) : n_items;
+    const int lane = (int)(threadIdx.x & 63);
+    for (;;) {
+        int k = xcd_contiguous(blockIdx.x, n_blocks) * pack + wave;
+        if (loop) {
+            if (lane == 0) k = atomicAdd(&next_item, 1);
+            k = __builtin_amdgcn_readfirstlane(k);
+        }
+        if (lo + k >= hi) break;
+        // (the thread index goes in through an opaque copy: what a component's phases derive
+        // from it must not be hoisted out of this loop and live across all of them)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        update_component<NPL, MODE, T>(v, G, it, e_rel, prox_max_iter, v.work[lo + k + v.work0],
+                                       us, sed_new[wave], staged, plan_lds, tid);
+        if (!loop) break;
+    }
 }
 
 // Components of several size classes (a blend with boxes of 21^2 .. 61^2 pixels): a launch
@@ -1630,6 +1862,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void up
         update_component<kUpdateNpl[3], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else
         update_component<kUpdateNpl[4], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
+}
+
+// development aid: shader clocks of `n_rep` sweeps of one plan per wavefront, every wavefront
+// on an image of its own in LDS (mode 0: slot plan, 1: ring schedule); the images come back
+// for comparison
+__global__ void sweep_timing_kernel(const SweepPlanDev *plans, int plan_id, int mode, int n_rep,
+                                    float one_minus_g, long long *cycles, float *images) {
+    const SweepPlanDev &pl = plans[plan_id];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = pl.h * pl.w, stride = ((n + 3) & ~3) + 4;
+    float *us = lds_dyn + wave * stride + 4;
+    const int gw = blockIdx.x * (blockDim.x >> 6) + wave;
+    us[-4 + (lane & 3)] = 0.f;
+    // mode 2: the plan stream staged behind the images
+    char *plan_lds = reinterpret_cast<char *>(lds_dyn + (blockDim.x >> 6) * stride);
+    if (mode == 2) {
+        const uint32_t *src = static_cast<const uint32_t *>(pl.ring);
+        for (uint32_t i = threadIdx.x; i < pl.ring_bytes / 4; i += blockDim.x)
+            reinterpret_cast<uint32_t *>(plan_lds)[i] = src[i];
+        __syncthreads();
+    }
+    long long total = 0;
+    for (int rep = 0; rep < n_rep; ++rep) {
+        for (int i = lane; i < n; i += 64) {
+            uint32_t hsh = (uint32_t)(i * 2654435761u) ^ (uint32_t)(gw * 40503u + rep * 977u);
+            hsh ^= hsh >> 13;
+            hsh *= 0x5bd1e995u;
+            hsh ^= hsh >> 15;
+            us[i] = (float)(hsh & 0xffff) * (1.f / 65536.f);
+        }
+        wave_lds_fence();
+        const long long t0 = __builtin_readcyclecounter();
+        if (mode == 2)
+            sweep_ring_loop(us, RingLds(plan_lds, pl.ring_pad, lane), pl.ring_pad, pl.ring_rmax,
+                            pl.ring_perm, pl.ring_centre, one_minus_g, lane);
+        else if (mode == 1)
+            sweep_ring(us, pl, one_minus_g, lane);
+        else
+            sweep_slots(us, pl.slots, pl.n_slots, one_minus_g, lane);
+        wave_lds_fence();
+        total += __builtin_readcyclecounter() - t0;
+    }
+    if (lane == 0) cycles[gw] = total;
+    for (int i = lane; i < n; i += 64) images[(int64_t)gw * n + i] = us[i];
 }
 
 // log_norm of Observation (observation.py:172-186): D/2 ln(2 pi) + sum ln(1/sqrt(w))
@@ -1806,9 +2083,20 @@ struct PendingFinalize {
 };
 static thread_local PendingFinalize pending_finalize;
 
+static int cu_count() {
+    static int count[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    if (!count[dev]) {
+        hipDeviceProp_t prop;
+        count[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    return count[dev];
+}
+
 template <int NPL, int T>
 static int launch_update_reg(const BatchView &v, const float *G, int32_t it, float e_rel,
-                             int32_t prox_max_iter, int32_t item0, int32_t n_items,
+                             int32_t prox_max_iter, int32_t cls, int32_t item0, int32_t n_items,
                              hipStream_t s) {
     BatchView vi = v;
     vi.work0 = item0;
@@ -1822,10 +2110,45 @@ static int launch_update_reg(const BatchView &v, const float *G, int32_t it, flo
         const char *e = getenv("SMI_UPDATE_PACK");
         return e ? atoi(e) : 0;
     }();
-    int pack = n_items <= kUpdatePackLimit ? update_pack_max(NPL, T) : 1;
-    if (forced > 0) pack = std::min(forced, update_pack_max(NPL, T));
-    const size_t lds = (size_t)pack * (T * NPL + 4) * sizeof(float);
-    const dim3 grid((n_items + pack - 1) / pack + n_fin), block(T * pack);
+    // SMI_STAGE_PLAN=0 (development aid): never stage the ring plan in LDS
+    static const bool may_stage = [] {
+        const char *e = getenv("SMI_STAGE_PLAN");
+        return !e || atoi(e) != 0;
+    }();
+    constexpr int kPack = update_pack_max(NPL, T);
+    int pack = n_items <= kUpdatePackLimit ? kPack : 1;
+    if (forced > 0) pack = std::min(forced, kPack);
+    // the ring plan of the class staged in LDS: full workgroups, persistent when the list is
+    // longer than the chip is wide
+    int stage = -1, persistent = 0;
+    int n_blocks = (n_items + pack - 1) / pack;
+    size_t lds = (size_t)pack * (T * NPL + 4) * sizeof(float);
+    if (T == 64 && may_stage && v.stage_plan[cls] >= 0) {
+        const size_t need = (size_t)kPack * (T * NPL + 4) * sizeof(float) + v.stage_bytes[cls];
+        if (need + (size_t)kPack * 64 * sizeof(float) + 64 <= 160 * 1024) {
+            stage = v.stage_plan[cls];
+            pack = forced > 0 ? pack : kPack;
+            lds = (size_t)pack * (T * NPL + 4) * sizeof(float) + v.stage_bytes[cls];
+            n_blocks = (n_items + pack - 1) / pack;
+            const int resident = cu_count() * std::max(1, (int)((160 * 1024) / (lds + kPack * 256 + 64)));
+            static const bool may_persist = [] {  // development aid
+                const char *e = getenv("SMI_PERSIST");
+                return !e || atoi(e) != 0;
+            }();
+            static const int forced_blocks = [] {  // development aid
+                const char *e = getenv("SMI_PERSIST_BLOCKS");
+                return e ? atoi(e) : 0;
+            }();
+            if (forced_blocks > 0 && n_blocks > forced_blocks) {
+                n_blocks = forced_blocks;
+                persistent = 1;
+            } else if (n_blocks > resident && may_persist) {
+                n_blocks = resident;
+                persistent = 1;
+            }
+        }
+    }
+    const dim3 grid(n_blocks + n_fin), block(T * pack);
 #define SMI_LAUNCH(MODE)                                                                        \
     {                                                                                           \
         static size_t configured[kMaxDevices] = {};                                             \
@@ -1834,7 +2157,7 @@ static int launch_update_reg(const BatchView &v, const float *G, int32_t it, flo
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) \
                 return rc;                                                                      \
         hipLaunchKernelGGL(kern, grid, block, lds, s, vi, G, it, e_rel, prox_max_iter, n_items, \
-                           n_fin, fin.min_iter, fin.check);                                     \
+                           n_fin, fin.min_iter, fin.check, stage, persistent);                         \
     }
     if (v.scheme == SMI_SCHEME_FISTA) SMI_LAUNCH(2)
     else if (v.lite) SMI_LAUNCH(1)
@@ -1938,7 +2261,7 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
                 SMI_HIP(hipStreamWaitEvent(sc, side.fork, 0));
             }
 #define SMI_CLASS(i) \
-    case i: if (int rc = launch_update_reg<kUpdateNpl[i], kUpdateTeam[i]>(v, G, it, e_rel, prox_max_iter, lo, hi - lo, sc)) return rc; break;
+    case i: if (int rc = launch_update_reg<kUpdateNpl[i], kUpdateTeam[i]>(v, G, it, e_rel, prox_max_iter, i, lo, hi - lo, sc)) return rc; break;
             switch (cls) {
                 SMI_CLASS(0) SMI_CLASS(1) SMI_CLASS(2) SMI_CLASS(3) SMI_CLASS(4)
                 SMI_CLASS(5) SMI_CLASS(6) SMI_CLASS(7) SMI_CLASS(8)
@@ -1980,6 +2303,22 @@ int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e
     SMI_REQUIRE(lds <= 64 * 1024, "component box too large for the point-source kernel");
     hipLaunchKernelGGL(point_source_kernel, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
                        prox_max_iter, g_sed_out, g_center_out, mode);
+    return SMI_OK;
+}
+
+int launch_sweep_timing(const SweepPlanDev *d_plans, const SweepPlanDev &host_plan, int plan_id,
+                        int mode, int n_rep, float one_minus_g, int waves, int groups,
+                        long long *cycles, float *images, hipStream_t s) {
+    const int n = host_plan.h * host_plan.w;
+    const size_t lds = (size_t)waves * (((n + 3) & ~3) + 4) * sizeof(float) +
+                       (mode == 2 ? host_plan.ring_bytes : 0);
+    SMI_REQUIRE(lds <= 160 * 1024 && waves >= 1 && waves <= 16, "images do not fit the LDS");
+    SMI_REQUIRE(mode == 0 ? host_plan.slots != nullptr : host_plan.ring != nullptr, "plan has no such schedule");
+    static size_t configured[kMaxDevices] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sweep_timing_kernel), lds, configured))
+        return rc;
+    hipLaunchKernelGGL(sweep_timing_kernel, dim3(groups), dim3(64 * waves), lds, s, d_plans, plan_id,
+                       mode, n_rep, one_minus_g, cycles, images);
     return SMI_OK;
 }
 

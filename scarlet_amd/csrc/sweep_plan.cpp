@@ -92,4 +92,121 @@ bool build_sweep_plan(int32_t n_pix, const double *weights, const int32_t *offse
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Ring schedule (common.h).  The builder accepts any tables in which every weighted neighbour
+// of a pixel is one of its roles A .. D and precedes it in the sweep order -- then the lane
+// program reproduces the sequential loop bit for bit -- and says no otherwise.
+// ---------------------------------------------------------------------------
+namespace {
+struct Octant {
+    bool major_x;
+    int smaj, smin;
+};
+// rows: octant pairs sharing the +x, +y, -x, -y axis; halves: sign along the minor axis
+const Octant kOctants[8] = {{true, +1, -1}, {true, +1, +1}, {false, +1, +1}, {false, +1, -1},
+                            {true, -1, +1}, {true, -1, -1}, {false, -1, -1}, {false, -1, +1}};
+// (dy, dx) of the roles A, B, C, D
+void octant_roles(const Octant &o, int (&dy)[4], int (&dx)[4]) {
+    if (o.major_x) {
+        const int sx = o.smaj, sy = o.smin;
+        const int ry[4] = {-sy, 0, sy, -sy}, rx[4] = {-sx, -sx, -sx, 0};
+        for (int k = 0; k < 4; ++k) dy[k] = ry[k], dx[k] = rx[k];
+    } else {
+        const int sy = o.smaj, sx = o.smin;
+        const int ry[4] = {-sy, -sy, -sy, 0}, rx[4] = {-sx, 0, sx, -sx};
+        for (int k = 0; k < 4; ++k) dy[k] = ry[k], dx[k] = rx[k];
+    }
+}
+}  // namespace
+
+bool build_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t *offsets,
+                     int32_t n_off, const int32_t *dist_idx, int32_t n_idx, RingPlanHost *out) {
+    const int32_t n_pix = h * w;
+    if (h <= 0 || w <= 0 || n_off != 8 || n_idx != n_pix - 1 || !weights || !offsets || !dist_idx)
+        return false;
+    if (16 + 4 * (int64_t)n_pix > 65535) return false;  // 16-bit LDS addresses
+    static const int ndy[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, ndx[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+    for (int i = 0; i < 8; ++i)
+        if (offsets[i] != ndy[i] * w + ndx[i]) return false;
+    std::vector<int32_t> order(n_pix, -1);
+    for (int32_t d = 0; d < n_idx; ++d) {
+        const int32_t p = dist_idx[d];
+        if (p < 0 || p >= n_pix || order[p] >= 0) return false;
+        order[p] = d;
+    }
+    int32_t centre = -1;
+    for (int32_t p = 0; p < n_pix; ++p)
+        if (order[p] < 0) centre = p;  // (exactly one: n_idx distinct entries)
+    const int cy = centre / w, cx = centre % w;
+    const int rmax = std::max(std::max(cy, h - 1 - cy), std::max(cx, w - 1 - cx));
+    if (rmax < 1 || rmax > 8 * kRingMaxPlanes * 3 - 1) return false;
+    // at most 8 P rings of an octant are active at a level: ceil((L+1)/3) .. (L+1)/2 <= rmax
+    const int planes = rmax <= 23 ? 1 : 2;
+    if (rmax > (planes == 1 ? 23 : 47)) return false;
+    const int span = 8 * planes;
+
+    RingPlanHost &rp = *out;
+    rp.planes = planes;
+    rp.rmax = rmax;
+    rp.centre = centre;
+    rp.n_steps = 3 * rmax - 1;
+    rp.n_pad = (rp.n_steps + kRingUnroll - 1) / kRingUnroll * kRingUnroll;
+    const size_t lanes = (size_t)(rp.n_pad + kRingAhead) * planes * 64;
+    rp.wts.assign(lanes * 4, 0.f);
+    rp.addr.assign(lanes, 0);
+    rp.perm = 0;
+    int role_idx[8][4];
+    for (int o = 0; o < 8; ++o) {
+        int dy[4], dx[4];
+        octant_roles(kOctants[o], dy, dx);
+        for (int k = 0; k < 4; ++k) role_idx[o][k] = (dy[k] + 1) * 3 + (dx[k] + 1) - ((dy[k] + 1) * 3 + (dx[k] + 1) > 4);
+        // order of the sum = ascending neighbour index: A, B, C must come out ascending or
+        // descending, D wherever
+        const bool asc = role_idx[o][0] < role_idx[o][1] && role_idx[o][1] < role_idx[o][2];
+        const bool desc = role_idx[o][0] > role_idx[o][1] && role_idx[o][1] > role_idx[o][2];
+        if (!asc && !desc) return false;
+        int pd = 0;
+        for (int k = 0; k < 3; ++k) pd += role_idx[o][k] < role_idx[o][3];
+        rp.perm |= (uint32_t)((asc ? 1 : 0) | (pd << 1)) << (3 * o);
+    }
+    int32_t covered = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int Y = y - cy, X = x - cx;
+            if (!Y && !X) continue;
+            const int r = std::max(std::abs(Y), std::abs(X)), j = std::min(std::abs(Y), std::abs(X));
+            const int L = 2 * r + j - 1;  // 1-based level; step index L - 1
+            const int32_t pix = y * w + x;
+            bool placed = false;
+            for (int o = 0; o < 8; ++o) {
+                const Octant &oc = kOctants[o];
+                const int maj = oc.major_x ? X : Y, mn = oc.major_x ? Y : X;
+                if (std::abs(maj) != r || (maj > 0) != (oc.smaj > 0) || std::abs(mn) != j) continue;
+                if (mn != 0 && (mn > 0) != (oc.smin > 0)) continue;
+                const int q = r % span;
+                const size_t e = ((size_t)(L - 1) * planes + q / 8) * 64 + (o / 2) * 16 + (o & 1) * 8 + q % 8;
+                if (rp.addr[e]) return false;  // (cannot happen for rmax within the planes)
+                rp.addr[e] = (uint16_t)(16 + 4 * pix);
+                int hits = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const double wgt = weights[(int64_t)role_idx[o][k] * n_pix + pix];
+                    if (wgt > 0) {
+                        rp.wts[e * 4 + k] = (float)wgt;
+                        ++hits;
+                        // the sequential loop must have updated this neighbour already
+                        const int32_t nb = pix + offsets[role_idx[o][k]];
+                        if (nb < 0 || nb >= n_pix || (nb != centre && order[nb] > order[pix])) return false;
+                    }
+                }
+                int weighted = 0;
+                for (int i = 0; i < 8; ++i) weighted += weights[(int64_t)i * n_pix + pix] > 0;
+                if (weighted != hits) return false;  // a weighted neighbour that is no role
+                placed = true;
+            }
+            if (!placed) return false;
+            ++covered;
+        }
+    return covered == n_idx;
+}
+
 }  // namespace smi

@@ -116,6 +116,52 @@ def test_monotonic_tables_match_reference():
     assert offsets == [-5, -4, -3, -1, 1, 3, 4, 5]
 
 
+@pytest.mark.parametrize("shape", [(3, 3), (5, 5), (21, 21), (31, 31), (41, 41), (47, 47),
+                                   (31, 41), (22, 30), (40, 40), (41, 40), (7, 47), (46, 11)])
+def test_ring_schedule_of_the_sweep_is_the_sequential_loop(shape):
+    """The ring plan (library builder, csrc/sweep_plan.cpp) run by a numpy model of the
+    device loop gives the bits of the reference's sequential loop
+    (operators_pybind11.cc:14-36 via the oracle) for the three weightings, the default and a
+    shifted peak (fit_center plans)."""
+    import ring_model
+
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    h, w = shape
+    for kind in ("angle", "flat", "nearest"):
+        for centre in ((h // 2, w // 2), (min(h // 2 + 1, h - 1), max(w // 2 - 1, 0))):
+            weights, offsets, didx = operator.monotonic_tables(shape, kind, centre)
+            plan = ring_model.ring_plan(shape, weights, offsets, didx)
+            rmax = max(centre[0], h - 1 - centre[0], centre[1], w - 1 - centre[1])
+            assert (plan is not None) == (rmax <= 47)
+            if plan is None:
+                continue
+            assert plan["planes"] == (1 if rmax <= 23 else 2)
+            assert plan["n_steps"] == 3 * rmax - 1
+            for g in (0.0, 0.25):
+                img = rng.random(h * w).astype(np.float32)
+                img[rng.integers(0, h * w, 5)] = 0  # exact zeros among the inputs
+                ref = proxops.sweep(img.copy(), weights, offsets, didx, g)
+                got = ring_model.run(plan, img, g)
+                assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_ring_schedule_is_refused_for_other_tables():
+    """Tables without the radial structure (a weighted neighbour farther out, a sweep order
+    that is not by radius) have no ring plan; the kernels keep the level plan for them."""
+    import ring_model
+
+    shape = (21, 21)
+    weights, offsets, didx = operator.monotonic_tables(shape, "angle", (10, 10))
+    assert ring_model.ring_plan(shape, weights, offsets, didx) is not None
+    outward = weights.copy()
+    p = 3 * 21 + 4
+    outward[:, p] = 0
+    outward[0, p] = 1.0  # towards the corner: away from the peak
+    assert ring_model.ring_plan(shape, outward, offsets, didx) is None
+    assert ring_model.ring_plan(shape, weights, offsets, didx[::-1].copy()) is None
+    assert ring_model.ring_plan(shape, weights, offsets[::-1].copy(), didx) is None
+
+
 def test_elementwise_constraints_like_reference():
     # reference tests/test_constraint.py:9-71, 137-171
     rng = np.random.default_rng(0)
