@@ -34,8 +34,10 @@ Output: ONE JSON line on rank 0 with the contract's fields plus
                (HIP events on the batch stream over the same K iterations, replayed
                in one range of blends), at the FFT shape the kernel runs; counter-derived
                fields from profiles/ (HBM traffic, VALU busy; listed with their source in
-               `counter_fields`); `bound` is what the counters say binds the kernel (null
-               without counters); `speed_of_light`: the iteration against
+               `counter_fields`); `bound` names the roofline priced against ("hbm"), `limiter`
+               what the counters say limits the kernel ("unknown" without counters);
+               `frac_physical` / `hbm_frac_whole_iteration`: the chip's physical utilisation
+               over the whole iteration, to be read before the saturated `frac`; `speed_of_light`: the iteration against
                max(compulsory bytes / 8 TB/s, butterfly flops / f32 peak); `measured_hbm`: HBM
                bytes of the whole iteration by the PMC counters against the compulsory bytes
   parity       first and last blend of every rank's shard against the CPU oracle over the
@@ -51,10 +53,6 @@ import os
 import subprocess
 import sys
 import time
-
-# before the HIP runtime starts (scarlet_amd._lib explains): eight hardware queues, so that a
-# small shard can step four ranges of blends side by side
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 
@@ -305,6 +303,22 @@ def build_cfg4(n):
     return np.ascontiguousarray(data), weights, [one] * n, g["diff_kernel"]
 
 
+def dominant_kernel(phases, conv_path, by):
+    """(name, algorithmic bytes per blend, ms per launch) of the kernel the roofline object
+    prices: the larger of the two kernels of a fused-path iteration -- the convolution kernel or
+    the update phase -- by the event times of this run; the update kernel without a
+    convolution; the whole iteration for the rocFFT pipeline, which has no single dominant
+    kernel of ours.  `conv_path` is what the library says it runs (BlendBatch.conv_path), not
+    something inferred from the times."""
+    if conv_path == "none":
+        return "update_kernel_reg", by["update"], phases["update"]
+    if conv_path == "fused":
+        if phases["update"] > phases["conv"]:
+            return "update kernels (update phase of the iteration)", by["update"], phases["update"]
+        return "fused_conv_kernel", by["conv"], phases["conv"]
+    return "whole iteration (rocFFT pipeline)", by["whole"], phases["total"]
+
+
 def counters(kernel):
     """Counter-derived figures of the dominant kernel from the committed rocprofv3 PMC
     summaries (profiles/hbm_traffic.json, written by tools/hbm_counters.py)."""
@@ -353,6 +367,11 @@ def main():
                          "same scenes instead of Blend.fit's")
     args = ap.parse_args()
 
+    # before the HIP runtime starts (scarlet_amd._lib explains): eight hardware queues, so that
+    # a small shard can step four ranges of blends side by side
+    from scarlet_amd import configure
+
+    configure(hw_queues=8)
     if args.config == "cfg5":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_cfg5
@@ -440,11 +459,14 @@ def main():
     # parity at the benchmark's own size: first and last blend of every rank's shard against
     # the oracle, same K iterations (checker only, after the clock has stopped)
     parity = None
-    if scenes is not None and not lite and not args.steady and not args.null_renderer and nb:
-        picks = sorted({0, nb - 1})
-        early, late = oracle_check(scenes, picks, loss, K, e_rel)
+    if scenes is not None and not lite and not args.steady and not args.null_renderer:
+        # (every rank enters the gather, a rank with an empty shard with an empty record)
+        picks = sorted({0, nb - 1}) if nb else []
+        early, late = oracle_check(scenes, picks, loss, K, e_rel) if picks else (0.0, 0.0)
         parity = sdist.gather_objects({"rank": rank, "blends": [lo + i for i in picks],
                                        "first_12": early, "all": late})
+        if not any(p["blends"] for p in parity):
+            parity = None
 
     # Roofline pass: the SAME K iterations again with HIP events around every kernel, all
     # of the rank's blends in ONE range.  In the timed region ranges of blends run on
@@ -460,6 +482,7 @@ def main():
     phases = {k: round(v, 4) for k, v in batch.timing().items()}  # mean ms over the K steps
     batch.enable_timing(False)
     fft_shape = batch.fft_shape
+    conv_path = batch.conv_path  # "none" | "rocfft" | "fused": what the library runs
 
     if rank == 0:
         value = n_total * K / elapsed
@@ -471,18 +494,8 @@ def main():
         by_survey = algorithmic_bytes(C, H, W, boxes, 180, 180, kb) if args.config == "cfg3" else by
         bytes_per = by["null"] if args.null_renderer else by["whole"]
         ms_iter = elapsed / K * 1e3
-        # the fused path has no kernel between the loss and the update (conv_adj = 0)
-        fused = (not args.null_renderer) and phases["conv_adj"] < 0.05 * phases["conv"]
-        if fused and phases["update"] > phases["conv"]:
-            # the update phase is the larger share (cfg1 / cfg4 batches: few, large boxes)
-            k_name, k_bytes, k_ms = "update kernels (update phase of the iteration)", by["update"], phases["update"]
-        elif fused:
-            k_name, k_bytes, k_ms = "fused_conv_kernel", by["conv"], phases["conv"]
-        elif args.null_renderer:
-            k_name, k_bytes, k_ms = "update_kernel_reg", by["update"], phases["update"]
-        else:
-            # rocFFT pipeline: no single dominant kernel of ours; price the whole iteration
-            k_name, k_bytes, k_ms = "whole iteration (rocFFT pipeline)", bytes_per, phases["total"]
+        fused = conv_path == "fused"
+        k_name, k_bytes, k_ms = dominant_kernel(phases, conv_path, by)
         achieved = k_bytes * nb / (k_ms * 1e-3) / 1e9
         cnt = counters(k_name) if args.config == "cfg3" and nb == 1024 else {}
         traffic = cnt["bytes_per_blend"] * nb if "bytes_per_blend" in cnt else None
@@ -501,9 +514,23 @@ def main():
         sol_ms = max(hbm_ms, flop_ms)
         measured_iter = (sum(c["bytes_per_blend"] for c in all_cnt.values())
                          if all_cnt and all("bytes_per_blend" in c for c in all_cnt.values()) else None)
+        sol_frac = round(sol_ms / ms_iter, 4)
+        hbm_whole = (round(measured_iter * nb / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                     if measured_iter else None)
+        frac = round(achieved / HBM_PEAK_GBS, 5)
         roofline = {
-            # what binds the dominant kernel according to the counters; null without counters
-            "bound": cnt.get("bound"),
+            # the roofline `achieved` / `peak` are priced against (HBM bandwidth; no MFMA work
+            # on this path), and what the PMC counters say limits the dominant kernel
+            # ("unknown" without a counter summary for this workload)
+            "bound": "hbm",
+            "limiter": cnt.get("bound") or "unknown",
+            # READ THESE FIRST.  frac_physical: share of the chip's physical limit the whole
+            # iteration reaches (speed_of_light.sol_frac); hbm_frac_whole_iteration: HBM bytes
+            # of the whole iteration by the PMC counters over ms_per_step against 8 TB/s (null
+            # without a counter summary for this workload).  `frac` further down prices SURVEY
+            # 8d's byte model for the dominant kernel and saturates (frac_note).
+            "frac_physical": sol_frac,
+            "hbm_frac_whole_iteration": hbm_whole,
             "speed_of_light": {
                 "compulsory_bytes_per_blend_iteration": by["null"],
                 "hbm_ms": round(hbm_ms, 4),
@@ -511,7 +538,7 @@ def main():
                                                         if not args.null_renderer else 0),
                 "valu_ms": round(flop_ms, 4),
                 "sol_ms": round(sol_ms, 4),
-                "sol_frac": round(sol_ms / ms_iter, 4),
+                "sol_frac": sol_frac,
                 "note": "sol_ms = max(compulsory bytes / 8 TB/s, butterfly flops / 157.3 TFLOP/s) "
                         "for this rank's %d blends; sol_frac = sol_ms / ms_per_step: the share of "
                         "the chip's physical limit the iteration reaches.  `frac` below prices the "
@@ -520,28 +547,28 @@ def main():
             "measured_hbm": {
                 "bytes_per_blend_iteration": measured_iter,
                 "over_compulsory": (round(measured_iter / by["null"], 3) if measured_iter else None),
-                "frac_of_peak": (round(measured_iter * nb / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                 if measured_iter else None),
+                "frac_of_peak": hbm_whole,
                 "per_kernel": {k: c.get("bytes_per_blend") for k, c in all_cnt.items()} or None,
                 "source": ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                            "passes of tools/collect_profiles.sh on 1024-blend launches "
                            "(committed constants, not measured in this run)" if all_cnt else None),
             },
             "counter_fields": {
-                "fields": ["bound", "traffic", "hbm_frac_measured", "valu_busy", "measured_hbm"],
+                "fields": ["limiter", "traffic", "hbm_frac_measured", "valu_busy", "measured_hbm"],
                 "source": "profiles/hbm_traffic.json (committed PMC summary); every other field is "
                           "measured in this run",
             },
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            # above 1 for the fused convolution since round 3: SURVEY 8d prices four FFT passes
-            # through HBM, this kernel keeps them in LDS and moves ~1.4 MB of the 5.05 MB per
-            # blend; `speed_of_light.sol_frac` and `hbm_frac_measured` say how busy the chip is
-            "frac_note": ("algorithmic (SURVEY 8d) bytes over the measured launch time; not a "
-                          "utilisation -- most of these bytes never leave the LDS"
-                          if achieved > HBM_PEAK_GBS else None),
+            "frac": frac,
+            # SURVEY 8d prices four FFT passes through HBM; the fused convolution keeps them
+            # in LDS and moves ~1.1 MB of the 5.05 MB per blend, so its `frac` sits at or above
+            # 1 and measures nothing: frac_physical / hbm_frac_measured say how busy the chip is
+            "frac_note": ("algorithmic (SURVEY 8d) bytes over the measured launch time, not a "
+                          "utilisation: most of these bytes never leave the LDS -- read "
+                          "frac_physical (%.3f of the chip's physical limit)" % sol_frac
+                          if frac > 0.95 else None),
             "traffic": traffic,
             "kernel": k_name,
             "algorithmic_bytes_per_launch": k_bytes * nb,

@@ -231,10 +231,13 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w,
 
 /* The ring schedule the update kernels derive from such tables when they are the radial ones
  * of operator.py:591-667 (host only, no GPU; csrc/common.h describes the schedule).  Returns
- * 1 and fills info = {planes, n_steps, n_pad, rmax, centre, perm, lanes, 0} when the tables
- * qualify, 0 when they do not (the kernels then keep the level plan), < 0 on bad arguments.
- * With capacity >= lanes also wts[lanes][4] (weights by role A, B, C, D) and addr[lanes]
- * (16 + 4 * pixel, 0 = idle); lanes = (n_pad + 6) * planes * 64, step major. */
+ * 1 and fills info = {planes, n_steps, n_pad, rmax, centre, perm, lanes, stream_bytes} when the
+ * tables qualify, 0 when they do not (the kernels then keep the level plan), < 0 on bad
+ * arguments.  stream_bytes = size of the device stream with the weights stored once per ring,
+ * 0 when the octants differ (off-centre peak, even or oblong box): only tables with such a
+ * stream run the ring schedule on the device.  With capacity >= lanes also wts[lanes][4]
+ * (weights by role A, B, C, D) and addr[lanes] (16 + 4 * pixel, 0 = idle);
+ * lanes = (n_pad + 6) * planes * 64, step major. */
 int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t *offsets,
                         const int32_t *dist_idx, int32_t n_idx, int32_t info[8], float *wts,
                         uint16_t *addr, int64_t capacity);
@@ -362,11 +365,18 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel,
 /* Blends are independent, so a step can run ranges of blends on streams of their own:
  * while one range's update kernel drains, the others' next convolution fills the chip.
  * n = 0 (default): automatic (with the fused convolution 3 ranges from 128 blends on, 4 below
- * 768 blends when GPU_MAX_HW_QUEUES >= 8; else 1);
+ * 768 blends when smi_set_hw_queues said that eight hardware queues exist; else 1);
  * point sources, free shifts and a low-resolution observation keep it at 1.  Results are
  * identical for every n.  The caller's stream (smi_batch_set_stream) still brackets the
  * step: the ranges start after its pending work and it waits for all of them. */
 int smi_batch_set_sub_ranges(smi_batch *b, int32_t n);
+
+/* Hardware queues the HIP runtime of this process maps streams onto (GPU_MAX_HW_QUEUES when
+ * the runtime started; HIP's default is 4).  The library cannot see that number and does not
+ * read the environment: it assumes 4 until the host says otherwise, and runs four ranges of
+ * blends side by side only with n >= 8 (streams that share a queue run one after the other).
+ * Process-wide; returns the previous value. */
+int smi_set_hw_queues(int32_t n);
 int smi_batch_get_sub_ranges(smi_batch *b, int32_t *n);
 
 /* A batch of nothing but factorized components under one fused convolution (no point
@@ -416,6 +426,10 @@ int smi_batch_get_timing(smi_batch *b, double *ms_per_phase, int32_t n_phases);
 
 /* FFT shape actually used (fft_h, fft_w) */
 int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w);
+
+/* The convolution path the batch runs (what conv_path = 0 "auto" resolved to):
+ * 0 none (NullRenderer, no difference kernel), 1 rocFFT pipeline, 2 fused_conv_kernel. */
+int smi_batch_conv_path_used(smi_batch *b, int32_t *path);
 
 /* ---------------------------------------------------------------------------------
  * Multi-resolution rendering: the per-call part of ResolutionRenderer

@@ -58,5 +58,6 @@ from .source import (  # noqa: F401
 )
 from .model import Model, UpdateException  # noqa: F401
 from . import fft, initialization, measure, operator, synthetic  # noqa: F401
+from ._lib import configure  # noqa: F401
 
 __version__ = "0.1.0"

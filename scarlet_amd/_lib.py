@@ -190,6 +190,8 @@ SYMBOLS = {
     "smi_batch_enable_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "smi_batch_get_timing": (ctypes.c_int, [ctypes.c_void_p, c_f64p, ctypes.c_int32]),
     "smi_batch_fft_shape": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
+    "smi_batch_conv_path_used": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
+    "smi_set_hw_queues": (ctypes.c_int, [ctypes.c_int32]),
 }
 
 _lib = None
@@ -210,21 +212,10 @@ def load():
                     LIB_PATH
                 )
             )
-        started = False
         try:
             import torch  # noqa: F401  (see module docstring)
-
-            started = torch.cuda.is_initialized()
         except ImportError:
             pass
-        # Ranges of blends are stepped on streams of their own (smi_batch_set_sub_ranges); HIP
-        # maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that
-        # share a queue run one after the other.  Eight queues let a small batch -- one GPU's
-        # shard of a multi-GPU job -- run four ranges side by side (128 blends: 540 k -> 615 k
-        # blend-iterations/s).  The HIP runtime reads the variable when it starts, so it is only
-        # set while the runtime has not started; the library reads it back to choose the ranges.
-        if "GPU_MAX_HW_QUEUES" not in os.environ and not started:
-            os.environ["GPU_MAX_HW_QUEUES"] = "8"
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SYMBOLS.items():
             if not hasattr(lib, name) and os.environ.get("SCARLET_AMD_LIB"):
@@ -233,7 +224,75 @@ def load():
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = lib
+        lib.smi_set_hw_queues(_effective_hw_queues())
     return _lib
+
+
+# ---------------------------------------------------------------------------
+# Hardware queues.  Ranges of blends are stepped on streams of their own
+# (smi_batch_set_sub_ranges); HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4) and streams that share a queue run one after the other.  Eight queues let a
+# small batch -- one GPU's shard of a multi-GPU job -- run four ranges side by side (128
+# blends: 540 k -> 615 k blend-iterations/s).  The HIP runtime reads the variable once, when it
+# starts, and nothing reports the number it took, so the package never changes the environment
+# behind the caller's back: ``configure(hw_queues=8)`` does it on request, before the runtime
+# starts, and the library is told the number that is known to be in effect (4 otherwise).
+# ---------------------------------------------------------------------------
+_hw_queues = None  # set by configure()
+_warned = False
+
+
+def _hip_started():
+    try:
+        import torch
+
+        return torch.cuda.is_initialized()
+    except ImportError:
+        return False
+
+
+def _effective_hw_queues():
+    if _hw_queues is not None:
+        return _hw_queues
+    # exported by the caller's environment (the shell, a launcher): in effect from the start
+    try:
+        return max(1, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+    except ValueError:
+        return 4
+
+
+def configure(hw_queues=None):
+    """Process-wide settings; call before anything touches the GPU.
+
+    hw_queues: number of hardware queues the HIP runtime should map streams onto (sets
+        ``GPU_MAX_HW_QUEUES`` for this process and its children).  With 8, batches of 128 to
+        767 blends run four ranges of blends side by side instead of three.  When the HIP
+        runtime has already started (``torch.cuda`` initialised) the setting cannot take
+        effect any more: a warning is issued once, nothing is changed and the library keeps
+        three ranges.
+    Returns the number of hardware queues the library assumes."""
+    global _hw_queues, _warned
+    if hw_queues is not None:
+        hw_queues = int(hw_queues)
+        if os.environ.get("GPU_MAX_HW_QUEUES") == str(hw_queues):
+            _hw_queues = hw_queues  # already what the runtime reads / has read
+        elif _hip_started():
+            if not _warned:
+                import warnings
+
+                warnings.warn(
+                    "scarlet_amd.configure(hw_queues=%d): the HIP runtime has already started "
+                    "with GPU_MAX_HW_QUEUES=%s; small batches keep three ranges of blends. "
+                    "Call configure() before the first use of torch.cuda, or export "
+                    "GPU_MAX_HW_QUEUES=%d." % (hw_queues, os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)"),
+                                               hw_queues), RuntimeWarning, stacklevel=2)
+                _warned = True
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(hw_queues)
+            _hw_queues = hw_queues
+        if _lib is not None:
+            _lib.smi_set_hw_queues(_effective_hw_queues())
+    return _effective_hw_queues()
 
 
 def check(status):

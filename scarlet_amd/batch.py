@@ -253,6 +253,13 @@ class BlendBatch:
         _lib.check(self._lib.smi_batch_fft_shape(self._h, ctypes.byref(fy), ctypes.byref(fx)))
         return fy.value, fx.value
 
+    @property
+    def conv_path(self):
+        """The convolution path this batch runs: "none" (NullRenderer), "rocfft" or "fused"."""
+        path = ctypes.c_int32()
+        _lib.check(self._lib.smi_batch_conv_path_used(self._h, ctypes.byref(path)))
+        return ("none", "rocfft", "fused")[path.value]
+
     def set_kernel(self, kernel):
         """Replace the difference kernel (same stamp shape as at construction)."""
         kernel = _lib.f32(kernel)

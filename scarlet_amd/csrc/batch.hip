@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -359,7 +360,13 @@ void refresh_view(smi_batch *b) {
     v.nb_total = b->d.n_blends;
     for (int cls = 0; cls < kNumUpdateClasses; ++cls) {
         const int p = b->have_components ? b->stage_plan[cls] : -1;
-        const bool ok = p >= 0 && p < (int)b->plans.size() && b->plans[p].ring;
+        // One-wavefront classes, one plane (boxes up to 47^2).  The two-plane schedule of
+        // larger boxes is bit-exact too but slower than the level plan -- 61^2: 32.8 k clocks
+        // per sweep against 28.4 k, 51^2: 28.5 k against 20.3 k (tools/sweep_cycles.py): a lane
+        // issues two pixels per step while at most eleven of its sixteen rings are under way
+        // -- so those boxes keep the level plan.
+        const bool ok = p >= 0 && p < (int)b->plans.size() && b->plans[p].ring &&
+                        kUpdateTeam[cls] == 64 && b->plans[p].ring_planes == 1;
         v.stage_plan[cls] = ok ? p : -1;
         v.stage_bytes[cls] = ok ? b->plans[p].ring_bytes : 0;
     }
@@ -888,21 +895,18 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
         return !e || atoi(e) != 0;
     }();
     RingPlanHost rp;
+    std::vector<uint8_t> stream;
     if (use_ring && dp.slots && build_ring_plan(h, w, weights, offsets, 8, dist_idx, n_idx, &rp) &&
-        rp.planes == 1) {
-        const size_t lanes = rp.addr.size();
-        std::vector<uint8_t> buf(lanes * 18);
-        memcpy(buf.data(), rp.wts.data(), lanes * 16);
-        memcpy(buf.data() + lanes * 16, rp.addr.data(), lanes * 2);
+        ring_device_stream(rp, &stream)) {
         uint8_t *d_ring = nullptr;
-        if ((rc = upload(&d_ring, buf.data(), buf.size()))) return rc;
+        if ((rc = upload(&d_ring, stream.data(), stream.size()))) return rc;
         dp.ring = d_ring;
         dp.ring_planes = rp.planes;
         dp.ring_pad = rp.n_pad;
         dp.ring_rmax = rp.rmax;
         dp.ring_centre = rp.centre;
         dp.ring_perm = rp.perm;
-        dp.ring_bytes = (uint32_t)buf.size();
+        dp.ring_bytes = (uint32_t)stream.size();
     }
     b->plans.push_back(dp);
     if (dp.n_levels > b->max_levels) b->max_levels = dp.n_levels;
@@ -917,8 +921,10 @@ int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32
     SMI_REQUIRE(h > 0 && w > 0, "empty box");
     RingPlanHost rp;
     if (!build_ring_plan(h, w, weights, offsets, 8, dist_idx, n_idx, &rp)) return 0;
+    std::vector<uint8_t> stream;
     const int32_t vals[8] = {rp.planes, rp.n_steps, rp.n_pad, rp.rmax, rp.centre, (int32_t)rp.perm,
-                             (int32_t)rp.addr.size(), 0};
+                             (int32_t)rp.addr.size(),
+                             ring_device_stream(rp, &stream) ? (int32_t)stream.size() : 0};
     memcpy(info, vals, sizeof(vals));
     if (wts && addr && capacity >= (int64_t)rp.addr.size()) {
         memcpy(wts, rp.wts.data(), rp.wts.size() * sizeof(float));
@@ -1797,6 +1803,9 @@ static bool inline_render(const smi_batch *b) {
     return allowed && b->inline_render && plain_batch(b) && b->view.render_slots > 0;
 }
 
+// hardware queues the runtime has, as far as the host told us (smi_set_hw_queues)
+static std::atomic<int> g_hw_queues{4};
+
 // number of blend ranges a step is split into
 static int sub_ranges(const smi_batch *b) {
     if (!plain_batch(b)) return 1;
@@ -1811,10 +1820,7 @@ static int sub_ranges(const smi_batch *b) {
     // throughput where a fourth hardware queue exists -- GPU_MAX_HW_QUEUES = 8 (k blend-it/s,
     // 3 / 4 / 5 ranges): 128 blends 537 / 615 / 391, 256: 746 / 776 / 603, 512: 809 / 814 /
     // 740, 1024: 919 / 857 / 826.
-    static const int queues = [] {
-        const char *e = getenv("GPU_MAX_HW_QUEUES");
-        return e ? atoi(e) : 4;
-    }();
+    const int queues = g_hw_queues.load(std::memory_order_relaxed);  // smi_set_hw_queues
     int n = b->n_sub > 0 ? b->n_sub : (nb < 128 ? 1 : (queues >= 8 && nb < 768) ? 4 : 3);
     return std::max(1, std::min(n, nb));
 }
@@ -2020,6 +2026,8 @@ int smi_batch_get_states(smi_batch *b, int32_t *state) {
     SMI_HIP(hipSetDevice(b->device));
     SMI_HIP(hipStreamSynchronize(b->stream));
     SMI_HIP(hipMemcpy(state, b->state, b->d.n_blends * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // (on the device a failed blend carries 3 + the iteration it failed in: finalize_blend)
+    for (int32_t i = 0; i < b->d.n_blends; ++i) state[i] = std::min(state[i], 3);
     return SMI_OK;
 }
 
@@ -2200,6 +2208,16 @@ int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w) {
     SMI_REQUIRE(b, "null batch");
     if (fft_h) *fft_h = b->Fy;
     if (fft_w) *fft_w = b->Fx;
+    return SMI_OK;
+}
+
+int smi_set_hw_queues(int32_t n) {
+    return g_hw_queues.exchange(n > 0 ? n : 4, std::memory_order_relaxed);
+}
+
+int smi_batch_conv_path_used(smi_batch *b, int32_t *path) {
+    SMI_REQUIRE(b && path, "null argument");
+    *path = b->null_renderer ? 0 : b->fused ? 2 : 1;
     return SMI_OK;
 }
 

@@ -136,9 +136,16 @@ inline int update_image_stride(int n_pix) {
 // Lane layout: lane = row * 16 + half * 8 + (r mod 8); rows = octant pairs that share an axis
 // (+x, +y, -x, -y), halves = sign along the minor axis ((-,+), (+,-), (+,-), (-,+)).
 //
-// Device stream, `n_pad` + kRingAhead steps of 64 P lanes each (n_pad = steps rounded up to
-// the unrolling of the loop, idle entries behind): float4 weights by role (A, B, C, D), then
-// uint16 LDS byte addresses 16 + 4 * pixel (0 = idle: the spare cell in front of the image).
+// Device stream, `n_pad` + kRingAhead steps (n_pad = steps rounded up to the unrolling of the
+// loop, idle entries behind).  The radial tables of a centred odd square box are the same in
+// all eight octants once the weights are sorted by role (checked bit for bit by
+// ring_device_stream, which refuses anything else), so a step stores the float4 weights
+// (A, B, C, D) once per ring: [step][plane][r mod 8] float4, 128 P bytes per step -- the eight
+// lanes of a ring read one address, a broadcast -- followed by the uint16 LDS byte addresses
+// [step][plane][lane] 16 + 4 * pixel (0 = idle: the spare cell in front of the image), another
+// 128 P bytes per step: 17 KB for a 41^2 box, 49 KB for 61^2.  With two planes a lane handles
+// the rings r = m + 8 (mod 16) and r = m (mod 16) in the same step; the lane below ring
+// r = 8 k is m = 7 of the other plane.
 // ---------------------------------------------------------------------------
 constexpr int kRingUnroll = 6;   // steps per loop iteration (period of the axis / diagonal phases)
 constexpr int kRingAhead = 6;    // steps the address stream is requested ahead
@@ -156,6 +163,9 @@ struct RingPlanHost {
 // false (no error set) when the tables do not have the radial structure or the box is too large
 bool build_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t *offsets,
                      int32_t n_off, const int32_t *dist_idx, int32_t n_idx, RingPlanHost *out);
+// the stream the kernels read (above); false when the weights differ between octants or the
+// octants do not hold the same pixels (off-centre peak, even or oblong box)
+bool ring_device_stream(const RingPlanHost &rp, std::vector<uint8_t> *out);
 
 struct SweepPlanDev {
     int32_t h = 0, w = 0, n_entries = 0, max_terms = 0, n_levels = 0;
@@ -253,6 +263,9 @@ struct BatchView {
     // the bytes of its stream
     int32_t stage_plan[kNumUpdateClasses];
     uint32_t stage_bytes[kNumUpdateClasses];
+    // value a failing update stores in state[b]: 3 + the iteration (launch_update stamps it;
+    // anything >= 3 means non-finite parameters, finalize_blend explains the iteration)
+    int32_t fail_code = 3;
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);

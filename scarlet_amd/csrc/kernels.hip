@@ -202,11 +202,17 @@ __global__ __launch_bounds__(kPixBlock) void residual_kernel(BatchView v, const 
 // loss bookkeeping + convergence test of Blend._callback (blend.py:294-299) for blend b, by
 // one wavefront.  Nothing here is read by the component updates of the same iteration (they
 // only ask whether state >= 2, which advance_kernel sets afterwards), so the workgroups that
-// run this may share a launch with them (update_kernel_reg); the non-finite flag (state 3)
-// an update may raise at the same time survives: 0 -> 1 is a compare-and-swap.
+// run this may share a launch with them (update_kernel_reg); the non-finite flag an update
+// may raise at the same time survives: 0 -> 1 is a compare-and-swap.  That flag carries the
+// iteration it was raised in (state = 3 + it, BatchView::fail_code): the loss of iteration
+// `it` is recorded whenever the blend was still iterating when `it` began, whether an update
+// of the same launch has already failed or not -- as in the reference, where _callback
+// appends the loss before the step is taken (blend.py:294-299) -- so the length of the loss
+// history of a failed blend does not depend on how the workgroups were scheduled.
 __device__ __forceinline__ void finalize_blend(const BatchView &v, int b, int it, float e_rel,
                                                int min_iter, int check) {
-    if (v.state[b] >= 2) return;
+    const int st = v.state[b];
+    if (st == 2 || (st >= 3 && st - 3 < it)) return;
     const int lane = threadIdx.x & 63;
     double t = 0.0;
     for (int i = lane; i < v.n_partial; i += 64)
@@ -241,7 +247,7 @@ __global__ void count_active_kernel(const int32_t *state, int nb, int32_t *out) 
     int active = 0, err = 0x7fffffff;
     for (int b = threadIdx.x; b < nb; b += 64) {
         active += state[b] < 2;
-        if (state[b] == 3) err = min(err, b);
+        if (state[b] >= 3) err = min(err, b);
     }
     for (int o = 32; o > 0; o >>= 1) {
         active += __shfl_xor(active, o, 64);
@@ -711,8 +717,6 @@ __device__ __forceinline__ void monotonic_mask(const float *us, float *ws, uint8
 // -- generic variant: everything in LDS, plans with any number of terms -----
 __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slots, int n_slots,
                                             float one_minus_g, int lane);
-__device__ __forceinline__ void sweep_ring(float *us, const SweepPlanDev &pl, float one_minus_g,
-                                           int lane);
 // T threads per component (Team): 64, or 256 for boxes of more than 64 x 59 pixels
 template <int T>
 __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, int it,
@@ -919,7 +923,7 @@ __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, 
         c.morph_out[i] = z;
         bad |= !isfinite(z);
     }
-    if (Team<T>::any(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
+    if (Team<T>::any(bad) && lane == 0) atomicExch(&v.state[c.b], v.fail_code);  // model.py:153-165
 }
 
 // -- point sources ---------------------------------------------------------------
@@ -1044,7 +1048,7 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
         v.morph[c.moff + i] = z;
         bad |= !isfinite(z);
     }
-    if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], 3);
+    if (wave_or(bad) && lane == 0) atomicExch(&v.state[c.b], v.fail_code);
 }
 
 // -- fast variant --------------------------------------------------------------
@@ -1217,11 +1221,12 @@ __device__ __forceinline__ void sweep_slots(float *us, const SweepSlotEntry *slo
 }
 
 // -- ring schedule of the radial tables (common.h: RingPlanHost) --------------------------
-// One lane per (octant, ring mod 8): the operands of a step are the lane's own previous result
-// and the last three results of the lane of the next inner ring, fetched by DPP row rotations
-// (lane = row * 16 + half * 8 + m: the inner ring is lane - 1, or lane + 7 when m = 0; the
-// same two rotations with the roles swapped reach the octant across the axis).  The image in
-// LDS is touched once per pixel: read ahead of the step, written behind it.
+// One lane per (octant, ring mod 8) and plane: the operands of a step are the lane's own
+// previous result and the last three results of the lane of the next inner ring, fetched by
+// DPP row rotations (lane = row * 16 + half * 8 + m: the inner ring is lane - 1, or lane + 7
+// -- of the other plane when there are two -- for m = 0; the same two rotations with the roles
+// swapped reach the octant across the axis).  The image in LDS is touched once per pixel: read
+// ahead of the step, written behind it.
 __device__ __forceinline__ float dpp_ror1(float x) {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));
@@ -1232,53 +1237,35 @@ __device__ __forceinline__ float dpp_ror9(float x) {
 }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Where the plan stream of a ring sweep comes from: the plan's device buffer (buffer loads,
-// weights three and addresses six steps ahead; lanes without a pixel do not fetch weights), or
-// a copy in LDS that the workgroup staged (RingLds: one and two steps ahead).
-struct RingGlobal {
-    static constexpr int kWeightsAhead = 3, kAddrAhead = kRingAhead;
-    rsrc_t r;
-    uint32_t vo_w, vo_a;
-    __device__ __forceinline__ RingGlobal(const SweepPlanDev &pl, int n_pad, int lane) {
-        const uint64_t sp = reinterpret_cast<uint64_t>(pl.ring);
-        const uint32_t sp_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sp);
-        const uint32_t sp_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sp >> 32));
-        r = make_rsrc(reinterpret_cast<const void *>((uint64_t)sp_lo | ((uint64_t)sp_hi << 32)),
-                      (uint32_t)(n_pad + kRingAhead) * (1024u + 128u));
-        vo_w = (uint32_t)lane * 16u;
-        vo_a = (uint32_t)(n_pad + kRingAhead) * 1024u + (uint32_t)lane * 2u;
-    }
-    __device__ __forceinline__ uint32_t addr(int step) const {
-        return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, vo_a, step * 128, 0);
-    }
-    __device__ __forceinline__ f32x4 weights(int step, uint32_t a) const {
-        return __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a ? vo_w : kOutOfRange, step * 1024, 0));
-    }
-};
+// The plan stream in LDS, staged there by the workgroup (common.h: weights once per ring, the
+// eight lanes of a ring read one address; addresses per lane): weights one step ahead,
+// addresses two.
+template <int P>
 struct RingLds {
     static constexpr int kWeightsAhead = 1, kAddrAhead = 2;
-    const char *w, *a;  // this lane's entries of step 0
+    const char *w, *a;  // this lane's entries of step 0, plane 0
     __device__ __forceinline__ RingLds(const char *plan, int n_pad, int lane) {
-        w = plan + lane * 16;
-        a = plan + (n_pad + kRingAhead) * 1024 + lane * 2;
+        w = plan + (lane & 7) * 16;
+        a = plan + (n_pad + kRingAhead) * (128 * P) + lane * 2;
     }
-    __device__ __forceinline__ uint32_t addr(int step) const {
-        return *reinterpret_cast<const uint16_t *>(a + step * 128);
+    __device__ __forceinline__ uint32_t addr(int step, int p) const {
+        return *reinterpret_cast<const uint16_t *>(a + (step * P + p) * 128);
     }
-    __device__ __forceinline__ f32x4 weights(int step, uint32_t) const {
-        return *reinterpret_cast<const f32x4 *>(w + step * 1024);
+    __device__ __forceinline__ f32x4 weights(int step, int p) const {
+        return *reinterpret_cast<const f32x4 *>(w + (step * P + p) * 128);
     }
 };
 
 // The 16 bytes in front of `us` are the spare cell (idle lanes); n_pad, rmax, perm, centre:
-// the plan's ring_* fields, wave-uniform.
-template <class Plan>
-__device__ __forceinline__ void sweep_ring_loop(float *us, const Plan &plan, int n_pad, int rmax,
-                                                uint32_t perm, int centre_pix, float one_minus_g,
-                                                int lane) {
-    constexpr int DW = Plan::kWeightsAhead, DA = Plan::kAddrAhead;
-    static_assert(kRingUnroll == 6 && DA <= 6 && DW < DA, "register rotation of the loop");
+// the plan's ring_* fields, wave-uniform.  P planes: the lane works on ring m + 8 p (mod 8 P)
+// of its octant in every step, P independent chains.
+template <int P>
+__device__ __forceinline__ void sweep_ring_loop(float *us, const RingLds<P> &plan, int n_pad,
+                                                int rmax, uint32_t perm, int centre_pix,
+                                                float one_minus_g, int lane) {
+    constexpr int DW = RingLds<P>::kWeightsAhead, DA = RingLds<P>::kAddrAhead;
+    static_assert(kRingUnroll == 6 && DA < 6 && DW < DA && (P == 1 || P == 2),
+                  "register rotation of the loop");
     char *base = reinterpret_cast<char *>(us) - 16;
     auto lds = [&](uint32_t a) { return reinterpret_cast<float *>(base + a); };
 
@@ -1297,58 +1284,69 @@ __device__ __forceinline__ void sweep_ring_loop(float *us, const Plan &plan, int
     // is added to their neighbours' sums)
     *lds(0) = 0.f;
     const float centre = us[centre_pix];
-    float out = centre, c1 = centre, c2 = centre, c3 = centre;
-
-    uint32_t a[6];
-    f32x4 w[6];
+    float out[P], c1[P], c2[P], c3[P], cur[P];
+    uint32_t a[6][P];
+    f32x4 w[6][P];
 #pragma unroll
-    for (int i = 0; i < DA; ++i) a[i] = plan.addr(i);
+    for (int p = 0; p < P; ++p) {
+        out[p] = c1[p] = c2[p] = c3[p] = centre;
 #pragma unroll
-    for (int i = 0; i < DW; ++i) w[i] = plan.weights(i, a[i]);
-    float cur = *lds(a[0]);
+        for (int i = 0; i < DA; ++i) a[i][p] = plan.addr(i, p);
+#pragma unroll
+        for (int i = 0; i < DW; ++i) w[i][p] = plan.weights(i, p);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) cur[p] = *lds(a[0][p]);
 
     // one level; I = step within the unrolled iteration (levels L = s + I + 1: axis pixels at
     // odd L, diagonal pixels at L = 3 r - 1)
     auto step = [&](auto Ic, int s) {
         constexpr int I = decltype(Ic)::value;
-        w[(I + DW) % 6] = plan.weights(s + I + DW, a[(I + DW) % 6]);
-        if (DA < 6) a[(I + DA) % 6] = plan.addr(s + I + DA);
-#if SMI_EXP_NOLDS
-        const float cur_next = __uint_as_float(a[(I + 1) % 6]);
-#else
-        const float cur_next = *lds(a[(I + 1) % 6]);
-#endif
-        const float f1 = dpp_ror1(out), f9 = dpp_ror9(out);
-        c3 = c2;
-        c2 = c1;
-        c1 = inner ? f1 : f9;
-        float A = c3, B = c2;
-        if (I % 2 == 0) {  // ring (L + 1) / 2 starts on the axis
-            const int ra = (s + I + 2) >> 1;
-            const int ma = ra <= rmax ? (ra & 7) : 8;
-            A = m == ma ? (inner ? f9 : f1) : c3;
+        float cur_next[P], f1[P], f9[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            w[(I + DW) % 6][p] = plan.weights(s + I + DW, p);
+            a[(I + DA) % 6][p] = plan.addr(s + I + DA, p);
+            cur_next[p] = *lds(a[(I + 1) % 6][p]);
+            f1[p] = dpp_ror1(out[p]);
+            f9[p] = dpp_ror9(out[p]);
         }
-        if (I % 3 == 1 && !SMI_EXP_NODIAG) {  // ring (L + 1) / 3 ends on the diagonal
-            const int md = ((s + I + 2) / 3) & 7;
-            const float y = __builtin_bit_cast(
-                float, __builtin_amdgcn_ds_bpermute(diag_addr, __builtin_bit_cast(int, out)));
-            B = m == md ? y : c2;
+        float y = 0.f;
+        int md = 8, pdiag = 0;
+        if (I % 3 == 1) {  // ring (L + 1) / 3 ends on the diagonal
+            const int rd = (s + I + 2) / 3;
+            md = rd & 7;
+            pdiag = (rd >> 3) & (P - 1);
+            const float src = (P == 2 && pdiag) ? out[P - 1] : out[0];
+            y = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(diag_addr, __builtin_bit_cast(int, src)));
         }
-        const f32x4 &wn = w[I];
-        const float pA = __fmul_rn(A, wn.x), pB = __fmul_rn(B, wn.y);
-        const float pC = __fmul_rn(c1, wn.z), pD = __fmul_rn(out, wn.w);
-        const float e0 = asc ? pA : pC, e2 = asc ? pC : pA;
-        float ref = __fadd_rn(0.f, e0);
-        ref = __fadd_rn(ref, pd01 ? pD : pB);
-        ref = __fadd_rn(ref, pd01 ? pB : (pd2 ? pD : e2));
-        ref = __fadd_rn(ref, pd3 ? pD : e2);
-        const float lim = __fmul_rn(ref, one_minus_g);
-        out = lim < cur ? lim : cur;
-#if !SMI_EXP_NOLDS
-        *lds(a[I]) = out;
-#endif
-        if (DA == 6) a[I] = plan.addr(s + I + 6);
-        cur = cur_next;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            constexpr int below = P - 1;  // (p + P - 1) % P for P <= 2 is p ^ (P - 1)
+            c3[p] = c2[p];
+            c2[p] = c1[p];
+            c1[p] = inner ? f1[p] : f9[p ^ below];
+            float A = c3[p], B = c2[p];
+            if (I % 2 == 0) {  // ring (L + 1) / 2 starts on the axis
+                const int ra = (s + I + 2) >> 1;
+                const int ma = (ra <= rmax && ((ra >> 3) & (P - 1)) == p) ? (ra & 7) : 8;
+                A = m == ma ? (inner ? f9[p] : f1[p ^ below]) : c3[p];
+            }
+            if (I % 3 == 1) B = (m == md && pdiag == p) ? y : c2[p];
+            const f32x4 &wn = w[I][p];
+            const float pA = __fmul_rn(A, wn.x), pB = __fmul_rn(B, wn.y);
+            const float pC = __fmul_rn(c1[p], wn.z), pD = __fmul_rn(out[p], wn.w);
+            const float e0 = asc ? pA : pC, e2 = asc ? pC : pA;
+            float ref = __fadd_rn(0.f, e0);
+            ref = __fadd_rn(ref, pd01 ? pD : pB);
+            ref = __fadd_rn(ref, pd01 ? pB : (pd2 ? pD : e2));
+            ref = __fadd_rn(ref, pd3 ? pD : e2);
+            const float lim = __fmul_rn(ref, one_minus_g);
+            out[p] = lim < cur[p] ? lim : cur[p];
+            *lds(a[I][p]) = out[p];
+            cur[p] = cur_next[p];
+        }
     };
     for (int s = 0; s < n_pad; s += kRingUnroll) {
         step(std::integral_constant<int, 0>(), s);
@@ -1360,14 +1358,21 @@ __device__ __forceinline__ void sweep_ring_loop(float *us, const Plan &plan, int
     }
 }
 
-// `pl` must be wave-uniform; the plan stream comes from its device buffer.
-__device__ __forceinline__ void sweep_ring(float *us, const SweepPlanDev &pl, float one_minus_g,
-                                           int lane) {
+// `pl` wave-uniform, its stream at `plan_lds`; kMaxPlanes: what the caller can meet (the update
+// kernels stage one-plane plans only, refresh_view in batch.hip says why)
+template <int kMaxPlanes>
+__device__ __forceinline__ void sweep_ring(float *us, const SweepPlanDev &pl, const char *plan_lds,
+                                           float one_minus_g, int lane) {
     const int n_pad = __builtin_amdgcn_readfirstlane(pl.ring_pad);
-    sweep_ring_loop(us, RingGlobal(pl, n_pad, lane), n_pad,
-                    __builtin_amdgcn_readfirstlane(pl.ring_rmax),
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.ring_perm),
-                    __builtin_amdgcn_readfirstlane(pl.ring_centre), one_minus_g, lane);
+    const int rmax = __builtin_amdgcn_readfirstlane(pl.ring_rmax);
+    const uint32_t perm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.ring_perm);
+    const int centre = __builtin_amdgcn_readfirstlane(pl.ring_centre);
+    if (kMaxPlanes == 2 && __builtin_amdgcn_readfirstlane(pl.ring_planes) == 2)
+        sweep_ring_loop<2>(us, RingLds<2>(plan_lds, n_pad, lane), n_pad, rmax, perm, centre,
+                           one_minus_g, lane);
+    else
+        sweep_ring_loop<1>(us, RingLds<1>(plan_lds, n_pad, lane), n_pad, rmax, perm, centre,
+                           one_minus_g, lane);
 }
 
 // occupancy the register allocator has to reach (waves per SIMD): three arrays of NPL
@@ -1693,7 +1698,7 @@ __device__ __forceinline__ void upd_store(const BatchView &v, UpdState<NPL> &S) 
         buf_store(r_out, (uint32_t)(lane + T * j) * 4u, S.zs[j]);
         bad |= !isfinite(S.zs[j]);
     }
-    if (Team<T>::any(bad) && lane == 0) atomicExch(&v.state[c.b], 3);  // model.py:153-165
+    if (Team<T>::any(bad) && lane == 0) atomicExch(&v.state[c.b], v.fail_code);  // model.py:153-165
 }
 
 template <int NPL, int MODE, int T = 64>
@@ -1723,14 +1728,9 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
         if (S.monotonic) {
             // one wavefront sweeps (the steps are sequential and at most 64 pixels wide)
             if (T == 64 || threadIdx.x < 64) {
-                if (S.ring && S.ring == S.staged) {
-                    const int n_pad = __builtin_amdgcn_readfirstlane(S.ring->ring_pad);
-                    sweep_ring_loop(S.us, RingLds(S.plan_lds, n_pad, S.c.lane), n_pad,
-                                    __builtin_amdgcn_readfirstlane(S.ring->ring_rmax),
-                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ring->ring_perm),
-                                    __builtin_amdgcn_readfirstlane(S.ring->ring_centre),
-                                    S.one_minus_g, S.c.lane);
-                } else
+                if (S.ring && S.ring == S.staged)
+                    sweep_ring<1>(S.us, *S.ring, S.plan_lds, S.one_minus_g, S.c.lane);
+                else
                     sweep_slots(S.us, S.slots, S.n_slots, S.one_minus_g, S.c.lane);
             }
             if (T > 64) __syncthreads();
@@ -1865,8 +1865,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void up
 }
 
 // development aid: shader clocks of `n_rep` sweeps of one plan per wavefront, every wavefront
-// on an image of its own in LDS (mode 0: slot plan, 1: ring schedule); the images come back
-// for comparison
+// on an image of its own in LDS (mode 0: slot plan, 2: ring schedule with the plan stream staged
+// behind the images); the images come back for comparison
 __global__ void sweep_timing_kernel(const SweepPlanDev *plans, int plan_id, int mode, int n_rep,
                                     float one_minus_g, long long *cycles, float *images) {
     const SweepPlanDev &pl = plans[plan_id];
@@ -1896,10 +1896,7 @@ __global__ void sweep_timing_kernel(const SweepPlanDev *plans, int plan_id, int 
         wave_lds_fence();
         const long long t0 = __builtin_readcyclecounter();
         if (mode == 2)
-            sweep_ring_loop(us, RingLds(plan_lds, pl.ring_pad, lane), pl.ring_pad, pl.ring_rmax,
-                            pl.ring_perm, pl.ring_centre, one_minus_g, lane);
-        else if (mode == 1)
-            sweep_ring(us, pl, one_minus_g, lane);
+            sweep_ring<2>(us, pl, plan_lds, one_minus_g, lane);
         else
             sweep_slots(us, pl.slots, pl.n_slots, one_minus_g, lane);
         wave_lds_fence();
@@ -2124,11 +2121,15 @@ static int launch_update_reg(const BatchView &v, const float *G, int32_t it, flo
     int n_blocks = (n_items + pack - 1) / pack;
     size_t lds = (size_t)pack * (T * NPL + 4) * sizeof(float);
     if (T == 64 && may_stage && v.stage_plan[cls] >= 0) {
-        const size_t need = (size_t)kPack * (T * NPL + 4) * sizeof(float) + v.stage_bytes[cls];
-        if (need + (size_t)kPack * 64 * sizeof(float) + 64 <= 160 * 1024) {
+        // as many wavefronts as fit the LDS beside the stream (61^2 boxes: seven images of 15 KB
+        // and 49 KB of plan)
+        const size_t per_wave = (size_t)(T * NPL + 4) * sizeof(float);
+        const size_t fixed = (size_t)kPack * 64 * sizeof(float) + 64 + v.stage_bytes[cls];
+        const int fit = fixed < 160 * 1024 ? (int)((160 * 1024 - fixed) / per_wave) : 0;
+        if (fit >= 4) {
             stage = v.stage_plan[cls];
-            pack = forced > 0 ? pack : kPack;
-            lds = (size_t)pack * (T * NPL + 4) * sizeof(float) + v.stage_bytes[cls];
+            pack = std::min(forced > 0 ? pack : kPack, fit);
+            lds = (size_t)pack * per_wave + v.stage_bytes[cls];
             n_blocks = (n_items + pack - 1) / pack;
             const int resident = cu_count() * std::max(1, (int)((160 * 1024) / (lds + kPack * 256 + 64)));
             static const bool may_persist = [] {  // development aid
@@ -2191,10 +2192,12 @@ int launch_update_finalize(const BatchView &v, const float *G, int32_t it, float
     return SMI_OK;
 }
 
-int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
+int launch_update(const BatchView &v_in, const float *G, int32_t it, float e_rel,
                   int32_t prox_max_iter, float *g_sed_out, float *g_morph_out,
                   int32_t grad_only, hipStream_t s) {
-    if (v.n_comp == 0) return SMI_OK;
+    if (v_in.n_comp == 0) return SMI_OK;
+    BatchView v = v_in;
+    v.fail_code = 3 + std::max(it, 0);  // (finalize_blend)
     // chains that repeat take the general kernel (the register-resident ones apply it once)
     if (!grad_only && v.fast_plans && v.max_box_pixels <= kMaxRegisterBox && !v.c_chain_repeat &&
         !v.mono_mask) {
@@ -2206,7 +2209,11 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
             classes += present;
             large += present && cls >= kNumSmallClasses;
         }
-        if (classes > 1 && !large && v.n_comp <= kMixedUpdateLimit) {
+        static const int mixed_limit = [] {  // development aid
+            const char *e = getenv("SMI_MIXED_LIMIT");
+            return e ? atoi(e) : kMixedUpdateLimit;
+        }();
+        if (classes > 1 && !large && v.n_comp <= mixed_limit) {
             const size_t lds = (size_t)(64 * kUpdateNpl[kNumUpdateClasses - 1] + 4) * sizeof(float);
             const PendingFinalize fin = pending_finalize;
             pending_finalize.on = false;
@@ -2229,7 +2236,13 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
         // launch is one latency-bound chain per component, so the classes go to streams of
         // their own, forked from and joined to `s` (multi-resolution tutorial scene: three
         // launches of 0.23 + 0.13 + 0.10 ms in a row).
-        const bool side_by_side = classes > 1 && v.n_comp <= kMixedUpdateLimit;
+        // SMI_CLASS_STREAMS (development aid): 0 never, 1 always
+        static const int class_streams = [] {
+            const char *e = getenv("SMI_CLASS_STREAMS");
+            return e ? atoi(e) : -1;
+        }();
+        const bool side_by_side = classes > 1 && (class_streams < 0 ? v.n_comp <= kMixedUpdateLimit
+                                                                    : class_streams > 0);
         struct Side {
             hipStream_t stream[kNumUpdateClasses] = {};
             hipEvent_t fork = nullptr, join[kNumUpdateClasses] = {};
@@ -2295,10 +2308,12 @@ int launch_update(const BatchView &v, const float *G, int32_t it, float e_rel,
     return SMI_OK;
 }
 
-int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e_rel,
+int launch_point_sources(const BatchView &v_in, const float *G, int32_t it, float e_rel,
                          int32_t prox_max_iter, float *g_sed_out, double *g_center_out,
                          int32_t mode, hipStream_t s) {
-    if (v.n_point == 0 || v.n_comp == 0) return SMI_OK;
+    if (v_in.n_point == 0 || v_in.n_comp == 0) return SMI_OK;
+    BatchView v = v_in;
+    v.fail_code = 3 + std::max(it, 0);
     const size_t lds = (size_t)(((v.max_box_pixels + 3) & ~3) + 4) * sizeof(float);
     SMI_REQUIRE(lds <= 64 * 1024, "component box too large for the point-source kernel");
     hipLaunchKernelGGL(point_source_kernel, dim3(v.n_comp), dim3(64), lds, s, v, G, it, e_rel,
@@ -2313,6 +2328,7 @@ int launch_sweep_timing(const SweepPlanDev *d_plans, const SweepPlanDev &host_pl
     const size_t lds = (size_t)waves * (((n + 3) & ~3) + 4) * sizeof(float) +
                        (mode == 2 ? host_plan.ring_bytes : 0);
     SMI_REQUIRE(lds <= 160 * 1024 && waves >= 1 && waves <= 16, "images do not fit the LDS");
+    SMI_REQUIRE(mode == 0 || mode == 2, "mode: 0 slot plan, 2 ring schedule");
     SMI_REQUIRE(mode == 0 ? host_plan.slots != nullptr : host_plan.ring != nullptr, "plan has no such schedule");
     static size_t configured[kMaxDevices] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sweep_timing_kernel), lds, configured))

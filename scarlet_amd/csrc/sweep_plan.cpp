@@ -13,6 +13,8 @@
 // the sequential result for any weight table, not only the radial ones.
 #include <algorithm>
 
+#include <cstring>
+
 #include "common.h"
 
 namespace smi {
@@ -207,6 +209,26 @@ bool build_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t 
             ++covered;
         }
     return covered == n_idx;
+}
+
+bool ring_device_stream(const RingPlanHost &rp, std::vector<uint8_t> *out) {
+    const size_t P = (size_t)rp.planes, steps = (size_t)rp.n_pad + kRingAhead;
+    if (rp.addr.size() != steps * P * 64) return false;
+    out->assign(steps * P * (8 * 16 + 64 * 2), 0);
+    float *wts = reinterpret_cast<float *>(out->data());
+    uint16_t *addr = reinterpret_cast<uint16_t *>(out->data() + steps * P * 8 * 16);
+    for (size_t sp = 0; sp < steps * P; ++sp)
+        for (int m = 0; m < 8; ++m) {
+            const size_t first = sp * 64 + m;  // octant 0
+            for (int o = 0; o < 8; ++o) {
+                const size_t e = sp * 64 + (size_t)o * 8 + m;
+                if ((rp.addr[e] != 0) != (rp.addr[first] != 0)) return false;
+                if (memcmp(&rp.wts[e * 4], &rp.wts[first * 4], 16) != 0) return false;
+                addr[e] = rp.addr[e];
+            }
+            memcpy(&wts[(sp * 8 + m) * 4], &rp.wts[first * 4], 16);
+        }
+    return true;
 }
 
 }  // namespace smi

@@ -28,7 +28,7 @@ def ring_plan(shape, weights, offsets, didx):
                                        _lib.ptr(addr, ctypes.c_uint16), lanes))
     steps = lanes // (planes * 64)
     return dict(planes=planes, n_steps=n_steps, n_pad=n_pad, rmax=rmax, centre=centre,
-                perm=perm & 0xFFFFFFFF, wts=wts.reshape(steps, planes, 64, 4),
+                perm=perm & 0xFFFFFFFF, stream_bytes=int(info[7]), wts=wts.reshape(steps, planes, 64, 4),
                 addr=addr.reshape(steps, planes, 64).astype(np.int64))
 
 

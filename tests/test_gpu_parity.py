@@ -533,6 +533,41 @@ def test_convergence_freezes_blend_and_error_flag(amd, hsc):
         bad.fit(max_iter=10, e_rel=1e-4)
 
 
+@pytest.mark.parametrize("n_blends", [3, 48, 128])
+def test_loss_history_of_a_blend_that_goes_non_finite(amd, n_blends):
+    """The loss of the iteration in which a blend's parameters become non-finite is recorded
+    (Blend._callback appends it before the step, blend.py:294-299), whatever launch the
+    bookkeeping rides in: workgroups of the update launch (<= 1024 components) or a launch of
+    its own (1280 components), and whichever of them the hardware ran first."""
+    from scarlet_amd import synthetic
+
+    scenes = synthetic.make_batch(range(1234, 1234 + n_blends))
+    kern = synthetic.psfs()
+    comps = [[amd.ComponentSpec(s["seds"][k], s["morphs"][k], s["origins"][k],
+                                sed_min_step=s["noise_rms"]) for k in range(len(s["morphs"]))]
+             for s in scenes]
+    victims = sorted({0, n_blends // 2, n_blends - 1})
+    for trial in range(3):
+        b = amd.BlendBatch(np.stack([s["data"] for s in scenes]),
+                           np.stack([s["weights"] for s in scenes]), comps, kernel=kern[2],
+                           max_iter=12)
+        b.step(0, 3, e_rel=1e-3)
+        seds, morphs = b.parameters()
+        for j in victims:   # a different component of each victim
+            seds[10 * j + (j + trial) % 10, 1] = np.nan
+        b.set_parameters(seds, morphs)
+        b.step(3, 4, e_rel=1e-3)
+        n_active, first_bad = b.status()
+        assert first_bad == victims[0] and n_active == n_blends - len(victims)
+        states = b.states()
+        lengths = [len(h) for h in b.loss_history()]
+        for j in range(n_blends):
+            assert states[j] == (3 if j in victims else 0), (trial, j)
+            # iterations 0 .. 2, plus iteration 3 whose update failed; the others all seven
+            assert lengths[j] == (4 if j in victims else 7), (trial, j, lengths[j])
+        b.close()
+
+
 def test_make_batch_matches_host_generator(amd):
     from scarlet_amd import synthetic
 

@@ -117,6 +117,7 @@ def test_monotonic_tables_match_reference():
 
 
 @pytest.mark.parametrize("shape", [(3, 3), (5, 5), (21, 21), (31, 31), (41, 41), (47, 47),
+                                   (51, 51), (61, 61), (81, 81), (95, 95),
                                    (31, 41), (22, 30), (40, 40), (41, 40), (7, 47), (46, 11)])
 def test_ring_schedule_of_the_sweep_is_the_sequential_loop(shape):
     """The ring plan (library builder, csrc/sweep_plan.cpp) run by a numpy model of the
@@ -137,6 +138,11 @@ def test_ring_schedule_of_the_sweep_is_the_sequential_loop(shape):
                 continue
             assert plan["planes"] == (1 if rmax <= 23 else 2)
             assert plan["n_steps"] == 3 * rmax - 1
+            # the device stream stores the weights once per ring: only where all eight octants
+            # hold the same pixels with bit-identical weights (centred odd squares)
+            regular = h == w and h % 2 == 1 and centre == (h // 2, w // 2)
+            steps = plan["n_pad"] + 6
+            assert plan["stream_bytes"] == (steps * plan["planes"] * 256 if regular else 0)
             for g in (0.0, 0.25):
                 img = rng.random(h * w).astype(np.float32)
                 img[rng.integers(0, h * w, 5)] = 0  # exact zeros among the inputs
@@ -507,6 +513,64 @@ def test_bench_prices_the_bytes_of_survey_8d():
     run = bench.algorithmic_bytes(5, 128, 128, [41 * 41] * 10, 160, 160, 1)
     assert run["conv"] == 5051760 and run["update"] == 808280  # what the bench line prices
 
+
+def test_bench_names_the_dominant_kernel_from_the_library_path():
+    """The kernel the roofline object prices follows the convolution path the library reports
+    and the larger of the two phase times -- not a threshold on an empty phase's event
+    overhead (a 128-blend shard: conv 0.10 ms, conv_adj 5 us of events, update 0.13 ms)."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    by = bench.algorithmic_bytes(5, 128, 128, [41 * 41] * 10, 160, 160, 1)
+    shard = {"render": 0.0052, "conv": 0.0994, "residual": 0.0047, "conv_adj": 0.0053,
+             "update": 0.1329, "total": 0.2474}
+    name, nbytes, ms = bench.dominant_kernel(shard, "fused", by)
+    assert name.startswith("update kernels") and nbytes == by["update"] and ms == 0.1329
+    full = dict(shard, conv=0.6511, update=0.3353, total=1.0017)
+    assert bench.dominant_kernel(full, "fused", by) == ("fused_conv_kernel", by["conv"], 0.6511)
+    assert bench.dominant_kernel(full, "rocfft", by)[0] == "whole iteration (rocFFT pipeline)"
+    assert bench.dominant_kernel(full, "rocfft", by)[1:] == (by["whole"], 1.0017)
+    assert bench.dominant_kernel(full, "none", by) == ("update_kernel_reg", by["update"], 0.3353)
+
+
+def test_configure_sets_the_hardware_queues_only_on_request(monkeypatch):
+    """Loading the library leaves the environment alone; ``configure(hw_queues=8)`` sets
+    GPU_MAX_HW_QUEUES while the HIP runtime has not started, warns and changes nothing once
+    it has, and the library is told the number in effect."""
+    import os
+    import warnings
+
+    import scarlet_amd
+    from scarlet_amd import _lib
+
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(_lib, "_hw_queues", None)
+    monkeypatch.setattr(_lib, "_warned", False)
+    lib = _lib.load()
+    assert "GPU_MAX_HW_QUEUES" not in os.environ
+    assert scarlet_amd.configure() == 4
+    # the runtime is up: nothing changes, one warning
+    monkeypatch.setattr(_lib, "_hip_started", lambda: True)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        assert scarlet_amd.configure(hw_queues=8) == 4
+        assert scarlet_amd.configure(hw_queues=8) == 4
+    assert len(seen) == 1 and "already started" in str(seen[0].message)
+    assert "GPU_MAX_HW_QUEUES" not in os.environ
+    # ... unless the variable was exported before (the runtime has read it)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert scarlet_amd.configure(hw_queues=8) == 8
+    assert lib.smi_set_hw_queues(8) == 8
+    # before the runtime starts: set on request
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.setattr(_lib, "_hw_queues", None)
+    monkeypatch.setattr(_lib, "_hip_started", lambda: False)
+    assert scarlet_amd.configure(hw_queues=8) == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    assert lib.smi_set_hw_queues(4) == 8  # (back to the default for the other tests)
 
 
 def test_set_spectra_to_match_reproduces_the_reference_on_the_host():
