@@ -319,6 +319,117 @@ def dominant_kernel(phases, conv_path, by):
     return "whole iteration (rocFFT pipeline)", by["whole"], phases["total"]
 
 
+def build_facade_blends(lo, hi, device):
+    """configs[2]'s scenes as the objects a scarlet script holds: one ``Blend`` per scene,
+    a Frame / Observation pair matched by the difference kernel, ten ExtendedSource-style
+    components (TabulatedSpectrum + ExtendedSourceMorphology, ``resizing=True`` -- the
+    reference's default, source.py:215-260) from the same initial parameters as the C-ABI
+    bench."""
+    import scarlet_amd as scarlet
+    from scarlet_amd import synthetic
+
+    kern = synthetic.psfs()
+    scenes = synthetic.make_batch(range(1234 + lo, 1234 + hi), kernel=kern, device=device)
+    channels = list("grizy")
+    model_psf = scarlet.GaussianPSF(sigma=(synthetic.SIGMA_MODEL,) * 5)
+    obs_psf = scarlet.ImagePSF(np.repeat(kern[0], 5, axis=0))
+    frame = scarlet.Frame((5, synthetic.H, synthetic.W), psf=model_psf, channels=channels)
+    renderer = None
+    blends = []
+    for s in scenes:
+        obs = scarlet.Observation(s["data"], psf=obs_psf, weights=s["weights"], channels=channels)
+        # (one difference kernel for all: the PSFs are the same objects)
+        obs.match(frame, renderer=renderer)
+        if renderer is None:
+            renderer = obs.renderer
+        sources = []
+        for k in range(len(s["morphs"])):
+            oy, ox = (int(v) for v in s["origins"][k])
+            h, w = s["morphs"][k].shape
+            box = scarlet.Box((5, h, w), origin=(0, oy, ox))
+            spectrum = scarlet.TabulatedSpectrum(frame, s["seds"][k].copy(), bbox=box[0],
+                                                 min_step=s["noise_rms"])
+            morphology = scarlet.ExtendedSourceMorphology(
+                frame, (oy + h // 2, ox + w // 2), s["morphs"][k].copy(), bbox=box[1:],
+                monotonic="angle", resizing=True)
+            sources.append(scarlet.FactorizedComponent(frame, spectrum, morphology))
+        blends.append(scarlet.Blend(sources, obs))
+    return blends
+
+
+def facade(args):
+    """``--facade``: the path a scarlet user calls.  N Blend objects in, fit_blends(blends,
+    K, e_rel=1e-4) with box resizing on, fitted Blend objects out; wall clock around the
+    call, blend-iterations actually run / that time, beside the C-ABI rate of the same box
+    for the same number of iterations (BlendBatch.step on device-resident inputs, no
+    resizing: the headline measurement)."""
+    import cProfile
+    import pstats
+
+    import torch
+    import scarlet_amd as scarlet
+    from scarlet_amd import BlendBatch, _lib
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    n, K = args.blends, args.steps
+    t0 = time.perf_counter()
+    warm = build_facade_blends(0, min(n, 8), 0)
+    scarlet.fit_blends(warm, 12, e_rel=1e-4)  # library load, plan cache, first launches
+    blends = build_facade_blends(0, n, 0)
+    t_build = time.perf_counter() - t0
+    lib = _lib.load()
+    uploads0 = lib.smi_observation_uploads()
+    prof = cProfile.Profile() if args.profile else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if prof:
+        prof.enable()
+    results = scarlet.fit_blends(blends, K, e_rel=1e-4)
+    if prof:
+        prof.disable()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    uploads = lib.smi_observation_uploads() - uploads0
+    its = int(sum(r[0] for r in results))
+    if prof:
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
+    # the C-ABI rate on the same scenes: same number of iterations per blend, no resizing
+    data, weights, comps, kernel, _ = build_cfg3(0, n, 0, None)
+    batch = BlendBatch(data, weights, comps, kernel=kernel, max_iter=K + 1)
+    batch.save_state()
+    batch.step(0, min(K, 10), e_rel=1e-3)
+    batch.restore_state()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    batch.step(0, K, e_rel=1e-3)
+    torch.cuda.synchronize()
+    abi = n * K / (time.perf_counter() - t1)
+    batch.close()
+    resized = sum(1 for b in blends for src in b.sources
+                  if tuple(src.children[1].bbox.shape) != (41, 41))
+    line = {
+        "metric": "PGM iters/sec over batched blends, through scarlet's Python API "
+                  "(fit_blends: Blend objects in, fitted Blend objects out)",
+        "value": round(its / elapsed, 1), "unit": "blend-iterations/s", "n_gpus": 1,
+        "steps": K, "warmup": 0, "ms_per_step": round(elapsed / K * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[2] scenes as %d scarlet Blend objects (10 components each, "
+                        "ExtendedSourceMorphology with resizing=True), fit_blends(blends, %d, "
+                        "e_rel=1e-4); wall clock around the call" % (n, K),
+            "blend_iterations": its, "wall_s": round(elapsed, 4),
+            "iterations_per_blend": [int(min(r[0] for r in results)), int(max(r[0] for r in results))],
+            "components_resized": resized,
+            "observation_uploads_during_fit": int(uploads),
+            "c_abi_rate_same_box": round(abi, 1),
+            "ratio_to_c_abi": round(its / elapsed / abi, 4),
+            "object_construction_s": round(t_build, 2),
+        },
+    }
+    print(json.dumps(line), flush=True)
+
+
 def counters(kernel):
     """Counter-derived figures of the dominant kernel from the committed rocprofv3 PMC
     summaries (profiles/hbm_traffic.json, written by tools/hbm_counters.py)."""
@@ -365,6 +476,10 @@ def main():
     ap.add_argument("--loop", default="blend", choices=["blend", "lite-adaprox", "lite-fista"],
                     help="ablation: run the scarlet.lite loop (LiteBlend.fit semantics) on the "
                          "same scenes instead of Blend.fit's")
+    ap.add_argument("--facade", action="store_true",
+                    help="time scarlet_amd.fit_blends on Blend objects built from the cfg3 "
+                         "scenes (resizing on) instead of the C-ABI batch")
+    ap.add_argument("--profile", action="store_true", help="--facade: cProfile of the call")
     args = ap.parse_args()
 
     # before the HIP runtime starts (scarlet_amd._lib explains): eight hardware queues, so that
@@ -372,6 +487,8 @@ def main():
     from scarlet_amd import configure
 
     configure(hw_queues=8)
+    if args.facade:
+        return facade(args)
     if args.config == "cfg5":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_cfg5

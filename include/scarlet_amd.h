@@ -427,6 +427,42 @@ int smi_batch_get_timing(smi_batch *b, double *ms_per_phase, int32_t n_phases);
 /* FFT shape actually used (fft_h, fft_w) */
 int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w);
 
+/* ---------------------------------------------------------------------------------
+ * Box resizing (ImageMorphology.update, morphology.py:132-207; Blend.fit's hook every ten
+ * iterations, blend.py:284-292) for a batch that stays on the device between hooks.
+ *
+ * smi_batch_resize_test: the two reductions update() decides on, per component --
+ *   margin[k]: width of the frame of pixels <= 0 around the image (shrink_box; INT32_MAX for
+ *   an image without a pixel > 0), edge_pull[k]: the largest of the four edge means of
+ *   -m / sqrt(sqrt(v)) * step * (image > 0) over the pixels with v != 0 (-inf if there is
+ *   none; summed in another order than NumPy does and with the float32 step: callers treat
+ *   values within 1e-6 of the threshold 0.1 as "ask the host").  Point sources and shifted
+ *   images report (-1, nan).
+ * State record of a component, float32: [sed C][m C][v C][vhat C][image N][m N][v N][vhat N],
+ *   N = box_h * box_w.  smi_batch_get_component_states packs the records of the listed
+ *   components back to back into `states`.
+ * smi_batch_update_components: a new component table (same components per blend, `sed` and
+ *   `morph` of *c are not read) in which the components with keep[k] != 0 keep their device-
+ *   resident parameters and moments (their boxes must not have changed) and the others take
+ *   theirs from `states`, records in the order of k.  The observation, the kernel, the loss
+ *   histories and the per-blend states stay.  Factorized image components under AMSGrad
+ *   only.  On an error the batch is left without components.
+ * smi_batch_set_states / smi_batch_get_progress: per-blend state (0 iterating, 2 finished or
+ *   paused -- its workgroups return at once --, 3 failed) and number of recorded losses.
+ * --------------------------------------------------------------------------------- */
+int smi_batch_resize_test(smi_batch *b, int32_t *margin, double *edge_pull);
+int smi_batch_get_component_states(smi_batch *b, const int32_t *components, int32_t n,
+                                   float *states);
+int smi_batch_update_components(smi_batch *b, const smi_components *c, const int32_t *keep,
+                                const float *states);
+int smi_batch_set_states(smi_batch *b, const int32_t *state);
+int smi_batch_get_progress(smi_batch *b, int32_t *state, int32_t *n_loss);
+
+/* Number of host-to-device uploads of observation cubes (smi_batch_set_observation and
+ * smi_batch_add_observation) this process has made so far: lets a caller -- and the tests --
+ * check that a driver which keeps its batch alive does not ship the data again. */
+int64_t smi_observation_uploads(void);
+
 /* The convolution path the batch runs (what conv_path = 0 "auto" resolved to):
  * 0 none (NullRenderer, no difference kernel), 1 rocFFT pipeline, 2 fused_conv_kernel. */
 int smi_batch_conv_path_used(smi_batch *b, int32_t *path);

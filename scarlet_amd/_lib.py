@@ -192,6 +192,12 @@ SYMBOLS = {
     "smi_batch_fft_shape": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
     "smi_batch_conv_path_used": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "smi_set_hw_queues": (ctypes.c_int, [ctypes.c_int32]),
+    "smi_observation_uploads": (ctypes.c_int64, []),
+    "smi_batch_resize_test": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_f64p]),
+    "smi_batch_get_component_states": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.c_int32, c_f32p]),
+    "smi_batch_update_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Components), c_i32p, c_f32p]),
+    "smi_batch_set_states": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
+    "smi_batch_get_progress": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
 }
 
 _lib = None

@@ -138,9 +138,30 @@ class BlendBatch:
             self._h, {"amsgrad": _lib.SCHEME_AMSGRAD, "fista": _lib.SCHEME_FISTA}[scheme]))
         _lib.check(lib.smi_batch_set_log_norm(self._h, int(bool(log_norm))))
 
+        self._plan_ids = {}
+        comps = self._pack_components(flat)
+        _lib.check(lib.smi_batch_set_components(self._h, ctypes.byref(comps)))
+        _lib.check(
+            lib.smi_batch_set_observation(
+                self._h, _lib.ptr(data, ctypes.c_float), _lib.ptr(weights, ctypes.c_float)
+            )
+        )
+        self._kernel_shape = None if kernel is None else kernel.shape
+        if kernel is not None:
+            _lib.check(lib.smi_batch_set_kernel(self._h, _lib.ptr(kernel, ctypes.c_float)))
+
+    # -- component tables ---------------------------------------------------
+    def _pack_components(self, flat, values=True, rows=None):
+        """``smi_components`` of the ComponentSpecs ``flat`` (all blends, in order); registers
+        the monotonicity plans their boxes need.  ``values=False``: ``sed`` and ``morph`` are
+        left unset (``smi_batch_update_components`` does not read them).  ``rows``: indices of
+        the components that differ from the last call -- only their rows are written again
+        (the per-component loops below are what a thousand-blend ``fit_blends`` would
+        otherwise spend its hook rounds in)."""
+        lib, nb, C = self._lib, self.n_blends, self.C
         # monotonicity plans, one per (box shape, weighting); with centre fitting
         # (PROX_FIT_CENTER) nine consecutive ones for the centres around the box centre
-        plan_ids = {}
+        plan_ids = self._plan_ids
 
         def add_plan(shape, weighting, center):
             wts, off, didx = operator.monotonic_tables(shape, weighting, center)
@@ -151,7 +172,8 @@ class BlendBatch:
                 )
             )
 
-        for c in flat:
+        part = flat if rows is None else [flat[k] for k in rows]
+        for c in part:
             if c.prox_flags & _lib.PROX_MONOTONIC:
                 fit = bool(c.prox_flags & _lib.PROX_FIT_CENTER)
                 key = (c.morph.shape, c.neighbor_weight, fit)
@@ -167,66 +189,149 @@ class BlendBatch:
                        for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
                 assert ids == list(range(ids[0], ids[0] + 9))
                 plan_ids[key] = ids[0]
-        self._shapes = [c.morph.shape for c in flat]
-        self._flags = [c.prox_flags for c in flat]
-        self._morph_offsets = np.concatenate(
-            [[0], np.cumsum([s[0] * s[1] for s in self._shapes])]
-        ).astype(np.int64)
 
-        arrays = dict(
-            blend=_lib.i32(np.repeat(np.arange(nb), self.n_comp_per_blend)),
-            origin_y=_lib.i32([c.origin[0] for c in flat]),
-            origin_x=_lib.i32([c.origin[1] for c in flat]),
-            box_h=_lib.i32([s[0] for s in self._shapes]),
-            box_w=_lib.i32([s[1] for s in self._shapes]),
-            sed=_lib.f32(np.stack([c.sed for c in flat]) if flat else np.zeros((0, C))),
-            morph=_lib.f32(
-                np.concatenate([c.morph.reshape(-1) for c in flat]) if flat else np.zeros(0)
-            ),
+        shapes = [c.morph.shape for c in part]
+        fields = dict(
+            origin_y=_lib.i32([c.origin[0] for c in part]),
+            origin_x=_lib.i32([c.origin[1] for c in part]),
+            box_h=_lib.i32([s[0] for s in shapes]),
+            box_w=_lib.i32([s[1] for s in shapes]),
             sed_min_step=_lib.f32(
-                np.stack([c.sed_min_step for c in flat]) if flat else np.zeros((0, C))
+                np.stack([c.sed_min_step for c in part]) if part else np.zeros((0, C))
             ),
-            sed_rel_step=_lib.f32([c.sed_rel_step for c in flat]),
-            morph_step=_lib.f32([c.morph_step for c in flat]),
-            prox_flags=_lib.i32([c.prox_flags for c in flat]),
+            sed_rel_step=_lib.f32([c.sed_rel_step for c in part]),
+            morph_step=_lib.f32([c.morph_step for c in part]),
+            prox_flags=_lib.i32([c.prox_flags for c in part]),
             sweep_plan=_lib.i32(
                 [
                     plan_ids.get((c.morph.shape, c.neighbor_weight,
                                   bool(c.prox_flags & _lib.PROX_FIT_CENTER)), -1)
                     if c.prox_flags & _lib.PROX_MONOTONIC else -1
-                    for c in flat
+                    for c in part
                 ]
             ),
-            min_gradient=_lib.f32([c.min_gradient for c in flat]),
-            l_thresh=_lib.f32([c.l_thresh for c in flat]),
-            morph_rel_step=_lib.f32([c.morph_rel_step for c in flat]),
+            min_gradient=_lib.f32([c.min_gradient for c in part]),
+            l_thresh=_lib.f32([c.l_thresh for c in part]),
+            morph_rel_step=_lib.f32([c.morph_rel_step for c in part]),
             center=np.ascontiguousarray(
-                [getattr(c, "center", (0.0, 0.0)) for c in flat], dtype=np.float64
+                [getattr(c, "center", (0.0, 0.0)) for c in part], dtype=np.float64
             ).reshape(-1, 2),
-            psf_sigma=_lib.f32([getattr(c, "psf_sigma", 0.0) for c in flat]),
-            shift_step=_lib.f32([c.shift_step for c in flat]),
-            center_floor=_lib.f32([c.center_floor for c in flat]),
+            psf_sigma=_lib.f32([getattr(c, "psf_sigma", 0.0) for c in part]),
+            shift_step=_lib.f32([c.shift_step for c in part]),
+            center_floor=_lib.f32([c.center_floor for c in part]),
             bg_level=_lib.f32(
                 np.stack([c.bg_level if c.bg_level is not None else np.zeros(C, np.float32)
-                          for c in flat]) if flat else np.zeros((0, C))
+                          for c in part]) if part else np.zeros((0, C))
             ),
-            fista_step=_lib.f32([c.fista_step for c in flat]),
-            sym_strength=_lib.f32([c.sym_strength for c in flat]),
-            chain_repeat=np.ascontiguousarray([c.chain_repeat for c in flat], dtype=np.int32),
-            pos_floor=_lib.f32([c.pos_floor for c in flat]),
+            fista_step=_lib.f32([c.fista_step for c in part]),
+            sym_strength=_lib.f32([c.sym_strength for c in part]),
+            chain_repeat=np.ascontiguousarray([c.chain_repeat for c in part], dtype=np.int32),
+            pos_floor=_lib.f32([c.pos_floor for c in part]),
         )
+        if rows is None:
+            arrays = fields
+            arrays["blend"] = _lib.i32(np.repeat(np.arange(nb), self.n_comp_per_blend))
+            self._shapes = shapes
+            self._flags = [c.prox_flags for c in flat]
+        else:
+            arrays = self._component_arrays
+            for name, sub in fields.items():
+                arrays[name][rows] = sub
+            for k, c in zip(rows, part):
+                self._shapes[k] = c.morph.shape
+                self._flags[k] = c.prox_flags
+        self._component_arrays = arrays
+        self._morph_offsets = np.concatenate(
+            [[0], np.cumsum(arrays["box_h"].astype(np.int64) * arrays["box_w"])]
+        ).astype(np.int64)
+        arrays["sed"] = _lib.f32(np.stack([c.sed for c in flat]) if flat and values
+                                 else np.zeros((0, C)))
+        arrays["morph"] = _lib.f32(np.concatenate([c.morph.reshape(-1) for c in flat])
+                                   if flat and values else np.zeros(0))
         comps = _lib.Components()
         for name, ctype in _lib.Components._fields_:
             setattr(comps, name, arrays[name].ctypes.data_as(ctype))
-        _lib.check(lib.smi_batch_set_components(self._h, ctypes.byref(comps)))
-        _lib.check(
-            lib.smi_batch_set_observation(
-                self._h, _lib.ptr(data, ctypes.c_float), _lib.ptr(weights, ctypes.c_float)
-            )
-        )
-        self._kernel_shape = None if kernel is None else kernel.shape
-        if kernel is not None:
-            _lib.check(lib.smi_batch_set_kernel(self._h, _lib.ptr(kernel, ctypes.c_float)))
+        comps._keepalive = arrays  # the ctypes struct only holds pointers
+        return comps
+
+    # -- box resizing on a live batch (include/scarlet_amd.h) ---------------------------
+    def resize_test(self):
+        """(margin, edge_pull) per component: the reductions ``ImageMorphology.update``
+        decides on (morphology.py:132-207), computed on the device."""
+        margin = np.zeros(self.n_components, dtype=np.int32)
+        pull = np.zeros(self.n_components, dtype=np.float64)
+        _lib.check(self._lib.smi_batch_resize_test(
+            self._h, _lib.ptr(margin, ctypes.c_int32), _lib.ptr(pull, ctypes.c_double)))
+        return margin, pull
+
+    def component_states(self, indices):
+        """Parameters and AMSGrad moments of the components ``indices``: one dict per
+        component with ``sed, m_sed, v_sed, vhat_sed`` (C,) and ``morph, m_morph, v_morph,
+        vhat_morph`` (h, w) float32 views into one download."""
+        idx = _lib.i32(indices)
+        C = self.C
+        sizes = [4 * C + 4 * self._shapes[k][0] * self._shapes[k][1] for k in idx]
+        buf = np.empty(int(np.sum(sizes)), dtype=np.float32)
+        _lib.check(self._lib.smi_batch_get_component_states(
+            self._h, _lib.ptr(idx, ctypes.c_int32), idx.size, _lib.ptr(buf, ctypes.c_float)))
+        out, pos = [], 0
+        for k, size in zip(idx, sizes):
+            rec = buf[pos:pos + size]
+            pos += size
+            shape = self._shapes[k]
+            n = shape[0] * shape[1]
+            small = rec[:4 * C].reshape(4, C)
+            px = rec[4 * C:].reshape(4, n)
+            out.append(dict(sed=small[0], m_sed=small[1], v_sed=small[2], vhat_sed=small[3],
+                            morph=px[0].reshape(shape), m_morph=px[1].reshape(shape),
+                            v_morph=px[2].reshape(shape), vhat_morph=px[3].reshape(shape)))
+        return out
+
+    def update_components(self, components, keep, states):
+        """New component table on the live batch (after a box resize).  ``components``: the
+        ComponentSpecs of all blends like at construction; ``keep`` (bool per component): the
+        device-resident parameters and moments stay (box unchanged); ``states``: for the
+        others, in order, dicts like ``component_states`` returns (missing moments = zeros)
+        with the arrays of the new box."""
+        flat = [c for blend in components for c in blend]
+        assert len(flat) == self.n_components and \
+            [len(c) for c in components] == self.n_comp_per_blend
+        keep = np.ascontiguousarray(keep, dtype=np.int32)
+        comps = self._pack_components(flat, values=False, rows=np.flatnonzero(keep == 0))
+        C = self.C
+        parts = []
+        it = iter(states)
+        for k in np.flatnonzero(keep == 0):
+            st = next(it)
+            shape = self._shapes[k]
+            zero_c, zero_n = np.zeros(C, np.float32), np.zeros(shape, np.float32)
+            for name in ("sed", "m_sed", "v_sed", "vhat_sed"):
+                a = st.get(name)
+                parts.append(zero_c if a is None else np.asarray(a, dtype=np.float32).reshape(C))
+            for name in ("morph", "m_morph", "v_morph", "vhat_morph"):
+                a = st.get(name)
+                a = zero_n if a is None else np.asarray(a, dtype=np.float32)
+                assert a.shape == tuple(shape), (name, a.shape, shape)
+                parts.append(a.reshape(-1))
+        buf = np.concatenate(parts) if parts else np.zeros(1, np.float32)
+        _lib.check(self._lib.smi_batch_update_components(
+            self._h, ctypes.byref(comps), _lib.ptr(keep, ctypes.c_int32),
+            _lib.ptr(_lib.f32(buf), ctypes.c_float)))
+
+    def set_states(self, states):
+        """Per-blend state: 0 iterating, 2 finished or paused (skipped by every kernel),
+        3 failed."""
+        st = np.ascontiguousarray(states, dtype=np.int32)
+        assert st.shape == (self.n_blends,)
+        _lib.check(self._lib.smi_batch_set_states(self._h, _lib.ptr(st, ctypes.c_int32)))
+
+    def progress(self):
+        """(state, number of recorded losses) per blend; blocks until the steps are done."""
+        st = np.zeros(self.n_blends, dtype=np.int32)
+        n = np.zeros(self.n_blends, dtype=np.int32)
+        _lib.check(self._lib.smi_batch_get_progress(
+            self._h, _lib.ptr(st, ctypes.c_int32), _lib.ptr(n, ctypes.c_int32)))
+        return st, n
 
     # -- lifetime ----------------------------------------------------------
     def close(self):

@@ -9,6 +9,7 @@ iterations for the box-resizing hook (``src.update()``, blend.py:284-292).
 """
 
 import logging
+import os
 from functools import partial
 
 import numpy as np
@@ -21,9 +22,10 @@ from .component import CombinedComponent, FactorizedComponent
 from .constraint import PositivityConstraint, device_flags
 from .hoststep import HostParameter
 from .model import UpdateException
-from .morphology import PointSourceMorphology
+from .model import Model
+from .morphology import ImageMorphology, PointSourceMorphology
 from .psf import GaussianPSF
-from .parameter import relative_step
+from .parameter import relative_step, STD_FROM_V
 from .renderer import ConvolutionRenderer, NullRenderer, ResolutionRenderer
 
 logger = logging.getLogger("scarlet_amd.blend")
@@ -550,7 +552,7 @@ class Blend(CombinedComponent):
             len(self.loss), -self.loss[-1]))
         for p in self.parameters + extra:
             if p.v is not None:
-                p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))  # rough estimate, blend.py:189-192
+                p.std = STD_FROM_V  # rough estimate, blend.py:189-192
         # what _specs / _observation read is per call: nothing of this fit's renderer
         # parameters or scheme may steer a later fit_blends
         self._psf_stepped_on_device = self._psf is not None
@@ -686,7 +688,7 @@ class Blend(CombinedComponent):
             it = len(self.loss)
         for p in self.parameters + (shift,):
             if p.v is not None:
-                p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
+                p.std = STD_FROM_V
         return len(self.loss), -self.loss[-1]
 
     def _host_render_ops(self):
@@ -823,7 +825,7 @@ class Blend(CombinedComponent):
             it = len(self.loss)
         for p in self.parameters:
             if p.v is not None:
-                p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
+                p.std = STD_FROM_V
         self._scheme = ("amsgrad", 0.25)
         return len(self.loss), -self.loss[-1]
 
@@ -965,11 +967,23 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, devices=None, **alg
                     _import_state(blend, state)
                     for p in blend.parameters:
                         if p.v is not None:
-                            p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
+                            p.std = STD_FROM_V
         return out
     if devices is None or np.isscalar(devices) or len(devices) == 1:
         device = 0 if devices is None else int(devices if np.isscalar(devices) else devices[0])
-        out, fit_blends.errors = _fit_blends_on(blends, device, **kw)
+        # A thousand blends are a few million live Python objects, none of them garbage; the
+        # cyclic collector would walk them again and again while the loop below allocates
+        # its temporaries (measured: a quarter of the call).  Reference counting still frees
+        # everything the loop drops.
+        import gc
+
+        was_on = gc.isenabled()
+        gc.disable()
+        try:
+            out, fit_blends.errors = _fit_blends_on(blends, device, **kw)
+        finally:
+            if was_on:
+                gc.enable()
         return out
     from concurrent.futures import ThreadPoolExecutor
     from .dist import shard_range
@@ -989,97 +1003,65 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, devices=None, **alg
 fit_blends.errors = []
 
 
-def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
-    """``fit_blends`` of ``blends`` on GPU ``device``: (results, [(index, error)])."""
-    if alg_kwargs.get("callback") is not None:
-        raise NotImplementedError("callback= needs the host-stepped mode of Blend.fit")
-    scheme = alg_kwargs.pop("scheme", "amsgrad")
-    if scheme != "amsgrad":
-        raise NotImplementedError("fit_blends batches the device's AMSGrad loop; use Blend.fit "
-                                  "for scheme={!r} (host-stepped)".format(scheme))
-    prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
-    opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
-               eps=alg_kwargs.pop("eps", 1e-8))
-    alg_kwargs.pop("callback", None)
-    if alg_kwargs:
-        raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
+def _device_hook_covers(node):
+    """True when everything ``node.update()`` can do is an ``ImageMorphology.update`` of a
+    factorized component (no shift, no point source) below it -- what the device's resize test
+    stands for.  Any other ``update`` in the tree (a user subclass) keeps the blend on the path
+    that calls every hook on the host."""
+    if isinstance(node, FactorizedComponent):
+        spectrum, morphology = node.children
+        return (type(node).update is FactorizedComponent.update
+                and type(spectrum).update is Model.update
+                and type(morphology).update is ImageMorphology.update
+                and not getattr(morphology, "shifting", False))
+    if isinstance(node, CombinedComponent):
+        return (type(node).update is CombinedComponent.update
+                and all(_device_hook_covers(c) for c in node.children))
+    return False
 
-    class _Run:
-        def __init__(self, blend):
-            # `base + local` is the reference's `it`: 0 at the start of fit(), the length
-            # of the whole loss history after a restart (blend.py:101, 198)
-            self.blend, self.base, self.local, self.result = blend, 0, 0, None
-            blend._scheme = ("amsgrad", 0.25)  # the batched device loop
-            self.obs = blend._observation()
-            if blend._lowres or blend._extra_layers:
-                raise NotImplementedError(
-                    "fit_blends: blends with a ResolutionRenderer observation or with several "
-                    "observations of one channel fit one by one")
 
-        @property
-        def total(self):
-            return self.base + self.local
+def _next_round(local, budget):
+    """Iterations until the resize hook after local iterations 10, 20, ... has to run (once
+    11, 21, ... iterations of this adaprox call are done), capped by ``budget``."""
+    n_hook = (11 if local == 0 else ((local - 1) // 10 + 1) * 10 + 1) - local
+    return min(n_hook, budget)
 
-    # blends with host-updated parameters (hoststep.py) step one iteration per device call
-    solo = set()
-    for i, b in enumerate(blends):
-        b._psf, b._scheme = None, ("amsgrad", 0.25)  # nothing left over from an earlier fit()
-        if any(not p.fixed for obs in b.observations for p in obs.parameters):
-            solo.add(i)  # free renderer parameters (psf_shift): Blend.fit's own loop
-            continue
-        b._observation()
-        if b._lowres or b._extra_layers:
-            # a ResolutionRenderer observation / several observations of one channel are
-            # terms of ONE blend's loss on the device (smi_batch_attach_lowres,
-            # smi_batch_add_observation): such a blend is fitted by itself, like
-            # [b.fit() for b in blends] would (scarlet/testing/api.py:216-224)
-            solo.add(i)
-            continue
-        b._specs(_flatten(b.sources))
-        if b._host:
-            solo.add(i)
-    solo_results = {}
-    for i in sorted(solo):
-        blends[i].device = device
-        try:
-            solo_results[i] = blends[i].fit(max_iter, e_rel, min_iter, prox_max_iter=prox_max_iter, **opt)
-        except ArithmeticError as e:
-            solo_results[i] = e
-    runs = [_Run(b) for i, b in enumerate(blends) if i not in solo]
+
+def _fit_group_rebuilt(group, device, max_iter, opt, step_kw):
+    """Blends that share the frame and kernel shapes, with components the resident path does
+    not cover (point sources, free shifts): a device batch per round and iteration counter,
+    state over the host in between."""
     while True:
-        todo = [r for r in runs if r.result is None and r.total < max_iter]
+        todo = [r for r in group if r.result is None and r.total < max_iter]
         if not todo:
-            break
-        groups = {}
+            return
+        by_local = {}
         for r in todo:
-            data, _, kernel = r.obs
-            key = (data.shape, None if kernel is None else kernel.shape, r.local)
-            groups.setdefault(key, []).append(r)
-        for (shape, kshape, local), group in groups.items():
-            comps = [_flatten(r.blend.sources) for r in group]
-            n_hook = (11 if local == 0 else ((local - 1) // 10 + 1) * 10 + 1) - local
-            n = min([n_hook] + [max_iter - r.total for r in group])
+            by_local.setdefault(r.local, []).append(r)
+        for local, part in by_local.items():
+            comps = [_flatten(r.blend.sources) for r in part]
+            n = _next_round(local, min(max_iter - r.total for r in part))
+            kernel = part[0].obs[2]
             batch = BlendBatch(
-                np.stack([r.obs[0] for r in group]), np.stack([r.obs[1] for r in group]),
-                [r.blend._specs(c) for r, c in zip(group, comps)],
-                kernel=None if kshape is None else np.stack([r.obs[2] for r in group]),
+                np.stack([r.obs[0] for r in part]), np.stack([r.obs[1] for r in part]),
+                [r.blend._specs(c) for r, c in zip(part, comps)],
+                kernel=None if kernel is None else np.stack([r.obs[2] for r in part]),
                 max_iter=n, device=device)
             try:
                 flat = [c for cs in comps for c in cs]
-                if any(r.blend._loss_constant for r in group):
-                    batch.add_loss_constant([r.blend._loss_constant for r in group])
+                if any(r.blend._loss_constant for r in part):
+                    batch.add_loss_constant([r.blend._loss_constant for r in part])
                 Blend._upload_state(batch, flat)
                 batch.set_optimizer(**opt)
                 if local > 0:  # the stopping rule compares with the loss before this round
-                    batch.set_previous_loss(np.array([r.blend.loss[-1] for r in group]))
-                batch.step(local, n, e_rel=e_rel, min_iter=min_iter, prox_max_iter=prox_max_iter,
-                           check_convergence=True)
+                    batch.set_previous_loss(np.array([r.blend.loss[-1] for r in part]))
+                batch.step(local, n, check_convergence=True, **step_kw)
                 states = batch.states()
                 losses = batch.loss_history()
                 Blend._download_all(batch, flat)
             finally:
                 batch.close()
-            for r, state, loss in zip(group, states, losses):
+            for r, state, loss in zip(part, states, losses):
                 blend = r.blend
                 blend.loss.extend(loss)
                 done = len(loss)
@@ -1099,6 +1081,221 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
                     r.base, r.local = len(blend.loss), 0
                 elif state == 2 or r.total >= max_iter:
                     r.result = True
+
+
+def _fit_group_resident(group, device, max_iter, opt, step_kw):
+    """Blends that share the frame and kernel shapes, factorized image components only: ONE
+    device batch for the whole fit.  The observation is uploaded once; every round steps the
+    blends that share an iteration counter while the others pause (per-blend state); at a
+    resize hook the device evaluates the two reductions ``ImageMorphology.update`` decides on
+    for every component (``smi_batch_resize_test``), and only the blends in which a box may
+    change come to the host, have their sources' ``update()`` run -- the host keeps the last
+    word -- and go back as new rows of the component table (``smi_batch_update_components``)."""
+    nb = len(group)
+    comps = [_flatten(r.blend.sources) for r in group]
+    specs = [r.specs for r in group]
+    first = np.concatenate([[0], np.cumsum([len(c) for c in comps])]).astype(np.int64)
+    kernel = group[0].obs[2]
+    batch = BlendBatch(
+        np.stack([r.obs[0] for r in group]), np.stack([r.obs[1] for r in group]), specs,
+        kernel=None if kernel is None else np.stack([r.obs[2] for r in group]),
+        max_iter=max(max_iter, 1), device=device)
+    try:
+        flat = [c for cs in comps for c in cs]
+        if any(r.blend._loss_constant for r in group):
+            batch.add_loss_constant([r.blend._loss_constant for r in group])
+        Blend._upload_state(batch, flat)
+        batch.set_optimizer(**opt)
+        prior = np.array([len(r.blend.loss) for r in group])  # losses of earlier fits
+        base = np.zeros(nb, dtype=np.int64)
+        local = np.zeros(nb, dtype=np.int64)
+        count = np.zeros(nb, dtype=np.int64)  # losses recorded on the device so far
+        state = np.zeros(nb, dtype=np.int32)  # 0 iterating, 2 finished, 3 failed
+        # per component: may update() act, and does the device test stand for it
+        resizable = np.array([bool(c.children[1].resizing) and not c.children[1].parameters[0].fixed
+                              for c in flat])
+        blend_of = np.repeat(np.arange(nb), np.diff(first))
+        while True:
+            live = (state == 0) & (base + local < max_iter)
+            if not live.any():
+                break
+            # (the rounds of this pass, fixed before any of them changes a counter)
+            rounds = [(L, np.flatnonzero(live & (local == L))) for L in np.unique(local[live])]
+            for L, part in rounds:
+                n = _next_round(int(L), int((max_iter - base[part] - local[part]).min()))
+                paused = np.full(nb, 2, dtype=np.int32)
+                paused[part] = 0
+                batch.set_states(paused)
+                batch.step(int(L), n, check_convergence=True, **step_kw)
+                now, cnt = batch.progress()
+                done = cnt[part] - count[part]
+                count[part] = cnt[part]
+                local[part] = L + done
+                state[part] = now[part]
+                ok = part[now[part] != 3]
+                done_ok = done[now[part] != 3]
+                hook = ok[(done_ok == n) & (L + done_ok > 1) & ((L + done_ok - 1) % 10 == 0)]
+                if hook.size == 0 or not resizable.any():
+                    continue
+                # candidates by the device's reductions; 1e-6: the host decides what is close
+                margin, pull = batch.resize_test()
+                shapes = np.array(batch._shapes)
+                size = shapes.max(axis=1)
+                inner = size - 2 * np.where(margin == np.iinfo(np.int32).max,
+                                            (shapes.min(axis=1) + 1) // 2, margin)
+                standard = 21 + 10 * np.ceil(np.maximum(inner - 21, 0) / 10).astype(np.int64)
+                wanted = resizable & ((standard < size) | (pull > 0.1 * (1 - 1e-6)))
+                visit = [int(i) for i in hook if wanted[first[i]:first[i + 1]].any()]
+                if not visit:
+                    continue
+                # Only the sources with a candidate below them go over the host: update() of
+                # the others is a no-op by the test above.  (Within a source the reference stops
+                # at the first child that resizes, component.py:172-185: a source is visited
+                # as a whole.)
+                calls = []  # (blend, source, index of its first component, components)
+                for i in visit:
+                    k = int(first[i])
+                    for src in group[i].blend.sources:
+                        below = _flatten([src])
+                        if wanted[k:k + len(below)].any():
+                            calls.append((i, src, k, below))
+                        k += len(below)
+                idx = np.concatenate([np.arange(k, k + len(below)) for _, _, k, below in calls])
+                for k, rec in zip(idx, batch.component_states(idx)):
+                    _record_to_parameters(flat[k], rec)
+                changed = set()
+                images = {i: [c.children[1].parameters[0] for c in comps[i]] for i in visit}
+                for i, src, k, below in calls:
+                    try:
+                        src.update()
+                    except UpdateException:
+                        changed.add(i)
+                if not changed:
+                    continue
+                # new rows of the component table: a component whose image Parameter was
+                # replaced (sliced or padded, step halved) takes its state from the host, all
+                # others keep theirs on the device
+                keep = np.ones(len(flat), dtype=bool)
+                states = []
+                for i in sorted(changed):
+                    base[i], local[i] = prior[i] + count[i], 0
+                    before = images[i]
+                    comps[i] = _flatten(group[i].blend.sources)
+                    flat[first[i]:first[i + 1]] = comps[i]
+                    moved = [j for j, c in enumerate(comps[i])
+                             if c.children[1].parameters[0] is not before[j]]
+                    fresh = group[i].blend._specs([comps[i][j] for j in moved])
+                    assert not group[i].blend._host
+                    for j, spec in zip(moved, fresh):
+                        specs[i][j] = spec
+                        keep[first[i] + j] = False
+                        states.append(_parameters_to_record(comps[i][j]))
+                batch.update_components(specs, keep, states)
+                # (a restarted blend that was about to stop goes on: adaprox starts anew)
+                state[[i for i in changed if state[i] == 2]] = 0
+            # a blend whose last round ended with the stopping rule is done
+        Blend._download_all(batch, flat)
+        history = batch.loss_history()
+    finally:
+        batch.close()
+    for i, r in enumerate(group):
+        r.blend.loss.extend(history[i][:count[i]])
+        r.base, r.local = int(base[i]), int(local[i])
+        r.result = (ArithmeticError("parameters of the blend are not finite")
+                    if state[i] == 3 else True)
+
+
+def _record_to_parameters(comp, rec):
+    """A state record of the device (``BlendBatch.component_states``) into the Parameters of
+    a factorized component: values in place, moments as float64 arrays."""
+    sed = comp.children[0].parameters[0]
+    image = comp.children[1].parameters[0]
+    sed[...] = rec["sed"]
+    sed.m, sed.v, sed.vhat = (rec[n].astype(np.float64) for n in ("m_sed", "v_sed", "vhat_sed"))
+    image[...] = rec["morph"]
+    image.m, image.v, image.vhat = (rec[n].astype(np.float64)
+                                    for n in ("m_morph", "v_morph", "vhat_morph"))
+
+
+def _parameters_to_record(comp):
+    sed = comp.children[0].parameters[0]
+    image = comp.children[1].parameters[0]
+    return dict(sed=np.asarray(sed), m_sed=sed.m, v_sed=sed.v, vhat_sed=sed.vhat,
+                morph=np.asarray(image), m_morph=image.m, v_morph=image.v, vhat_morph=image.vhat)
+
+
+def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
+    """``fit_blends`` of ``blends`` on GPU ``device``: (results, [(index, error)])."""
+    if alg_kwargs.get("callback") is not None:
+        raise NotImplementedError("callback= needs the host-stepped mode of Blend.fit")
+    scheme = alg_kwargs.pop("scheme", "amsgrad")
+    if scheme != "amsgrad":
+        raise NotImplementedError("fit_blends batches the device's AMSGrad loop; use Blend.fit "
+                                  "for scheme={!r} (host-stepped)".format(scheme))
+    prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
+    opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
+               eps=alg_kwargs.pop("eps", 1e-8))
+    alg_kwargs.pop("callback", None)
+    if alg_kwargs:
+        raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
+
+    class _Run:
+        def __init__(self, blend, obs):
+            # `base + local` is the reference's `it`: 0 at the start of fit(), the length
+            # of the whole loss history after a restart (blend.py:101, 198)
+            self.blend, self.base, self.local, self.result = blend, 0, 0, None
+            blend._scheme = ("amsgrad", 0.25)  # the batched device loop
+            self.obs = obs
+
+        @property
+        def total(self):
+            return self.base + self.local
+
+    # blends with host-updated parameters (hoststep.py) step one iteration per device call
+    solo, observed, described = set(), {}, {}
+    for i, b in enumerate(blends):
+        b._psf, b._scheme = None, ("amsgrad", 0.25)  # nothing left over from an earlier fit()
+        if any(not p.fixed for obs in b.observations for p in obs.parameters):
+            solo.add(i)  # free renderer parameters (psf_shift): Blend.fit's own loop
+            continue
+        if any(type(obs.renderer) not in (NullRenderer, ConvolutionRenderer, ResolutionRenderer)
+               for obs in b.observations):
+            solo.add(i)  # a user-defined renderer: Blend.fit's host-rendered mode
+            continue
+        observed[i] = b._observation()  # (built once: the data, weight and kernel cubes)
+        if b._lowres or b._extra_layers:
+            # a ResolutionRenderer observation / several observations of one channel are
+            # terms of ONE blend's loss on the device (smi_batch_attach_lowres,
+            # smi_batch_add_observation): such a blend is fitted by itself, like
+            # [b.fit() for b in blends] would (scarlet/testing/api.py:216-224)
+            solo.add(i)
+            continue
+        described[i] = b._specs(_flatten(b.sources))  # (once: 20 us per component)
+        if b._host:
+            solo.add(i)
+    solo_results = {}
+    for i in sorted(solo):
+        blends[i].device = device
+        try:
+            solo_results[i] = blends[i].fit(max_iter, e_rel, min_iter, prox_max_iter=prox_max_iter, **opt)
+        except ArithmeticError as e:
+            solo_results[i] = e
+    runs = [_Run(b, observed[i]) for i, b in enumerate(blends) if i not in solo]
+    for r, i in zip(runs, (i for i in range(len(blends)) if i not in solo)):
+        r.specs = described[i]
+    step_kw = dict(e_rel=e_rel, min_iter=min_iter, prox_max_iter=prox_max_iter)
+    by_shape = {}
+    for r in runs:
+        data, _, kernel = r.obs
+        by_shape.setdefault((data.shape, None if kernel is None else kernel.shape), []).append(r)
+    for group in by_shape.values():
+        plain = all(_device_hook_covers(src) for r in group for src in r.blend.sources)
+        if os.environ.get("SCARLET_AMD_FIT_BLENDS") == "rebuild":  # development aid: A/B runs
+            plain = False
+        if plain:
+            _fit_group_resident(group, device, max_iter, opt, step_kw)
+        else:
+            _fit_group_rebuilt(group, device, max_iter, opt, step_kw)
     out, errors = [], []
     batched = iter(runs)
     for i, blend in enumerate(blends):
@@ -1116,6 +1313,6 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
             continue
         for p in blend.parameters:
             if p.v is not None:
-                p.std = 1 / np.sqrt(ma.masked_equal(p.v, 0))
+                p.std = STD_FROM_V
         out.append((len(blend.loss), -blend.loss[-1]))
     return out, errors

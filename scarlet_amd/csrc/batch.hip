@@ -34,6 +34,9 @@
 namespace smi {
 
 static thread_local std::string g_error;
+// hardware queues the runtime has, as far as the host told us (smi_set_hw_queues)
+static std::atomic<int> g_hw_queues{4};
+static std::atomic<long long> g_observation_uploads{0};  // smi_observation_uploads
 // rocFFT plans kept between batches (see PlanCache below)
 static std::mutex g_plan_mutex;
 void set_error(const std::string &msg) { g_error = msg; }
@@ -218,6 +221,7 @@ struct smi_batch {
     int32_t *c_shift_fft = nullptr;
     std::vector<char> is_shift;
     std::vector<int64_t> h_moff;
+    std::vector<int32_t> h_blend;  // owning blend of every component
     // scarlet.lite
     float *c_center_floor = nullptr, *c_bg_level = nullptr, *c_fista_step = nullptr;
     float *c_sym_strength = nullptr;
@@ -945,6 +949,7 @@ int smi_batch_set_observation(smi_batch *b, const float *data, const float *weig
     int rc;
     if ((rc = upload(&b->data, data, n))) return rc;
     if ((rc = upload(&b->weights, weights, n))) return rc;
+    g_observation_uploads.fetch_add(1);
     b->own_obs = true;
     launch_log_norm(b->weights, b->log_norm, b->d.n_blends, (int64_t)b->d.C * b->d.H * b->d.W,
                     b->stream);
@@ -1270,6 +1275,7 @@ int smi_batch_add_observation(smi_batch *b, const float *data, const float *weig
     int rc;
     if ((rc = upload(&layer.data, data, n))) return rc;
     if ((rc = upload(&layer.weights, weights, n))) return rc;
+    g_observation_uploads.fetch_add(1);
     // kernel spectrum: the routine of smi_batch_set_kernel, into a buffer of its own
     float2 *first = b->Kt;
     b->Kt = nullptr;
@@ -1304,14 +1310,50 @@ int smi_batch_add_observation(smi_batch *b, const float *data, const float *weig
     return SMI_OK;
 }
 
-int smi_batch_set_components(smi_batch *b, const smi_components *c) {
+// smi_batch_set_components, and with `keep` smi_batch_update_components: the table of
+// components replaced while the components with keep[k] != 0 hold on to their parameters and
+// moments on the device (same number of components per blend; the others take theirs from
+// the state records in `states`, in the order of k)
+static int set_components_impl(smi_batch *b, const smi_components *c, const int32_t *keep,
+                               const float *states) {
     SMI_REQUIRE(b && c, "null argument");
-    SMI_REQUIRE(c->blend && c->origin_y && c->origin_x && c->box_h && c->box_w && c->sed &&
-                    c->morph && c->sed_min_step && c->morph_step && c->prox_flags,
+    SMI_REQUIRE(c->blend && c->origin_y && c->origin_x && c->box_h && c->box_w &&
+                    (keep || (c->sed && c->morph)) && c->sed_min_step && c->morph_step && c->prox_flags,
                 "missing component array");
     SMI_HIP(hipSetDevice(b->device));
     SMI_HIP(hipStreamSynchronize(b->stream));  // pending steps may still read the old arrays
     const int n = b->d.n_components, nb = b->d.n_blends, C = b->d.C;
+    // what the kept components carry over: the four pixel arrays get a new packing (the
+    // spectra and their moments stay where they are: [n][C] either way)
+    std::vector<int64_t> old_moff;
+    float *old_px[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (keep) {
+        SMI_REQUIRE(b->have_components && states, "smi_batch_update_components follows smi_batch_set_components");
+        SMI_REQUIRE(b->n_point == 0 && b->n_shift == 0 && b->scheme != SMI_SCHEME_FISTA && !b->ks.stamp,
+                    "smi_batch_update_components: factorized image components under AMSGrad only");
+        for (int k = 0; k < n; ++k) {
+            SMI_REQUIRE(!(c->prox_flags[k] & (SMI_COMPONENT_POINT_SOURCE | SMI_COMPONENT_SHIFTING)),
+                        "smi_batch_update_components: factorized image components only");
+            SMI_REQUIRE(c->blend[k] == b->h_blend[k], "smi_batch_update_components: components moved between blends");
+            if (keep[k])
+                SMI_REQUIRE((int64_t)c->box_h[k] * c->box_w[k] == b->h_moff[k + 1] - b->h_moff[k],
+                            "smi_batch_update_components: a kept component changed its box size");
+        }
+        old_moff = b->h_moff;
+        old_px[0] = b->morph;
+        b->morph = nullptr;
+        for (int i = 0; i < 3; ++i) {
+            old_px[1 + i] = b->mom[3 + i];
+            b->mom[3 + i] = nullptr;
+        }
+    }
+    struct FreeOld {
+        float **p;
+        ~FreeOld() {
+            for (int i = 0; i < 4; ++i)
+                if (p[i]) (void)hipFree(p[i]);
+        }
+    } free_old{old_px};
     std::vector<int32_t> start(nb + 1, 0);
     std::vector<int64_t> moff(n + 1, 0);
     int max_pix = 1, prev = 0;
@@ -1377,8 +1419,12 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     UP(c_morph_rel, c->morph_rel_step ? c->morph_rel_step : zeros_n.data(), n);
     UP(c_min_grad, c->min_gradient ? c->min_gradient : zeros_n.data(), n);
     UP(c_lthresh, c->l_thresh ? c->l_thresh : zeros_n.data(), n);
-    UP(sed, c->sed, (size_t)n * C);
-    UP(morph, c->morph, (size_t)b->n_morph);
+    if (keep) {
+        SMI_HIP(dev_alloc(&b->morph, (size_t)b->n_morph));
+    } else {
+        UP(sed, c->sed, (size_t)n * C);
+        UP(morph, c->morph, (size_t)b->n_morph);
+    }
     std::vector<float> cfloor(n, 1e-6f);
     UP(c_center_floor, c->center_floor ? c->center_floor : cfloor.data(), n);
     std::vector<float> full_strength(n, 1.f);
@@ -1414,11 +1460,11 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         UP(fista_t, ones.data(), (size_t)n * 2);
     }
 #undef UP
-    for (int i = 0; i < 6; ++i) {
+    for (int i = keep ? 3 : 0; i < 6; ++i) {
         const size_t cnt = i < 3 ? (size_t)n * C : (size_t)b->n_morph;
         if (b->mom[i]) SMI_HIP(hipFree(b->mom[i]));
         SMI_HIP(dev_alloc(&b->mom[i], cnt));
-        SMI_HIP(hipMemset(b->mom[i], 0, (cnt ? cnt : 1) * sizeof(float)));
+        if (!keep) SMI_HIP(hipMemset(b->mom[i], 0, (cnt ? cnt : 1) * sizeof(float)));
     }
     if (b->scheme == SMI_SCHEME_FISTA) {
         // FistaParameter: z0 = x (lite/parameters.py:126-131)
@@ -1450,6 +1496,7 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
     b->max_box_w = 1;
     b->is_shift.assign((size_t)n, 0);
     b->h_moff = moff;
+    b->h_blend.assign(c->blend, c->blend + n);
     std::vector<float> shift_step(n, 1e-1f);
     std::vector<int32_t> shift_fft((size_t)n * 2, 0);
     for (int k = 0; k < n; ++k) {
@@ -1534,15 +1581,118 @@ int smi_batch_set_components(smi_batch *b, const smi_components *c) {
         }
     }
     b->have_components = true;
-    const int keep = b->view.max_box_pixels;
+    const int max_pixels = b->view.max_box_pixels;
     refresh_view(b);
-    b->view.max_box_pixels = keep;
+    b->view.max_box_pixels = max_pixels;
     // the morphology of a point source is derived from its centre
     const BatchView v = unmasked_view(b);
+    if (keep) {
+        // kept components: pixel arrays from the old packing; the others: their records
+        std::vector<int64_t> rec(n, -1);
+        int64_t total = 0;
+        std::vector<int32_t> kept(keep, keep + n);
+        for (int k = 0; k < n; ++k) {
+            kept[k] = keep[k] != 0;
+            if (kept[k]) continue;
+            rec[k] = total;
+            total += 4 * (int64_t)C + 4 * (moff[k + 1] - moff[k]);
+        }
+        int32_t *d_keep = nullptr;
+        int64_t *d_old = nullptr, *d_rec = nullptr;
+        float *d_states = nullptr;
+        if ((rc = upload(&d_keep, kept.data(), (size_t)n))) return rc;
+        if ((rc = upload(&d_old, old_moff.data(), (size_t)n + 1))) return rc;
+        if ((rc = upload(&d_rec, rec.data(), (size_t)n))) return rc;
+        if ((rc = upload(&d_states, states, (size_t)total))) return rc;
+        float *new_px[4] = {b->morph, b->mom[3], b->mom[4], b->mom[5]};
+        launch_carry_states(d_keep, d_old, b->c_moff, n, old_px, new_px, b->stream);
+        launch_scatter_states(v, d_rec, d_states, b->stream);
+        SMI_HIP(hipStreamSynchronize(b->stream));
+        for (void *p : {(void *)d_keep, (void *)d_old, (void *)d_rec, (void *)d_states}) (void)hipFree(p);
+        SMI_HIP(hipGetLastError());
+        return SMI_OK;
+    }
     if ((rc = launch_point_sources(v, nullptr, 0, 0.f, 0, nullptr, nullptr, 2, b->stream))) return rc;
     if ((rc = launch_shift_forward(v, 0, b->stream))) return rc;
     SMI_HIP(hipStreamSynchronize(b->stream));
     SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_batch_set_components(smi_batch *b, const smi_components *c) {
+    return set_components_impl(b, c, nullptr, nullptr);
+}
+
+int smi_batch_update_components(smi_batch *b, const smi_components *c, const int32_t *keep,
+                                const float *states) {
+    SMI_REQUIRE(keep, "null argument");
+    return set_components_impl(b, c, keep, states);
+}
+
+int smi_batch_resize_test(smi_batch *b, int32_t *margin, double *edge_pull) {
+    SMI_REQUIRE(b && b->have_components && margin && edge_pull, "components not set / null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    const int n = b->d.n_components;
+    int32_t *d_margin = nullptr;
+    double *d_pull = nullptr;
+    SMI_HIP(dev_alloc(&d_margin, (size_t)n));
+    SMI_HIP(dev_alloc(&d_pull, (size_t)n));
+    launch_resize_test(unmasked_view(b), d_margin, d_pull, b->stream);
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipMemcpy(margin, d_margin, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    SMI_HIP(hipMemcpy(edge_pull, d_pull, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_margin);
+    (void)hipFree(d_pull);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_batch_get_component_states(smi_batch *b, const int32_t *components, int32_t n_sel,
+                                   float *states) {
+    SMI_REQUIRE(b && b->have_components && (n_sel == 0 || (components && states)),
+                "components not set / null argument");
+    SMI_REQUIRE(b->n_point == 0 && b->n_shift == 0, "state records: factorized image components only");
+    if (n_sel == 0) return SMI_OK;
+    SMI_HIP(hipSetDevice(b->device));
+    const int n = b->d.n_components, C = b->d.C;
+    std::vector<int64_t> off(n_sel);
+    int64_t total = 0;
+    for (int j = 0; j < n_sel; ++j) {
+        SMI_REQUIRE(components[j] >= 0 && components[j] < n, "component index out of range");
+        off[j] = total;
+        total += 4 * (int64_t)C + 4 * (b->h_moff[components[j] + 1] - b->h_moff[components[j]]);
+    }
+    int32_t *d_sel = nullptr;
+    int64_t *d_off = nullptr;
+    float *d_states = nullptr;
+    int rc;
+    if ((rc = upload(&d_sel, components, (size_t)n_sel))) return rc;
+    if ((rc = upload(&d_off, off.data(), (size_t)n_sel))) return rc;
+    SMI_HIP(dev_alloc(&d_states, (size_t)total));
+    launch_gather_states(unmasked_view(b), d_sel, d_off, n_sel, d_states, b->stream);
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipMemcpy(states, d_states, (size_t)total * sizeof(float), hipMemcpyDeviceToHost));
+    for (void *p : {(void *)d_sel, (void *)d_off, (void *)d_states}) (void)hipFree(p);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_batch_set_states(smi_batch *b, const int32_t *state) {
+    SMI_REQUIRE(b && state, "null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipMemcpy(b->state, state, b->d.n_blends * sizeof(int32_t), hipMemcpyHostToDevice));
+    return SMI_OK;
+}
+
+int smi_batch_get_progress(smi_batch *b, int32_t *state, int32_t *n_loss) {
+    SMI_REQUIRE(b && state && n_loss, "null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const size_t nb = (size_t)b->d.n_blends;
+    SMI_HIP(hipMemcpy(state, b->state, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+    SMI_HIP(hipMemcpy(n_loss, b->n_loss, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nb; ++i) state[i] = std::min(state[i], 3);
     return SMI_OK;
 }
 
@@ -1803,8 +1953,6 @@ static bool inline_render(const smi_batch *b) {
     return allowed && b->inline_render && plain_batch(b) && b->view.render_slots > 0;
 }
 
-// hardware queues the runtime has, as far as the host told us (smi_set_hw_queues)
-static std::atomic<int> g_hw_queues{4};
 
 // number of blend ranges a step is split into
 static int sub_ranges(const smi_batch *b) {
@@ -2210,6 +2358,8 @@ int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w) {
     if (fft_w) *fft_w = b->Fx;
     return SMI_OK;
 }
+
+int64_t smi_observation_uploads(void) { return g_observation_uploads.load(); }
 
 int smi_set_hw_queues(int32_t n) {
     return g_hw_queues.exchange(n > 0 ? n : 4, std::memory_order_relaxed);

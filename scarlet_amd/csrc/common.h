@@ -342,6 +342,14 @@ int lowres_get_rendered(LowRes *l, float *out, hipStream_t s);
 int launch_sweep_timing(const SweepPlanDev *d_plans, const SweepPlanDev &host_plan, int plan_id,
                         int mode, int n_rep, float one_minus_g, int waves, int groups,
                         long long *cycles, float *images, hipStream_t s);
+// box resizing (kernels.hip: resize_test_kernel and the state records)
+void launch_resize_test(const BatchView &v, int32_t *margin, double *pull, hipStream_t s);
+void launch_gather_states(const BatchView &v, const int32_t *sel, const int64_t *off, int32_t n_sel,
+                          float *staging, hipStream_t s);
+void launch_scatter_states(const BatchView &v, const int64_t *off, const float *staging,
+                           hipStream_t s);
+void launch_carry_states(const int32_t *keep, const int64_t *old_moff, const int64_t *new_moff,
+                         int32_t n, float *const from[4], float *const to[4], hipStream_t s);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);
 void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,

@@ -1906,6 +1906,111 @@ __global__ void sweep_timing_kernel(const SweepPlanDev *plans, int plan_id, int 
     for (int i = lane; i < n; i += 64) images[(int64_t)gw * n + i] = us[i];
 }
 
+// ---------------------------------------------------------------------------
+// Box resizing of image morphologies (morphology.py:132-207), the device's share: the two
+// reductions ImageMorphology.update() decides on, for every component of the batch, so that
+// only blends in which a box really changes have to visit the host.
+//   margin[k] = width of the frame of pixels <= 0 around the image (shrink_box: min over the
+//               pixels > 0 of their distance to the nearest edge; INT32_MAX if none is > 0)
+//   pull[k]   = largest of the four edge means of  -m / sqrt(sqrt(v)) * step * (image > 0),
+//               pixels with v == 0 left out as the masked array leaves them out
+//               (-inf if every edge pixel is left out).  Double precision like the host, but
+//               summed in another order and with the float32 step: a filter -- the caller
+//               asks the host for the verdict on everything near the threshold.
+// One wavefront per component; point sources and shifted images report (-1, nan).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void resize_test_kernel(BatchView v, int32_t *margin, double *pull) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int flags = v.c_flags[k];
+    if (flags & (SMI_COMPONENT_POINT_SOURCE | SMI_COMPONENT_SHIFTING)) {
+        if (lane == 0) {
+            margin[k] = -1;
+            pull[k] = (double)NAN;
+        }
+        return;
+    }
+    const int h = v.c_h[k], w = v.c_w[k], N = h * w;
+    const int64_t off = v.c_moff[k];
+    const float *img = v.morph + off, *m = v.m_morph + off, *vv = v.v_morph + off;
+    const double step = (double)v.c_morph_step[k];
+    int mn = 0x7fffffff;
+    double sum[4] = {0, 0, 0, 0};
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = lane; i < N; i += 64) {
+        const int y = i / w, x = i - y * w;
+        const float val = img[i];
+        if (val > 0.f) mn = min(mn, min(min(y, h - 1 - y), min(x, w - 1 - x)));
+        const bool edge[4] = {x == 0, x == w - 1, y == 0, y == h - 1};
+        if ((edge[0] || edge[1] || edge[2] || edge[3]) && vv[i] != 0.f) {
+            const double g = -(double)m[i] / sqrt(sqrt((double)vv[i])) * step * (val > 0.f ? 1.0 : 0.0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (edge[e]) {
+                    sum[e] += g;
+                    cnt[e]++;
+                }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
+    double best = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double t = wave_sum(sum[e]);
+        int c = cnt[e];
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (c > 0) best = fmax(best, t / (double)c);
+    }
+    if (lane == 0) {
+        margin[k] = mn;
+        pull[k] = best;
+    }
+}
+
+// State of a component as one record of floats: [sed C][m C][v C][vhat C] then
+// [image N][m N][v N][vhat N] (N = h w): what a resize on the host needs and hands back.
+// gather: component sel[j] -> staging + off[j]; scatter: staging + off[k] -> component k for
+// every k with off[k] >= 0.  carry: the four pixel arrays of the components with keep[k] != 0
+// from their old offsets to the new ones (the boxes, hence the packing, changed around them).
+__global__ __launch_bounds__(256) void gather_states_kernel(BatchView v, const int32_t *sel,
+                                                            const int64_t *off, float *staging) {
+    const int k = sel[blockIdx.x], C = v.C, N = v.c_h[k] * v.c_w[k];
+    float *dst = staging + off[blockIdx.x];
+    const float *small[4] = {v.sed, v.m_sed, v.v_sed, v.vh_sed};
+    const float *px[4] = {v.morph, v.m_morph, v.v_morph, v.vh_morph};
+    const int64_t moff = v.c_moff[k];
+    for (int i = threadIdx.x; i < 4 * C; i += 256) dst[i] = small[i / C][(int64_t)k * C + i % C];
+    for (int a = 0; a < 4; ++a)
+        for (int i = threadIdx.x; i < N; i += 256) dst[4 * C + (int64_t)a * N + i] = px[a][moff + i];
+}
+
+__global__ __launch_bounds__(256) void scatter_states_kernel(BatchView v, const int64_t *off,
+                                                             const float *staging) {
+    const int k = blockIdx.x;
+    if (off[k] < 0) return;
+    const int C = v.C, N = v.c_h[k] * v.c_w[k];
+    const float *src = staging + off[k];
+    float *small[4] = {v.sed, v.m_sed, v.v_sed, v.vh_sed};
+    float *px[4] = {v.morph, v.m_morph, v.v_morph, v.vh_morph};
+    const int64_t moff = v.c_moff[k];
+    for (int i = threadIdx.x; i < 4 * C; i += 256) small[i / C][(int64_t)k * C + i % C] = src[i];
+    for (int a = 0; a < 4; ++a)
+        for (int i = threadIdx.x; i < N; i += 256) px[a][moff + i] = src[4 * C + (int64_t)a * N + i];
+}
+
+struct PixelArrays {
+    float *p[4];
+};
+__global__ __launch_bounds__(256) void carry_states_kernel(const int32_t *keep, const int64_t *old_moff,
+                                                           const int64_t *new_moff, PixelArrays from,
+                                                           PixelArrays to) {
+    const int k = blockIdx.x;
+    if (!keep[k]) return;
+    const int64_t src = old_moff[k], dst = new_moff[k];
+    const int N = (int)(old_moff[k + 1] - src);
+    for (int a = 0; a < 4; ++a)
+        for (int i = threadIdx.x; i < N; i += 256) to.p[a][dst + i] = from.p[a][src + i];
+}
+
 // log_norm of Observation (observation.py:172-186): D/2 ln(2 pi) + sum ln(1/sqrt(w))
 __global__ __launch_bounds__(256) void log_norm_kernel(const float *weights, double *out,
                                                        int64_t n) {
@@ -2336,6 +2441,34 @@ int launch_sweep_timing(const SweepPlanDev *d_plans, const SweepPlanDev &host_pl
     hipLaunchKernelGGL(sweep_timing_kernel, dim3(groups), dim3(64 * waves), lds, s, d_plans, plan_id,
                        mode, n_rep, one_minus_g, cycles, images);
     return SMI_OK;
+}
+
+void launch_resize_test(const BatchView &v, int32_t *margin, double *pull, hipStream_t s) {
+    if (v.n_comp)
+        hipLaunchKernelGGL(resize_test_kernel, dim3(v.n_comp), dim3(64), 0, s, v, margin, pull);
+}
+
+void launch_gather_states(const BatchView &v, const int32_t *sel, const int64_t *off, int32_t n_sel,
+                          float *staging, hipStream_t s) {
+    if (n_sel)
+        hipLaunchKernelGGL(gather_states_kernel, dim3(n_sel), dim3(256), 0, s, v, sel, off, staging);
+}
+
+void launch_scatter_states(const BatchView &v, const int64_t *off, const float *staging,
+                           hipStream_t s) {
+    if (v.n_comp)
+        hipLaunchKernelGGL(scatter_states_kernel, dim3(v.n_comp), dim3(256), 0, s, v, off, staging);
+}
+
+void launch_carry_states(const int32_t *keep, const int64_t *old_moff, const int64_t *new_moff,
+                         int32_t n, float *const from[4], float *const to[4], hipStream_t s) {
+    PixelArrays a, b;
+    for (int i = 0; i < 4; ++i) {
+        a.p[i] = from[i];
+        b.p[i] = to[i];
+    }
+    if (n)
+        hipLaunchKernelGGL(carry_states_kernel, dim3(n), dim3(256), 0, s, keep, old_moff, new_moff, a, b);
 }
 
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,

@@ -40,6 +40,28 @@ def _empty_margin(image, thresh):
     return int(min(lo.min(), hi.min()))
 
 
+def _edge_pull(image, m, v, step):
+    """Mean pull of the next Adam step over each of the four edges of the box
+    (morphology.py:166-176): ``-m / sqrt(sqrt(v)) * step * (image > 0)`` averaged over the
+    edge pixels with ``v != 0``.  The reference evaluates the whole image as a masked array
+    and takes the means of four slices; this is the same arithmetic on the four edges only --
+    the masked mean is the sum of the zero-filled slice over the count of unmasked entries --
+    bit for bit (tests/test_host_logic.py), at a tenth of the cost.  An edge without an
+    unmasked pixel gives nan, as the masked constant does when it is put into an array."""
+    out = np.empty(4)
+    for e, sl in enumerate(((slice(None), 0), (slice(None), -1), (0, slice(None)), (-1, slice(None)))):
+        vv = v[sl]
+        seen = vv != 0
+        count = int(seen.sum())
+        if count == 0:
+            out[e] = np.nan
+            continue
+        gu = -m[sl] / np.sqrt(np.sqrt(np.where(seen, vv, 1.0))) * step
+        pull = gu * (image[sl] > 0)
+        out[e] = np.where(seen, pull, 0.0).sum() * 1.0 / count
+    return out
+
+
 class Morphology(Model):
     """Spatial part of a factorized component inside ``bbox`` (default: the box of
     ``frame``)."""
@@ -120,10 +142,7 @@ class ImageMorphology(Morphology):
             self._parameters = (image,) + self._parameters[1:]
             raise UpdateException
         if image.m is not None:
-            gu = -image.m / np.sqrt(np.sqrt(ma.masked_equal(image.v, 0))) * image.step
-            pull = gu * (image > 0)
-            edge_pull = np.array((pull[:, 0].mean(), pull[:, -1].mean(),
-                                  pull[0, :].mean(), pull[-1, :].mean()))
+            edge_pull = _edge_pull(np.asarray(image), image.m, image.v, image.step)
             if np.any(edge_pull > 0.1):
                 size = max(bbox.shape)
                 newsize = get_minimal_boxsize(size + 1)

@@ -4,6 +4,7 @@ with the reference's attribute names (scarlet/parameter.py:9-71) so that warm
 starts, pickling and user code that inspects ``p.std`` keep working."""
 
 import numpy as np
+import numpy.ma as ma
 
 from .constraint import Constraint, ConstraintChain
 from .prior import Prior
@@ -12,6 +13,21 @@ _ATTRS = (
     ("name", "unnamed"), ("prior", None), ("constraint", None), ("step", 0),
     ("std", None), ("m", None), ("v", None), ("vhat", None), ("fixed", False),
 )
+
+
+def std_estimate(v):
+    """``1 / sqrt(masked_equal(v, 0))`` (the rough error estimate of blend.py:189-192): the same
+    masked array -- mask, fill value and unmasked values -- without numpy.ma's per-operation
+    bookkeeping."""
+    v = np.asarray(v)
+    mask = v == 0
+    with np.errstate(divide="ignore"):
+        data = 1 / np.sqrt(v)
+    return ma.array(data, mask=mask, fill_value=0.0)
+
+
+# value of Parameter.std that stands for "std_estimate(self.v), when somebody asks"
+STD_FROM_V = "1/sqrt(v)"
 
 
 class Parameter(np.ndarray):
@@ -47,6 +63,19 @@ class Parameter(np.ndarray):
     def __setstate__(self, state):
         self.__dict__.update(state[-1])
         super().__setstate__(state[:-1])
+
+    @property
+    def std(self):
+        """Rough error estimate.  A fit leaves ``STD_FROM_V`` here instead of twenty thousand
+        masked arrays nobody may look at: the estimate is made from ``v`` on first access."""
+        value = self.__dict__.get("_std")
+        if isinstance(value, str):
+            value = self.__dict__["_std"] = None if self.v is None else std_estimate(self.v)
+        return value
+
+    @std.setter
+    def std(self, value):
+        self.__dict__["_std"] = value
 
     @property
     def _data(self):

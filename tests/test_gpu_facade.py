@@ -458,9 +458,12 @@ def test_lite_init_all_sources_main_matches_the_reference(hsc):
 
 
 def test_fit_blends_equals_individual_fits(hsc):
-    """fit_blends: several Blend objects in one device batch (regrouped after every
-    resize round) give exactly the per-blend results of Blend.fit"""
+    """fit_blends: several Blend objects in one device batch that stays on the device for the
+    whole call (the resize hooks change its component table in place) give exactly the
+    per-blend results of Blend.fit -- and the observation is uploaded once, not once per
+    hook round"""
     import scarlet_amd as scarlet
+    from scarlet_amd import _lib
 
     def make(k):
         full, obs = build_blend(hsc, resizing=True)
@@ -475,7 +478,12 @@ def test_fit_blends_equals_individual_fits(hsc):
     single = [make(k) for k in range(3)]
     want = [b.fit(35, e_rel=1e-5) for b in single]
     many = [make(k) for k in range(3)]
+    boxes = [[tuple(c.children[1].bbox.shape) for c in components_of(b)] for b in many]
+    uploads = _lib.load().smi_observation_uploads()
     got = scarlet.fit_blends(many, 35, e_rel=1e-5)
+    assert _lib.load().smi_observation_uploads() - uploads == 1
+    # (the hooks did resize boxes in this fit)
+    assert boxes != [[tuple(c.children[1].bbox.shape) for c in components_of(b)] for b in many]
     for a, b, r1, r2 in zip(single, many, want, got):
         assert r1 == r2
         assert_allclose(a.loss, b.loss, rtol=0, atol=0)
@@ -489,6 +497,46 @@ def test_fit_blends_equals_individual_fits(hsc):
     small = make(0)
     res = scarlet.fit_blends([other, small], 5, e_rel=1e-9)
     assert res[0][0] == res[1][0] == 5
+
+
+def test_fit_blends_resident_batch_equals_rebuilt_batches_and_single_fits(monkeypatch):
+    """48 scenes of the benchmark workload as Blend objects with resizing on: the batch that
+    stays on the device (device-side resize test, component table changed in place, blends at
+    different iteration counters paused in turn) gives what the per-round rebuilt batches give
+    -- iteration counts, every loss, boxes, parameters -- and what ``Blend.fit`` gives for
+    blends of it fitted alone."""
+    import os
+    import sys
+
+    import scarlet_amd as scarlet
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    n = 48
+    a = bench.build_facade_blends(0, n, 0)
+    ra = scarlet.fit_blends(a, 60, e_rel=1e-4)
+    monkeypatch.setenv("SCARLET_AMD_FIT_BLENDS", "rebuild")
+    b = bench.build_facade_blends(0, n, 0)
+    rb = scarlet.fit_blends(b, 60, e_rel=1e-4)
+    monkeypatch.delenv("SCARLET_AMD_FIT_BLENDS")
+    assert ra == rb
+    resized = 0
+    for x, y in zip(a, b):
+        assert x.loss == y.loss
+        for p, q in zip(x.parameters, y.parameters):
+            assert p.shape == q.shape
+            assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
+            if p.m is not None:
+                assert_allclose(p.m, q.m, rtol=0, atol=0)
+                assert_allclose(p.v, q.v, rtol=0, atol=0)
+            assert callable(p.step) or p.step == q.step
+        resized += sum(tuple(src.children[1].bbox.shape) != (41, 41) for src in x.sources)
+    assert resized > 10 and len({r[0] for r in ra}) > 3  # boxes changed, blends stopped apart
+    for i in (0, 17, 47):
+        one = bench.build_facade_blends(i, i + 1, 0)[0]
+        assert one.fit(60, e_rel=1e-4) == ra[i]
+        assert one.loss == a[i].loss
 
 
 def test_fit_blends_fits_unbatchable_blends_by_themselves(hsc):

@@ -568,6 +568,110 @@ def test_loss_history_of_a_blend_that_goes_non_finite(amd, n_blends):
         b.close()
 
 
+def test_resize_on_a_live_batch_equals_a_rebuilt_batch(amd):
+    """smi_batch_resize_test / smi_batch_get_component_states / smi_batch_update_components:
+    the reductions of ImageMorphology.update (morphology.py:132-207) on the device against
+    the host's expressions, state records against the full download, and a batch whose
+    component table changed under it (one box shrunk, one grown, the others kept on the
+    device; one blend paused) against a batch built anew from the same state: the same bits
+    after further iterations."""
+    from scarlet_amd import synthetic
+    from scarlet_amd.morphology import _edge_pull, _empty_margin
+
+    n_blends = 5
+    scenes = synthetic.make_batch(range(1234, 1234 + n_blends))
+    kern = synthetic.psfs()
+    data = np.stack([s["data"] for s in scenes])
+    weights = np.stack([s["weights"] for s in scenes])
+
+    def specs_of(seds, morphs, origins, steps):
+        return [[amd.ComponentSpec(seds[10 * i + k], morphs[10 * i + k], origins[10 * i + k],
+                                   sed_min_step=scenes[i]["noise_rms"], morph_step=steps[10 * i + k])
+                 for k in range(10)] for i in range(n_blends)]
+
+    origins = [tuple(int(v) for v in s["origins"][k]) for s in scenes for k in range(10)]
+    steps = [1e-2] * (10 * n_blends)
+    seds0 = [s["seds"][k] for s in scenes for k in range(10)]
+    morphs0 = [s["morphs"][k] for s in scenes for k in range(10)]
+    live = amd.BlendBatch(data, weights, specs_of(seds0, morphs0, origins, steps), kernel=kern[2],
+                          max_iter=40)
+    live.step(0, 11, e_rel=1e-3)
+    seds, morphs = live.parameters()
+    mom = live.moments()
+
+    # the device's reductions against the host's
+    margin, pull = live.resize_test()
+    for k in range(10 * n_blends):
+        assert margin[k] == _empty_margin(morphs[k], 0), k
+        want = np.nanmax(_edge_pull(morphs[k], mom["m_morph"][k].astype(np.float64),
+                                    mom["v_morph"][k].astype(np.float64), 1e-2))
+        assert abs(pull[k] - want) <= 1e-6 * abs(want) + 1e-300, (k, pull[k], want)
+    # state records against the full download
+    pick = [3, 17, 18, 49]
+    for k, rec in zip(pick, live.component_states(pick)):
+        assert_array_equal(rec["sed"], seds[k])
+        assert_array_equal(rec["morph"], morphs[k])
+        for name in ("m_sed", "v_sed", "vhat_sed"):
+            assert_array_equal(rec[name], mom[name][k])
+        for name in ("m_morph", "v_morph", "vhat_morph"):
+            assert_array_equal(rec[name], mom[name][k])
+
+    # component 12 shrinks to 31^2, component 37 grows to 51^2 (zero padding), steps halved
+    def resized(a, k):
+        if k == 12:
+            return a[5:-5, 5:-5]
+        if k == 37:
+            return np.pad(a, 5)
+        return a
+
+    new_morphs = [resized(morphs[k], k) for k in range(10 * n_blends)]
+    new_origins = list(origins)
+    new_origins[12] = (origins[12][0] + 5, origins[12][1] + 5)
+    new_origins[37] = (origins[37][0] - 5, origins[37][1] - 5)
+    new_steps = list(steps)
+    new_steps[12] = new_steps[37] = 5e-3
+    new_specs = specs_of(list(seds), new_morphs, new_origins, new_steps)
+    keep = np.ones(10 * n_blends, dtype=bool)
+    keep[10:20] = False   # blend 1 goes over the host entirely, blend 3 only its resized box
+    keep[37] = False
+    records = [dict(sed=seds[k], m_sed=mom["m_sed"][k], v_sed=mom["v_sed"][k],
+                    vhat_sed=mom["vhat_sed"][k], morph=new_morphs[k],
+                    m_morph=resized(mom["m_morph"][k], k), v_morph=resized(mom["v_morph"][k], k),
+                    vhat_morph=resized(mom["vhat_morph"][k], k))
+               for k in np.flatnonzero(~keep)]
+    live.update_components(new_specs, keep, records)
+    paused = np.zeros(n_blends, dtype=np.int32)
+    paused[2] = 2
+    live.set_states(paused)
+    live.step(11, 6, e_rel=1e-3)
+    state, count = live.progress()
+    assert list(count) == [17, 17, 11, 17, 17] and list(state) == [0, 0, 2, 0, 0]
+
+    fresh = amd.BlendBatch(data, weights, new_specs, kernel=kern[2], max_iter=40)
+    fresh.set_moments(m_sed=mom["m_sed"], v_sed=mom["v_sed"], vhat_sed=mom["vhat_sed"],
+                      m_morph=[resized(a, k) for k, a in enumerate(mom["m_morph"])],
+                      v_morph=[resized(a, k) for k, a in enumerate(mom["v_morph"])],
+                      vhat_morph=[resized(a, k) for k, a in enumerate(mom["vhat_morph"])])
+    fresh.set_states(paused)
+    fresh.step(11, 6, e_rel=1e-3)
+    s1, m1 = live.parameters()
+    s2, m2 = fresh.parameters()
+    assert_array_equal(s1, s2)
+    for a, b_ in zip(m1, m2):
+        assert_array_equal(a, b_)
+    for name, got in live.moments().items():
+        for a, b_ in zip(got, fresh.moments()[name]):
+            assert_array_equal(a, b_)
+    # the paused blend did not move, the others did
+    assert_array_equal(s1[20:30], seds[20:30])
+    assert not np.array_equal(s1[:10], seds[:10])
+    new_loss = [h[11:] for h in live.loss_history()]
+    for i, h in enumerate(fresh.loss_history()):
+        assert_array_equal(new_loss[i], h)
+    live.close()
+    fresh.close()
+
+
 def test_make_batch_matches_host_generator(amd):
     from scarlet_amd import synthetic
 

@@ -514,6 +514,39 @@ def test_bench_prices_the_bytes_of_survey_8d():
     assert run["conv"] == 5051760 and run["update"] == 808280  # what the bench line prices
 
 
+def test_edge_pull_of_the_resize_hook_is_the_masked_array_formula():
+    """morphology._edge_pull (four edge slices, plain arrays) gives the bits of the
+    reference's expression on the whole image as a masked array (morphology.py:166-176),
+    including edges where the second moment is zero in places or everywhere."""
+    import warnings
+
+    import numpy.ma as ma
+    from scarlet_amd.morphology import _edge_pull
+
+    rng = np.random.default_rng(11)
+    for shape in ((21, 21), (41, 41), (31, 41), (5, 3), (61, 61)):
+        for trial in range(6):
+            image = (rng.random(shape) - 0.3).astype(np.float32)
+            m = rng.standard_normal(shape).astype(np.float32).astype(np.float64)
+            v = (rng.random(shape) ** 4).astype(np.float32).astype(np.float64)
+            v[rng.random(shape) < 0.2] = 0
+            if trial == 1:
+                v[:, 0] = 0            # one edge without a single unmasked pixel
+            if trial == 2:
+                v[...] = 0
+            step = 1e-2 / 2 ** trial
+            gu = -m / np.sqrt(np.sqrt(ma.masked_equal(v, 0))) * step
+            pull = gu * (image > 0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")  # "converting a masked element to nan"
+                want = np.array((pull[:, 0].mean(), pull[:, -1].mean(),
+                                 pull[0, :].mean(), pull[-1, :].mean()))
+            got = _edge_pull(image, m, v, step)
+            assert_array_equal(np.isnan(got), np.isnan(want))
+            ok = ~np.isnan(want)
+            assert_array_equal(got[ok].view(np.uint64), want[ok].view(np.uint64))
+
+
 def test_bench_names_the_dominant_kernel_from_the_library_path():
     """The kernel the roofline object prices follows the convolution path the library reports
     and the larger of the two phase times -- not a threshold on an empty phase's event
