@@ -694,9 +694,9 @@ class Blend(CombinedComponent):
     def _host_render_ops(self):
         """Per observation ``(obs, forward, adjoint, log_norm)`` for the host-rendered mode:
         ``forward(model cube) -> observation frame`` and its transpose, both float64.
-        Built-in renderers have theirs; a user renderer supplies ``adjoint`` (checked
-        against its forward with a random dot product -- a renderer that is not linear, or
-        whose ``adjoint`` is not its transpose, is refused)."""
+        Built-in renderers have theirs; a user renderer supplies ``adjoint``.  Every pair is
+        checked with a random dot product: a renderer that is not linear, or whose ``adjoint``
+        is not its transpose, is refused."""
         ops = []
         rng = np.random.default_rng(0)
         for obs in self.observations:
@@ -709,6 +709,12 @@ class Blend(CombinedComponent):
             if type(r) in (NullRenderer, ConvolutionRenderer):
                 data_sl, model_sl = r.slices
                 kernel = None if type(r) is NullRenderer else np.asarray(r.kernel_image(), np.float64)
+                if kernel is not None and (kernel.shape[1] % 2 == 0 or kernel.shape[2] % 2 == 0):
+                    # the transpose below flips the stamp about its centre pixel: an even side
+                    # gets a zero row / column behind it (the centre h // 2 stays the centre),
+                    # like _observation does for the device
+                    kernel = np.pad(kernel, ((0, 0), (0, 1 - kernel.shape[1] % 2),
+                                             (0, 1 - kernel.shape[2] % 2)))
 
                 def forward(model, r=r, kernel=kernel, data_sl=data_sl, model_sl=model_sl):
                     m = np.asarray(r.map_channels(model), dtype=np.float64)
@@ -742,17 +748,18 @@ class Blend(CombinedComponent):
                 def adjoint(res, r=r):
                     return np.asarray(r.adjoint(np.asarray(res, dtype=np.float64)), dtype=np.float64)
 
-                x = rng.standard_normal(self.frame.shape)
-                y = rng.standard_normal(obs.data.shape)
-                fx = forward(x)
-                lhs, rhs = float(np.sum(fx * y)), float(np.sum(x * adjoint(y)))
-                lin = forward(2.0 * x) - 2.0 * fx
-                if (abs(lhs - rhs) > 1e-6 * (abs(lhs) + abs(rhs)) + 1e-12
-                        or np.abs(lin).max() > 1e-6 * np.abs(fx).max() + 1e-12):
-                    raise NotImplementedError(
-                        "renderer {} is not linear, or its `adjoint` is not the transpose of its "
-                        "forward map (<R x, y> = {:.6g}, <x, R^T y> = {:.6g})".format(
-                            type(r).__name__, lhs, rhs))
+            # <R x, y> = <x, R^T y> and R(2x) = 2 R(x), for the built-in pairs above as well
+            x = rng.standard_normal(self.frame.shape)
+            y = rng.standard_normal(obs.data.shape)
+            fx = forward(x)
+            lhs, rhs = float(np.sum(fx * y)), float(np.sum(x * adjoint(y)))
+            lin = forward(2.0 * x) - 2.0 * fx
+            if (abs(lhs - rhs) > 1e-6 * (abs(lhs) + abs(rhs)) + 1e-12
+                    or np.abs(lin).max() > 1e-6 * np.abs(fx).max() + 1e-12):
+                raise NotImplementedError(
+                    "renderer {} is not linear, or its `adjoint` is not the transpose of its "
+                    "forward map (<R x, y> = {:.6g}, <x, R^T y> = {:.6g})".format(
+                        type(r).__name__, lhs, rhs))
             ops.append((obs, forward, adjoint, float(obs.log_norm)))
         return ops
 

@@ -229,7 +229,12 @@ def set_spectra_to_match(sources, observations):
         # are several hundred (250 .. 700 on the quickstart scene), so float32 convolutions
         # of the device would show up as 1e-4 in the spectra.  This one-off solve therefore
         # renders on the host in double where the renderer is a plain convolution.
-        precise = getattr(obs.renderer, "render_float64", None)
+        # (a subclass that overrides the rendering inherits render_float64 without meaning it)
+        from .renderer import ConvolutionRenderer, NullRenderer
+
+        precise = (obs.renderer.render_float64
+                   if type(obs.renderer) in (ConvolutionRenderer, NullRenderer)
+                   and hasattr(obs.renderer, "render_float64") else None)
         if precise is not None and not obs.parameters:
             rendered = np.stack([precise(m) for m in models], axis=0)
         else:
