@@ -157,9 +157,13 @@ class ResolutionRenderer(Renderer):
         pixels = np.stack((np.arange(lr_shape[0]), np.arange(lr_shape[1])), axis=1)
         coord_hr = data_frame.convert_pixel_to(model_frame, pixel=pixels)
         diff_psf, psf_lr_hr = self.build_diffkernel(data_frame, model_frame)
+        # (np.stack above, renderer.py:274 in the reference, takes the two pixel ranges as
+        # columns of one array: it raises for every observation that is not square -- checked
+        # by running the reference on 28 x 38 and 38 x 28 crops, oracle/refshim -- and a
+        # square one has small_axis = True, so the reference's other unrotated branch
+        # (renderer.py:354-363, 536-545) cannot be reached and has no counterpart here)
         self.small_axis = data_frame.Nx <= data_frame.Ny
-        if not self.small_axis:
-            raise NotImplementedError("ResolutionRenderer for observations wider than tall")
+        assert self.small_axis
         self._fft_shape = fft._get_fft_shape(psf_lr_hr, np.zeros(model_frame.shape), padding=3,
                                              axes=[-2, -1], max=False)
         if (self._fft_shape[-2] < diff_psf.shape[-2]) or (self._fft_shape[-1] < diff_psf.shape[-1]):
