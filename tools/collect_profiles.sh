@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the rocprofv3 summaries behind bench.py's roofline object on the GPU box and leave
 # them under gpurun_out/<tag>/ (copy the CSVs / JSON you want judged into profiles/).
-#   gpurun -- 'bash tools/collect_profiles.sh r03'
+#   gpurun -- 'bash tools/collect_profiles.sh r04'
 # Kernel trace and counters are separate runs (gpurun refuses --pmc with trace domains other
 # than --kernel-trace; counters in passes of their own as MI355X_MICROARCH.md prescribes).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -17,6 +17,7 @@ stats() {  # name, bench arguments
     rocprofv3 --kernel-trace --stats -d "$OUT/$name" -o run --output-format csv -- \
         python "$R/bench.py" "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
     cp "$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats_$name.csv"
+    grep '^{' "$OUT/$name.json" | tail -1 > "$OUT/${TAG}_bench_$name.json"
 }
 stats single_range --steps 100 --warmup 10 --no-cpu --sub-ranges 1
 stats default --steps 100 --warmup 10 --no-cpu
@@ -28,6 +29,8 @@ stats shard128 --steps 20 --warmup 5 --no-cpu --blends 128   # one GPU's shard o
 stats shard128_100 --steps 100 --warmup 10 --no-cpu --blends 128
 stats shard256 --steps 20 --warmup 5 --no-cpu --blends 256
 stats shard512 --steps 20 --warmup 5 --no-cpu --blends 512
+# the path a scarlet script calls: Blend objects in, fit_blends, fitted objects out
+python "$R/bench.py" --facade --blends 1024 --steps 100 > "$OUT/${TAG}_bench_facade.json" 2> "$OUT/facade.err"
 
 pmc() {  # name, counters...
     local name=$1; shift
