@@ -1809,7 +1809,10 @@ __global__ __launch_bounds__(T * update_pack_max(NPL, T)) SMI_WAVES void update_
     // persistent: share blockIdx.x of the list (contiguous: the components of a blend stay
     // together, in one L2 and mostly in one CU); otherwise one item per wavefront
     const bool loop = T == 64 && persistent;
-    const int q = n_items / n_blocks, r = n_items % n_blocks, b = (int)blockIdx.x;
+    // (shares in the order of xcd_contiguous: the blend that straddles two shares is read
+    // through one L2 by both)
+    const int q = n_items / n_blocks, r = n_items % n_blocks;
+    const int b = loop ? xcd_contiguous((int)blockIdx.x, n_blocks) : (int)blockIdx.x;
     const int lo = loop ? b * q + (b < r ? b : r) : 0;
     const int hi = loop ? lo + q + (b < r) : n_items;
     const int lane = (int)(threadIdx.x & 63);
