@@ -162,25 +162,38 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t 
             }
 }
 
-// C_b = sum over the slices of Cpart[b][z] (double, in the order of z), b < n_batch.  A
-// workgroup of four wavefronts per 64 outputs: wavefront w sums the slices w, w + 4, ...,
-// the four sums are combined in a fixed order.
-__global__ __launch_bounds__(256) void reduce_slices_kernel(const double *Cpart, float *C,
-                                                           int64_t strideC, int64_t MN,
-                                                           int n_slices) {
-    __shared__ double part[4][64];
+// C_b = sum over the slices of Cpart[b][z] (double), b < n_batch.  A workgroup of sixteen
+// wavefronts per 64 outputs: wavefront w sums the slices w, w + 16, ... four at a time (the
+// loads of a group are independent: a wavefront that adds one slice after the other waits for
+// every load in turn, which is what this kernel used to spend its 20 us on), the sixteen sums
+// are combined in a fixed order.
+__global__ __launch_bounds__(1024) void reduce_slices_kernel(const double *Cpart, float *C,
+                                                            int64_t strideC, int64_t MN,
+                                                            int n_slices) {
+    __shared__ double part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     const int b = blockIdx.y;
     double t = 0.0;
     if (i < MN) {
         const double *p = Cpart + (int64_t)b * n_slices * MN + i;
-        for (int z = w; z < n_slices; z += 4) t += p[(int64_t)z * MN];
+        int z = w;
+        for (; z + 48 < n_slices; z += 64) {
+            const double v0 = p[(int64_t)z * MN], v1 = p[(int64_t)(z + 16) * MN];
+            const double v2 = p[(int64_t)(z + 32) * MN], v3 = p[(int64_t)(z + 48) * MN];
+            t += (v0 + v1) + (v2 + v3);
+        }
+        for (; z < n_slices; z += 16) t += p[(int64_t)z * MN];
     }
     part[w][lane] = t;
     __syncthreads();
-    if (w == 0 && i < MN)
-        C[b * strideC + i] = (float)((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    if (w == 0 && i < MN) {
+        double total = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4)
+            total += (part[q][lane] + part[q + 1][lane]) + (part[q + 2][lane] + part[q + 3][lane]);
+        C[b * strideC + i] = (float)total;
+    }
 }
 
 int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float *C,
@@ -191,7 +204,10 @@ int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float
     const int bm = 64 * tm, bn = 64 * tn;
     const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * n_batch;
     // slices of ~kSliceTerms terms (float32 accumulation length); fewer when the tiles
-    // alone fill the chip several times over and the partials would not fit the scratch
+    // alone fill the chip several times over and the partials would not fit the scratch.
+    // (Round 4: fewer, longer slices -- 18 instead of 47 for the 300 x 300 x 15 000 product, 61
+    // instead of 169 MB of partials -- were measured and are slower, 260 against 230 us: the
+    // 2 115 workgroups of the fine slicing hide each other's load latency, 810 do not.)
     int n_slices = std::max(1, (K + kSliceTerms - 1) / kSliceTerms);
     const size_t MN = (size_t)M * N;
     while (n_slices > 1 && ((size_t)n_slices * n_batch * MN > scratch_elems ||
@@ -212,8 +228,24 @@ int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float
 #undef SMI_GEMM
     if (n_slices > 1)
         hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((MN + 63) / 64), n_batch),
-                           dim3(256), 0, s, scratch, C, strideC, (int64_t)MN, n_slices);
+                           dim3(1024), 0, s, scratch, C, strideC, (int64_t)MN, n_slices);
     return SMI_OK;
+}
+
+__global__ void transpose_kernel(const float *in, float *out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (r0 + j < rows && c < cols) tile[j][threadIdx.x] = in[(int64_t)(r0 + j) * cols + c];
+    __syncthreads();
+    const int r = r0 + threadIdx.x, c0 = blockIdx.x * 32;
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (c0 + j < cols && r < rows) out[(int64_t)(c0 + j) * rows + r] = tile[threadIdx.x][j];
+}
+
+void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0,
+                       s, in, out, rows, cols);
 }
 
 }  // namespace
@@ -225,9 +257,8 @@ struct Resampler {
     float *model = nullptr, *B = nullptr, *out = nullptr;  // B: [C][Fy * Fx * n_b]
     double *scratch = nullptr;
     size_t scratch_elems = 0;
-    // transposed operators for the adjoint (built when a fit attaches the resampler)
-    float *At = nullptr;   // [C][Fy * Fx][n_a]
-    float *P = nullptr;    // [Fx * n_b][Fx]
+    float *At = nullptr;   // [C][Fy * Fx][n_a]: A transposed (left operand of the adjoint)
+    float *P = nullptr;    // [Fx * n_b][Fx]: built when a fit attaches the resampler (adjoint)
 };
 
 int resampler_create(const float *A, const float *Pt, int C, int n_a, int n_b, int Fy, int Fx,
@@ -251,6 +282,13 @@ int resampler_create(const float *A, const float *Pt, int C, int n_a, int n_b, i
     SMI_HIP(hipMalloc((void **)&r->scratch, r->scratch_elems * sizeof(double)));
     SMI_HIP(hipMemcpy(r->A, A, nA * sizeof(float), hipMemcpyHostToDevice));
     SMI_HIP(hipMemcpy(r->Pt, Pt, nP * sizeof(float), hipMemcpyHostToDevice));
+    // At[C][Fy Fx][n_a]: the left operand of the adjoint's first product
+    SMI_HIP(hipMalloc((void **)&r->At, nA * sizeof(float)));
+    for (int c = 0; c < C; ++c)
+        launch_transpose(r->A + (size_t)c * n_a * Fy * Fx, r->At + (size_t)c * n_a * Fy * Fx, n_a,
+                         Fy * Fx, nullptr);
+    SMI_HIP(hipGetLastError());
+    SMI_HIP(hipDeviceSynchronize());
     return SMI_OK;
 }
 
@@ -317,22 +355,6 @@ int resampler_time(Resampler *r, int n_rep, double *ms_per_render) {
 // One blend only: every blend of a batch would need its own operators.
 // ---------------------------------------------------------------------------------------
 namespace {
-
-__global__ void transpose_kernel(const float *in, float *out, int rows, int cols) {
-    __shared__ float tile[32][33];
-    const int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
-    for (int j = threadIdx.y; j < 32; j += 8)
-        if (r0 + j < rows && c < cols) tile[j][threadIdx.x] = in[(int64_t)(r0 + j) * cols + c];
-    __syncthreads();
-    const int r = r0 + threadIdx.x, c0 = blockIdx.x * 32;
-    for (int j = threadIdx.y; j < 32; j += 8)
-        if (c0 + j < cols && r < rows) out[(int64_t)(c0 + j) * rows + r] = tile[threadIdx.x][j];
-}
-
-void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0,
-                       s, in, out, rows, cols);
-}
 
 // centred zero padding of the observed bands of the model cube (fft._pad, fft.py:82-113)
 __global__ void lowres_pad_kernel(const float *P, int Py, int Px, const int32_t *channels, int H,
@@ -417,12 +439,8 @@ int lowres_create(Resampler *r, const int32_t *channels, const float *data, cons
     SMI_HIP(hipMemcpy(l->data, data, n * sizeof(float), hipMemcpyHostToDevice));
     SMI_HIP(hipMemcpy(l->weights, weights, n * sizeof(float), hipMemcpyHostToDevice));
     SMI_HIP(hipMemset(l->term, 0, sizeof(double)));
-    if (!r->At) {
-        SMI_HIP(hipMalloc((void **)&r->At, (size_t)r->C * r->n_a * plane * sizeof(float)));
+    if (!r->P) {  // transposed shift operator for the adjoint
         SMI_HIP(hipMalloc((void **)&r->P, (size_t)r->Fx * r->Fx * r->n_b * sizeof(float)));
-        for (int c = 0; c < r->C; ++c)
-            launch_transpose(r->A + (size_t)c * r->n_a * plane, r->At + (size_t)c * r->n_a * plane,
-                             r->n_a, (int)plane, nullptr);
         launch_transpose(r->Pt, r->P, r->Fx, r->Fx * r->n_b, nullptr);
         SMI_HIP(hipGetLastError());
         SMI_HIP(hipDeviceSynchronize());

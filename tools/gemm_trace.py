@@ -7,8 +7,8 @@ for p in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
 g = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    if "gemm_mfma" in n or "reduce_slices" in n:
-        key = (n.split("(")[0].replace("smi::(anonymous namespace)::", "").replace("void ", ""),
+    if "gemm_" in n or "reduce_slices" in n:
+        key = (n.replace("smi::(anonymous namespace)::", "").replace("void ", "").split("(")[0],
                r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r.get("VGPR_Count"), r.get("Accum_VGPR_Count"))
         g[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1])):
