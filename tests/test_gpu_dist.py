@@ -156,3 +156,17 @@ def test_result_gather_through_rccl(tmp_path):
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_bench_facade_leg():
+    """`bench.py --facade`: Blend objects through fit_blends with box resizing on, the wall
+    clock around the call, ONE observation upload for the whole fit, and the C-ABI rate of the
+    same box beside it."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--facade", "--blends",
+                          "24", "--steps", "30"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert cfg["observation_uploads_during_fit"] == 1
+    assert cfg["blend_iterations"] > 24 * 7 and line["value"] > 0
+    assert 0 < cfg["ratio_to_c_abi"] < 1 and cfg["c_abi_rate_same_box"] > line["value"]
