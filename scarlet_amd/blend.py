@@ -100,6 +100,24 @@ class Blend(CombinedComponent):
         layers = []  # dict(data, weights, kernels[C], taken[C])
         self._lowres = []
         self._loss_constant = 0.0  # observed pixels outside the model frame
+        if len(self.observations) == 1:
+            # the common case -- one observation on the model's own grid and channels -- needs
+            # no merging: its arrays are the cube (no copies: a thousand blends are 0.7 GB)
+            obs = self.observations[0]
+            r = obs.renderer
+            if (type(r) in (NullRenderer, ConvolutionRenderer) and not obs.parameters
+                    and tuple(obs.shape) == tuple(self.frame.shape)
+                    and list(obs.channels) == channels
+                    and type(obs.data) is np.ndarray and obs.data.dtype == np.float32
+                    and type(obs.weights) is np.ndarray and obs.weights.dtype == np.float32):
+                self._extra_layers = []
+                if type(r) is NullRenderer:
+                    return obs.data, obs.weights, None
+                k = np.asarray(r.kernel_image(), dtype=np.float32)
+                if k.shape[-2] % 2 == 1 and k.shape[-1] % 2 == 1 and k.shape[0] in (1, C):
+                    if k.shape[0] > 1 and all(np.array_equal(k[0], k[c]) for c in range(1, C)):
+                        k = k[:1]
+                    return obs.data, obs.weights, k
 
         def layer_for(idx):
             for layer in layers:

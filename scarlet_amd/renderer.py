@@ -159,7 +159,7 @@ class ResolutionRenderer(Renderer):
         diff_psf, psf_lr_hr = self.build_diffkernel(data_frame, model_frame)
         # (np.stack above, renderer.py:274 in the reference, takes the two pixel ranges as
         # columns of one array: it raises for every observation that is not square -- checked
-        # by running the reference on 28 x 38 and 38 x 28 crops, oracle/refshim -- and a
+        # by running the reference on 28 x 38 and 38 x 28 crops, DESIGN.md 8.5 -- and a
         # square one has small_axis = True, so the reference's other unrotated branch
         # (renderer.py:354-363, 536-545) cannot be reached and has no counterpart here)
         self.small_axis = data_frame.Nx <= data_frame.Ny
