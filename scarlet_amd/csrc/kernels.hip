@@ -1111,18 +1111,6 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 #ifndef SMI_SWEEP_DRAIN
 #define SMI_SWEEP_DRAIN 0
 #endif
-#ifndef SMI_EXP_NOPLAN
-#define SMI_EXP_NOPLAN 0
-#endif
-#ifndef SMI_EXP_NODYN
-#define SMI_EXP_NODYN 0
-#endif
-#ifndef SMI_EXP_NODIAG
-#define SMI_EXP_NODIAG 0
-#endif
-#ifndef SMI_EXP_NOLDS
-#define SMI_EXP_NOLDS 0
-#endif
 __device__ __forceinline__ void sweep_fence() {
 #if SMI_SWEEP_DRAIN
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
