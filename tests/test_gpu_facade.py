@@ -539,6 +539,31 @@ def test_fit_blends_resident_batch_equals_rebuilt_batches_and_single_fits(monkey
         assert one.loss == a[i].loss
 
 
+def test_fit_blends_keeps_going_when_one_blend_fails():
+    """A blend whose parameters turn non-finite gets ``(n_iter, nan)`` and an entry in
+    ``fit_blends.errors``; its loss history ends with the iteration that failed (the loss is
+    recorded before the step, blend.py:294-299); the blends that share its device batch are
+    fitted as if it were not there."""
+    import os
+    import sys
+
+    import scarlet_amd as scarlet
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    alone = bench.build_facade_blends(0, 3, 0)
+    want = [b.fit(25, e_rel=1e-4) for b in (alone[0], alone[2])]
+    blends = bench.build_facade_blends(0, 3, 0)
+    blends[1].sources[4].children[0].parameters[0][2] = np.nan   # one band of one spectrum
+    got = scarlet.fit_blends(blends, 25, e_rel=1e-4)
+    assert [i for i, _ in scarlet.fit_blends.errors] == [1]
+    assert isinstance(scarlet.fit_blends.errors[0][1], ArithmeticError)
+    assert got[1][0] == 1 and np.isnan(got[1][1]) and len(blends[1].loss) == 1
+    assert [got[0], got[2]] == want
+    assert blends[0].loss == alone[0].loss and blends[2].loss == alone[2].loss
+
+
 def test_fit_blends_fits_unbatchable_blends_by_themselves(hsc):
     """``fit_blends`` stands for ``[b.fit() for b in blends]`` (scarlet/testing/api.py:216-224).
     A blend with a second observation of the same channels (one more term of ITS loss on the
