@@ -32,9 +32,11 @@ share GPUs over gloo -- a functional check, flagged in ``config``).
 Output: ONE JSON line on rank 0 with the contract's fields plus
   roofline     dominant kernel: algorithmic bytes per launch / mean launch duration
                (HIP events on the batch stream over the same K iterations, replayed
-               in one range of blends), at the FFT shape the kernel runs; counter-derived
-               fields from profiles/ (HBM traffic, VALU busy; listed with their source in
-               `counter_fields`); `bound` names the roofline priced against ("hbm"), `limiter`
+               in one range of blends), at the FFT shape the kernel runs; `traffic`,
+               `hbm_frac_measured` and `measured_hbm` from FETCH_SIZE / WRITE_SIZE passes of THIS
+               run (the script re-runs itself under rocprofv3 for a few iterations; --no-counters
+               or a missing profiler fall back to the committed profiles/hbm_traffic.json), VALU
+               busy and the limiter from profiles/ (`counter_fields` lists what came from where); `bound` names the roofline priced against ("hbm"), `limiter`
                what the counters say limits the kernel ("unknown" without counters);
                `frac_physical` / `hbm_frac_whole_iteration`: the chip's physical utilisation
                over the whole iteration, to be read before the saturated `frac`; `speed_of_light`: the iteration against
@@ -440,6 +442,61 @@ def counters(kernel):
         return json.load(fh).get(kernel, {})
 
 
+def live_hbm_counters(nb, timeout=150):
+    """HBM bytes per blend of the two kernels of the iteration, measured now: this script run
+    again under ``rocprofv3 --kernel-trace --pmc`` (FETCH_SIZE and WRITE_SIZE in passes of their
+    own, a few iterations in one range of blends), reduced like tools/hbm_counters.py does --
+    both counters are reported in KiB, FETCH_SIZE counts 64 B per 128-byte request on gfx950 and
+    is doubled, the mean is taken over the full-batch launches.  Returns ``{kernel: bytes per
+    blend}`` or ``None`` when the profiler is missing, fails or takes longer than ``timeout``
+    seconds per pass (the line then falls back to the committed summary and says so)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="smi_pmc_", dir="/tmp")
+    try:
+        sums = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run",
+                   "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "6", "--warmup", "2", "--no-cpu", "--sub-ranges", "1",
+                   "--blends", str(nb), "--no-counters"]
+            env = dict(os.environ, TMPDIR="/tmp", GPU_MAX_HW_QUEUES="8")
+            res = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout,
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if res.returncode != 0:
+                return None
+            per_kernel = {}
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] != counter:
+                            continue
+                        name = row["Kernel_Name"].replace("(anonymous namespace)::", "")
+                        name = name.replace("void ", "").replace("smi::", "").split("<")[0].split("(")[0]
+                        per_kernel.setdefault(name, []).append(float(row["Counter_Value"]))
+            for name, vals in per_kernel.items():
+                if len(vals) < 6:
+                    continue  # (not a kernel of the iteration)
+                vals = sorted(vals)[len(vals) // 2:]  # the full-batch launches
+                sums.setdefault(name, {})[counter] = sum(vals) / len(vals)
+        for name, c in sums.items():
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                out[name] = int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / nb))
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out or None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torchrun: start N ranks of this script."""
     import torch
@@ -476,6 +533,9 @@ def main():
     ap.add_argument("--loop", default="blend", choices=["blend", "lite-adaprox", "lite-fista"],
                     help="ablation: run the scarlet.lite loop (LiteBlend.fit semantics) on the "
                          "same scenes instead of Blend.fit's")
+    ap.add_argument("--no-counters", action="store_true",
+                    help="do not re-run under rocprofv3 for the HBM byte counters (roofline.traffic "
+                         "then comes from the committed profiles/hbm_traffic.json)")
     ap.add_argument("--facade", action="store_true",
                     help="time scarlet_amd.fit_blends on Blend objects built from the cfg3 "
                          "scenes (resizing on) instead of the C-ABI batch")
@@ -615,6 +675,15 @@ def main():
         k_name, k_bytes, k_ms = dominant_kernel(phases, conv_path, by)
         achieved = k_bytes * nb / (k_ms * 1e-3) / 1e9
         cnt = counters(k_name) if args.config == "cfg3" and nb == 1024 else {}
+        # HBM bytes by the PMC counters, measured in this run where that is possible (N = 1,
+        # the benchmark's own workload, the fused path); the committed summary otherwise
+        live = None
+        if (args.config == "cfg3" and world == 1 and conv_path == "fused" and not lite
+                and not args.steady and not args.no_counters):
+            live = live_hbm_counters(nb)
+        live_name = "update_kernel_reg" if k_name.startswith("update") else k_name
+        if live and live_name in live:
+            cnt = dict(cnt, bytes_per_blend=live[live_name])
         traffic = cnt["bytes_per_blend"] * nb if "bytes_per_blend" in cnt else None
         # Speed of light of one iteration of this rank's shard: what cannot be avoided is the
         # compulsory traffic B0 (data and weights once, parameters and moments once each way)
@@ -625,6 +694,9 @@ def main():
         # the convolution kernel renders its own model rows)
         all_cnt = {k: counters(k) for k in ("fused_conv_kernel", "update_kernel_reg",
                                             "render_kernel") if counters(k)} if counted else {}
+        if live:
+            all_cnt = {k: {"bytes_per_blend": v} for k, v in live.items()
+                       if k in ("fused_conv_kernel", "update_kernel_reg", "render_kernel")}
         hbm_ms = by["null"] * nb / (HBM_PEAK_GBS * 1e9) * 1e3
         flop_ms = (fft_flops(C, Fy, Fx) * nb / (F32_VECTOR_PEAK_TFLOPS * 1e12) * 1e3
                    if not args.null_renderer else 0.0)
@@ -666,14 +738,19 @@ def main():
                 "over_compulsory": (round(measured_iter / by["null"], 3) if measured_iter else None),
                 "frac_of_peak": hbm_whole,
                 "per_kernel": {k: c.get("bytes_per_blend") for k, c in all_cnt.items()} or None,
-                "source": ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                "source": ("this run: bench.py re-run under rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
+                           "WRITE_SIZE (separate passes, 6 iterations, one range of %d blends; KiB, "
+                           "FETCH_SIZE doubled for gfx950)" % nb if live else
+                           "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                            "passes of tools/collect_profiles.sh on 1024-blend launches "
                            "(committed constants, not measured in this run)" if all_cnt else None),
             },
             "counter_fields": {
-                "fields": ["limiter", "traffic", "hbm_frac_measured", "valu_busy", "measured_hbm"],
+                "fields": (["limiter", "valu_busy"] if live else
+                           ["limiter", "traffic", "hbm_frac_measured", "valu_busy", "measured_hbm"]),
                 "source": "profiles/hbm_traffic.json (committed PMC summary); every other field is "
-                          "measured in this run",
+                          "measured in this run" + (" -- traffic, hbm_frac_measured and measured_hbm "
+                                                    "by counter passes of this run" if live else ""),
             },
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
