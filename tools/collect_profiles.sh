@@ -15,7 +15,7 @@ export GPU_MAX_HW_QUEUES=8   # what bench.py sets for itself (the profiler start
 stats() {  # name, bench arguments
     local name=$1; shift
     rocprofv3 --kernel-trace --stats -d "$OUT/$name" -o run --output-format csv -- \
-        python "$R/bench.py" "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
+        python "$R/bench.py" "$@" --no-counters > "$OUT/$name.json" 2> "$OUT/$name.err"
     cp "$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats_$name.csv"
     grep '^{' "$OUT/$name.json" | tail -1 > "$OUT/${TAG}_bench_$name.json"
 }
@@ -29,13 +29,16 @@ stats shard128 --steps 20 --warmup 5 --no-cpu --blends 128   # one GPU's shard o
 stats shard128_100 --steps 100 --warmup 10 --no-cpu --blends 128
 stats shard256 --steps 20 --warmup 5 --no-cpu --blends 256
 stats shard512 --steps 20 --warmup 5 --no-cpu --blends 512
+# the driver's command as the driver runs it (no profiler around it: the bench measures its own
+# HBM counters in passes of its own)
+python "$R/bench.py" --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_live_counters.json" 2> "$OUT/driver_live.err"
 # the path a scarlet script calls: Blend objects in, fit_blends, fitted objects out
 python "$R/bench.py" --facade --blends 1024 --steps 100 > "$OUT/${TAG}_bench_facade.json" 2> "$OUT/facade.err"
 
 pmc() {  # name, counters...
     local name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/pmc_$name" -o run --output-format csv -- \
-        python "$R/bench.py" --steps 20 --warmup 2 --no-cpu --sub-ranges 1 > /dev/null 2> "$OUT/pmc_$name.err"
+        python "$R/bench.py" --steps 20 --warmup 2 --no-cpu --sub-ranges 1 --no-counters > /dev/null 2> "$OUT/pmc_$name.err"
 }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE

@@ -11,7 +11,7 @@ export GPU_MAX_HW_QUEUES=8
 pmc() {
     local name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/pmc_$name" -o run --output-format csv -- \
-        python "$R/bench.py" --steps 20 --warmup 2 --no-cpu --sub-ranges 1 > /dev/null 2> "$OUT/pmc_$name.err"
+        python "$R/bench.py" --steps 20 --warmup 2 --no-cpu --sub-ranges 1 --no-counters > /dev/null 2> "$OUT/pmc_$name.err"
 }
 pmc valu SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES
 pmc busy SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY
