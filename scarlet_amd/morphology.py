@@ -32,12 +32,13 @@ def _empty_margin(image, thresh):
     """Width of the frame of pixels <= ``thresh`` around ``image``: the largest ``d`` such
     that the d outermost rows and columns on every side hold nothing above ``thresh``
     (the whole image counts as margin when it is empty)."""
-    occupied = np.argwhere(np.asarray(image) > thresh)
-    if len(occupied) == 0:
+    mask = np.asarray(image) > thresh
+    rows = mask.any(axis=1)
+    if not rows.any():
         return (min(image.shape) + 1) // 2
-    lo = occupied.min(axis=0)
-    hi = np.array(image.shape) - 1 - occupied.max(axis=0)
-    return int(min(lo.min(), hi.min()))
+    cols = mask.any(axis=0)
+    # first and last occupied row / column, counted from the nearer edge
+    return int(min(rows.argmax(), cols.argmax(), rows[::-1].argmax(), cols[::-1].argmax()))
 
 
 def _edge_pull(image, m, v, step):

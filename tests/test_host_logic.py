@@ -514,6 +514,33 @@ def test_bench_prices_the_bytes_of_survey_8d():
     assert run["conv"] == 5051760 and run["update"] == 808280  # what the bench line prices
 
 
+def test_empty_margin_is_the_reference_loop():
+    """morphology._empty_margin against the loop of the reference's shrink_box
+    (morphology.py:50-67): peel while all four outermost rows / columns hold nothing above
+    the threshold."""
+    from scarlet_amd.morphology import _empty_margin
+
+    def loop(image, thresh):
+        dist = 0  # (the reference's loop; it ends before the middle when a pixel is occupied)
+        while (np.all(image[dist, :] <= thresh) and np.all(image[-dist - 1, :] <= thresh)
+               and np.all(image[:, dist] <= thresh) and np.all(image[:, -dist - 1] <= thresh)):
+            dist += 1
+        return dist
+
+    rng = np.random.default_rng(3)
+    for trial in range(300):
+        n = int(rng.integers(3, 40)) | 1
+        image = np.zeros((n, n), dtype=np.float32)
+        k = int(rng.integers(0, n // 2 + 1))
+        if k < n - k:
+            image[k:n - k, k:n - k] = rng.random((n - 2 * k, n - 2 * k)) - 0.2
+        got = _empty_margin(image, 0)
+        if (image > 0).any():
+            assert got == loop(image, 0), (n, k)
+        else:
+            assert got == (n + 1) // 2
+
+
 def test_edge_pull_of_the_resize_hook_is_the_masked_array_formula():
     """morphology._edge_pull (four edge slices, plain arrays) gives the bits of the
     reference's expression on the whole image as a masked array (morphology.py:166-176),
