@@ -546,7 +546,7 @@ def main():
     # a small shard can step four ranges of blends side by side
     from scarlet_amd import configure
 
-    configure(hw_queues=8)
+    configure(hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "8")))
     if args.facade:
         return facade(args)
     if args.config == "cfg5":
