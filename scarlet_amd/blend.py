@@ -1209,10 +1209,8 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
                     flat[first[i]:first[i + 1]] = comps[i]
                     moved = [j for j, c in enumerate(comps[i])
                              if c.children[1].parameters[0] is not before[j]]
-                    fresh = group[i].blend._specs([comps[i][j] for j in moved])
-                    assert not group[i].blend._host
-                    for j, spec in zip(moved, fresh):
-                        specs[i][j] = spec
+                    for j in moved:
+                        specs[i][j] = _resized_spec(specs[i][j], comps[i][j])
                         keep[first[i] + j] = False
                         states.append(_parameters_to_record(comps[i][j]))
                 batch.update_components(specs, keep, states)
@@ -1228,6 +1226,23 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
         r.base, r.local = int(base[i]), int(local[i])
         r.result = (ArithmeticError("parameters of the blend are not finite")
                     if state[i] == 3 else True)
+
+
+def _resized_spec(spec, comp):
+    """The device description of a component whose box ``ImageMorphology.update`` has just
+    changed: the update replaces the image Parameter by its slice or padded copy in a new box
+    and halves its (constant) step (morphology.py:146-193); spectrum, constraints and everything
+    else of the description stay.  Same as ``Blend._specs`` would make from scratch
+    (tests/test_host_logic.py), without walking through the constraint chain again."""
+    import copy
+
+    morphology = comp.children[1]
+    image = morphology.parameters[0]
+    new = copy.copy(spec)
+    new.morph = np.asarray(image, dtype=np.float32)
+    new.origin = tuple(int(o) for o in morphology.bbox.origin[-2:])
+    new.morph_step = float(image.step)
+    return new
 
 
 def _record_to_parameters(comp, rec):

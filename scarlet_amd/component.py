@@ -44,8 +44,22 @@ class Component(Model):
         super().__init__(*parameters, children=children)
 
     def _reslice(self):
-        placement = overlapped_slices(self._frame.bbox, self._bbox)
-        self._model_frame_slices, self._model_slices = placement
+        # (worked out when somebody asks: a fit that resizes thousands of boxes on the
+        # device never looks at most of them)
+        self._placement = None
+
+    def _place(self):
+        if self._placement is None:
+            self._placement = overlapped_slices(self._frame.bbox, self._bbox)
+        return self._placement
+
+    @property
+    def _model_frame_slices(self):
+        return self._place()[0]
+
+    @property
+    def _model_slices(self):
+        return self._place()[1]
 
     @property
     def bbox(self):

@@ -131,7 +131,9 @@ class ImageMorphology(Morphology):
         bbox = self.bbox.copy()
         self.shrink_box(image)
         if bbox != self.bbox:
-            sl, _ = overlapped_slices(bbox, self.bbox)
+            # the new box sits `inset` pixels inside the old one on every side (shrink_box)
+            inset = self.bbox.origin[-1] - bbox.origin[-1]
+            sl = tuple(slice(inset, inset + n) for n in self.bbox.shape)
 
             def cut(a):
                 return a[sl] if a is not None else None

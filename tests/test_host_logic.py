@@ -514,7 +514,48 @@ def test_bench_prices_the_bytes_of_survey_8d():
     assert run["conv"] == 5051760 and run["update"] == 808280  # what the bench line prices
 
 
-def test_empty_margin_is_the_reference_loop():
+def test_resized_component_description_is_what_specs_would_make(hsc):
+    """fit_blends derives the device description of a resized component from the old one
+    (blend._resized_spec: new image, new origin, halved step); it must be field for field what
+    Blend._specs makes from scratch after ImageMorphology.update shrank or grew the box."""
+    import scarlet_amd as scarlet
+    from scarlet_amd.blend import _flatten, _resized_spec
+    from scarlet_amd.model import UpdateException
+    from test_gpu_facade import build_blend
+
+    blend, _ = build_blend(hsc, resizing=True)
+    comps = _flatten(blend.sources)
+    before = blend._specs(comps)
+    assert not blend._host
+    changed = 0
+    for k, comp in enumerate(comps):
+        morphology = comp.children[1]
+        image = morphology.parameters[0]
+        h, w = image.shape
+        if k % 2:   # make it shrink: nothing but the centre above zero
+            image[...] = 0
+            image[h // 2, w // 2] = 1
+        else:       # make it grow: a strong pull on one edge
+            image.m = np.zeros(image.shape)
+            image.v = np.ones(image.shape)
+            image.m[:, 0] = -1e3
+            image[...] = 1
+        try:
+            morphology.update()
+        except UpdateException:
+            changed += 1
+            fresh = blend._specs([comp])[0]
+            derived = _resized_spec(before[k], comp)
+            assert derived.morph.shape != before[k].morph.shape
+            for name, want in vars(fresh).items():
+                got = getattr(derived, name)
+                if isinstance(want, np.ndarray):
+                    assert_array_equal(got, want, err_msg=name)
+                else:
+                    assert got == want, name
+    assert changed >= 6
+
+
     """morphology._empty_margin against the loop of the reference's shrink_box
     (morphology.py:50-67): peel while all four outermost rows / columns hold nothing above
     the threshold."""
