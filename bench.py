@@ -442,7 +442,7 @@ def counters(kernel):
         return json.load(fh).get(kernel, {})
 
 
-def live_hbm_counters(nb, timeout=150):
+def live_hbm_counters(nb, timeout=90):
     """HBM bytes per blend of the two kernels of the iteration, measured now: this script run
     again under ``rocprofv3 --kernel-trace --pmc`` (FETCH_SIZE and WRITE_SIZE in passes of their
     own, a few iterations in one range of blends), reduced like tools/hbm_counters.py does --
@@ -457,6 +457,9 @@ def live_hbm_counters(nb, timeout=150):
 
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
+        return None
+    # already under a profiler (rocprofv3 around this run): no profiler inside a profiler
+    if any(k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES") or k.startswith("ROCPROF") for k in os.environ):
         return None
     out = {}
     tmp = tempfile.mkdtemp(prefix="smi_pmc_", dir="/tmp")
