@@ -1266,12 +1266,21 @@ def _parameters_to_record(comp):
 
 def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_kwargs):
     """``fit_blends`` of ``blends`` on GPU ``device``: (results, [(index, error)])."""
-    if alg_kwargs.get("callback") is not None:
-        raise NotImplementedError("callback= needs the host-stepped mode of Blend.fit")
-    scheme = alg_kwargs.pop("scheme", "amsgrad")
-    if scheme != "amsgrad":
-        raise NotImplementedError("fit_blends batches the device's AMSGrad loop; use Blend.fit "
-                                  "for scheme={!r} (host-stepped)".format(scheme))
+    if alg_kwargs.get("callback") is not None or alg_kwargs.get("scheme", "amsgrad") != "amsgrad":
+        # a callback sees every blend's parameters after every iteration, another scheme of
+        # proxmin.adaprox steps on the host from the device's gradients: both are Blend.fit's
+        # host-stepped modes, one blend at a time -- which is what this call stands for
+        # (scarlet/testing/api.py:216-224)
+        out, errors = [], []
+        for i, b in enumerate(blends):
+            b.device = device
+            try:
+                out.append(b.fit(max_iter, e_rel, min_iter, **alg_kwargs))
+            except ArithmeticError as e:
+                errors.append((i, e))
+                out.append((len(b.loss), float("nan")))
+        return out, errors
+    alg_kwargs.pop("scheme", None)
     prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
     opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
                eps=alg_kwargs.pop("eps", 1e-8))

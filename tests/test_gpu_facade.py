@@ -564,6 +564,27 @@ def test_fit_blends_keeps_going_when_one_blend_fails():
     assert blends[0].loss == alone[0].loss and blends[2].loss == alone[2].loss
 
 
+def test_fit_blends_with_a_callback_or_another_scheme_fits_one_by_one(hsc):
+    """``fit_blends(..., callback=...)`` and ``scheme="adam"`` are Blend.fit's host-stepped
+    modes: the call goes through the blends one at a time and returns what they return."""
+    import warnings
+
+    import scarlet_amd as scarlet
+
+    seen = []
+    a, _ = build_blend(hsc, resizing=False)
+    b, _ = build_blend(hsc, resizing=False)
+    got = scarlet.fit_blends([a, b], 6, e_rel=1e-9, callback=lambda *X, it: seen.append(it))
+    assert seen == list(range(6)) * 2 and [r[0] for r in got] == [6, 6]
+    one, _ = build_blend(hsc, resizing=False)
+    assert one.fit(6, e_rel=1e-9) == got[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # "parity unpinned" for the published adam formulas
+        c, _ = build_blend(hsc, resizing=False)
+        d, _ = build_blend(hsc, resizing=False)
+        assert scarlet.fit_blends([c], 5, e_rel=1e-9, scheme="adam")[0] == d.fit(5, e_rel=1e-9, scheme="adam")
+
+
 def test_fit_blends_fits_unbatchable_blends_by_themselves(hsc):
     """``fit_blends`` stands for ``[b.fit() for b in blends]`` (scarlet/testing/api.py:216-224).
     A blend with a second observation of the same channels (one more term of ITS loss on the
