@@ -62,8 +62,11 @@ def _step_rule(step, what):
     """(constant, relative factor, minimum) of a Parameter.step."""
     if isinstance(step, partial) and step.func is relative_step:
         kw = step.keywords
-        if kw.get("axis") is not None or step.args:
-            raise NotImplementedError("relative_step along an axis is not supported")
+        axis = kw.get("axis")
+        # (the mean of a spectrum along its only axis is its mean: parameter.py:126-129)
+        along_all = axis is None or (what == "spectrum" and axis in (0, -1, (0,), (-1,)))
+        if not along_all or step.args:
+            raise NotImplementedError("relative_step along an axis of an image: stepped on the host")
         return 0.0, float(kw.get("factor", 0.1)), kw.get("minimum", 0)
     if step is relative_step:
         return 0.0, 0.1, 0
