@@ -1122,6 +1122,39 @@ def test_user_constraint_subclass_reproduces_the_device_result(hsc):
             assert_allclose(np.ma.filled(q.std, 0), np.ma.filled(p.std, 0), rtol=0, atol=0)
 
 
+def test_chains_the_device_cannot_express_step_on_the_host(hsc):
+    """Built-in constraints in combinations the fused device chain has no slot for -- an L0
+    and an L1 threshold in one chain, ``MonotonicityConstraint(fit_center_radius=2)`` -- are
+    not refused: ``device_flags`` says no, and the parameter is stepped on the host with the
+    reference's own operators (plug-in seam, hoststep.py) from the device's gradients."""
+    import scarlet_amd as scarlet
+
+    def sparse(blend):
+        for comp in components_of(blend)[:3]:
+            image = comp.children[1].parameters[0]
+            image.constraint = scarlet.ConstraintChain(
+                scarlet.L0Constraint(1e-3, type="absolute"), scarlet.L1Constraint(1e-4, type="absolute"),
+                scarlet.PositivityConstraint())
+
+    ref, blend = _fit_pair(hsc, sparse, n_it=8)
+    assert sorted(k for k, _ in blend._host) == [0, 1, 2] and len(blend.loss) == 8
+    assert np.isfinite(blend.loss).all() and blend.loss[-1] < blend.loss[0]
+    for comp in components_of(blend)[:3]:
+        image = np.asarray(comp.children[1].parameters[0])
+        assert image.min() >= 0 and not np.any((image > 0) & (image < 1e-3 - 1e-4 - 1e-7))
+
+    def wide_centre(blend):
+        comp = components_of(blend)[0]
+        image = comp.children[1].parameters[0]
+        image.constraint = scarlet.ConstraintChain(
+            scarlet.MonotonicityConstraint(neighbor_weight="angle", fit_center_radius=2),
+            scarlet.PositivityConstraint(), scarlet.NormalizationConstraint("max"))
+
+    ref, blend = _fit_pair(hsc, wide_centre, n_it=6)
+    assert [k for k, _ in blend._host] == [0] and np.isfinite(blend.loss).all()
+    assert np.asarray(components_of(blend)[0].children[1].parameters[0]).max() == 1
+
+
 def test_priors_join_the_gradient_on_the_host(hsc):
     """``Parameter.prior`` (reference parameter.py:42-71; blend.py:120-131 adds ``x.prior(x)``
     to the likelihood's gradient): parameters with a prior are stepped on the host.  A prior
