@@ -170,3 +170,27 @@ def test_bench_facade_leg():
     assert cfg["observation_uploads_during_fit"] == 1
     assert cfg["blend_iterations"] > 24 * 7 and line["value"] > 0
     assert 0 < cfg["ratio_to_c_abi"] < 1 and cfg["c_abi_rate_same_box"] > line["value"]
+
+
+def test_bench_measures_its_own_hbm_counters():
+    """At N = 1 the bench re-runs itself under rocprofv3 --pmc for the FETCH_SIZE / WRITE_SIZE
+    counters: `roofline.traffic` and `measured_hbm` are this run's, per kernel, and plausible
+    (between the compulsory bytes and three times as much)."""
+    import shutil
+
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--blends", "96", "--steps",
+                          "6", "--warmup", "2", "--no-cpu"], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    hbm = line["roofline"]["measured_hbm"]
+    if not (hbm["source"] or "").startswith("this run"):
+        pytest.skip("the counter passes did not run here (profiler unusable): the line fell back "
+                    "to the committed summary, as designed")
+    assert set(hbm["per_kernel"]) == {"fused_conv_kernel", "update_kernel_reg"}
+    compulsory = line["roofline"]["speed_of_light"]["compulsory_bytes_per_blend_iteration"]
+    assert compulsory < hbm["bytes_per_blend_iteration"] < 3 * compulsory
+    assert line["roofline"]["traffic"] is not None
+    assert "traffic" not in line["roofline"]["counter_fields"]["fields"]
