@@ -61,9 +61,16 @@ constexpr size_t conv_lds_bytes(int fy, int fx) {
            sizeof(double) * (kThreads / 64);
 }
 
-template <int FY1, int FX1>
+// ZB: trailing 16-element blocks of BOTH axes that hold nothing but zero padding (frame rows
+// < 16 (FY1 - ZB), frame columns < 16 (FX1 - ZB); chosen at launch, 0 .. 2).  The radix-F1
+// passes over stride 16 own exactly one element of every block, so a padding block is a
+// literal zero input of the forward butterflies (no load, and the butterfly is pruned by
+// constant folding) and a dead output of the inverse ones (no store).
+template <int FY1, int FX1, int ZB>
 struct Cfg {
     static constexpr int FY = FY1 * kF2, FX = FX1 * kF2;
+    static constexpr int NY1 = FY1 - ZB, NX1 = FX1 - ZB;  // blocks that can hold frame rows / columns
+    static_assert(ZB >= 0 && NY1 >= 1 && NX1 >= 1, "padding blocks");
     static constexpr int NKX = FX / 2 + 1;
     // column stride of T (complex).  A column stores element y at y + y / 16 (one pad
     // per radix-16 block, so that the lanes that each own a block hit different banks).
@@ -84,22 +91,24 @@ struct Cfg {
 __device__ __forceinline__ int sk(int y) { return y + (y >> 4); }
 
 // radix-F1 pass on a column of T (element 16 n1 + n2 lives at 17 n1 + n2).
-// forward: A[k1] = w_F^(n2 k1) DFT_F1(x)[k1] written to a[16 k1 + n2]; inputs with
-// index >= valid are taken as zero.  inverse: the inputs B[k1] are first multiplied by
+// forward: A[k1] = w_F^(n2 k1) DFT_F1(x)[k1] written to a[16 k1 + n2]; the blocks n1 >= LIVE are
+// zero padding (literal zeros), the rows below 16 LIVE that lie beyond the frame HOLD zeros
+// (Conv::zero_tail), so no load is guarded.  inverse: the inputs B[k1] are first multiplied by
 // w_F^(-n2 k1) (both directions carry their twiddles in this pass, which has the most
-// work items, so the radix-16 pass stays short), then inverse DFT_F1.
-template <int F1, bool INV>
-__device__ __forceinline__ void pass_stride_col(float2 *a, int n2, const float2 *tw, int valid) {
+// work items, so the radix-16 pass stays short), then inverse DFT_F1; only the blocks
+// k1 < LIVE are stored.
+template <int F1, bool INV, int LIVE>
+__device__ __forceinline__ void pass_stride_col(float2 *a, int n2, const float2 *tw) {
     cf v[F1];
 #pragma unroll
     for (int n1 = 0; n1 < F1; ++n1) {
-        const int idx = kF2 * n1 + n2;
-        v[n1] = (INV || idx < valid) ? ld(a[(kF2 + 1) * n1 + n2]) : cf{0.f, 0.f};
+        v[n1] = (INV || n1 < LIVE) ? ld(a[(kF2 + 1) * n1 + n2]) : cf{0.f, 0.f};
         if (INV && n1 > 0) v[n1] = cmulc(v[n1], ld(tw[kF2 * n1 + n2]));
     }
     fftk::Dft<F1, INV>::run(v);
 #pragma unroll
     for (int k1 = 0; k1 < F1; ++k1) {
+        if (INV && k1 >= LIVE) continue;
         if (!INV && k1 > 0) v[k1] = cmul(v[k1], ld(tw[kF2 * k1 + n2]));
         a[(kF2 + 1) * k1 + n2] = st(v[k1]);
     }
@@ -175,11 +184,21 @@ __device__ __forceinline__ cf pair_load(plane_t r, PairRows a) {
               __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, a.o1 + 4u * kF2 * N1, 0, 0))};
 }
 
-template <int FY1, int FX1>
+template <int FY1, int FX1, int ZB>
 struct Conv {
-    using C = Cfg<FY1, FX1>;
+    using C = Cfg<FY1, FX1, ZB>;
+    static constexpr int NX1 = C::NX1;
     float2 *T, *twy, *twx;
     int tid, n_pairs;
+
+    // The rows 2 n_pairs .. 16 NY1 - 1 of a column lie beyond the frame but inside a block
+    // that the forward column pass reads: they hold zeros whenever that pass starts.  The
+    // row passes never touch them; the inverse column pass leaves its (unused) outputs
+    // there, so the wavefront that ran it clears them again.  (Nothing to do for a frame
+    // that fills its blocks, e.g. 128 rows.)
+    __device__ __forceinline__ void zero_tail(float2 *a, int g) const {
+        for (int y = 2 * n_pairs + g; y < kF2 * C::NY1; y += kF2) a[sk(y)] = make_float2(0.f, 0.f);
+    }
 
     // column transforms fused with the spectral product:
     //   T <- IFFT_y( FFT_y(T) * K )   for every column kx, K in digit-swapped order.
@@ -189,12 +208,12 @@ struct Conv {
     // The three passes of a column only exchange data inside that group, so no
     // workgroup barrier separates them and the wavefronts drift through the stage
     // independently.  The two columns of a half-wave are four apart (16 slots mod 32).
-    __device__ __forceinline__ void columns(const float2 *Kt, int H, bool conj) {
+    __device__ __forceinline__ void columns(const float2 *Kt, bool conj) {
         const int g = tid & (kF2 - 1), G = tid >> 4;
         const int col = 8 * (G >> 3) + ((G >> 1) & 3) + 4 * (G & 1);
         for (int kx = col; kx < C::NKX; kx += kThreads / kF2) {
             float2 *a = T + kx * C::SY;
-            pass_stride_col<FY1, false>(a, g, twy, H);
+            pass_stride_col<FY1, false, C::NY1>(a, g, twy);
             wave_lds_fence();
             if (g < FY1) {
                 float2 *blk = a + (kF2 + 1) * g;
@@ -213,7 +232,8 @@ struct Conv {
                 for (int j = 0; j < kF2; ++j) blk[j] = st(v[j]);
             }
             wave_lds_fence();
-            pass_stride_col<FY1, true>(a, g, twy, C::FY);
+            pass_stride_col<FY1, true, C::NY1>(a, g, twy);
+            zero_tail(a, g);
         }
         lds_barrier();
     }
@@ -240,9 +260,12 @@ struct Conv {
         return s;
     }
     __device__ __forceinline__ int stride_items() const { return n_pairs * kF2; }
-    // forward butterfly of v (v[n1] = element 16 n1 + n2 of the pair) into the pair's slots
+    // forward butterfly of v (v[n1] = element 16 n1 + n2 of the pair; the padding blocks
+    // n1 >= NX1 are set to zero here) into the pair's slots
     __device__ __forceinline__ void stride_forward(cf *v, const StrideItem &s) {
         float2 *a = T + s.zb;
+#pragma unroll
+        for (int n1 = NX1; n1 < FX1; ++n1) v[n1] = cf{0.f, 0.f};
         fftk::Dft<FX1, false>::run(v);
 #pragma unroll
         for (int k1 = 0; k1 < FX1; ++k1) {
@@ -250,7 +273,8 @@ struct Conv {
             a[8 * C::SY * k1] = st(v[k1]);
         }
     }
-    // inverse butterfly: v[k1] = element 16 k1 + n2 of the pair's rows
+    // inverse butterfly: v[k1] = element 16 k1 + n2 of the pair's rows (the caller uses
+    // k1 < NX1 only; the rest is dead code)
     __device__ __forceinline__ void stride_inverse(cf *v, const StrideItem &s) {
         const float2 *a = T + s.zb;
 #pragma unroll
@@ -437,7 +461,8 @@ struct Conv {
 // column or row lies outside the box (or the frame) get an out-of-range offset, for which the
 // buffer load returns 0 without touching memory, and fma(sed, 0, acc) = acc.  Only the
 // accumulation branches (wave-uniformly) on n1lo, to keep the register indices static.
-template <int FX1, int M>
+// (FX1 blocks per row, of which the first NX1 can hold frame columns)
+template <int FX1, int NX1, int M>
 struct ModelGather {
     static constexpr uint32_t kNone = 0x40000000u;  // rowbase + column stays out of range
     const BatchView &v;
@@ -482,12 +507,12 @@ struct ModelGather {
     }
     __device__ __forceinline__ void close(int n1lo_, float sd_, const cf (&mv)[M], cf (&acc)[FX1]) const {
         const cf sd = cf{sd_, sd_};
-        fftk::static_for<0, FX1>([&](auto lo) {
+        fftk::static_for<0, NX1>([&](auto lo) {
             constexpr int n1lo = decltype(lo)::value;
             if (n1lo_ == n1lo) {
 #pragma unroll
                 for (int m = 0; m < M; ++m)
-                    if (n1lo + m < FX1) acc[n1lo + m] = fftk::fma2(mv[m], sd, acc[n1lo + m]);
+                    if (n1lo + m < NX1) acc[n1lo + m] = fftk::fma2(mv[m], sd, acc[n1lo + m]);
                 // (keeps the cases apart: merged, they index `acc` dynamically and the
                 // array moves to scratch memory)
                 asm volatile("; n1lo = %0" ::"n"(n1lo));
@@ -496,7 +521,7 @@ struct ModelGather {
     }
     __device__ __forceinline__ void run(int b, int lane, cf (&acc)[FX1]) const {
 #pragma unroll
-        for (int n1 = 0; n1 < FX1; ++n1) acc[n1] = cf{0.f, 0.f};
+        for (int n1 = 0; n1 < NX1; ++n1) acc[n1] = cf{0.f, 0.f};
         const int cs = v.comp_start[b], ce = v.comp_start[b + 1];
         for (int kb = cs; kb < ce; kb += 64) {
             const int kk = kb + lane;
@@ -532,12 +557,13 @@ extern __shared__ __attribute__((aligned(16))) float2 lds_conv[];
 // model: the model cube [nb][C][H][W] (render_kernel)
 // mode 0: full (writes the gradient image G[nb][C][H][W] and the loss partial)
 // mode 1: forward only (writes the rendered cube instead and the loss partial)
-template <int FY1, int FX1>
+template <int FY1, int FX1, int ZB>
 __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const float *model,
                                                               const float2 *Kt, int k_bands,
                                                               int k_per_blend, float *out,
                                                               int mode, long long *dbg) {
-    using C = Cfg<FY1, FX1>;
+    using C = Cfg<FY1, FX1, ZB>;
+    constexpr int NX1 = C::NX1;
     // XCD-aware placement: consecutive logical ids (the bands of one blend) share an
     // XCD and therefore its L2 (morphologies, data of neighbouring bands)
     const int total = gridDim.x;
@@ -548,7 +574,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     const int tid = threadIdx.x;
     const int H = v.H, W = v.W;
 
-    Conv<FY1, FX1> cv;
+    Conv<FY1, FX1, ZB> cv;
     cv.T = lds_conv;
     cv.twy = cv.T + C::NKX * C::SY;
     cv.twx = cv.twy + C::FY;
@@ -557,7 +583,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     double *loss_part = reinterpret_cast<double *>(cv.twx + C::FX);
     const int64_t band = ((int64_t)b * v.C + c) * H * W;
     const int n_items = cv.stride_items();
-    using Item = typename Conv<FY1, FX1>::StrideItem;
+    using Item = typename Conv<FY1, FX1, ZB>::StrideItem;
 
     // the first model rows are requested before the twiddle tables are made
     // (model == nullptr: the rows are rendered here, ModelGather)
@@ -566,7 +592,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     cf mrow[FX1];
     auto fetch_model = [&](const Item &s) {
         const PairRows a = pair_rows(2 * s.j, s.n2, W);
-        fftk::static_for<0, FX1>([&](auto n1c) {
+        fftk::static_for<0, NX1>([&](auto n1c) {
             constexpr int n1 = decltype(n1c)::value;
             mrow[n1] = pair_load<n1>(r_model, a);
         });
@@ -575,10 +601,10 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         // the four row pairs of this wavefront start at pair (item / 64) * 4
         const int j0 = __builtin_amdgcn_readfirstlane(s.j - ((tid & 63) >> 4));
         if (v.render_slots <= 4) {
-            const ModelGather<FX1, 4> g{v, c, H, W, 2 * s.j, s.n2, 2 * j0};
+            const ModelGather<FX1, NX1, 4> g{v, c, H, W, 2 * s.j, s.n2, 2 * j0};
             g.run(b, tid & 63, mrow);
         } else {
-            const ModelGather<FX1, (FX1 < 6 ? FX1 : 6)> g{v, c, H, W, 2 * s.j, s.n2, 2 * j0};
+            const ModelGather<FX1, NX1, (FX1 < 6 ? FX1 : 6)> g{v, c, H, W, 2 * s.j, s.n2, 2 * j0};
             g.run(b, tid & 63, mrow);
         }
     };
@@ -592,6 +618,11 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         float s, co;
         sincospif(2.0f * (float)((j / kF2) * (j % kF2)) / (float)C::FX, &s, &co);
         cv.twx[j] = make_float2(co, -s);
+    }
+    {   // zero padding rows inside the blocks that the column passes read (Conv::zero_tail)
+        const int y0 = 2 * cv.n_pairs, tail = kF2 * C::NY1 - y0;
+        for (int i = tid; i < tail * C::NKX; i += kThreads)
+            cv.T[(i / tail) * C::SY + sk(y0 + i % tail)] = make_float2(0.f, 0.f);
     }
     const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
                                C::FY * C::NKX;
@@ -614,7 +645,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         if (have_cube) {
             if (it != tid) fetch_model(s);
 #pragma unroll
-            for (int n1 = 0; n1 < FX1; ++n1)  // the zero padding beyond column W - 1
+            for (int n1 = 0; n1 < NX1; ++n1)  // the zero padding beyond column W - 1
                 if (kF2 * n1 + s.n2 >= W) mrow[n1] = cf{0.f, 0.f};
         } else {
             render_rows(s);
@@ -626,7 +657,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     cv.blocks_forward();
     SMI_STAMP(1);
     // ---- B: columns, x K^ --------------------------------------------------------
-    cv.columns(K, H, false);
+    cv.columns(K, false);
     SMI_STAMP(2);
     // ---- C: rendered rows -> residual, loss, forward rows of the residual ------------
     // (observation.py:147-170)  One pass between the two radix-16 passes: inverse
@@ -643,8 +674,8 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
 #ifndef SMI_CONV_PRE
 #define SMI_CONV_PRE 0
 #endif
-        constexpr int kPre = SMI_CONV_PRE < FX1 ? SMI_CONV_PRE : FX1;
-        cf dv[FX1], wv[FX1];
+        constexpr int kPre = SMI_CONV_PRE < NX1 ? SMI_CONV_PRE : NX1;
+        cf dv[NX1], wv[NX1];
         auto fetch = [&](const Item &s, auto from, auto to) {
             const PairRows a = pair_rows(2 * s.j, s.n2, W);
             fftk::static_for<decltype(from)::value, decltype(to)::value>([&](auto n1c) {
@@ -656,16 +687,16 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         using std::integral_constant;
         const Item s0 = cv.stride_item(tid);
         fetch(s0, integral_constant<int, 0>{}, integral_constant<int, kPre>{});
-        cv.blocks_inverse([&] { fetch(s0, integral_constant<int, kPre>{}, integral_constant<int, FX1>{}); });
+        cv.blocks_inverse([&] { fetch(s0, integral_constant<int, kPre>{}, integral_constant<int, NX1>{}); });
         SMI_STAMP(10);
         for (int it = tid; it < n_items; it += kThreads) {
             const Item s = cv.stride_item(it);
             const int y = 2 * s.j;
-            if (it != tid) fetch(s, integral_constant<int, 0>{}, integral_constant<int, FX1>{});
+            if (it != tid) fetch(s, integral_constant<int, 0>{}, integral_constant<int, NX1>{});
             cf m[FX1];
             cv.stride_inverse(m, s);
 #pragma unroll
-            for (int n1 = 0; n1 < FX1; ++n1) {
+            for (int n1 = 0; n1 < NX1; ++n1) {
                 const int x = kF2 * n1 + s.n2;
                 if (mode == 1) {
                     plane_store(r_rendered, y, x, W, m[n1].x);
@@ -694,7 +725,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     SMI_STAMP(3);
     if (mode == 1) return;
     // ---- B': columns, x conj(K^) ---------------------------------------------------
-    cv.columns(K, H, true);
+    cv.columns(K, true);
     SMI_STAMP(4);
     // ---- D: gradient image rows -----------------------------------------------------
     {
@@ -707,7 +738,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
             cf g[FX1];
             cv.stride_inverse(g, s);
 #pragma unroll
-            for (int k1 = 0; k1 < FX1; ++k1) {
+            for (int k1 = 0; k1 < NX1; ++k1) {
                 plane_store(r_out, 2 * s.j, kF2 * k1 + s.n2, W, g[k1].x);
                 plane_store(r_out, 2 * s.j + 1, kF2 * k1 + s.n2, W, g[k1].y);
             }
@@ -779,17 +810,28 @@ __global__ void stamp_dft_y(const double2 *A, float2 *Kt, int ph, int NKX, doubl
 
 #endif  // SMI_CONV_SHORT_ROWS
 
-template <int FY1, int FX1>
-int launch_impl(const BatchView &v, const float *model, const float2 *Kt, int k_bands,
-                int k_per_blend, float *out, int mode, long long *dbg, hipStream_t s) {
-    using C = Cfg<FY1, FX1>;
-    auto kern = fused_conv_kernel<FY1, FX1>;
+template <int FY1, int FX1, int ZB>
+int launch_zb(const BatchView &v, const float *model, const float2 *Kt, int k_bands,
+              int k_per_blend, float *out, int mode, long long *dbg, hipStream_t s) {
+    using C = Cfg<FY1, FX1, ZB>;
+    auto kern = fused_conv_kernel<FY1, FX1, ZB>;
     static size_t configured[kMaxDevices] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), C::lds_bytes, configured))
         return rc;
     hipLaunchKernelGGL(kern, dim3(v.nb * v.C), dim3(kThreads), C::lds_bytes, s, v, model, Kt,
                        k_bands, k_per_blend, out, mode, dbg);
     return SMI_OK;
+}
+
+// the kernel variant for the frame: as many all-padding blocks (of both axes) as it has, up to 2
+template <int FY1, int FX1>
+int launch_impl(const BatchView &v, const float *model, const float2 *Kt, int k_bands,
+                int k_per_blend, float *out, int mode, long long *dbg, hipStream_t s) {
+    const int zy = FY1 - (v.H + kF2 - 1) / kF2, zx = FX1 - (v.W + kF2 - 1) / kF2;
+    const int zb = zy < zx ? zy : zx;
+    if (zb >= 2) return launch_zb<FY1, FX1, 2>(v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s);
+    if (zb == 1) return launch_zb<FY1, FX1, 1>(v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s);
+    return launch_zb<FY1, FX1, 0>(v, model, Kt, k_bands, k_per_blend, out, mode, dbg, s);
 }
 
 }  // namespace
