@@ -134,10 +134,14 @@ __device__ __forceinline__ int pos(int k) {
     return kF2 * (k % F1) + k / F1;
 }
 
-__device__ __forceinline__ double block_sum(double v, double *part) {
+// sum over the workgroup in two halves around a barrier the caller has anyway: every
+// wavefront leaves its partial sum (wave_partial, before the barrier), one thread adds them
+// up (sum_partials, after it)
+__device__ __forceinline__ void wave_partial(double v, double *part) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
-    __syncthreads();
+}
+__device__ __forceinline__ double sum_partials(const double *part) {
     double t = 0.0;
     for (int i = 0; i < kThreads / 64; ++i) t += part[i];
     return t;
@@ -211,13 +215,15 @@ struct Conv {
     __device__ __forceinline__ void columns(const float2 *Kt, bool conj) {
         const int g = tid & (kF2 - 1), G = tid >> 4;
         const int col = 8 * (G >> 3) + ((G >> 1) & 3) + 4 * (G & 1);
-        for (int kx = col; kx < C::NKX; kx += kThreads / kF2) {
+        constexpr int kStep = kThreads / kF2;
+        for (int kx = col; kx < C::NKX; kx += kStep) {
             float2 *a = T + kx * C::SY;
             pass_stride_col<FY1, false, C::NY1>(a, g, twy);
             wave_lds_fence();
             if (g < FY1) {
                 float2 *blk = a + (kF2 + 1) * g;
-                // (requesting K^ before the first pass was measured: slower, 12.9 -> 13.9 k cycles)
+                // (requesting K^ before the first pass was measured: slower, 12.9 -> 13.9 k cycles;
+                // so was requesting the next trip's behind the product: 11.5 -> 13.0 k)
                 const float2 *kp = Kt + (int64_t)kx * C::FY + kF2 * g;
                 cf v[kF2], kv[kF2];
 #pragma unroll
@@ -311,20 +317,37 @@ struct Conv {
     // of 32, the pad slot of an odd FX1) repeat the work item of a neighbour -- the last
     // pair, block 0 -- and store the same values to the same slots: no lane is masked, and
     // the wavefronts that have no work item at all (`wave_on`, uniform) skip the pass.
+    // (what the four radix-16 passes of a band need of it, in three registers; the item of the
+    // first trip is worked out once per band and kept -- `first_block_item` --, the passes used
+    // to spend a sixth of their instructions on recomputing it)
     struct BlockItem {
-        int j, slot, k1;
+        int z;     // slot of the pair's rows in the first column of the block: 8 k1 SY + sk(2 j)
+        int nyq;   // slot of the pair's rows in the Nyquist column
+        int kind;  // 0: block with a mirror block in the partner half-wave, 1: block 0, 2: block FX1 / 2
         bool wave_on;
     };
+    BlockItem first;
     __device__ __forceinline__ BlockItem block_item(int group0) const {
         BlockItem b;
         const int grp = tid >> 5;
-        b.slot = grp % kSlots;
-        b.j = (tid & 31) + 32 * (group0 + grp / kSlots);
+        const int slot = grp % kSlots;
+        int j = (tid & 31) + 32 * (group0 + grp / kSlots);
         const int wgrp = __builtin_amdgcn_readfirstlane(tid >> 6) * 2;  // first group of the wavefront
         b.wave_on = wgrp < kGroupsPerTrip * kSlots && 32 * (group0 + wgrp / kSlots) < n_pairs;
-        if (b.j >= n_pairs) b.j = n_pairs - 1;
-        b.k1 = b.slot < FX1 ? slot_block(b.slot) : 0;
+        if (j >= n_pairs) j = n_pairs - 1;
+        const int k1 = slot < FX1 ? slot_block(slot) : 0;
+        b.z = 8 * k1 * C::SY + sk(2 * j);
+        b.nyq = (FX1 * 8) * C::SY + sk(2 * j);
+        b.kind = slot < 2 * kDouble ? 0 : k1 == 0 ? 1 : 2;
         return b;
+    }
+    __device__ __forceinline__ void first_block_item() {
+        first = block_item(0);
+        // (opaque: values the compiler cannot recompute stay in their registers)
+        asm volatile("" : "+v"(first.z), "+v"(first.nyq), "+v"(first.kind));
+    }
+    __device__ __forceinline__ BlockItem trip_item(int trip) const {
+        return trip == 0 ? first : block_item(trip * kGroupsPerTrip);
     }
     __device__ __forceinline__ int block_trips() const {
         // (one trip whenever every pair group of the tallest frame fits the workgroup)
@@ -334,26 +357,33 @@ struct Conv {
     static __device__ __forceinline__ cf from_partner(cf v) {
         return cf{__shfl_xor(v.x, 32, 64), __shfl_xor(v.y, 32, 64)};
     }
-    // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^); one packed
-    // operation each (a multiplication by +-1 is exact)
+    // Xa = za + conj(zb), Xb = -i (za - conj(zb))   (the 1/2 lives in K^); one packed addition
+    // each, the swaps of halves and the signs in the operand modifiers (the compiler builds a
+    // swapped operand with two register copies more often than not)
     static __device__ __forceinline__ void sep(cf za, cf zb, cf &xa, cf &xb) {
-        xa = fftk::fma2(zb, cf{1.f, -1.f}, za);                        // (za.x + zb.x, za.y - zb.y)
-        xb = fftk::fma2(fftk::swp(za), cf{1.f, -1.f}, fftk::swp(zb));  // (za.y + zb.y, zb.x - za.x)
+        // (za.x + zb.x, za.y - zb.y)
+        asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(xa) : "v"(za), "v"(zb));
+        // (za.y + zb.y, zb.x - za.x)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(xb) : "v"(za), "v"(zb));
     }
-    static __device__ __forceinline__ cf plus(cf xa, cf xb) {   // Xa + i Xb
-        return fftk::fma2(fftk::swp(xb), cf{-1.f, 1.f}, xa);    // (xa.x - xb.y, xa.y + xb.x)
+    static __device__ __forceinline__ cf plus(cf xa, cf xb) {  // Xa + i Xb = (xa.x - xb.y, xa.y + xb.x)
+        cf r;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(xa), "v"(xb));
+        return r;
     }
-    static __device__ __forceinline__ cf minus(cf xa, cf xb) {  // conj(Xa) + i conj(Xb)
-        return fftk::fma2(xa, cf{1.f, -1.f}, fftk::swp(xb));    // (xa.x + xb.y, xb.x - xa.y)
+    static __device__ __forceinline__ cf minus(cf xa, cf xb) {  // conj(Xa) + i conj(Xb) = (xa.x + xb.y, xb.x - xa.y)
+        cf r;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(xa), "v"(xb));
+        return r;
     }
 
     // forward: radix-16 pass of every pair and separation into the pair's rows
     __device__ __forceinline__ void blocks_forward() {
         const int trips = block_trips();
         for (int trip = 0; trip < trips; ++trip) {
-            const BlockItem b = block_item(trip * kGroupsPerTrip);
+            const BlockItem b = trip_item(trip);
             if (!b.wave_on) continue;
-            float2 *z = T + 8 * b.k1 * C::SY + sk(2 * b.j);
+            float2 *z = T + b.z;
             cf va[kF2], xa[8], xb[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -361,27 +391,34 @@ struct Conv {
                 va[2 * i + 1] = ld(z[i * C::SY + 1]);
             }
             fftk::Dft<kF2, false>::run(va);
-            if (b.slot < 2 * kDouble) {  // uniform over the wavefront
+            // (the stores sit in every branch: a common tail would have the three branches
+            // hand over xa / xb through sixteen register copies each)
+            auto store = [&] {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    z[k2 * C::SY] = st(xa[k2]);
+                    z[k2 * C::SY + 1] = st(xb[k2]);
+                }
+            };
+            if (b.kind == 0) {  // uniform over the wavefront
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) sep(va[k2], from_partner(va[15 - k2]), xa[k2], xb[k2]);
-            } else if (b.k1 == 0) {
+                store();
+            } else if (b.kind == 1) {
                 // (two branches: a select between va[a] and va[b] would be compiled into a
                 // select of the index, i.e. a dynamically indexed register array)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) sep(va[k2], va[(16 - k2) & 15], xa[k2], xb[k2]);
                 cf na, nb;  // the Nyquist frequency
                 sep(va[8], va[8], na, nb);
-                float2 *t = T + (FX1 * 8) * C::SY + sk(2 * b.j);
+                float2 *t = T + b.nyq;
                 t[0] = st(na);
                 t[1] = st(nb);
+                store();
             } else {
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) sep(va[k2], va[15 - k2], xa[k2], xb[k2]);
-            }
-#pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) {
-                z[k2 * C::SY] = st(xa[k2]);
-                z[k2 * C::SY + 1] = st(xb[k2]);
+                store();
             }
         }
         lds_barrier();
@@ -394,26 +431,40 @@ struct Conv {
     __device__ __forceinline__ void blocks_inverse(F &&mid) {
         const int trips = block_trips();
         for (int trip = 0; trip < trips; ++trip) {
-            const BlockItem b = block_item(trip * kGroupsPerTrip);
+            const BlockItem b = trip_item(trip);
             if (!b.wave_on) {
                 if (trip == 0) mid();
                 continue;
             }
-            float2 *z = T + 8 * b.k1 * C::SY + sk(2 * b.j);
+            float2 *z = T + b.z;
             cf va[kF2], xa[8], xb[8];
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 xa[k2] = ld(z[k2 * C::SY]);
                 xb[k2] = ld(z[k2 * C::SY + 1]);
             }
-            if (b.slot < 2 * kDouble) {
+            // (the global loads of `mid` go out behind the LDS loads, in front of the branches;
+            // transform and stores in every branch: see blocks_forward)
+            __builtin_amdgcn_sched_barrier(0);
+            if (trip == 0) mid();
+            __builtin_amdgcn_sched_barrier(0);
+            auto tail = [&] {
+                fftk::Dft<kF2, true>::run(va);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    z[i * C::SY] = st(va[2 * i]);
+                    z[i * C::SY + 1] = st(va[2 * i + 1]);
+                }
+            };
+            if (b.kind == 0) {
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
                     va[k2] = plus(xa[k2], xb[k2]);
                     va[15 - k2] = from_partner(minus(xa[k2], xb[k2]));
                 }
-            } else if (b.k1 == 0) {
-                const float2 *t = T + (FX1 * 8) * C::SY + sk(2 * b.j);
+                tail();
+            } else if (b.kind == 1) {
+                const float2 *t = T + b.nyq;
                 va[0] = plus(xa[0], xb[0]);
                 va[8] = plus(ld(t[0]), ld(t[1]));
 #pragma unroll
@@ -421,22 +472,14 @@ struct Conv {
                     va[k2] = plus(xa[k2], xb[k2]);
                     va[16 - k2] = minus(xa[k2], xb[k2]);
                 }
+                tail();
             } else {
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
                     va[k2] = plus(xa[k2], xb[k2]);
                     va[15 - k2] = minus(xa[k2], xb[k2]);
                 }
-            }
-            fftk::Dft<kF2, true>::run(va);
-            // (the scheduler must not move the loads above the transform: registers)
-            __builtin_amdgcn_sched_barrier(0);
-            if (trip == 0) mid();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                z[i * C::SY] = st(va[2 * i]);
-                z[i * C::SY + 1] = st(va[2 * i + 1]);
+                tail();
             }
         }
         lds_barrier();
@@ -580,6 +623,7 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     cv.twx = cv.twy + C::FY;
     cv.tid = tid;
     cv.n_pairs = (H + 1) / 2;
+    cv.first_block_item();
     double *loss_part = reinterpret_cast<double *>(cv.twx + C::FX);
     const int64_t band = ((int64_t)b * v.C + c) * H * W;
     const int n_items = cv.stride_items();
@@ -714,14 +758,13 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
             loss += (double)loss2.x + (double)loss2.y;
             loss2 = cf{0.f, 0.f};
         }
+        wave_partial(loss, loss_part);
         lds_barrier();
         SMI_STAMP(11);
         cv.blocks_forward();
     }
-    {
-        const double t = block_sum(loss, loss_part);
-        if (tid == 0) v.loss_partial[(int64_t)b * v.n_partial + c] = t;
-    }
+    // (behind the barrier of the pass; the other wavefronts go on)
+    if (tid == 0) v.loss_partial[(int64_t)b * v.n_partial + c] = sum_partials(loss_part);
     SMI_STAMP(3);
     if (mode == 1) return;
     // ---- B': columns, x conj(K^) ---------------------------------------------------
