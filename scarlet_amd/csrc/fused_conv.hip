@@ -11,7 +11,8 @@
 // for a batch of nothing but factorized components, is rendered here row by row from the
 // components' spectra and morphologies (ModelGather below): no cube, no launch.
 //
-// Layout: ONE array T[kx][y], kx in [0, FX/2]; element y of a column sits at y + y / 16
+// Layout: ONE array T[kx][y], kx in [0, FX/2) (the Nyquist frequency rides in the imaginary
+// part of column 0); element y of a column sits at y + y / 16
 // and the column stride SY is 4 mod 8 complex.  1-D transforms of length F = F1 * 16 are
 // two in-place passes (radix F1 over stride 16, radix 16 over contiguous blocks); the
 // forward transform leaves the spectrum in the digit-swapped order pos(k1 + F1 k2) =
@@ -57,7 +58,7 @@ constexpr int kF2 = 16;      // second radix of every 1-D transform
 
 constexpr int conv_column_stride(int fy) { return ((fy + fy / kF2 + 3) / 8) * 8 + 4; }
 constexpr size_t conv_lds_bytes(int fy, int fx) {
-    return sizeof(float2) * ((size_t)(fx / 2 + 1) * conv_column_stride(fy) + fy + fx) +
+    return sizeof(float2) * ((size_t)(fx / 2) * conv_column_stride(fy) + 2 * fy + fx) +
            sizeof(double) * (kThreads / 64);
 }
 
@@ -71,7 +72,9 @@ struct Cfg {
     static constexpr int FY = FY1 * kF2, FX = FX1 * kF2;
     static constexpr int NY1 = FY1 - ZB, NX1 = FX1 - ZB;  // blocks that can hold frame rows / columns
     static_assert(ZB >= 0 && NY1 >= 1 && NX1 >= 1, "padding blocks");
-    static constexpr int NKX = FX / 2 + 1;
+    // columns of K^ (kx = 0 .. FX / 2) and of T: the DC and the Nyquist frequency of a real row
+    // are both real, so they share column 0 of T as its real and imaginary part (Conv::columns)
+    static constexpr int NKX = FX / 2 + 1, NT = FX / 2;
     // column stride of T (complex).  A column stores element y at y + y / 16 (one pad
     // per radix-16 block, so that the lanes that each own a block hit different banks).
     // SY = 4 (mod 8): the eight columns 8 k1 + a that hold the elements 16 k1 + n2 of a
@@ -82,8 +85,8 @@ struct Cfg {
     // are chosen that way.
     static constexpr int SY = conv_column_stride(FY);
     static_assert(SY >= FY + FY / kF2 && SY % 8 == 4, "column stride");
-    // + twiddle tables tw[k1 * 16 + n2] = exp(-2 pi i n2 k1 / F) for both axes, + the
-    // partial sums of the loss
+    // + twiddle tables tw[k1 * 16 + n2] = exp(-2 pi i n2 k1 / F) for both axes, + column FX / 2
+    // of the kernel spectrum (Conv::columns, column 0), + the partial sums of the loss
     static constexpr size_t lds_bytes = conv_lds_bytes(FY, FX);
 };
 
@@ -192,7 +195,7 @@ template <int FY1, int FX1, int ZB>
 struct Conv {
     using C = Cfg<FY1, FX1, ZB>;
     static constexpr int NX1 = C::NX1;
-    float2 *T, *twy, *twx;
+    float2 *T, *twy, *twx, *qtab;
     int tid, n_pairs;
 
     // The rows 2 n_pairs .. 16 NY1 - 1 of a column lie beyond the frame but inside a block
@@ -216,7 +219,11 @@ struct Conv {
         const int g = tid & (kF2 - 1), G = tid >> 4;
         const int col = 8 * (G >> 3) + ((G >> 1) & 3) + 4 * (G & 1);
         constexpr int kStep = kThreads / kF2;
-        for (int kx = col; kx < C::NKX; kx += kStep) {
+        for (int kt = col; kt < C::NT; kt += kStep) {
+            // (columns 0 .. 15 and 16 .. 31 change places: column 0, which costs its wavefront
+            // a few hundred instructions more, goes to a wavefront that has no column of the
+            // second trip on top)
+            const int kx = kt < 32 ? kt ^ 16 : kt;
             float2 *a = T + kx * C::SY;
             pass_stride_col<FY1, false, C::NY1>(a, g, twy);
             wave_lds_fence();
@@ -231,8 +238,41 @@ struct Conv {
 #pragma unroll
                 for (int j = 0; j < kF2; ++j) v[j] = ld(blk[j]);
                 fftk::Dft<kF2, false>::run(v);
+                // Column 0 carries two real columns, c = dc + i nyquist (both spectra of real
+                // rows are real there), so its transform is C = A + i B with A, B Hermitian, and
+                // what has to come out is K0 A + i KN B (K0, KN: K^ at kx = 0 and FX / 2,
+                // Hermitian too).  With C~[ky] = conj(C[-ky]), A = (C + C~) / 2 and i B =
+                // (C - C~) / 2, that is P C + Q C~, P = (K0 + KN) / 2, Q = (K0 - KN) / 2 -- the
+                // kernel spectrum holds P in column 0 and Q in column FX / 2 (pack_dc_nyquist;
+                // Q staged in LDS: `qtab`); for the adjoint conj(P) C + conj(Q) C~.  Frequency
+                // -ky of entry j of block g: entry 15 - j of block FY1 - g, for block 0 its own
+                // entry (16 - j) % 16.  The transformed blocks go back to the column, the common
+                // product P C runs, then every lane of the column adds Q C~ entry by entry from
+                // its mirror entries there (in place: the two sides of this lane-dependent
+                // branch must not meet in different registers).
+                if (kx == 0) {
+#pragma unroll
+                    for (int j = 0; j < kF2; ++j) blk[j] = st(v[j]);
+                }
 #pragma unroll
                 for (int j = 0; j < kF2; ++j) v[j] = conj ? cmulc(v[j], kv[j]) : cmul(v[j], kv[j]);
+                if (kx == 0) {
+                    wave_lds_fence();
+                    // (mirror entry of j: base[15 - j], base = the partner block, or for block 0
+                    // its own entries from 1 on -- where entry 0 is its own mirror)
+                    const float2 *base = g == 0 ? a + 1 : a + (kF2 + 1) * (FY1 - g);
+                    const float2 *base0 = g == 0 ? a - 15 : base;
+                    const float2 *qb = qtab + kF2 * g;
+#pragma unroll
+                    for (int j = 0; j < kF2; ++j) {
+                        const cf m = ld((j == 0 ? base0 : base)[15 - j]), q = ld(qb[j]);
+                        v[j] += conj ? cmul(cf{q.x, -q.y}, cf{m.x, -m.y}) : cmulc(q, m);
+                        // (four entries at a time: all thirty-two loads up front would not
+                        // fit the registers)
+                        if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    wave_lds_fence();
+                }
                 fftk::Dft<kF2, true>::run(v);
 #pragma unroll
                 for (int j = 0; j < kF2; ++j) blk[j] = st(v[j]);
@@ -317,12 +357,11 @@ struct Conv {
     // of 32, the pad slot of an odd FX1) repeat the work item of a neighbour -- the last
     // pair, block 0 -- and store the same values to the same slots: no lane is masked, and
     // the wavefronts that have no work item at all (`wave_on`, uniform) skip the pass.
-    // (what the four radix-16 passes of a band need of it, in three registers; the item of the
+    // (what the four radix-16 passes of a band need of it, in two registers; the item of the
     // first trip is worked out once per band and kept -- `first_block_item` --, the passes used
     // to spend a sixth of their instructions on recomputing it)
     struct BlockItem {
         int z;     // slot of the pair's rows in the first column of the block: 8 k1 SY + sk(2 j)
-        int nyq;   // slot of the pair's rows in the Nyquist column
         int kind;  // 0: block with a mirror block in the partner half-wave, 1: block 0, 2: block FX1 / 2
         bool wave_on;
     };
@@ -337,14 +376,13 @@ struct Conv {
         if (j >= n_pairs) j = n_pairs - 1;
         const int k1 = slot < FX1 ? slot_block(slot) : 0;
         b.z = 8 * k1 * C::SY + sk(2 * j);
-        b.nyq = (FX1 * 8) * C::SY + sk(2 * j);
         b.kind = slot < 2 * kDouble ? 0 : k1 == 0 ? 1 : 2;
         return b;
     }
     __device__ __forceinline__ void first_block_item() {
         first = block_item(0);
         // (opaque: values the compiler cannot recompute stay in their registers)
-        asm volatile("" : "+v"(first.z), "+v"(first.nyq), "+v"(first.kind));
+        asm volatile("" : "+v"(first.z), "+v"(first.kind));
     }
     __device__ __forceinline__ BlockItem trip_item(int trip) const {
         return trip == 0 ? first : block_item(trip * kGroupsPerTrip);
@@ -409,11 +447,12 @@ struct Conv {
                 // select of the index, i.e. a dynamically indexed register array)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) sep(va[k2], va[(16 - k2) & 15], xa[k2], xb[k2]);
-                cf na, nb;  // the Nyquist frequency
+                // the Nyquist frequency: real like the DC term (both imaginary parts are exact
+                // zeros), it takes the imaginary part of the DC term's slot (Conv::columns)
+                cf na, nb;
                 sep(va[8], va[8], na, nb);
-                float2 *t = T + b.nyq;
-                t[0] = st(na);
-                t[1] = st(nb);
+                xa[0].y = na.x;
+                xb[0].y = nb.x;
                 store();
             } else {
 #pragma unroll
@@ -464,9 +503,9 @@ struct Conv {
                 }
                 tail();
             } else if (b.kind == 1) {
-                const float2 *t = T + b.nyq;
-                va[0] = plus(xa[0], xb[0]);
-                va[8] = plus(ld(t[0]), ld(t[1]));
+                // (slot 0 of the rows: DC term in the real, Nyquist term in the imaginary part)
+                va[0] = cf{xa[0].x, xb[0].x};
+                va[8] = cf{xa[0].y, xb[0].y};
 #pragma unroll
                 for (int k2 = 1; k2 < 8; ++k2) {
                     va[k2] = plus(xa[k2], xb[k2]);
@@ -619,12 +658,13 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
 
     Conv<FY1, FX1, ZB> cv;
     cv.T = lds_conv;
-    cv.twy = cv.T + C::NKX * C::SY;
+    cv.twy = cv.T + C::NT * C::SY;
     cv.twx = cv.twy + C::FY;
     cv.tid = tid;
     cv.n_pairs = (H + 1) / 2;
     cv.first_block_item();
-    double *loss_part = reinterpret_cast<double *>(cv.twx + C::FX);
+    cv.qtab = cv.twx + C::FX;
+    double *loss_part = reinterpret_cast<double *>(cv.qtab + C::FY);
     const int64_t band = ((int64_t)b * v.C + c) * H * W;
     const int n_items = cv.stride_items();
     using Item = typename Conv<FY1, FX1, ZB>::StrideItem;
@@ -665,11 +705,12 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     }
     {   // zero padding rows inside the blocks that the column passes read (Conv::zero_tail)
         const int y0 = 2 * cv.n_pairs, tail = kF2 * C::NY1 - y0;
-        for (int i = tid; i < tail * C::NKX; i += kThreads)
+        for (int i = tid; i < tail * C::NT; i += kThreads)
             cv.T[(i / tail) * C::SY + sk(y0 + i % tail)] = make_float2(0.f, 0.f);
     }
     const float2 *K = Kt + ((int64_t)(k_per_blend ? b : 0) * k_bands + (k_bands == 1 ? 0 : c)) *
                                C::FY * C::NKX;
+    for (int j = tid; j < C::FY; j += kThreads) cv.qtab[j] = K[(int64_t)(C::FX / 2) * C::FY + j];
     __syncthreads();
 // stage stamps of one workgroup (tools/stage_cycles.py): workgroup 0 runs in the first of a
 // launch's rounds, where every CU bursts its loads at the same moment; a development build
@@ -804,6 +845,18 @@ __global__ void permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int NKX,
     const float2 k = Khat[(int64_t)img * FY * NKX + i];
     Kt[((int64_t)img * NKX + column_of(kx, Fx)) * FY + pos<FY1>(ky)] =
         make_float2(k.x * scale, k.y * scale);
+}
+
+// Columns 0 and FX / 2 of the kernel spectrum (K0 and KN: the DC and the Nyquist frequency of
+// the rows) -> P = (K0 + KN) / 2 and Q = (K0 - KN) / 2, what Conv::columns multiplies the packed
+// column 0 of T and its mirrored conjugate by.
+__global__ void pack_dc_nyquist(float2 *Kt, int Fy, int NKX) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Fy) return;
+    float2 *k0 = Kt + (int64_t)blockIdx.y * NKX * Fy + i, *kn = k0 + (int64_t)(NKX - 1) * Fy;
+    const float2 a = *k0, b = *kn;
+    *k0 = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+    *kn = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
 }
 
 // Kernel spectrum for the fused path without rocFFT (whose plan creation costs ~0.6 s of
@@ -992,6 +1045,7 @@ int launch_stamp_spectrum(const float *d_kern, double2 *d_tmp, float2 *Kt, int n
             set_error("stamp spectrum: unsupported FFT height");
             return SMI_ERR_INVALID;
     }
+    hipLaunchKernelGGL(pack_dc_nyquist, dim3((Fy + 255) / 256, n_img), dim3(256), 0, s, Kt, Fy, NKX);
     return SMI_OK;
 }
 
@@ -1009,6 +1063,7 @@ int launch_permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int n_img, in
             set_error("permute_kernel_spectrum: unsupported FFT height");
             return SMI_ERR_INVALID;
     }
+    hipLaunchKernelGGL(pack_dc_nyquist, dim3((Fy + 255) / 256, n_img), dim3(256), 0, s, Kt, Fy, NKX);
     return SMI_OK;
 }
 
