@@ -447,8 +447,9 @@ def live_hbm_counters(nb, timeout=90):
     again under ``rocprofv3 --kernel-trace --pmc`` (FETCH_SIZE and WRITE_SIZE in passes of their
     own, a few iterations in one range of blends), reduced like tools/hbm_counters.py does --
     both counters are reported in KiB, FETCH_SIZE counts 64 B per 128-byte request on gfx950 and
-    is doubled, the mean is taken over the full-batch launches.  Returns ``{kernel: bytes per
-    blend}`` or ``None`` when the profiler is missing, fails or takes longer than ``timeout``
+    is doubled, the mean is taken over the full-batch launches -- and a third pass with
+    SQ_ACTIVE_INST_VALU / SQ_ACTIVE_INST_ANY / GRBM_GUI_ACTIVE for the pipe utilisations.  Returns
+    ``{kernel: {bytes_per_blend, valu_busy, issue_busy}}`` or ``None`` when the profiler is missing, fails or takes longer than ``timeout``
     seconds per pass (the line then falls back to the committed summary and says so)."""
     import csv
     import glob
@@ -465,9 +466,11 @@ def live_hbm_counters(nb, timeout=90):
     tmp = tempfile.mkdtemp(prefix="smi_pmc_", dir="/tmp")
     try:
         sums = {}
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run",
+        passes = (("FETCH_SIZE",), ("WRITE_SIZE",),
+                  ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"))
+        for n_pass, group in enumerate(passes):
+            d = os.path.join(tmp, "pass%d" % n_pass)
+            cmd = [prof, "--kernel-trace", "--pmc", *group, "-d", d, "-o", "run",
                    "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "6", "--warmup", "2", "--no-cpu", "--sub-ranges", "1",
                    "--blends", str(nb), "--no-counters"]
@@ -475,24 +478,35 @@ def live_hbm_counters(nb, timeout=90):
             res = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout,
                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             if res.returncode != 0:
-                return None
+                if n_pass < 2:
+                    return None
+                break  # (the byte counters stand without the utilisation pass)
             per_kernel = {}
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as fh:
                     for row in csv.DictReader(fh):
-                        if row["Counter_Name"] != counter:
+                        if row["Counter_Name"] not in group:
                             continue
                         name = row["Kernel_Name"].replace("(anonymous namespace)::", "")
                         name = name.replace("void ", "").replace("smi::", "").split("<")[0].split("(")[0]
-                        per_kernel.setdefault(name, []).append(float(row["Counter_Value"]))
-            for name, vals in per_kernel.items():
+                        per_kernel.setdefault((name, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+            for (name, counter), vals in per_kernel.items():
                 if len(vals) < 6:
                     continue  # (not a kernel of the iteration)
                 vals = sorted(vals)[len(vals) // 2:]  # the full-batch launches
                 sums.setdefault(name, {})[counter] = sum(vals) / len(vals)
         for name, c in sums.items():
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                out[name] = int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / nb))
+                rec = {"bytes_per_blend": int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / nb))}
+                # SQ_ACTIVE_INST_* count quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE
+                # cycles summed over the 8 XCDs (tools/hbm_counters.py)
+                if c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c:
+                    cycles = c["GRBM_GUI_ACTIVE"] / 8
+                    rec["valu_busy"] = round(4 * c["SQ_ACTIVE_INST_VALU"] / (cycles * 1024), 4)
+                    if "SQ_ACTIVE_INST_ANY" in c:
+                        rec["issue_busy"] = round(4 * c["SQ_ACTIVE_INST_ANY"] / (cycles * 1024), 4)
+                    rec["kernel_cycles"] = round(cycles)
+                out[name] = rec
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
         return None
     finally:
@@ -685,8 +699,16 @@ def main():
                 and not args.steady and not args.no_counters):
             live = live_hbm_counters(nb)
         live_name = "update_kernel_reg" if k_name.startswith("update") else k_name
+        live_util = False
         if live and live_name in live:
-            cnt = dict(cnt, bytes_per_blend=live[live_name])
+            cnt = dict(cnt, **live[live_name])
+            live_util = "valu_busy" in live[live_name]
+            if live_util:
+                # the rule of tools/hbm_counters.py, on this run's own counters
+                k_ms_now = dominant_kernel(phases, conv_path, by)[2]
+                hbm_now = live[live_name]["bytes_per_blend"] * nb / (k_ms_now * 1e-3) / 1e9 / HBM_PEAK_GBS
+                cnt["bound"] = ("hbm" if hbm_now > 0.6 else
+                                "valu-issue" if cnt.get("issue_busy", 0) > 0.85 else "latency-l2-lds")
         traffic = cnt["bytes_per_blend"] * nb if "bytes_per_blend" in cnt else None
         # Speed of light of one iteration of this rank's shard: what cannot be avoided is the
         # compulsory traffic B0 (data and weights once, parameters and moments once each way)
@@ -698,7 +720,7 @@ def main():
         all_cnt = {k: counters(k) for k in ("fused_conv_kernel", "update_kernel_reg",
                                             "render_kernel") if counters(k)} if counted else {}
         if live:
-            all_cnt = {k: {"bytes_per_blend": v} for k, v in live.items()
+            all_cnt = {k: dict(v) for k, v in live.items()
                        if k in ("fused_conv_kernel", "update_kernel_reg", "render_kernel")}
         hbm_ms = by["null"] * nb / (HBM_PEAK_GBS * 1e9) * 1e3
         flop_ms = (fft_flops(C, Fy, Fx) * nb / (F32_VECTOR_PEAK_TFLOPS * 1e12) * 1e3
@@ -749,11 +771,14 @@ def main():
                            "(committed constants, not measured in this run)" if all_cnt else None),
             },
             "counter_fields": {
-                "fields": (["limiter", "valu_busy"] if live else
+                "fields": ([] if live_util else ["limiter", "valu_busy"] if live else
                            ["limiter", "traffic", "hbm_frac_measured", "valu_busy", "measured_hbm"]),
-                "source": "profiles/hbm_traffic.json (committed PMC summary); every other field is "
-                          "measured in this run" + (" -- traffic, hbm_frac_measured and measured_hbm "
-                                                    "by counter passes of this run" if live else ""),
+                "source": ("none: every field of this line is measured in this run (traffic, "
+                           "hbm_frac_measured, measured_hbm, valu_busy, issue_busy and the limiter by "
+                           "its own rocprofv3 --pmc passes)" if live_util else
+                           "profiles/hbm_traffic.json (committed PMC summary); every other field is "
+                           "measured in this run" + (" -- traffic, hbm_frac_measured and measured_hbm "
+                                                     "by counter passes of this run" if live else "")),
             },
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
@@ -775,6 +800,7 @@ def main():
             "hbm_frac_measured": (round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                                   if traffic else None),
             "valu_busy": cnt.get("valu_busy"),
+            "issue_busy": cnt.get("issue_busy"),
             "flops_frac": (round(fft_flops(C, Fy, Fx) * nb / (k_ms * 1e-3) / 1e12
                                  / F32_VECTOR_PEAK_TFLOPS, 5)
                            if k_name == "fused_conv_kernel" else None),

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the rocprofv3 summaries behind bench.py's roofline object on the GPU box and leave
 # them under gpurun_out/<tag>/ (copy the CSVs / JSON you want judged into profiles/).
-#   gpurun -- 'bash tools/collect_profiles.sh r04'
+#   gpurun -- 'bash tools/collect_profiles.sh r05'
 # Kernel trace and counters are separate runs (gpurun refuses --pmc with trace domains other
 # than --kernel-trace; counters in passes of their own as MI355X_MICROARCH.md prescribes).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -32,6 +32,11 @@ stats shard512 --steps 20 --warmup 5 --no-cpu --blends 512
 # the driver's command as the driver runs it (no profiler around it: the bench measures its own
 # HBM counters in passes of its own)
 python "$R/bench.py" --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_live_counters.json" 2> "$OUT/driver_live.err"
+# one GPU's shard without the profiler around it, and one scene through the Python API
+for nbl in 128 256 512; do
+    python "$R/bench.py" --steps 20 --warmup 5 --no-cpu --no-counters --blends $nbl > "$OUT/${TAG}_bench_shard${nbl}_noprof.json" 2> /dev/null
+done
+python "$R/tools/single_scene.py" 2> "$OUT/single_scene.err" | grep '^{' > "$OUT/${TAG}_bench_single_scene.json"
 # the path a scarlet script calls: Blend objects in, fit_blends, fitted objects out
 python "$R/bench.py" --facade --blends 1024 --steps 100 > "$OUT/${TAG}_bench_facade.json" 2> "$OUT/facade.err"
 
