@@ -217,6 +217,11 @@ typedef struct smi_components {
     const int32_t *chain_repeat;/* [n_components] ConstraintChain(repeat) (constraint.py:  */
                                 /* 60-80): the whole chain applied that many times per     */
                                 /* proximal evaluation; NULL = 1                           */
+    const float *shift_rel_step;/* [n_components] relative_step of a free shift             */
+                                /* (parameter.py:126-129): step = max(shift_step, rel *     */
+                                /* mean(shift)); NULL = 0.  (The centre of a point source   */
+                                /* takes its rule from morph_step / morph_rel_step: step =  */
+                                /* max(morph_step, rel * mean(centre in frame pixels)).)    */
 } smi_components;
 
 int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out);
@@ -273,6 +278,10 @@ int smi_batch_set_kernel_shift(smi_batch *b, const float *kernel, int32_t h0, in
  * [n_sets][kernel_bands][kernel_h][kernel_w] at the current shift; any may be NULL */
 int smi_batch_get_kernel_shift(smi_batch *b, double *shift, double *moments, double *gradient,
                                float *kernel);
+/* relative_step for the kernel shift (parameter.py:126-129): step = max(step of
+ * smi_batch_set_kernel_shift, factor * mean(shift)); factor = 0 (default): constant step.
+ * Call after smi_batch_set_kernel_shift. */
+int smi_batch_set_kernel_shift_relative_step(smi_batch *b, double factor);
 int smi_batch_set_components(smi_batch *b, const smi_components *comps);
 
 /* AMSGrad moments (blend.py:153-163), same packing as sed / morph; NULL = zeros */

@@ -37,6 +37,7 @@ class Component:
         source=None,
         shift=None,
         shift_step=1e-1,
+        shift_rel_step=0.0,
         sparsity=None,
         tiny=1e-6,
         fixed=(False, False),
@@ -52,7 +53,8 @@ class Component:
         # is a free 2-vector, step 1e-1, no constraint (morphology.py:673-676); the
         # model uses the Fourier-shifted image (morphology.py:124-130)
         self.shift = None if shift is None else np.array(shift, dtype=np.float64)
-        self.shift_step = shift_step
+        # (a `relative_step` rule, parameter.py:126-129: max(shift_step, shift_rel_step * mean))
+        self.shift_step, self.shift_rel_step = shift_step, shift_rel_step
         self.m_shift, self.v_shift, self.vhat_shift = np.zeros(2), np.zeros(2), np.zeros(2)
         self.sed = sed
         self.morph = morph
@@ -159,7 +161,7 @@ class PointComponent:
     symmetric = False
 
     def __init__(self, sed, center, sigma, boxsize=None, sed_min_step=0.0, center_step=3e-2,
-                 sed_zero=1e-20):
+                 sed_zero=1e-20, center_rel_step=0.0):
         self.sed = sed
         self.center = np.array(center, dtype=np.float64)
         self.sigma = float(sigma)
@@ -172,6 +174,7 @@ class PointComponent:
         self.origin = (int(pixel_center[0]) - boxsize // 2, int(pixel_center[1]) - boxsize // 2)
         self.sed_min_step = sed_min_step
         self.center_step = center_step  # source.py:115
+        self.center_rel_step = center_rel_step  # relative_step instead (parameter.py:126-129)
         self.sed_zero = sed_zero
         self.m_sed = np.zeros(sed.shape)
         self.v_sed = np.zeros(sed.shape)
@@ -270,7 +273,7 @@ def resize_component(c):
 
 class Scene:
     def __init__(self, frame_shape, data, weights, kernel, components, dtype=np.float32,
-                 psf_shift=None, extra_observations=()):
+                 psf_shift=None, extra_observations=(), psf_shift_step=1e-2, psf_shift_rel_step=0.0):
         # further observations of the same model (blend.py:265-271 sums their
         # log-likelihoods), e.g. oracle.resample.LowResObservation
         self.extra_observations = list(extra_observations)
@@ -278,6 +281,7 @@ class Scene:
         # sub-pixel shift of the difference kernel, step 1e-2, no constraint
         self.psf_shift = None if psf_shift is None else np.array(psf_shift, dtype=np.float64)
         self.m_psf, self.v_psf, self.vhat_psf = np.zeros(2), np.zeros(2), np.zeros(2)
+        self.psf_shift_step, self.psf_shift_rel_step = psf_shift_step, psf_shift_rel_step
         self.frame_shape = tuple(frame_shape)
         self.dtype = dtype
         self.data = data
@@ -443,12 +447,19 @@ class Scene:
         blend.py:165-180 (amsgrad, prox_max_iter=10)."""
         _, grads = self.loss_and_gradients()
         # all steps are evaluated on the pre-update parameters (blend.py:135-138)
-        alphas = [(c.sed_step(it), c.center_step if isinstance(c, PointComponent) else c.morph_step)
+        alphas = [(c.sed_step(it),
+                   relative_step(c.center, c.center_rel_step, c.center_step)
+                   if isinstance(c, PointComponent) else c.morph_step)
                   for c in self.components]
+        shift_alphas = [None if getattr(c, "shift", None) is None else
+                        relative_step(c.shift, c.shift_rel_step, c.shift_step) for c in self.components]
+        if self.psf_shift is not None:
+            psf_alpha = relative_step(self.psf_shift, self.psf_shift_rel_step, self.psf_shift_step)
         if self.psf_shift is not None:
             # the renderer's parameter comes after the sources' in X (blend.py:103-105)
             g_psf = self.g_psf_shift
-        for c, (g_sed, g_morph, *g_shift), (a_sed, a_morph) in zip(self.components, grads, alphas):
+        for c, (g_sed, g_morph, *g_shift), (a_sed, a_morph), a_shift in zip(
+                self.components, grads, alphas, shift_alphas):
             adaprox_update(
                 it, c.sed, g_sed, c.m_sed, c.v_sed, c.vhat_sed, a_sed, c.sed_prox,
                 e_rel, prox_max_iter, b1, b2, eps,
@@ -466,11 +477,11 @@ class Scene:
             )
             if g_shift:
                 adaprox_update(
-                    it, c.shift, g_shift[0], c.m_shift, c.v_shift, c.vhat_shift, c.shift_step,
+                    it, c.shift, g_shift[0], c.m_shift, c.v_shift, c.vhat_shift, a_shift,
                     None, e_rel, prox_max_iter, b1, b2, eps,
                 )
         if self.psf_shift is not None:
-            adaprox_update(it, self.psf_shift, g_psf, self.m_psf, self.v_psf, self.vhat_psf, 1e-2,
+            adaprox_update(it, self.psf_shift, g_psf, self.m_psf, self.v_psf, self.vhat_psf, psf_alpha,
                            None, e_rel, prox_max_iter, b1, b2, eps)
 
     def check_parameters(self):
@@ -522,6 +533,12 @@ class Scene:
                 break
             it = len(self.loss)
         return len(self.loss), -self.loss[-1]
+
+
+def relative_step(X, factor, minimum):
+    """``relative_step`` (parameter.py:126-129) with ``axis=None``: ``max(minimum, factor *
+    X.mean())``; ``factor = 0`` stands for a constant step ``minimum``."""
+    return max(minimum, factor * float(np.mean(X))) if factor else minimum
 
 
 def l2sq(x):

@@ -63,6 +63,7 @@ class Components(ctypes.Structure):
         ("center", c_f64p), ("psf_sigma", c_f32p), ("shift_step", c_f32p),
         ("center_floor", c_f32p), ("bg_level", c_f32p), ("fista_step", c_f32p),
         ("sym_strength", c_f32p), ("pos_floor", c_f32p), ("chain_repeat", c_i32p),
+        ("shift_rel_step", c_f32p),
     ]
 
 
@@ -185,6 +186,7 @@ SYMBOLS = {
     "smi_batch_set_kernel_shift": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_int32, ctypes.c_int32,
                                                   c_i32p, c_f64p, c_f64p, ctypes.c_double]),
     "smi_batch_get_kernel_shift": (ctypes.c_int, [ctypes.c_void_p, c_f64p, c_f64p, c_f64p, c_f32p]),
+    "smi_batch_set_kernel_shift_relative_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
     "smi_batch_save_state": (ctypes.c_int, [ctypes.c_void_p]),
     "smi_batch_restore_state": (ctypes.c_int, [ctypes.c_void_p]),
     "smi_batch_enable_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),

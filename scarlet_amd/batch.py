@@ -20,7 +20,7 @@ class ComponentSpec:
                  morph_step=1e-2, morph_rel_step=0.0, prox_flags=_lib.PROX_EXTENDED_SOURCE,
                  neighbor_weight="angle", min_gradient=0.0, l_thresh=0.0, shift=None,
                  shift_step=1e-1, center_floor=1e-6, bg_level=None, fista_step=0.0,
-                 sym_strength=1.0, chain_repeat=1, pos_floor=0.0):
+                 sym_strength=1.0, chain_repeat=1, pos_floor=0.0, shift_rel_step=0.0):
         self.sed = np.asarray(sed, dtype=np.float32)
         self.morph = np.ascontiguousarray(morph, dtype=np.float32)
         self.origin = (int(origin[0]), int(origin[1]))
@@ -37,6 +37,7 @@ class ComponentSpec:
         # ExtendedSource(shifting=True): free sub-pixel Fourier shift of the image
         # (morphology.py:124-130, 673-676); the device keeps it in the `center` slot
         self.shift_step = float(shift_step)
+        self.shift_rel_step = float(shift_rel_step)  # relative_step factor (parameter.py:126-129)
         # scarlet.lite: floor of the centre pixel, background threshold per band
         # (bg_rms * bg_thresh; sets PROX_BG_THRESH), FistaParameter.step
         self.center_floor = float(center_floor)
@@ -61,7 +62,7 @@ class PointSourceSpec(ComponentSpec):
     (morphology.py:494-497) and stays fixed."""
 
     def __init__(self, sed, center, psf_sigma, boxsize=None, sed_min_step=0.0,
-                 sed_rel_step=1e-2, center_step=3e-2, origin=None):
+                 sed_rel_step=1e-2, center_step=3e-2, origin=None, center_rel_step=0.0):
         self.center = np.array(center, dtype=np.float64).reshape(2)
         self.psf_sigma = float(psf_sigma)
         if boxsize is None:
@@ -74,7 +75,8 @@ class PointSourceSpec(ComponentSpec):
         # else: the box of a source whose centre has already moved stays where it was
         super().__init__(sed, np.zeros((boxsize, boxsize), dtype=np.float32), origin,
                          sed_min_step=sed_min_step, sed_rel_step=sed_rel_step,
-                         morph_step=center_step, prox_flags=_lib.COMPONENT_POINT_SOURCE)
+                         morph_step=center_step, morph_rel_step=center_rel_step,
+                         prox_flags=_lib.COMPONENT_POINT_SOURCE)
 
 
 class BlendBatch:
@@ -227,6 +229,7 @@ class BlendBatch:
             sym_strength=_lib.f32([c.sym_strength for c in part]),
             chain_repeat=np.ascontiguousarray([c.chain_repeat for c in part], dtype=np.int32),
             pos_floor=_lib.f32([c.pos_floor for c in part]),
+            shift_rel_step=_lib.f32([c.shift_rel_step for c in part]),
         )
         if rows is None:
             arrays = fields
@@ -396,6 +399,11 @@ class BlendBatch:
             _lib.ptr(_lib.i32(fft_shape), ctypes.c_int32), _lib.ptr(shift, ctypes.c_double),
             _lib.ptr(moments, ctypes.c_double), float(step)))
         self._kernel_sets = n_sets
+
+    def set_kernel_shift_relative_step(self, factor):
+        """``relative_step`` for the kernel shift (parameter.py:126-129): step =
+        max(``step`` of :meth:`set_kernel_shift`, ``factor`` * mean(shift))."""
+        _lib.check(self._lib.smi_batch_set_kernel_shift_relative_step(self._h, float(factor)))
 
     def kernel_shift(self, kernel=False):
         """State of the free kernel shift: dict of ``(n_sets, 2)`` float64 arrays ``shift``,

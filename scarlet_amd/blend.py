@@ -232,14 +232,15 @@ class Blend(CombinedComponent):
                 if shift.prior is not None or shift.constraint is not None:
                     raise NotImplementedError("priors / constraints on a shift parameter")
                 if not shift.fixed or np.any(np.asarray(shift) != 0):
-                    const, rel, _ = _step_rule(shift.step, "shift")
-                    if rel:
-                        raise NotImplementedError("relative steps for a shift parameter")
+                    # (relative_step, parameter.py:126-129: max(minimum, factor * mean))
+                    const, rel, low = _step_rule(shift.step, "shift")
+                    const = max(const, float(np.max(low)))
                     if max(image.shape) > 100:
                         raise NotImplementedError(
                             "a component with a free Fourier shift is limited to boxes of "
                             "100 pixels a side on the device (got {})".format(image.shape))
-                    shift_kw = dict(shift=np.asarray(shift), shift_step=0.0 if shift.fixed else const)
+                    shift_kw = dict(shift=np.asarray(shift), shift_step=0.0 if shift.fixed else const,
+                                    shift_rel_step=0.0 if shift.fixed else rel)
             if shift_kw and (sed.prior is not None or image.prior is not None):
                 raise NotImplementedError("priors on a component with a free Fourier shift")
 
@@ -333,15 +334,15 @@ class Blend(CombinedComponent):
         if not (isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20):
             raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
         s_const, s_rel, s_min = _step_rule(sed.step, "spectrum")
-        c_const, c_rel, _ = (0.0, 0.0, 0.0) if center.fixed and center.step is None else \
+        c_const, c_rel, c_low = (0.0, 0.0, 0.0) if center.fixed and center.step is None else \
             _step_rule(center.step, "center")
-        if c_rel:
-            raise NotImplementedError("relative steps for a point-source centre")
+        c_const = max(c_const, float(np.max(c_low)))  # (relative_step: max(minimum, factor * mean))
         spec = PointSourceSpec(
             np.asarray(sed), np.asarray(center), float(psf.get_parameter(0)[0]),
             boxsize=morphology.bbox.shape[-1],
             sed_min_step=np.maximum(np.asarray(s_min, dtype=np.float64), s_const),
-            sed_rel_step=s_rel, center_step=c_const, origin=morphology.bbox.origin[-2:])
+            sed_rel_step=s_rel, center_step=c_const, center_rel_step=c_rel,
+            origin=morphology.bbox.origin[-2:])
         # Parameter(fixed=True): zero gradient for that parameter (blend.py:107-115)
         spec.prox_flags |= (_lib.COMPONENT_FIXED_SED if sed.fixed else 0) | (
             _lib.COMPONENT_FIXED_MORPH if center.fixed else 0)
@@ -361,6 +362,8 @@ class Blend(CombinedComponent):
                     image[:kernel.shape[0]], np.asarray(shift), step=self._psf_step,
                     fft_shape=fft._get_fft_shape(image, image, padding=10, axes=(-2, -1)),
                     m=shift.m, v=shift.v, vhat=shift.vhat)
+                if self._psf_rel:
+                    batch.set_kernel_shift_relative_step(self._psf_rel)
             except _lib.ScarletAmdError as err:
                 batch.close()
                 if "fused" in str(err):
@@ -612,9 +615,9 @@ class Blend(CombinedComponent):
             raise NotImplementedError("psf_shift needs an observation on the model frame")
         if shift.prior is not None or shift.constraint is not None:
             raise NotImplementedError("priors / constraints on psf_shift")
-        self._psf_step, rel, _ = _step_rule(shift.step, "psf_shift")
-        if rel:
-            raise NotImplementedError("relative steps for psf_shift")
+        # (relative_step, parameter.py:126-129: max(minimum, factor * mean(shift)))
+        const, self._psf_rel, low = _step_rule(shift.step, "psf_shift")
+        self._psf_step = max(const, float(np.max(low)))
         return shift, renderer
 
     def _fit_with_psf_shift(self, max_iter, e_rel, min_iter, prox_max_iter, opt, callback):
@@ -628,7 +631,7 @@ class Blend(CombinedComponent):
         unconstrained AMSGrad step (step 1e-2) on the host."""
         shift, renderer = self._free_psf_shift()
         obs = self.observations[0]
-        alpha = self._psf_step
+        alpha0, rel = self._psf_step, self._psf_rel
         self._psf = None  # _specs / _download: no device-side shift in this mode
         C = self.frame.C
         data = np.ascontiguousarray(obs.data, dtype=np.float32)
@@ -672,6 +675,7 @@ class Blend(CombinedComponent):
                     shift.m = (1 - b1) * g + b1 * shift.m
                     shift.v = (1 - b2) * g * g + b2 * shift.v
                     shift.vhat = shift.v.copy() if local == 0 else np.maximum(shift.vhat, shift.v)
+                    alpha = max(alpha0, rel * float(np.mean(np.asarray(shift))))
                     upd = alpha * shift.m / np.sqrt(np.maximum(shift.vhat, eps))
                     shift[...] = np.asarray(shift) - (upd / 10 if local == 0 else upd)
                     batch.set_kernel(stamp(renderer.kernel_image()))

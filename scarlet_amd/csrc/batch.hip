@@ -217,7 +217,7 @@ struct smi_batch {
     // free Fourier shifts
     int n_shift = 0, max_box_side = 1, max_box_w = 1;
     bool inline_render = true;  // smi_batch_set_inline_render
-    float *morph_param = nullptr, *c_shift_step = nullptr;
+    float *morph_param = nullptr, *c_shift_step = nullptr, *c_shift_rel = nullptr;
     int32_t *c_shift_fft = nullptr;
     std::vector<char> is_shift;
     std::vector<int64_t> h_moff;
@@ -344,6 +344,7 @@ void refresh_view(smi_batch *b) {
     v.g_sed_buf = b->g_sed;
     v.g_morph_buf = b->g_morph;
     v.c_shift_step = b->c_shift_step;
+    v.c_shift_rel = b->c_shift_rel;
     v.c_shift_fft = b->c_shift_fft;
     v.c_center_floor = b->c_center_floor;
     v.c_sym_strength = b->c_sym_strength;
@@ -810,7 +811,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
                     b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
-                    b->c_shift_step, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_pos_floor, b->c_bg_level,
+                    b->c_shift_step, b->c_shift_rel, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_pos_floor, b->c_bg_level,
                     b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans, b->work_items};
     for (void *p : bufs)
@@ -1078,6 +1079,14 @@ static int kernel_shift_backward(smi_batch *b, const BatchView &v, int it, int g
     return launch_psf_shift_backward(v, b->ks, b->ks_resid, b->P, it, grad_only, b->stream);
 }
 
+int smi_batch_set_kernel_shift_relative_step(smi_batch *b, double factor) {
+    SMI_REQUIRE(b != nullptr, "null batch");
+    SMI_REQUIRE(b->ks.stamp != nullptr, "smi_batch_set_kernel_shift has not been called");
+    SMI_REQUIRE(factor >= 0, "negative factor");
+    b->ks.rel = factor;
+    return SMI_OK;
+}
+
 int smi_batch_set_kernel_shift(smi_batch *b, const float *kernel, int32_t h0, int32_t w0,
                                const int32_t *fft_shape, const double *shift,
                                const double *moments, double step) {
@@ -1110,6 +1119,7 @@ int smi_batch_set_kernel_shift(smi_batch *b, const float *kernel, int32_t h0, in
     ks.slab = 8;
     ks.n_part = (ks.bands == 1 ? b->d.C : 1) * ((b->d.H + ks.slab - 1) / ks.slab);
     ks.step = step;
+    ks.rel = 0.0;
     const size_t n_img = (size_t)ks.n_sets * ks.bands, n0 = (size_t)h0 * w0;
     int rc;
     float *stamp = nullptr;
@@ -1497,7 +1507,7 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
     b->is_shift.assign((size_t)n, 0);
     b->h_moff = moff;
     b->h_blend.assign(c->blend, c->blend + n);
-    std::vector<float> shift_step(n, 1e-1f);
+    std::vector<float> shift_step(n, 1e-1f), shift_rel(n, 0.f);
     std::vector<int32_t> shift_fft((size_t)n * 2, 0);
     for (int k = 0; k < n; ++k) {
         b->max_box_side = std::max(b->max_box_side, std::max(c->box_h[k], c->box_w[k]));
@@ -1508,6 +1518,7 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
         pt[8 * k] = c->center[2 * k];
         pt[8 * k + 1] = c->center[2 * k + 1];
         if (c->shift_step) shift_step[k] = c->shift_step[k];
+        if (c->shift_rel_step) shift_rel[k] = c->shift_rel_step[k];
         // fft.shift: _get_fft_shape(image, image, padding=10) (fft.py:116-167, 401-403)
         int fy = next_fast_len(2 * c->box_h[k] + 10), fx = next_fast_len(2 * c->box_w[k] + 10);
         while (fx % 2) fx = next_fast_len(fx + 1);
@@ -1517,6 +1528,7 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
         shift_fft[2 * k + 1] = fx;
     }
     if ((rc = upload(&b->c_shift_step, shift_step.data(), (size_t)n))) return rc;
+    if ((rc = upload(&b->c_shift_rel, shift_rel.data(), (size_t)n))) return rc;
     if ((rc = upload(&b->c_shift_fft, shift_fft.data(), (size_t)n * 2))) return rc;
     if (b->n_shift) {
         // the uploaded images are the parameters; `morph` becomes the shifted image

@@ -228,6 +228,7 @@ struct BatchView {
     float *morph_param;
     float *g_sed_buf, *g_morph_buf;
     const float *c_shift_step;
+    const float *c_shift_rel;  // relative_step factor of a free shift (0: constant step)
     const int32_t *c_shift_fft;  // (Fy, Fx) per component, fft.py:116-167 with padding 10
     // scarlet.lite: centre floor, background threshold levels [n_comp][C], FISTA
     const float *c_center_floor;
@@ -302,7 +303,7 @@ struct KernelShiftView {
     int32_t Fy, Fx;    // FFT lengths of fft.shift for an (h0, w0) image (fft.py:116-167, padding 10)
     int32_t n_part;    // partial sums per stamp pixel of the kernel gradient
     int32_t slab;      // frame rows per partial sum
-    double step;
+    double step, rel;  // step = max(step, rel * mean(shift)) (parameter.py:126-129)
     const float *stamp;  // [n_sets bands][h0][w0] unshifted
     float *shifted;      // [n_sets bands][ph][pw] kernel at the current shift
     double *partial;     // [n_sets bands][n_part][h0 w0]

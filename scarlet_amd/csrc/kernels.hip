@@ -1008,7 +1008,11 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
         if (fixed & SMI_COMPONENT_FIXED_MORPH) gy = gx = 0.0;
         bad = update_spectrum(v, c, (fixed & SMI_COMPONENT_FIXED_SED) ? 0.f : g_sed, it,
                               e_rel * e_rel, prox_max_iter, 1.f, sed_new);
-        const double b1 = v.b1, b2 = v.b2, eps = v.eps, alpha = v.c_morph_step[c.k];
+        // step of the centre (source.py:115, or relative_step, parameter.py:126-129, on the
+        // centre in frame pixels = mean of the box bounds + offset)
+        const double b1 = v.b1, b2 = v.b2, eps = v.eps;
+        const double ctr_mean = 0.5 * ((c.oy + 0.5 * c.h + off_y) + (c.ox + 0.5 * c.w + off_x));
+        const double alpha = fmax((double)v.c_morph_step[c.k], (double)v.c_morph_rel[c.k] * ctr_mean);
         double upd[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {

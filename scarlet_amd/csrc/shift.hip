@@ -295,7 +295,10 @@ __global__ __launch_bounds__(kT) void shift_backward_kernel(BatchView v, const f
     }
     if (grad_only) return;
     // 6. the shift has no constraint: bare AMSGrad step
-    const int bad = amsgrad_pair(pt, gsy, gsx, it, v.b1, v.b2, v.eps, v.c_shift_step[k]);
+    // relative_step (parameter.py:126-129): max(minimum, factor * mean(shift)), on the shift
+    // before the update
+    const double alpha = fmax((double)v.c_shift_step[k], (double)v.c_shift_rel[k] * 0.5 * (pt[0] + pt[1]));
+    const int bad = amsgrad_pair(pt, gsy, gsx, it, v.b1, v.b2, v.eps, alpha);
     if (bad) atomicExch(&v.state[b], 3);
 }
 
@@ -402,7 +405,8 @@ __global__ __launch_bounds__(kT) void psf_shift_backward_kernel(BatchView v, Ker
     st[8] = gsy;
     st[9] = gsx;
     if (grad_only) return;
-    if (amsgrad_pair(st, gsy, gsx, it, v.b1, v.b2, v.eps, ks.step)) atomicExch(&v.state[b], 3);
+    const double alpha = fmax(ks.step, ks.rel * 0.5 * (st[0] + st[1]));  // (relative_step)
+    if (amsgrad_pair(st, gsy, gsx, it, v.b1, v.b2, v.eps, alpha)) atomicExch(&v.state[b], 3);
 }
 
 // grid (bands, kernel sets): the stamps at the current shift

@@ -263,6 +263,55 @@ def test_point_source_tutorial_scene():
     assert logL > float(g["logL"])
 
 
+
+def test_relative_step_on_psf_shift_through_the_facade(hsc):
+    """``Parameter.step = partial(relative_step, factor=..., minimum=...)`` (parameter.py:126-129)
+    on ``psf_shift``: ``Blend.fit`` hands the rule to the device and follows the oracle with
+    the same rule (round 4 refused it)."""
+    from functools import partial
+
+    import scarlet_amd as scarlet
+    from scarlet_amd.parameter import relative_step
+    from scarlet_amd.renderer import ConvolutionRenderer
+    from conftest import golden
+
+    gp = golden("hsc_psf_shift")
+    shift0 = np.abs(gp["psf_shift"]) + 0.05
+    filters = list("grizy")
+    frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5),
+                          channels=filters)
+    obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                              weights=hsc["weights"], channels=filters)
+    obs.match(frame, renderer=ConvolutionRenderer(obs, frame, psf_shift=shift0.copy()))
+    shift = obs.parameters[0]
+    shift.step = partial(relative_step, factor=0.2, minimum=1e-3)
+    comps = []
+    for k in range(int(hsc["n_comp"])):
+        h, w = hsc["morph_%d" % k].shape
+        oy, ox = hsc["origin_%d" % k]
+        box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+        comps.append(scarlet.FactorizedComponent(
+            frame,
+            scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                      min_step=hsc["min_step_%d" % k]),
+            scarlet.ExtendedSourceMorphology(frame, (oy + h // 2, ox + w // 2),
+                                             hsc["morph_%d" % k].copy(), bbox=box[1:],
+                                             resizing=False)))
+    blend = scarlet.Blend(comps, obs)
+    n, _ = blend.fit(8, e_rel=1e-9)
+    sc = hsc_scene(hsc)
+    for c in sc.components:
+        c.source = None
+    sc.psf_shift = shift0.copy()
+    sc.psf_shift_step, sc.psf_shift_rel_step = 1e-3, 0.2
+    n_ref, _ = sc.fit(8, e_rel=1e-9)
+    assert n == n_ref == 8
+    assert_allclose(np.array(blend.loss) - sc.log_norm, np.array(sc.loss) - sc.log_norm, rtol=1e-4)
+    assert np.abs(np.asarray(shift) - sc.psf_shift).max() < 2e-5
+    # the rule is in force: a constant step of 1e-3 moves the shift far less
+    assert np.abs(np.asarray(shift) - shift0).max() > 5 * 8 * 1e-3
+
+
 def test_shifting_image_morphology(hsc):
     """A bare ``ImageMorphology(shifting=True)`` gets a FIXED zero shift in the
     reference (``fixed=self.shifting``, morphology.py:113): the Fourier shift never

@@ -1569,6 +1569,97 @@ def test_shifting_scene_steps(amd, hsc, path):
     assert max(np.abs(c.shift - g["shift_%d" % k]).max() for k, c in enumerate(sc.components)) > 1e-2
 
 
+def test_relative_steps_of_centres_shifts_and_the_kernel_shift(amd, hsc):
+    """``relative_step`` (parameter.py:126-129: ``max(minimum, factor * X.mean())``) as the step
+    rule of a point-source centre, of a free Fourier shift and of ``psf_shift``: eight
+    iterations against the oracle with the same rule; the rule is in force (the parameters
+    end up elsewhere than with the constant minimum)."""
+    from conftest import golden, hsc_scene, point_scene, shifting_scene
+    from oracle import fftconv
+
+    n_it = 8
+    # point-source centres: step = max(3e-3, 1e-3 * mean(centre in frame pixels)) ~ 3e-2
+    g = golden("point_source")
+    ends = []
+    for rel in (1e-3, 0.0):
+        specs = []
+        for k in range(int(g["n_src"])):
+            if g["is_star"][k]:
+                specs.append(amd.PointSourceSpec(g["sed_%d" % k], g["center_%d" % k], 0.9,
+                                                 sed_min_step=g["min_step_%d" % k],
+                                                 center_step=3e-3, center_rel_step=rel))
+            else:
+                specs.append(amd.ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
+                                               sed_min_step=g["min_step_%d" % k]))
+        w = np.full(g["images"].shape, 0.25, dtype=np.float32)
+        batch = amd.BlendBatch(g["images"][None], w[None], [specs], kernel=g["diff_kernel"],
+                               max_iter=n_it + 1)
+        sc = point_scene(g)
+        for c in sc.components:
+            if hasattr(c, "center_step"):
+                c.center_step, c.center_rel_step = 3e-3, rel
+        batch.step(0, n_it, e_rel=1e-4)
+        for it in range(n_it):
+            sc.step(it, 1e-4)
+        ctr = batch.centers()["center"]
+        for k, c in enumerate(sc.components):
+            if g["is_star"][k]:
+                assert np.abs(ctr[k] - c.center).max() < 1e-4, (rel, k)
+        assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm, rtol=1e-4)
+        ends.append(ctr[np.asarray(g["is_star"], bool)].copy())
+        batch.close()
+    assert np.abs(ends[0] - ends[1]).max() > 1e-3
+
+    # free Fourier shifts: step = max(1e-2, 0.5 * mean(shift))
+    g = golden("hsc_shifting")
+    ends = []
+    for rel in (0.5, 0.0):
+        specs = [amd.ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
+                                   sed_min_step=g["min_step_%d" % k], shift=g["shift_%d" % k],
+                                   shift_step=1e-2, shift_rel_step=rel)
+                 for k in range(int(g["n_comp"]))]
+        batch = amd.BlendBatch(hsc["images"][None], hsc["weights"][None], [specs],
+                               kernel=hsc["diff_kernel"], max_iter=n_it + 1)
+        sc = shifting_scene(g, hsc)
+        for c in sc.components:
+            c.shift_step, c.shift_rel_step = 1e-2, rel
+        batch.step(0, n_it, e_rel=1e-4)
+        for it in range(n_it):
+            sc.step(it, 1e-4)
+        st = batch.centers()["center"]
+        for k, c in enumerate(sc.components):
+            assert np.abs(st[k] - c.shift).max() < 2e-3, (rel, k)
+        assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm, rtol=2e-4)
+        ends.append(st.copy())
+        batch.close()
+    assert np.abs(ends[0] - ends[1]).max() > 1e-3
+
+    # psf_shift: step = max(1e-3, 0.2 * mean(shift))
+    gp = golden("hsc_psf_shift")
+    kernel = hsc["diff_kernel"]
+    fft_shape = list(fftconv.fft_shape(kernel.shape, kernel.shape, padding=10, axes=(-2, -1)))
+    shift0 = np.abs(gp["psf_shift"]) + 0.05
+    ends = []
+    for rel in (0.2, 0.0):
+        sc = hsc_scene(hsc)
+        for c in sc.components:
+            c.source = None
+        sc.psf_shift = shift0.copy()
+        sc.psf_shift_step, sc.psf_shift_rel_step = 1e-3, rel
+        batch = hsc_batch(amd, hsc, max_iter=n_it + 1)
+        batch.set_kernel_shift(kernel, shift0, fft_shape, step=1e-3)
+        batch.set_kernel_shift_relative_step(rel)
+        batch.step(0, n_it, e_rel=1e-3)
+        for it in range(n_it):
+            sc.step(it, 1e-3)
+        state = batch.kernel_shift()
+        assert np.abs(state["shift"][0] - sc.psf_shift).max() < 2e-5, rel
+        assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm, rtol=5e-5)
+        ends.append(state["shift"][0].copy())
+        batch.close()
+    assert np.abs(ends[0] - ends[1]).max() > 1e-3
+
+
 # ---------------------------------------------------------------- scarlet.lite
 def _lite_batch(amd, g, hsc, kind, **kw):
     from scarlet_amd import _lib
