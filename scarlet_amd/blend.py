@@ -58,6 +58,26 @@ def _flatten(sources):
     return out
 
 
+def _adaprox_options(alg_kwargs):
+    """``(prox_max_iter, {b1, b2, eps})`` of ``proxmin.adaprox``'s keyword arguments as
+    ``Blend.fit`` passes them on (blend.py:165-180); ``scheme``, ``p`` and ``callback`` are the
+    caller's to pop.  Anything else is an option of proxmin this loop does not have."""
+    prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
+    opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
+               eps=alg_kwargs.pop("eps", 1e-8))
+    if alg_kwargs:
+        raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
+    return prox_max_iter, opt
+
+
+def _plain_2vector(p, what):
+    """A free 2-vector on the device (shift, point-source centre, psf_shift) takes the bare
+    AMSGrad step of the reference's defaults (morphology.py:673-676, source.py:115,
+    renderer.py:175-177): no prior, no constraint."""
+    if p.prior is not None or p.constraint is not None:
+        raise NotImplementedError("priors / constraints on {}".format(what))
+
+
 def _step_rule(step, what):
     """(constant, relative factor, minimum) of a Parameter.step."""
     if isinstance(step, partial) and step.func is relative_step:
@@ -229,8 +249,7 @@ class Blend(CombinedComponent):
                 # the reference's default for a bare ImageMorphology, morphology.py:113 --
                 # is the identity; a fixed non-zero one is applied with step 0
                 shift = morphology.parameters[1]
-                if shift.prior is not None or shift.constraint is not None:
-                    raise NotImplementedError("priors / constraints on a shift parameter")
+                _plain_2vector(shift, "a shift parameter")
                 if not shift.fixed or np.any(np.asarray(shift) != 0):
                     # (relative_step, parameter.py:126-129: max(minimum, factor * mean))
                     const, rel, low = _step_rule(shift.step, "shift")
@@ -327,10 +346,9 @@ class Blend(CombinedComponent):
         if not (isinstance(psf, GaussianPSF) and psf.integrate and psf.is_same):
             raise NotImplementedError(
                 "point sources need a pixel-integrated GaussianPSF model PSF with one sigma")
-        if sed.prior is not None or center.prior is not None:
-            raise NotImplementedError("priors are not supported on the device")
-        if center.constraint is not None:
-            raise NotImplementedError("constraints on a point-source centre are not supported")
+        _plain_2vector(center, "a point-source centre")
+        if sed.prior is not None:
+            raise NotImplementedError("a prior on the spectrum of a point source")
         if not (isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20):
             raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
         s_const, s_rel, s_min = _step_rule(sed.step, "spectrum")
@@ -473,15 +491,11 @@ class Blend(CombinedComponent):
                              type(self.observations[0].renderer) is ResolutionRenderer):
             raise NotImplementedError("noise_factor > 0 needs one observation on the model frame")
         scheme = alg_kwargs.pop("scheme", "amsgrad")
-        prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
         callback = alg_kwargs.pop("callback", None)
         # the device loop is AMSGrad (the reference's default); any other scheme of
         # proxmin.adaprox steps every parameter on the host from the device's gradients
         self._scheme = (scheme, alg_kwargs.pop("p", 0.25))
-        opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
-                   eps=alg_kwargs.pop("eps", 1e-8))
-        if alg_kwargs:
-            raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
+        prox_max_iter, opt = _adaprox_options(alg_kwargs)
         if any(type(obs.renderer) not in (NullRenderer, ConvolutionRenderer, ResolutionRenderer)
                for obs in self.observations):
             # plug-in seam (SURVEY 8b seam 3): user-written Renderer subclasses are host code
@@ -613,8 +627,7 @@ class Blend(CombinedComponent):
             raise NotImplementedError("only ConvolutionRenderer(psf_shift=...) has free parameters")
         if tuple(obs.shape) != tuple(self.frame.shape) or list(obs.channels) != list(self.frame.channels):
             raise NotImplementedError("psf_shift needs an observation on the model frame")
-        if shift.prior is not None or shift.constraint is not None:
-            raise NotImplementedError("priors / constraints on psf_shift")
+        _plain_2vector(shift, "psf_shift")
         # (relative_step, parameter.py:126-129: max(minimum, factor * mean(shift)))
         const, self._psf_rel, low = _step_rule(shift.step, "psf_shift")
         self._psf_step = max(const, float(np.max(low)))
@@ -1288,12 +1301,8 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, **alg_k
                 out.append((len(b.loss), float("nan")))
         return out, errors
     alg_kwargs.pop("scheme", None)
-    prox_max_iter = alg_kwargs.pop("prox_max_iter", 10)
-    opt = dict(b1=alg_kwargs.pop("b1", 0.9), b2=alg_kwargs.pop("b2", 0.999),
-               eps=alg_kwargs.pop("eps", 1e-8))
     alg_kwargs.pop("callback", None)
-    if alg_kwargs:
-        raise NotImplementedError("unsupported adaprox options: {}".format(sorted(alg_kwargs)))
+    prox_max_iter, opt = _adaprox_options(alg_kwargs)
 
     class _Run:
         def __init__(self, blend, obs):
