@@ -1020,15 +1020,15 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, devices=None, **alg
         # cyclic collector would walk them again and again while the loop below allocates
         # its temporaries (measured: a quarter of the call).  Reference counting still frees
         # everything the loop drops.
+        # gc.freeze() takes what exists now out of the collector's generations for the duration
+        # of the call; the collector itself stays on (other threads, callbacks).
         import gc
 
-        was_on = gc.isenabled()
-        gc.disable()
+        gc.freeze()
         try:
             out, fit_blends.errors = _fit_blends_on(blends, device, **kw)
         finally:
-            if was_on:
-                gc.enable()
+            gc.unfreeze()
         return out
     from concurrent.futures import ThreadPoolExecutor
     from .dist import shard_range

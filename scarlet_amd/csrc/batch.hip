@@ -2027,6 +2027,7 @@ static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter,
     for (int i = 0; i < n_iter; ++i) {
         const int it = it0 + i;
         for (int s = 0; s < n_sub; ++s) {
+            views[s].fail_code = 3 + it;  // (state word of a blend that fails in this iteration)
             const BatchView &v = views[s];
             hipStream_t st = s == 0 ? b->stream : b->sub_streams[s - 1];
             // phase times are those of range 0 (its kernels overlap the other ranges')
@@ -2099,6 +2100,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
     }
     for (int i = 0; i < n_iter; ++i) {
         const int it = it0 + i;
+        b->view.fail_code = 3 + it;  // (state word of a blend that fails in this iteration)
         hipEvent_t *ev = timing ? &b->events[(size_t)i * 6] : nullptr;
         if (ev) SMI_HIP(hipEventRecord(ev[0], b->stream));
         if (b->fused) {

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kT) void shift_backward_kernel(BatchView v, const f
     // before the update
     const double alpha = fmax((double)v.c_shift_step[k], (double)v.c_shift_rel[k] * 0.5 * (pt[0] + pt[1]));
     const int bad = amsgrad_pair(pt, gsy, gsx, it, v.b1, v.b2, v.eps, alpha);
-    if (bad) atomicExch(&v.state[b], 3);
+    if (bad) atomicExch(&v.state[b], v.fail_code);
 }
 
 __global__ __launch_bounds__(kT) void shift_forward_kernel(BatchView v, int respect_state) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kT) void shift_forward_kernel(BatchView v, int resp
                  AxisOut{L.tx, L.hx, nullptr, nullptr}, L.ct, L.st, L.cb, L.sb);
     const float beta = (float)by.x;
     const int bad = __syncthreads_or(shift_apply(L, h, w, beta, v.morph + moff, w));
-    if (bad) atomicExch(&v.state[b], 3);
+    if (bad) atomicExch(&v.state[b], v.fail_code);
 }
 
 
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kT) void psf_shift_backward_kernel(BatchView v, Ker
     st[9] = gsx;
     if (grad_only) return;
     const double alpha = fmax(ks.step, ks.rel * 0.5 * (st[0] + st[1]));  // (relative_step)
-    if (amsgrad_pair(st, gsy, gsx, it, v.b1, v.b2, v.eps, alpha)) atomicExch(&v.state[b], 3);
+    if (amsgrad_pair(st, gsy, gsx, it, v.b1, v.b2, v.eps, alpha)) atomicExch(&v.state[b], v.fail_code);
 }
 
 // grid (bands, kernel sets): the stamps at the current shift
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kT) void psf_shift_forward_kernel(BatchView v, Kern
                  L.cb, L.sb);
     float *out = ks.shifted + ((int64_t)img * ks.ph + ks.oy) * ks.pw + ks.ox;
     const int bad = __syncthreads_or(shift_apply(L, h, w, (float)by.x, out, ks.pw));
-    if (bad && tid == 0) atomicExch(&v.state[b], 3);
+    if (bad && tid == 0) atomicExch(&v.state[b], v.fail_code);
 }
 
 size_t stamp_lds_bytes(const KernelShiftView &ks) {

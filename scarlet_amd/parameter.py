@@ -54,14 +54,22 @@ class Parameter(np.ndarray):
         if obj is None:
             return
         for attr, default in _ATTRS:
-            setattr(self, attr, getattr(obj, attr, default))
+            if attr == "std":
+                # the stored value as it is (the `STD_FROM_V` marker included): a view, a
+                # slice or a comparison of a fitted Parameter must not make the estimate
+                self.__dict__["_std"] = getattr(obj, "__dict__", {}).get("_std", default)
+            else:
+                setattr(self, attr, getattr(obj, attr, default))
 
     def __reduce__(self):
         base = super().__reduce__()
         return base[0], base[1], base[2] + (self.__dict__,)
 
     def __setstate__(self, state):
-        self.__dict__.update(state[-1])
+        attrs = dict(state[-1])
+        if "std" in attrs:  # pickles from before `std` became a property
+            attrs["_std"] = attrs.pop("std")
+        self.__dict__.update(attrs)
         super().__setstate__(state[:-1])
 
     @property

@@ -701,3 +701,28 @@ def test_set_spectra_to_match_reproduces_the_reference_on_the_host():
     for k, c in enumerate(comps):
         sed, ref = np.asarray(c.children[0].parameters[0]), hsc["sed_%d" % k]
         assert np.abs(sed - ref).max() < 2e-6 * np.abs(ref).max(), k
+
+
+def test_lazy_std_survives_views_and_old_pickles():
+    """``Parameter.std`` after a fit is a marker that turns into the estimate on first access
+    (round-4 advice): views, slices and comparisons of the Parameter carry the marker on
+    without making the masked array, and a pickle from before ``std`` was a property loads."""
+    import pickle
+
+    from scarlet_amd.parameter import Parameter, STD_FROM_V
+
+    p = Parameter(np.arange(6, dtype=np.float64).reshape(2, 3), name="image", step=1e-2)
+    p.v = np.full((2, 3), 4.0)
+    p.std = STD_FROM_V
+    q = p[0]
+    _ = p > 0
+    assert p.__dict__["_std"] is STD_FROM_V and q.__dict__["_std"] is STD_FROM_V
+    assert np.allclose(p.std, 0.5) and not isinstance(p.__dict__["_std"], str)
+    # legacy pickle: the attribute dictionary holds 'std'
+    base = p.__reduce__()
+    legacy = dict(base[2][-1])
+    legacy["std"] = legacy.pop("_std")
+    r = Parameter(np.zeros((2, 3)), name="x")
+    r.__setstate__(base[2][:-1] + (legacy,))
+    assert np.allclose(r.std, 0.5)
+    assert np.allclose(pickle.loads(pickle.dumps(p)).std, 0.5)
