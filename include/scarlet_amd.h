@@ -236,12 +236,13 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w,
 
 /* The ring schedule the update kernels derive from such tables when they are the radial ones
  * of operator.py:591-667 (host only, no GPU; csrc/common.h describes the schedule).  Returns
- * 1 and fills info = {planes, n_steps, n_pad, rmax, centre, perm, lanes, stream_bytes} when the
- * tables qualify, 0 when they do not (the kernels then keep the level plan), < 0 on bad
+ * 1 and fills info = {planes | n_nat << 8, n_steps, n_pad, rmax, centre, perm, lanes,
+ * stream_bytes} (n_nat: steps of the plain schedule; from there on the address words carry
+ * flags: 0x8000 late ring, 1 axis pixel, 2 diagonal pixel) when the tables qualify, 0 when they do not (the kernels then keep the level plan), < 0 on bad
  * arguments.  stream_bytes = size of the device stream with the weights stored once per ring,
  * 0 when the octants differ (off-centre peak, even or oblong box): only tables with such a
  * stream run the ring schedule on the device.  With capacity >= lanes also wts[lanes][4]
- * (weights by role A, B, C, D) and addr[lanes] (16 + 4 * pixel, 0 = idle);
+ * (weights by role A, B, C, D) and addr[lanes] (16 + 4 * pixel | flags, 0 = idle);
  * lanes = (n_pad + 6) * planes * 64, step major. */
 int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t *offsets,
                         const int32_t *dist_idx, int32_t n_idx, int32_t info[8], float *wts,

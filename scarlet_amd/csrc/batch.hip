@@ -370,8 +370,15 @@ void refresh_view(smi_batch *b) {
         // per sweep against 28.4 k, 51^2: 28.5 k against 20.3 k (tools/sweep_cycles.py): a lane
         // issues two pixels per step while at most eleven of its sixteen rings are under way
         // -- so those boxes keep the level plan.
+        // SMI_RING_LATE=0 (development aid): plans with late rings (boxes of 49^2 .. 63^2) keep
+        // the level plan
+        static const bool may_late = [] {
+            const char *e = getenv("SMI_RING_LATE");
+            return !e || atoi(e) != 0;
+        }();
         const bool ok = p >= 0 && p < (int)b->plans.size() && b->plans[p].ring &&
-                        kUpdateTeam[cls] == 64 && b->plans[p].ring_planes == 1;
+                        kUpdateTeam[cls] == 64 && b->plans[p].ring_planes == 1 &&
+                        (may_late || b->plans[p].ring_nat == b->plans[p].ring_pad);
         v.stage_plan[cls] = ok ? p : -1;
         v.stage_bytes[cls] = ok ? b->plans[p].ring_bytes : 0;
     }
@@ -908,6 +915,7 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
         dp.ring = d_ring;
         dp.ring_planes = rp.planes;
         dp.ring_pad = rp.n_pad;
+        dp.ring_nat = rp.n_nat;
         dp.ring_rmax = rp.rmax;
         dp.ring_centre = rp.centre;
         dp.ring_perm = rp.perm;
@@ -927,8 +935,9 @@ int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32
     RingPlanHost rp;
     if (!build_ring_plan(h, w, weights, offsets, 8, dist_idx, n_idx, &rp)) return 0;
     std::vector<uint8_t> stream;
-    const int32_t vals[8] = {rp.planes, rp.n_steps, rp.n_pad, rp.rmax, rp.centre, (int32_t)rp.perm,
-                             (int32_t)rp.addr.size(),
+    // (n_nat rides in the upper half of the first word: the caller's array has eight entries)
+    const int32_t vals[8] = {rp.planes | (rp.n_nat << 8), rp.n_steps, rp.n_pad, rp.rmax, rp.centre,
+                             (int32_t)rp.perm, (int32_t)rp.addr.size(),
                              ring_device_stream(rp, &stream) ? (int32_t)stream.size() : 0};
     memcpy(info, vals, sizeof(vals));
     if (wts && addr && capacity >= (int64_t)rp.addr.size()) {

@@ -150,9 +150,22 @@ inline int update_image_stride(int n_pix) {
 constexpr int kRingUnroll = 6;   // steps per loop iteration (period of the axis / diagonal phases)
 constexpr int kRingAhead = 6;    // steps the address stream is requested ahead
 constexpr int kRingMaxPlanes = 2;
+constexpr uint16_t kRingLate = 0x8000, kRingAxis = 1, kRingDiag = 2;  // flags of an address word
+constexpr uint16_t kRingAddrMask = 0x7FFC;
+// Rings beyond 23 on ONE plane (round 5).  Ring r + 8 needs the lane of ring r, which walks its
+// r + 1 pixels during the levels 2 r - 1 .. 3 r - 1: from ring 24 on the next ring of a lane is
+// due before the lane is free.  Such a ring simply starts late: level S(r) = max(2 r - 1,
+// S(r - 1) + 2, S(r - 8) + r - 7), pixel (r, j) at level S(r) + j.  Its operands A, B, C are
+// then lam(r) = S(r) - S(r - 1) - 2 levels older than usual (lam <= 1 up to ring 31: boxes up to
+// 63^2, 96 instead of 89 steps for 61^2), which the lane program covers with one more entry of
+// DPP history.  The stream says which entries are late, which are the axis pixel (j = 0) and
+// the diagonal pixel (j = r) of their ring -- the level no longer does -- in bits 15, 0 and 1 of
+// the address word, from step `n_nat` on (a multiple of the unrolling, at least four steps
+// before the first late ring starts); the steps before it run the plain schedule.
 struct RingPlanHost {
-    int32_t planes = 0;   // 1: rings up to 23, 2: up to 47
-    int32_t n_steps = 0;  // 3 rmax - 1
+    int32_t planes = 0;   // 1: rings up to 31 (late starts from ring 24 on), 2: up to 47
+    int32_t n_steps = 0;  // 3 rmax - 1, or S(rmax) + rmax with late rings
+    int32_t n_nat = 0;    // steps of the plain schedule (== n_pad without late rings)
     int32_t n_pad = 0;
     int32_t rmax = 0;
     int32_t centre = 0;   // flat index of the peak
@@ -172,7 +185,7 @@ struct SweepPlanDev {
     int32_t n_slots = 0;
     // ring schedule (nullptr: the tables are not radial, or rings beyond 8 * kRingMaxPlanes - 1)
     const void *ring = nullptr;
-    int32_t ring_planes = 0, ring_pad = 0, ring_rmax = 0, ring_centre = 0;
+    int32_t ring_planes = 0, ring_pad = 0, ring_rmax = 0, ring_centre = 0, ring_nat = 0;
     uint32_t ring_perm = 0, ring_bytes = 0;
     SweepSlotEntry *slots = nullptr;  // nullptr when the plan does not fit the fast path
     int32_t *level_start = nullptr;

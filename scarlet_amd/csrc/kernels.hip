@@ -1251,11 +1251,20 @@ struct RingLds {
 // The 16 bytes in front of `us` are the spare cell (idle lanes); n_pad, rmax, perm, centre:
 // the plan's ring_* fields, wave-uniform.  P planes: the lane works on ring m + 8 p (mod 8 P)
 // of its octant in every step, P independent chains.
-template <int P>
+//
+// LATE (one plane, rings 24 .. 31 of boxes up to 63^2; common.h: RingPlanHost): from step n_nat
+// on a ring may start later than level 2 r - 1 -- when the lane of ring r - 8 is free --, its
+// operands A, B, C are then one level older (one more entry of the rotation history: c4, and
+// the mirror lane's last but one result g2), and the address words of the stream say which
+// entries are late and which are the axis / diagonal pixel of their ring.
+template <int P, bool LATE = false>
 __device__ __forceinline__ void sweep_ring_loop(float *us, const RingLds<P> &plan, int n_pad,
-                                                int rmax, uint32_t perm, int centre_pix,
-                                                float one_minus_g, int lane) {
+                                                int n_nat, int rmax, uint32_t perm,
+                                                int centre_pix, float one_minus_g, int lane) {
+    static_assert(!LATE || P == 1, "late rings: one plane");
     constexpr int DW = RingLds<P>::kWeightsAhead, DA = RingLds<P>::kAddrAhead;
+    // (address words of a stream with late rings carry flags, also while they are prefetched)
+    constexpr uint32_t kMask = LATE ? (uint32_t)kRingAddrMask : 0xFFFFFFFFu;
     static_assert(kRingUnroll == 6 && DA < 6 && DW < DA && (P == 1 || P == 2),
                   "register rotation of the loop");
     char *base = reinterpret_cast<char *>(us) - 16;
@@ -1288,7 +1297,7 @@ __device__ __forceinline__ void sweep_ring_loop(float *us, const RingLds<P> &pla
         for (int i = 0; i < DW; ++i) w[i][p] = plan.weights(i, p);
     }
 #pragma unroll
-    for (int p = 0; p < P; ++p) cur[p] = *lds(a[0][p]);
+    for (int p = 0; p < P; ++p) cur[p] = *lds(a[0][p] & kMask);
 
     // one level; I = step within the unrolled iteration (levels L = s + I + 1: axis pixels at
     // odd L, diagonal pixels at L = 3 r - 1)
@@ -1299,7 +1308,7 @@ __device__ __forceinline__ void sweep_ring_loop(float *us, const RingLds<P> &pla
         for (int p = 0; p < P; ++p) {
             w[(I + DW) % 6][p] = plan.weights(s + I + DW, p);
             a[(I + DA) % 6][p] = plan.addr(s + I + DA, p);
-            cur_next[p] = *lds(a[(I + 1) % 6][p]);
+            cur_next[p] = *lds(a[(I + 1) % 6][p] & kMask);
             f1[p] = dpp_ror1(out[p]);
             f9[p] = dpp_ror9(out[p]);
         }
@@ -1336,11 +1345,11 @@ __device__ __forceinline__ void sweep_ring_loop(float *us, const RingLds<P> &pla
             ref = __fadd_rn(ref, pd3 ? pD : e2);
             const float lim = __fmul_rn(ref, one_minus_g);
             out[p] = lim < cur[p] ? lim : cur[p];
-            *lds(a[I][p]) = out[p];
+            *lds(a[I][p] & kMask) = out[p];
             cur[p] = cur_next[p];
         }
     };
-    for (int s = 0; s < n_pad; s += kRingUnroll) {
+    for (int s = 0; s < (LATE ? n_nat : n_pad); s += kRingUnroll) {
         step(std::integral_constant<int, 0>(), s);
         step(std::integral_constant<int, 1>(), s);
         step(std::integral_constant<int, 2>(), s);
@@ -1348,22 +1357,72 @@ __device__ __forceinline__ void sweep_ring_loop(float *us, const RingLds<P> &pla
         step(std::integral_constant<int, 4>(), s);
         step(std::integral_constant<int, 5>(), s);
     }
+    if constexpr (LATE) {
+        // the flagged part of the stream (c4, g2 need no start values: the first late entry
+        // comes at least four steps in)
+        float c4 = c3[0], g2 = out[0];
+        auto late_step = [&](auto Ic, int s) {
+            constexpr int I = decltype(Ic)::value;
+            w[(I + DW) % 6][0] = plan.weights(s + I + DW, 0);
+            a[(I + DA) % 6][0] = plan.addr(s + I + DA, 0);
+            const float cur_next = *lds(a[(I + 1) % 6][0] & kMask);
+            const float f1 = dpp_ror1(out[0]), f9 = dpp_ror9(out[0]);
+            const float y = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(diag_addr, __builtin_bit_cast(int, out[0])));
+            const float f_mir = inner ? f9 : f1;
+            c4 = c3[0];
+            c3[0] = c2[0];
+            c2[0] = c1[0];
+            c1[0] = inner ? f1 : f9;
+            const uint32_t word = a[I][0];
+            const bool late = word & kRingLate, axis = word & kRingAxis, dg = word & kRingDiag;
+            const float A = axis ? (late ? g2 : f_mir) : (late ? c4 : c3[0]);
+            const float B = dg ? y : (late ? c3[0] : c2[0]);
+            const float C = late ? c2[0] : c1[0];
+            g2 = f_mir;
+            const f32x4 &wn = w[I][0];
+            const float pA = __fmul_rn(A, wn.x), pB = __fmul_rn(B, wn.y);
+            const float pC = __fmul_rn(C, wn.z), pD = __fmul_rn(out[0], wn.w);
+            const float e0 = asc ? pA : pC, e2 = asc ? pC : pA;
+            float ref = __fadd_rn(0.f, e0);
+            ref = __fadd_rn(ref, pd01 ? pD : pB);
+            ref = __fadd_rn(ref, pd01 ? pB : (pd2 ? pD : e2));
+            ref = __fadd_rn(ref, pd3 ? pD : e2);
+            const float lim = __fmul_rn(ref, one_minus_g);
+            out[0] = lim < cur[0] ? lim : cur[0];
+            *lds(word & kMask) = out[0];
+            cur[0] = cur_next;
+        };
+        for (int s = n_nat; s < n_pad; s += kRingUnroll) {
+            late_step(std::integral_constant<int, 0>(), s);
+            late_step(std::integral_constant<int, 1>(), s);
+            late_step(std::integral_constant<int, 2>(), s);
+            late_step(std::integral_constant<int, 3>(), s);
+            late_step(std::integral_constant<int, 4>(), s);
+            late_step(std::integral_constant<int, 5>(), s);
+        }
+    }
 }
 
 // `pl` wave-uniform, its stream at `plan_lds`; kMaxPlanes: what the caller can meet (the update
 // kernels stage one-plane plans only, refresh_view in batch.hip says why)
-template <int kMaxPlanes>
+// kLate: plans with late rings (rings 24 .. 31 on the one plane) can occur
+template <int kMaxPlanes, bool kLate = false>
 __device__ __forceinline__ void sweep_ring(float *us, const SweepPlanDev &pl, const char *plan_lds,
                                            float one_minus_g, int lane) {
     const int n_pad = __builtin_amdgcn_readfirstlane(pl.ring_pad);
+    const int n_nat = __builtin_amdgcn_readfirstlane(pl.ring_nat);
     const int rmax = __builtin_amdgcn_readfirstlane(pl.ring_rmax);
     const uint32_t perm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.ring_perm);
     const int centre = __builtin_amdgcn_readfirstlane(pl.ring_centre);
     if (kMaxPlanes == 2 && __builtin_amdgcn_readfirstlane(pl.ring_planes) == 2)
-        sweep_ring_loop<2>(us, RingLds<2>(plan_lds, n_pad, lane), n_pad, rmax, perm, centre,
+        sweep_ring_loop<2>(us, RingLds<2>(plan_lds, n_pad, lane), n_pad, n_pad, rmax, perm, centre,
                            one_minus_g, lane);
+    else if (kLate && n_nat < n_pad)
+        sweep_ring_loop<1, true>(us, RingLds<1>(plan_lds, n_pad, lane), n_pad, n_nat, rmax, perm,
+                                 centre, one_minus_g, lane);
     else
-        sweep_ring_loop<1>(us, RingLds<1>(plan_lds, n_pad, lane), n_pad, rmax, perm, centre,
+        sweep_ring_loop<1>(us, RingLds<1>(plan_lds, n_pad, lane), n_pad, n_pad, rmax, perm, centre,
                            one_minus_g, lane);
 }
 
@@ -1721,7 +1780,9 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
             // one wavefront sweeps (the steps are sequential and at most 64 pixels wide)
             if (T == 64 || threadIdx.x < 64) {
                 if (S.ring && S.ring == S.staged)
-                    sweep_ring<1>(S.us, *S.ring, S.plan_lds, S.one_minus_g, S.c.lane);
+                    // (boxes beyond 47^2 -- the classes beyond 27 pixels per lane -- have rings
+                    // that start late)
+                    sweep_ring<1, (NPL > 27)>(S.us, *S.ring, S.plan_lds, S.one_minus_g, S.c.lane);
                 else
                     sweep_slots(S.us, S.slots, S.n_slots, S.one_minus_g, S.c.lane);
             }
@@ -1891,7 +1952,7 @@ __global__ void sweep_timing_kernel(const SweepPlanDev *plans, int plan_id, int 
         wave_lds_fence();
         const long long t0 = __builtin_readcyclecounter();
         if (mode == 2)
-            sweep_ring<2>(us, pl, plan_lds, one_minus_g, lane);
+            sweep_ring<2, true>(us, pl, plan_lds, one_minus_g, lane);
         else
             sweep_slots(us, pl.slots, pl.n_slots, one_minus_g, lane);
         wave_lds_fence();

@@ -142,17 +142,35 @@ bool build_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t 
     const int cy = centre / w, cx = centre % w;
     const int rmax = std::max(std::max(cy, h - 1 - cy), std::max(cx, w - 1 - cx));
     if (rmax < 1 || rmax > 8 * kRingMaxPlanes * 3 - 1) return false;
-    // at most 8 P rings of an octant are active at a level: ceil((L+1)/3) .. (L+1)/2 <= rmax
-    const int planes = rmax <= 23 ? 1 : 2;
-    if (rmax > (planes == 1 ? 23 : 47)) return false;
+    // at most 8 P rings of an octant are active at a level of the plain schedule: ceil((L+1)/3)
+    // .. (L+1)/2 <= rmax.  One plane carries rings up to 31 with late starts (common.h), two
+    // planes rings up to 47 on the plain schedule.
+    const int planes = rmax <= 31 ? 1 : 2;
+    if (rmax > (planes == 1 ? 31 : 47)) return false;
     const int span = 8 * planes;
+    std::vector<int> start(rmax + 1, 0), lam(rmax + 1, 0);
+    int first_late = 0;
+    for (int r = 1; r <= rmax; ++r) {
+        start[r] = 2 * r - 1;
+        if (planes == 1 && r > 8) start[r] = std::max(start[r], start[r - 8] + r - 7);
+        if (r > 1) {
+            start[r] = std::max(start[r], start[r - 1] + 2);
+            lam[r] = start[r] - start[r - 1] - 2;
+        }
+        if (lam[r] > 1) return false;  // (cannot happen up to ring 31)
+        if (lam[r] && !first_late) first_late = r;
+    }
+    if (first_late && 16 + 4 * (int64_t)n_pix > kRingAddrMask) return false;
 
     RingPlanHost &rp = *out;
     rp.planes = planes;
     rp.rmax = rmax;
     rp.centre = centre;
-    rp.n_steps = 3 * rmax - 1;
+    rp.n_steps = start[rmax] + rmax;
     rp.n_pad = (rp.n_steps + kRingUnroll - 1) / kRingUnroll * kRingUnroll;
+    // the flagged part of the stream starts at least four steps before the first late ring
+    // (its lanes need four steps of history), on a multiple of the unrolling
+    rp.n_nat = first_late ? (start[first_late] - 5) / kRingUnroll * kRingUnroll : rp.n_pad;
     const size_t lanes = (size_t)(rp.n_pad + kRingAhead) * planes * 64;
     rp.wts.assign(lanes * 4, 0.f);
     rp.addr.assign(lanes, 0);
@@ -177,7 +195,7 @@ bool build_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t 
             const int Y = y - cy, X = x - cx;
             if (!Y && !X) continue;
             const int r = std::max(std::abs(Y), std::abs(X)), j = std::min(std::abs(Y), std::abs(X));
-            const int L = 2 * r + j - 1;  // 1-based level; step index L - 1
+            const int L = start[r] + j;  // 1-based level; step index L - 1
             const int32_t pix = y * w + x;
             bool placed = false;
             for (int o = 0; o < 8; ++o) {
@@ -189,6 +207,8 @@ bool build_ring_plan(int32_t h, int32_t w, const double *weights, const int32_t 
                 const size_t e = ((size_t)(L - 1) * planes + q / 8) * 64 + (o / 2) * 16 + (o & 1) * 8 + q % 8;
                 if (rp.addr[e]) return false;  // (cannot happen for rmax within the planes)
                 rp.addr[e] = (uint16_t)(16 + 4 * pix);
+                if (L - 1 >= rp.n_nat)
+                    rp.addr[e] |= (lam[r] ? kRingLate : 0) | (j == 0 ? kRingAxis : 0) | (j == r ? kRingDiag : 0);
                 int hits = 0;
                 for (int k = 0; k < 4; ++k) {
                     const double wgt = weights[(int64_t)role_idx[o][k] * n_pix + pix];

@@ -22,12 +22,13 @@ def ring_plan(shape, weights, offsets, didx):
     if rc == 0:
         return None
     planes, n_steps, n_pad, rmax, centre, perm, lanes = (int(v) for v in info[:7])
+    planes, n_nat = planes & 0xFF, planes >> 8
     wts = np.zeros((lanes, 4), dtype=np.float32)
     addr = np.zeros(lanes, dtype=np.uint16)
     _lib.check(lib.smi_sweep_ring_plan(*args, _lib.ptr(wts, ctypes.c_float),
                                        _lib.ptr(addr, ctypes.c_uint16), lanes))
     steps = lanes // (planes * 64)
-    return dict(planes=planes, n_steps=n_steps, n_pad=n_pad, rmax=rmax, centre=centre,
+    return dict(planes=planes, n_steps=n_steps, n_pad=n_pad, n_nat=n_nat, rmax=rmax, centre=centre,
                 perm=perm & 0xFFFFFFFF, stream_bytes=int(info[7]), wts=wts.reshape(steps, planes, 64, 4),
                 addr=addr.reshape(steps, planes, 64).astype(np.int64))
 
@@ -50,7 +51,8 @@ def run(plan, image, min_gradient):
     omg = f32(1) - f32(min_gradient)
     centre = lds[4 + plan["centre"]]
     out = np.full((P, 64), centre, dtype=f32)
-    c1, c2, c3 = out.copy(), out.copy(), out.copy()
+    c1, c2, c3, c4 = out.copy(), out.copy(), out.copy(), out.copy()
+    g2 = out.copy()  # the mirror lane's result of the step before the last
     for s in range(plan["n_pad"]):
         L = s + 1
         prev = out.copy()
@@ -58,18 +60,28 @@ def run(plan, image, min_gradient):
             below = prev[(p + P - 1) % P]  # plane that holds ring r - 1 of this plane's m = 0
             f_own = np.where(inner, prev[p][ror1], below[ror9])
             f_mir = np.where(inner, prev[p][ror9], below[ror1])
-            c3[p], c2[p], c1[p] = c2[p], c1[p], f_own
-            A, B = c3[p].copy(), c2[p].copy()
-            if L & 1:
-                ra = (L + 1) // 2
-                if ra <= plan["rmax"] and (ra % span) // 8 == p:
-                    A = np.where(m == (ra & 7), f_mir, A)
-            if (L + 1) % 3 == 0:
-                rd = (L + 1) // 3
-                if (rd % span) // 8 == p:
-                    B = np.where(m == (rd & 7), prev[p][diag], B)
+            c4[p], c3[p], c2[p], c1[p] = c3[p], c2[p], c1[p], f_own
+            if s < plan["n_nat"]:
+                # plain schedule: the level says where the axis and the diagonal pixels are
+                A, B, C = c3[p].copy(), c2[p].copy(), c1[p]
+                if L & 1:
+                    ra = (L + 1) // 2
+                    if ra <= plan["rmax"] and (ra % span) // 8 == p:
+                        A = np.where(m == (ra & 7), f_mir, A)
+                if (L + 1) % 3 == 0:
+                    rd = (L + 1) // 3
+                    if (rd % span) // 8 == p:
+                        B = np.where(m == (rd & 7), prev[p][diag], B)
+            else:
+                # flagged part (one plane): late rings take operands one level older
+                word = plan["addr"][s, p]
+                late, axis, dg = (word & 0x8000) != 0, (word & 1) != 0, (word & 2) != 0
+                A = np.where(axis, np.where(late, g2[p], f_mir), np.where(late, c4[p], c3[p]))
+                B = np.where(dg, prev[p][diag], np.where(late, c3[p], c2[p]))
+                C = np.where(late, c2[p], c1[p])
+            g2[p] = f_mir
             w = plan["wts"][s, p]
-            pA, pB, pC, pD = A * w[:, 0], B * w[:, 1], c1[p] * w[:, 2], prev[p] * w[:, 3]
+            pA, pB, pC, pD = A * w[:, 0], B * w[:, 1], C * w[:, 2], prev[p] * w[:, 3]
             e0, e2 = np.where(asc, pA, pC), np.where(asc, pC, pA)
             q0 = np.where(pd == 0, pD, e0)
             q1 = np.where(pd == 0, e0, np.where(pd == 1, pD, pB))
@@ -80,7 +92,10 @@ def run(plan, image, min_gradient):
             ref = ref + q2
             ref = ref + q3
             lim = (ref * omg).astype(f32)
-            a = plan["addr"][s, p] // 4
+            a = plan["addr"][s, p]
+            if s >= plan["n_nat"]:
+                a = a & 0x7FFC  # (flags of the address word)
+            a = a // 4
             cur = lds[a]
             new = np.where(lim < cur, lim, cur).astype(f32)
             lds[a] = new
