@@ -100,19 +100,21 @@ __device__ __forceinline__ int sk(int y) { return y + (y >> 4); }
 // w_F^(-n2 k1) (both directions carry their twiddles in this pass, which has the most
 // work items, so the radix-16 pass stays short), then inverse DFT_F1; only the blocks
 // k1 < LIVE are stored.
+// `tw`: the lane's twiddles w_F^(n2 k1), k1 = 0 .. F1 - 1, in registers (the column stage reads
+// them from the table once for all its passes)
 template <int F1, bool INV, int LIVE>
-__device__ __forceinline__ void pass_stride_col(float2 *a, int n2, const float2 *tw) {
+__device__ __forceinline__ void pass_stride_col(float2 *a, int n2, const cf (&tw)[F1]) {
     cf v[F1];
 #pragma unroll
     for (int n1 = 0; n1 < F1; ++n1) {
         v[n1] = (INV || n1 < LIVE) ? ld(a[(kF2 + 1) * n1 + n2]) : cf{0.f, 0.f};
-        if (INV && n1 > 0) v[n1] = cmulc(v[n1], ld(tw[kF2 * n1 + n2]));
+        if (INV && n1 > 0) v[n1] = cmulc(v[n1], tw[n1]);
     }
     fftk::Dft<F1, INV>::run(v);
 #pragma unroll
     for (int k1 = 0; k1 < F1; ++k1) {
         if (INV && k1 >= LIVE) continue;
-        if (!INV && k1 > 0) v[k1] = cmul(v[k1], ld(tw[kF2 * k1 + n2]));
+        if (!INV && k1 > 0) v[k1] = cmul(v[k1], tw[k1]);
         a[(kF2 + 1) * k1 + n2] = st(v[k1]);
     }
 }
@@ -219,13 +221,16 @@ struct Conv {
         const int g = tid & (kF2 - 1), G = tid >> 4;
         const int col = 8 * (G >> 3) + ((G >> 1) & 3) + 4 * (G & 1);
         constexpr int kStep = kThreads / kF2;
+        cf tw[FY1];
+#pragma unroll
+        for (int k1 = 0; k1 < FY1; ++k1) tw[k1] = ld(twy[kF2 * k1 + g]);
         for (int kt = col; kt < C::NT; kt += kStep) {
             // (columns 0 .. 15 and 16 .. 31 change places: column 0, which costs its wavefront
             // a few hundred instructions more, goes to a wavefront that has no column of the
             // second trip on top)
             const int kx = kt < 32 ? kt ^ 16 : kt;
             float2 *a = T + kx * C::SY;
-            pass_stride_col<FY1, false, C::NY1>(a, g, twy);
+            pass_stride_col<FY1, false, C::NY1>(a, g, tw);
             wave_lds_fence();
             if (g < FY1) {
                 float2 *blk = a + (kF2 + 1) * g;
@@ -278,7 +283,7 @@ struct Conv {
                 for (int j = 0; j < kF2; ++j) blk[j] = st(v[j]);
             }
             wave_lds_fence();
-            pass_stride_col<FY1, true, C::NY1>(a, g, twy);
+            pass_stride_col<FY1, true, C::NY1>(a, g, tw);
             zero_tail(a, g);
         }
         lds_barrier();
@@ -308,27 +313,43 @@ struct Conv {
     __device__ __forceinline__ int stride_items() const { return n_pairs * kF2; }
     // forward butterfly of v (v[n1] = element 16 n1 + n2 of the pair; the padding blocks
     // n1 >= NX1 are set to zero here) into the pair's slots
-    __device__ __forceinline__ void stride_forward(cf *v, const StrideItem &s) {
+    // the item's twiddles w_FX^(n2 k1) from the table (keeping them in registers between the
+    // inverse and the forward butterfly of stage C was measured: no change)
+    __device__ __forceinline__ void stride_twiddles(cf (&tw)[FX1], const StrideItem &s) const {
+#pragma unroll
+        for (int k1 = 1; k1 < FX1; ++k1) tw[k1] = ld(twx[kF2 * k1 + s.n2]);
+    }
+    __device__ __forceinline__ void stride_forward(cf *v, const StrideItem &s, const cf (&tw)[FX1]) {
         float2 *a = T + s.zb;
 #pragma unroll
         for (int n1 = NX1; n1 < FX1; ++n1) v[n1] = cf{0.f, 0.f};
         fftk::Dft<FX1, false>::run(v);
 #pragma unroll
         for (int k1 = 0; k1 < FX1; ++k1) {
-            if (k1 > 0) v[k1] = cmul(v[k1], ld(twx[kF2 * k1 + s.n2]));
+            if (k1 > 0) v[k1] = cmul(v[k1], tw[k1]);
             a[8 * C::SY * k1] = st(v[k1]);
         }
     }
+    __device__ __forceinline__ void stride_forward(cf *v, const StrideItem &s) {
+        cf tw[FX1];
+        stride_twiddles(tw, s);
+        stride_forward(v, s, tw);
+    }
     // inverse butterfly: v[k1] = element 16 k1 + n2 of the pair's rows (the caller uses
     // k1 < NX1 only; the rest is dead code)
-    __device__ __forceinline__ void stride_inverse(cf *v, const StrideItem &s) {
+    __device__ __forceinline__ void stride_inverse(cf *v, const StrideItem &s, const cf (&tw)[FX1]) {
         const float2 *a = T + s.zb;
 #pragma unroll
         for (int n1 = 0; n1 < FX1; ++n1) {
             v[n1] = ld(a[8 * C::SY * n1]);
-            if (n1 > 0) v[n1] = cmulc(v[n1], ld(twx[kF2 * n1 + s.n2]));
+            if (n1 > 0) v[n1] = cmulc(v[n1], tw[n1]);
         }
         fftk::Dft<FX1, true>::run(v);
+    }
+    __device__ __forceinline__ void stride_inverse(cf *v, const StrideItem &s) {
+        cf tw[FX1];
+        stride_twiddles(tw, s);
+        stride_inverse(v, s, tw);
     }
 
     // ---- radix-16 passes of the row transforms, fused with the Hermitian separation ------
