@@ -197,6 +197,7 @@ struct smi_batch {
     rocfft_execution_info info = nullptr;
     // observation
     float *data = nullptr, *weights = nullptr;
+    float4 *dw = nullptr;  // data, weights by row pairs: BatchView::dw
     bool own_obs = false;
     double *log_norm = nullptr;
     // components
@@ -257,6 +258,7 @@ struct smi_batch {
     struct ObsLayer {
         float *data = nullptr, *weights = nullptr;
         float2 *Kt = nullptr;
+        float4 *dw = nullptr;
     };
     std::vector<ObsLayer> layers;
     float *Q2 = nullptr;
@@ -318,6 +320,7 @@ void refresh_view(smi_batch *b) {
     v.vh_morph = b->mom[5];
     v.data = b->data;
     v.weights = b->weights;
+    v.dw = b->dw;
     v.log_norm = b->log_norm;
     v.state = b->state;
     v.n_loss = b->n_loss;
@@ -812,7 +815,7 @@ int smi_batch_destroy(smi_batch *b) {
         if (pl.ring) (void)hipFree(const_cast<void *>(pl.ring));
     }
     void *bufs[] = {b->P, b->null_renderer ? nullptr : (void *)b->Q, b->S, b->Khat, b->Kt, b->work,
-                    b->own_obs ? b->data : nullptr, b->own_obs ? b->weights : nullptr,
+                    b->own_obs ? b->data : nullptr, b->own_obs ? b->weights : nullptr, b->dw,
                     b->log_norm, b->comp_start, b->c_blend, b->c_oy, b->c_ox, b->c_h, b->c_w,
                     b->c_flags, b->c_plan, b->c_moff, b->c_sed_min_step, b->c_sed_rel,
                     b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
@@ -828,7 +831,7 @@ int smi_batch_destroy(smi_batch *b) {
     for (auto st : b->sub_streams) (void)hipStreamDestroy(st);
     for (auto *l : b->lowres) lowres_destroy(l);
     for (auto &l : b->layers)
-        for (void *p : {(void *)l.data, (void *)l.weights, (void *)l.Kt})
+        for (void *p : {(void *)l.data, (void *)l.weights, (void *)l.Kt, (void *)l.dw})
             if (p) (void)hipFree(p);
     for (void *p : b->saved)
         if (p) (void)hipFree(p);
@@ -947,6 +950,25 @@ int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32
     return 1;
 }
 
+// the fused convolution kernel's copy of an observation (common.h: BatchView::dw).  The arrays
+// may have been written by another stream (adopted device buffers): the device is idle first.
+static int interleave_observation(smi_batch *b, const float *d_data, const float *d_weights,
+                                  float4 **dw) {
+    if (!b->fused) return SMI_OK;
+    const int H = b->d.H, W = b->d.W;
+    const int64_t planes = (int64_t)b->d.n_blends * b->d.C;
+    // (sixteen elements of slack, zero: the kernel's loads of the columns W .. W + 15 of the last
+    // pair, which it multiplies by a weight of 0 -- they have to be finite)
+    const size_t n = (size_t)planes * ((H + 1) / 2) * W;
+    if (!*dw) {
+        SMI_HIP(dev_alloc(dw, n + 16));
+        SMI_HIP(hipMemset(*dw + n, 0, 16 * sizeof(float4)));
+    }
+    SMI_HIP(hipDeviceSynchronize());
+    launch_interleave_obs(d_data, d_weights, *dw, planes, H, W, b->stream);
+    return SMI_OK;
+}
+
 int smi_batch_set_observation(smi_batch *b, const float *data, const float *weights) {
     SMI_REQUIRE(b && data && weights, "null argument");
     // (log_norm is recomputed from this observation alone: the terms of observations added
@@ -961,6 +983,7 @@ int smi_batch_set_observation(smi_batch *b, const float *data, const float *weig
     if ((rc = upload(&b->weights, weights, n))) return rc;
     g_observation_uploads.fetch_add(1);
     b->own_obs = true;
+    if ((rc = interleave_observation(b, b->data, b->weights, &b->dw))) return rc;
     launch_log_norm(b->weights, b->log_norm, b->d.n_blends, (int64_t)b->d.C * b->d.H * b->d.W,
                     b->stream);
     if (!b->include_log_norm)
@@ -1049,6 +1072,7 @@ int smi_batch_set_observation_device(smi_batch *b, const float *d_data, const fl
     }
     b->data = const_cast<float *>(d_data);
     b->weights = const_cast<float *>(d_weights);
+    if (int rc = interleave_observation(b, b->data, b->weights, &b->dw)) return rc;
     launch_log_norm(b->weights, b->log_norm, b->d.n_blends, (int64_t)b->d.C * b->d.H * b->d.W,
                     b->stream);
     if (!b->include_log_norm)
@@ -1258,6 +1282,7 @@ static int layers_evaluate(smi_batch *b, const BatchView &v, int backward, hipSt
         BatchView vl = v;
         vl.data = b->layers[l].data;
         vl.weights = b->layers[l].weights;
+        vl.dw = b->layers[l].dw;
         vl.loss_partial = v.loss_partial + (l + 1) * C;
         const int rc = launch_fused_conv(vl, b->Fy, b->Fx, b->P, b->layers[l].Kt, b->d.kernel_bands,
                                          b->d.kernel_per_blend, b->Q2, backward ? 0 : 1, nullptr, s);
@@ -1287,13 +1312,14 @@ int smi_batch_add_observation(smi_batch *b, const float *data, const float *weig
         smi_batch::ObsLayer *l;
         ~Guard() {
             if (!l) return;
-            for (void *p : {(void *)l->data, (void *)l->weights, (void *)l->Kt})
+            for (void *p : {(void *)l->data, (void *)l->weights, (void *)l->Kt, (void *)l->dw})
                 if (p) (void)hipFree(p);
         }
     } guard{&layer};
     int rc;
     if ((rc = upload(&layer.data, data, n))) return rc;
     if ((rc = upload(&layer.weights, weights, n))) return rc;
+    if ((rc = interleave_observation(b, layer.data, layer.weights, &layer.dw))) return rc;
     g_observation_uploads.fetch_add(1);
     // kernel spectrum: the routine of smi_batch_set_kernel, into a buffer of its own
     float2 *first = b->Kt;

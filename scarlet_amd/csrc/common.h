@@ -212,6 +212,12 @@ struct BatchView {
     float *m_sed, *v_sed, *vh_sed, *m_morph, *v_morph, *vh_morph;
     // observation
     const float *data, *weights;
+    // data and weights of a pair of rows side by side, [nb][C][(H + 1) / 2][W] x {data[2j][x],
+    // data[2j+1][x], weights[2j][x], weights[2j+1][x]} (zeros for row H of an odd frame): what the
+    // fused convolution kernel reads -- one 16-byte load per pixel pair instead of four 4-byte
+    // ones, and the operands of its packed arithmetic arrive as pairs (a copy made when the
+    // observation is registered; nullptr on the rocFFT path)
+    const float4 *dw;
     const double *log_norm;  // nb
     // per blend state
     int32_t *state;       // 0 active, 1 last iteration, 2 done, 3 non-finite
@@ -364,6 +370,8 @@ void launch_scatter_states(const BatchView &v, const int64_t *off, const float *
                            hipStream_t s);
 void launch_carry_states(const int32_t *keep, const int64_t *old_moff, const int64_t *new_moff,
                          int32_t n, float *const from[4], float *const to[4], hipStream_t s);
+void launch_interleave_obs(const float *data, const float *weights, float4 *dw, int64_t planes,
+                           int32_t H, int32_t W, hipStream_t s);
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
                      hipStream_t s);
 void launch_wrap_kernel(const float *kern, float *out, int32_t n_img, int32_t ph,

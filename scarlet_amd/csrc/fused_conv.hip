@@ -187,6 +187,15 @@ __device__ __forceinline__ PairRows pair_rows(int y, int n2, int W) {
     asm volatile("" : "+v"(a.o0), "+v"(a.o1));
     return a;
 }
+// data and weights of the row pair j at the columns 16 N1 + n2, from the plane of float4 elements
+// of BatchView::dw: d = (data[2j], data[2j+1]), w = (weights[2j], weights[2j+1])
+// (a global load: this compiler lowers the 8- and 16-byte raw buffer load builtins to one dword)
+template <int N1>
+__device__ __forceinline__ void dw_load(const char *plane, uint32_t o, cf &d, cf &w) {
+    const float4 t = *reinterpret_cast<const float4 *>(plane + (size_t)o + 16u * kF2 * N1);
+    d = cf{t.x, t.y};
+    w = cf{t.z, t.w};
+}
 template <int N1>
 __device__ __forceinline__ cf pair_load(plane_t r, PairRows a) {
     return cf{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, a.o0 + 4u * kF2 * N1, 0, 0)),
@@ -771,8 +780,9 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
     double loss = 0.0;
     {
         cf loss2 = cf{0.f, 0.f};
-        const plane_t r_data = band_plane(v.data + band, H * W);
-        const plane_t r_weights = band_plane(v.weights + band, H * W);
+        // data and weights by row pairs: one 16-byte load per pixel pair (BatchView::dw)
+        const int64_t pband = ((int64_t)b * v.C + c) * cv.n_pairs * W;
+        const char *p_dw = reinterpret_cast<const char *>(v.dw + pband);
         const plane_t r_rendered = band_plane(out + band, H * W);
         // data / weights of the first SMI_CONV_PRE columns of the butterfly are requested
         // before the inverse radix-16 pass (their HBM latency hides behind it, the registers
@@ -783,24 +793,31 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         constexpr int kPre = SMI_CONV_PRE < NX1 ? SMI_CONV_PRE : NX1;
         cf dv[NX1], wv[NX1];
         auto fetch = [&](const Item &s, auto from, auto to) {
-            const PairRows a = pair_rows(2 * s.j, s.n2, W);
+            // (a thread without an item of its own reads the last pair; columns beyond W read
+            // what follows the row -- the allocation has sixteen elements of slack -- and are
+            // discarded below.  One offset register, the column step an immediate.)
+            uint32_t o = (uint32_t)(min(s.j, cv.n_pairs - 1) * W + s.n2) * 16u;
+            asm volatile("" : "+v"(o));
             fftk::static_for<decltype(from)::value, decltype(to)::value>([&](auto n1c) {
                 constexpr int n1 = decltype(n1c)::value;
-                dv[n1] = pair_load<n1>(r_data, a);
-                wv[n1] = pair_load<n1>(r_weights, a);
+                dw_load<n1>(p_dw, o, dv[n1], wv[n1]);
             });
         };
         using std::integral_constant;
         const Item s0 = cv.stride_item(tid);
         fetch(s0, integral_constant<int, 0>{}, integral_constant<int, kPre>{});
-        cv.blocks_inverse([&] { fetch(s0, integral_constant<int, kPre>{}, integral_constant<int, NX1>{}); });
+        // (a butterfly of ten columns has no registers for all of them next to its twiddles:
+        // the last kLate columns are requested behind the butterfly)
+        constexpr int kLate = NX1 > 8 ? NX1 - 8 : 0;
+        cv.blocks_inverse([&] { fetch(s0, integral_constant<int, kPre>{}, integral_constant<int, NX1 - kLate>{}); });
         SMI_STAMP(10);
         for (int it = tid; it < n_items; it += kThreads) {
             const Item s = cv.stride_item(it);
             const int y = 2 * s.j;
-            if (it != tid) fetch(s, integral_constant<int, 0>{}, integral_constant<int, NX1>{});
+            if (it != tid) fetch(s, integral_constant<int, 0>{}, integral_constant<int, NX1 - kLate>{});
             cf m[FX1];
             cv.stride_inverse(m, s);
+            fetch(s, integral_constant<int, NX1 - kLate>{}, integral_constant<int, NX1>{});
 #pragma unroll
             for (int n1 = 0; n1 < NX1; ++n1) {
                 const int x = kF2 * n1 + s.n2;
@@ -808,8 +825,8 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
                     plane_store(r_rendered, y, x, W, m[n1].x);
                     plane_store(r_rendered, y + 1, x, W, m[n1].y);
                 }
-                // rows beyond H carry weight 0 (the descriptor's range check), columns beyond
-                // W whatever follows the row: a lane select.  Packed: d = m - data, r = w d,
+                // row H of an odd frame carries weight 0 (BatchView::dw), columns beyond W
+                // whatever follows the row: a lane select.  Packed: d = m - data, r = w d,
                 // loss += r d (per thread in float32 -- 2 FX1 terms --, across threads in double)
                 const cf w = x < W ? wv[n1] : cf{0.f, 0.f};
                 const cf d = m[n1] - dv[n1];

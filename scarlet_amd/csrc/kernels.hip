@@ -2067,6 +2067,21 @@ __global__ __launch_bounds__(256) void carry_states_kernel(const int32_t *keep, 
         for (int i = threadIdx.x; i < N; i += 256) to.p[a][dst + i] = from.p[a][src + i];
 }
 
+// data and weights by row pairs for the fused convolution kernel (BatchView::dw); grid.y = plane
+__global__ __launch_bounds__(256) void interleave_obs_kernel(const float *data, const float *weights,
+                                                            float4 *dw, int H, int W) {
+    const int np = (H + 1) / 2;
+    const int64_t plane = blockIdx.y;
+    const float *d = data + plane * H * W, *w = weights + plane * H * W;
+    float4 *o = dw + plane * np * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < np * W; i += gridDim.x * 256) {
+        const int j = i / W, x = i - j * W;
+        const bool two = 2 * j + 1 < H;
+        o[i] = make_float4(d[2 * j * W + x], two ? d[(2 * j + 1) * W + x] : 0.f, w[2 * j * W + x],
+                           two ? w[(2 * j + 1) * W + x] : 0.f);
+    }
+}
+
 // log_norm of Observation (observation.py:172-186): D/2 ln(2 pi) + sum ln(1/sqrt(w))
 __global__ __launch_bounds__(256) void log_norm_kernel(const float *weights, double *out,
                                                        int64_t n) {
@@ -2525,6 +2540,17 @@ void launch_carry_states(const int32_t *keep, const int64_t *old_moff, const int
     }
     if (n)
         hipLaunchKernelGGL(carry_states_kernel, dim3(n), dim3(256), 0, s, keep, old_moff, new_moff, a, b);
+}
+
+void launch_interleave_obs(const float *data, const float *weights, float4 *dw, int64_t planes,
+                           int32_t H, int32_t W, hipStream_t s) {
+    const int blocks = std::max(1, std::min(((H + 1) / 2 * W + 255) / 256, 64));
+    for (int64_t p0 = 0; p0 < planes; p0 += 65535) {  // (grid.y limit)
+        const int np = (int)std::min<int64_t>(planes - p0, 65535);
+        hipLaunchKernelGGL(interleave_obs_kernel, dim3(blocks, np), dim3(256), 0, s,
+                           data + p0 * H * W, weights + p0 * H * W,
+                           dw + p0 * ((H + 1) / 2) * W, H, W);
+    }
 }
 
 void launch_log_norm(const float *weights, double *log_norm, int32_t nb, int64_t n,
