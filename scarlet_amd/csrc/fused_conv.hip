@@ -189,7 +189,7 @@ __device__ __forceinline__ PairRows pair_rows(int y, int n2, int W) {
 }
 // data and weights of the row pair j at the columns 16 N1 + n2, from the plane of float4 elements
 // of BatchView::dw: d = (data[2j], data[2j+1]), w = (weights[2j], weights[2j+1])
-// (a global load: this compiler lowers the 8- and 16-byte raw buffer load builtins to one dword)
+// (a global load with a scalar base: offset register + immediate, like the buffer loads)
 template <int N1>
 __device__ __forceinline__ void dw_load(const char *plane, uint32_t o, cf &d, cf &w) {
     const float4 t = *reinterpret_cast<const float4 *>(plane + (size_t)o + 16u * kF2 * N1);
