@@ -457,8 +457,21 @@ int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w);
  *   theirs from `states`, records in the order of k.  The observation, the kernel, the loss
  *   histories and the per-blend states stay.  Factorized image components under AMSGrad
  *   only.  On an error the batch is left without components.
+ *   keep[k] = 2 / 3: the component keeps its device-resident state and its SQUARE box is resized
+ *   about its centre on the device, the way ImageMorphology.update does it on the host
+ *   (morphology.py:132-207): the new side is box_h[k] = box_w[k] (sides differ by an even
+ *   number, at most 1024 pixels), a smaller box takes the centred slice of image and moments, a
+ *   larger one pads the moments with zeros and the image with np.pad(mode="linear_ramp") in
+ *   float64 rounded to float32 -- keep 2 when the host image is float32 (the rows added along
+ *   axis 0 are rounded before the ramps along axis 1), keep 3 when it is float64.  origin and
+ *   morph_step of such a row are the caller's (origin -/+ the inset, step / 2).
  * smi_batch_set_states / smi_batch_get_progress: per-blend state (0 iterating, 2 finished or
  *   paused -- its workgroups return at once --, 3 failed) and number of recorded losses.
+ * smi_batch_set_iteration_base: per blend, the iteration counter at which its current adaprox
+ *   call began (NULL: 0 for all).  smi_batch_step(it0, n) then runs the blends of a batch at
+ *   different counters in one launch: a blend takes the rules of the first step (alpha / 10,
+ *   vhat = v: the restart after a box resize, blend.py:276-302) and min_iter from
+ *   it - base[b].  Factorized image components under AMSGrad only.
  * --------------------------------------------------------------------------------- */
 int smi_batch_resize_test(smi_batch *b, int32_t *margin, double *edge_pull);
 int smi_batch_get_component_states(smi_batch *b, const int32_t *components, int32_t n,
@@ -466,6 +479,7 @@ int smi_batch_get_component_states(smi_batch *b, const int32_t *components, int3
 int smi_batch_update_components(smi_batch *b, const smi_components *c, const int32_t *keep,
                                 const float *states);
 int smi_batch_set_states(smi_batch *b, const int32_t *state);
+int smi_batch_set_iteration_base(smi_batch *b, const int32_t *base);
 int smi_batch_get_progress(smi_batch *b, int32_t *state, int32_t *n_loss);
 
 /* Number of host-to-device uploads of observation cubes (smi_batch_set_observation and

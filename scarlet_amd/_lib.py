@@ -199,6 +199,7 @@ SYMBOLS = {
     "smi_batch_get_component_states": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.c_int32, c_f32p]),
     "smi_batch_update_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Components), c_i32p, c_f32p]),
     "smi_batch_set_states": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
+    "smi_batch_set_iteration_base": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "smi_batch_get_progress": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
 }
 

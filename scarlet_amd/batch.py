@@ -290,16 +290,23 @@ class BlendBatch:
                             v_morph=px[2].reshape(shape), vhat_morph=px[3].reshape(shape)))
         return out
 
-    def update_components(self, components, keep, states):
+    def update_components(self, components, keep, states, resized=None):
         """New component table on the live batch (after a box resize).  ``components``: the
-        ComponentSpecs of all blends like at construction; ``keep`` (bool per component): the
-        device-resident parameters and moments stay (box unchanged); ``states``: for the
-        others, in order, dicts like ``component_states`` returns (missing moments = zeros)
-        with the arrays of the new box."""
+        ComponentSpecs of all blends like at construction; ``keep`` (per component): 1 the
+        device-resident parameters and moments stay (box unchanged); 0 they come from
+        ``states``: in order, dicts like ``component_states`` returns (missing moments =
+        zeros) with the arrays of the new box; 2 / 3 the box is resized about its centre on the
+        device (include/scarlet_amd.h: centred slice, or zero-padded moments and a
+        ``linear_ramp``-padded image -- 3 when the host image is float64) -- such a row takes
+        its new table entries from ``resized``: ``rows`` (indices) with ``origin_y``,
+        ``origin_x``, ``size``, ``morph_step`` per row; its ComponentSpec is not looked at
+        except for the weighting of its monotonicity plan."""
         flat = [c for blend in components for c in blend]
         assert len(flat) == self.n_components and \
             [len(c) for c in components] == self.n_comp_per_blend
         keep = np.ascontiguousarray(keep, dtype=np.int32)
+        if resized is not None and len(resized["rows"]):
+            self._resize_rows(flat, **resized)
         comps = self._pack_components(flat, values=False, rows=np.flatnonzero(keep == 0))
         C = self.C
         parts = []
@@ -320,6 +327,41 @@ class BlendBatch:
         _lib.check(self._lib.smi_batch_update_components(
             self._h, ctypes.byref(comps), _lib.ptr(keep, ctypes.c_int32),
             _lib.ptr(_lib.f32(buf), ctypes.c_float)))
+
+    def _resize_rows(self, flat, rows, origin_y, origin_x, size, morph_step):
+        """Table entries of rows whose square boxes the device resizes (``update_components``)."""
+        arrays = self._component_arrays
+        rows = np.asarray(rows, dtype=np.int64)
+        size = np.asarray(size, dtype=np.int32)
+        arrays["origin_y"][rows] = origin_y
+        arrays["origin_x"][rows] = origin_x
+        arrays["box_h"][rows] = size
+        arrays["box_w"][rows] = size
+        arrays["morph_step"][rows] = morph_step
+        for k, n in zip(rows.tolist(), size.tolist()):
+            c = flat[k]
+            shape = (n, n)
+            self._shapes[k] = shape
+            if not c.prox_flags & _lib.PROX_MONOTONIC:
+                continue
+            assert not c.prox_flags & _lib.PROX_FIT_CENTER
+            key = (shape, c.neighbor_weight, False)
+            if key not in self._plan_ids:
+                wts, off, didx = operator.monotonic_tables(shape, c.neighbor_weight, None)
+                self._plan_ids[key] = _lib.check(self._lib.smi_batch_add_sweep_plan(
+                    self._h, n, n, _lib.ptr(wts, ctypes.c_double), _lib.ptr(off, ctypes.c_int32),
+                    _lib.ptr(didx, ctypes.c_int32), didx.size))
+            arrays["sweep_plan"][k] = self._plan_ids[key]
+
+    def set_iteration_base(self, base):
+        """Per blend: the iteration counter at which its current adaprox call began (``None``:
+        0 for all); ``step(it0, n)`` then runs blends at different counters in one launch."""
+        if base is None:
+            _lib.check(self._lib.smi_batch_set_iteration_base(self._h, None))
+            return
+        base = np.ascontiguousarray(base, dtype=np.int32)
+        assert base.shape == (self.n_blends,)
+        _lib.check(self._lib.smi_batch_set_iteration_base(self._h, _lib.ptr(base, ctypes.c_int32)))
 
     def set_states(self, states):
         """Per-blend state: 0 iterating, 2 finished or paused (skipped by every kernel),

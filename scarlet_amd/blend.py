@@ -23,9 +23,9 @@ from .constraint import PositivityConstraint, device_flags
 from .hoststep import HostParameter
 from .model import UpdateException
 from .model import Model
-from .morphology import ImageMorphology, PointSourceMorphology
+from .morphology import ImageMorphology, Morphology, PointSourceMorphology, _edge_pull
 from .psf import GaussianPSF
-from .parameter import relative_step, STD_FROM_V
+from .parameter import Parameter, relative_step, STD_FROM_V
 from .renderer import ConvolutionRenderer, NullRenderer, ResolutionRenderer
 
 logger = logging.getLogger("scarlet_amd.blend")
@@ -1128,14 +1128,41 @@ def _fit_group_rebuilt(group, device, max_iter, opt, step_kw):
                     r.result = True
 
 
+def _device_resize_covers(blend):
+    """True when the device can also carry out every resize below ``blend``
+    (``smi_batch_update_components`` with keep = 2 / 3): stock ``shrink_box``, odd square boxes,
+    a constant step on float32 / float64 images."""
+    for c in _flatten(blend.sources):
+        morphology = c.children[1]
+        image = morphology.parameters[0]
+        h, w = morphology.bbox.shape[-2:]
+        if (type(morphology).shrink_box is not Morphology.shrink_box or h != w or h % 2 == 0
+                or h > 1000 or image.dtype not in (np.float32, np.float64)):
+            return False
+        if morphology.resizing and not image.fixed and not isinstance(image.step, (int, float)):
+            return False
+    return True
+
+
+def _standard_size(size):
+    """``get_minimal_boxsize`` (initialization.py:173-177) of an array of sizes."""
+    return 21 + 10 * np.ceil(np.maximum(size - 21, 0) / 10).astype(np.int64)
+
+
 def _fit_group_resident(group, device, max_iter, opt, step_kw):
     """Blends that share the frame and kernel shapes, factorized image components only: ONE
-    device batch for the whole fit.  The observation is uploaded once; every round steps the
-    blends that share an iteration counter while the others pause (per-blend state); at a
-    resize hook the device evaluates the two reductions ``ImageMorphology.update`` decides on
-    for every component (``smi_batch_resize_test``), and only the blends in which a box may
-    change come to the host, have their sources' ``update()`` run -- the host keeps the last
-    word -- and go back as new rows of the component table (``smi_batch_update_components``)."""
+    device batch for the whole fit, and every launch steps ALL blends that are still
+    iterating.  The observation is uploaded once.  A blend whose boxes change starts its
+    adaprox call anew (blend.py:276-302) while its batch mates go on: the device keeps the
+    counter at which each blend's call began (``smi_batch_set_iteration_base``).  At a resize
+    hook the device evaluates the two reductions ``ImageMorphology.update`` decides on for
+    every component (``smi_batch_resize_test``); for blends made of the stock classes the
+    resize itself -- centred slice, or zero-padded moments and a ``linear_ramp``-padded
+    image, step halved (morphology.py:132-207) -- also happens on the device
+    (``smi_batch_update_components``, keep = 2 / 3) and the Python objects learn their new
+    boxes when the fit is over.  Other blends in which a box may change come to the host,
+    have their sources' ``update()`` run -- the host keeps the last word -- and go back as
+    new rows of the component table."""
     nb = len(group)
     comps = [_flatten(r.blend.sources) for r in group]
     specs = [r.specs for r in group]
@@ -1147,6 +1174,7 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
         max_iter=max(max_iter, 1), device=device)
     try:
         flat = [c for cs in comps for c in cs]
+        n_comp = len(flat)
         if any(r.blend._loss_constant for r in group):
             batch.add_loss_constant([r.blend._loss_constant for r in group])
         Blend._upload_state(batch, flat)
@@ -1156,47 +1184,97 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
         local = np.zeros(nb, dtype=np.int64)
         count = np.zeros(nb, dtype=np.int64)  # losses recorded on the device so far
         state = np.zeros(nb, dtype=np.int32)  # 0 iterating, 2 finished, 3 failed
+        frozen = np.zeros(nb, dtype=bool)  # out of iterations
+        g = 0  # the batch's iteration counter: blend i is at g - (its counter base) = local[i]
         # per component: may update() act, and does the device test stand for it
         resizable = np.array([bool(c.children[1].resizing) and not c.children[1].parameters[0].fixed
                               for c in flat])
         blend_of = np.repeat(np.arange(nb), np.diff(first))
+        # blends the device resizes by itself, and what the host tracks for their components
+        on_device = np.array([_device_resize_covers(r.blend) for r in group])
+        if os.environ.get("SCARLET_AMD_FIT_BLENDS") == "host-resize":  # development aid: A/B runs
+            on_device[:] = False
+        origin = np.array([c.children[1].bbox.origin[-2:] for c in flat], dtype=np.int64).reshape(-1, 2)
+        step = np.array([float(c.children[1].parameters[0].step)
+                         if isinstance(c.children[1].parameters[0].step, (int, float)) else np.nan
+                         for c in flat])
+        wide = np.array([c.children[1].parameters[0].dtype == np.float64 for c in flat])
+        moved = np.zeros(n_comp, dtype=bool)
+        # (update() of a source stops at its first child that resizes, component.py:172-185)
+        source_of = np.concatenate(
+            [np.full(len(_flatten([src])), j) for j, src in
+             enumerate(src for r in group for src in r.blend.sources)]).astype(np.int64) \
+            if n_comp else np.zeros(0, dtype=np.int64)
+        pushed = None  # what the device holds as per-blend states / counter bases
         while True:
-            live = (state == 0) & (base + local < max_iter)
+            live = (state == 0) & ~frozen
+            left = max_iter - base - local
+            frozen |= live & (left <= 0)
+            live &= ~frozen
             if not live.any():
                 break
-            # (the rounds of this pass, fixed before any of them changes a counter)
-            rounds = [(L, np.flatnonzero(live & (local == L))) for L in np.unique(local[live])]
-            for L, part in rounds:
-                n = _next_round(int(L), int((max_iter - base[part] - local[part]).min()))
-                paused = np.full(nb, 2, dtype=np.int32)
-                paused[part] = 0
-                batch.set_states(paused)
-                batch.step(int(L), n, check_convergence=True, **step_kw)
-                now, cnt = batch.progress()
-                done = cnt[part] - count[part]
-                count[part] = cnt[part]
-                local[part] = L + done
-                state[part] = now[part]
-                ok = part[now[part] != 3]
-                done_ok = done[now[part] != 3]
-                hook = ok[(done_ok == n) & (L + done_ok > 1) & ((L + done_ok - 1) % 10 == 0)]
-                if hook.size == 0 or not resizable.any():
-                    continue
-                # candidates by the device's reductions; 1e-6: the host decides what is close
-                margin, pull = batch.resize_test()
-                shapes = np.array(batch._shapes)
-                size = shapes.max(axis=1)
-                inner = size - 2 * np.where(margin == np.iinfo(np.int32).max,
-                                            (shapes.min(axis=1) + 1) // 2, margin)
-                standard = 21 + 10 * np.ceil(np.maximum(inner - 21, 0) / 10).astype(np.int64)
-                wanted = resizable & ((standard < size) | (pull > 0.1 * (1 - 1e-6)))
-                visit = [int(i) for i in hook if wanted[first[i]:first[i + 1]].any()]
-                if not visit:
-                    continue
-                # Only the sources with a candidate below them go over the host: update() of
-                # the others is a no-op by the test above.  (Within a source the reference stops
-                # at the first child that resizes, component.py:172-185: a source is visited
-                # as a whole.)
+            # up to the next resize hook of any blend (after local iterations 11, 21, ...)
+            n_hook = np.where(local == 0, 11, ((local - 1) // 10 + 1) * 10 + 1 - local)
+            n = int(min(n_hook[live].min(), left[live].min()))
+            now_push = (np.where(frozen & (state == 0), 2, state).astype(np.int32),
+                        np.where(live, g - local, 0))
+            if pushed is None or not np.array_equal(pushed[0], now_push[0]):
+                batch.set_states(now_push[0])
+            if pushed is None or not np.array_equal(pushed[1], now_push[1]):
+                batch.set_iteration_base(now_push[1])
+            pushed = now_push
+            batch.step(g, n, check_convergence=True, **step_kw)
+            g += n
+            now, cnt = batch.progress()
+            done = cnt - count
+            count = cnt.astype(np.int64)
+            local[live] += done[live]
+            state[live] = now[live]
+            pushed = (np.where(frozen & (state == 0), 2, state).astype(np.int32), pushed[1])
+            hook = live & (now != 3) & (done == n) & (local > 1) & ((local - 1) % 10 == 0)
+            if not hook.any() or not resizable.any():
+                continue
+            # candidates by the device's reductions; 1e-6: the host decides what is close
+            margin, pull = batch.resize_test()
+            shapes = np.array(batch._shapes)
+            size = shapes.max(axis=1)
+            inner = size - 2 * np.where(margin == np.iinfo(np.int32).max,
+                                        (shapes.min(axis=1) + 1) // 2, margin)
+            standard = _standard_size(inner)
+            at_hook = hook[blend_of] & resizable
+            shrink = at_hook & (standard < size)
+            grow = at_hook & ~shrink & (pull > 0.1 * (1 - 1e-6))
+            restart = np.zeros(nb, dtype=bool)
+            keep = np.ones(n_comp, dtype=np.int32)
+            states = []
+            resized = None
+            # -- blends of the stock classes: the device resizes
+            dev = (shrink | grow) & on_device[blend_of]
+            close = np.flatnonzero(dev & grow & (pull < 0.1 * (1 + 1e-6)))
+            if close.size:  # the host's own arithmetic on the edges of these few
+                for k, rec in zip(close, batch.component_states(close)):
+                    edges = _edge_pull(rec["morph"], rec["m_morph"].astype(np.float64),
+                                       rec["v_morph"].astype(np.float64), step[k])
+                    grow[k] = dev[k] = bool(np.any(edges > 0.1))
+            rows = np.flatnonzero(dev)
+            if rows.size:
+                rows = rows[np.unique(source_of[rows], return_index=True)[1]]  # first of its source
+                new_size = np.where(shrink[rows], standard[rows], _standard_size(size[rows] + 1))
+                inset = (size[rows] - new_size) // 2  # < 0: the pad of a growing box
+                origin[rows] += inset[:, None]
+                step[rows] /= 2
+                moved[rows] = True
+                keep[rows] = np.where(wide[rows], 3, 2)
+                resized = dict(rows=rows, origin_y=origin[rows, 0], origin_x=origin[rows, 1],
+                               size=new_size, morph_step=step[rows])
+                restart[blend_of[rows]] = True
+            # -- the others: only the sources with a candidate below them go over the host:
+            # update() of the others is a no-op by the test above.  (Within a source the
+            # reference stops at the first child that resizes: a source is visited as a whole.)
+            wanted = (shrink | grow) & ~on_device[blend_of]
+            visit = [int(i) for i in np.flatnonzero(hook & ~on_device)
+                     if wanted[first[i]:first[i + 1]].any()]
+            if visit:
                 calls = []  # (blend, source, index of its first component, components)
                 for i in visit:
                     k = int(first[i])
@@ -1215,28 +1293,42 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
                         src.update()
                     except UpdateException:
                         changed.add(i)
-                if not changed:
-                    continue
                 # new rows of the component table: a component whose image Parameter was
                 # replaced (sliced or padded, step halved) takes its state from the host, all
                 # others keep theirs on the device
-                keep = np.ones(len(flat), dtype=bool)
-                states = []
                 for i in sorted(changed):
-                    base[i], local[i] = prior[i] + count[i], 0
+                    restart[i] = True
                     before = images[i]
                     comps[i] = _flatten(group[i].blend.sources)
                     flat[first[i]:first[i + 1]] = comps[i]
-                    moved = [j for j, c in enumerate(comps[i])
-                             if c.children[1].parameters[0] is not before[j]]
-                    for j in moved:
-                        specs[i][j] = _resized_spec(specs[i][j], comps[i][j])
-                        keep[first[i] + j] = False
-                        states.append(_parameters_to_record(comps[i][j]))
-                batch.update_components(specs, keep, states)
-                # (a restarted blend that was about to stop goes on: adaprox starts anew)
-                state[[i for i in changed if state[i] == 2]] = 0
-            # a blend whose last round ended with the stopping rule is done
+                    for j, c in enumerate(comps[i]):
+                        if c.children[1].parameters[0] is before[j]:
+                            continue
+                        specs[i][j] = _resized_spec(specs[i][j], c)
+                        keep[first[i] + j] = 0
+                        states.append(_parameters_to_record(c))
+            if not restart.any():
+                continue
+            batch.update_components(specs, keep, states, resized=resized)
+            # adaprox starts anew (a restarted blend that was about to stop goes on)
+            base[restart] = prior[restart] + count[restart]
+            local[restart] = 0
+            state[restart & (state == 2)] = 0
+        # the Python objects of the components the device has resized: new image Parameters
+        # (morphology.py:155-163, 180-193) and boxes; the values follow with the download
+        for k in np.flatnonzero(moved):
+            morphology = flat[k].children[1]
+            image = morphology.parameters[0]
+            shape = tuple(batch._shapes[k])
+            morphology._parameters = (
+                Parameter(np.zeros(shape, dtype=image.dtype), name=image.name, prior=image.prior,
+                          constraint=image.constraint, step=float(step[k]), fixed=image.fixed),
+            ) + morphology._parameters[1:]
+            morphology.bbox.origin = tuple(int(o) for o in origin[k])
+            morphology.bbox.shape = shape
+        for i in np.unique(blend_of[moved]):
+            for src in group[i].blend.sources:
+                _refresh_boxes(src)
         Blend._download_all(batch, flat)
         history = batch.loss_history()
     finally:

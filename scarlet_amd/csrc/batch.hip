@@ -270,6 +270,7 @@ struct smi_batch {
     std::vector<hipEvent_t> sub_events;  // [0] fork, [s] join of range s >= 1
     // per blend
     int32_t *state = nullptr, *zero_state = nullptr, *n_loss = nullptr, *status_out = nullptr;
+    int32_t *it_base = nullptr;  // BatchView::it_base (smi_batch_set_iteration_base)
     double *loss_hist = nullptr, *last_loss = nullptr, *loss_partial = nullptr;
     // plans
     std::vector<SweepPlanDev> plans;
@@ -321,6 +322,7 @@ void refresh_view(smi_batch *b) {
     v.data = b->data;
     v.weights = b->weights;
     v.dw = b->dw;
+    v.it_base = b->it_base;
     v.log_norm = b->log_norm;
     v.state = b->state;
     v.n_loss = b->n_loss;
@@ -822,7 +824,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
                     b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
                     b->c_shift_step, b->c_shift_rel, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_pos_floor, b->c_bg_level,
-                    b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out,
+                    b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out, b->it_base,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans, b->work_items};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -1380,9 +1382,17 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
             SMI_REQUIRE(!(c->prox_flags[k] & (SMI_COMPONENT_POINT_SOURCE | SMI_COMPONENT_SHIFTING)),
                         "smi_batch_update_components: factorized image components only");
             SMI_REQUIRE(c->blend[k] == b->h_blend[k], "smi_batch_update_components: components moved between blends");
-            if (keep[k])
+            if (keep[k] == 1)
                 SMI_REQUIRE((int64_t)c->box_h[k] * c->box_w[k] == b->h_moff[k + 1] - b->h_moff[k],
                             "smi_batch_update_components: a kept component changed its box size");
+            if (keep[k] >= 2) {  // resized on the device about its centre
+                const int64_t n_old = b->h_moff[k + 1] - b->h_moff[k];
+                const int ow = (int)std::lround(std::sqrt((double)n_old));
+                SMI_REQUIRE(keep[k] <= 3 && (int64_t)ow * ow == n_old && c->box_h[k] == c->box_w[k] &&
+                                c->box_h[k] <= 1024 && (c->box_h[k] - ow) % 2 == 0,
+                            "smi_batch_update_components: device resize needs square boxes of at most "
+                            "1024 pixels a side whose sides differ by an even number");
+            }
         }
         old_moff = b->h_moff;
         old_px[0] = b->morph;
@@ -1637,9 +1647,8 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
         // kept components: pixel arrays from the old packing; the others: their records
         std::vector<int64_t> rec(n, -1);
         int64_t total = 0;
-        std::vector<int32_t> kept(keep, keep + n);
+        std::vector<int32_t> kept(keep, keep + n);  // (the codes: carry_states_kernel)
         for (int k = 0; k < n; ++k) {
-            kept[k] = keep[k] != 0;
             if (kept[k]) continue;
             rec[k] = total;
             total += 4 * (int64_t)C + 4 * (moff[k + 1] - moff[k]);
@@ -1721,6 +1730,23 @@ int smi_batch_get_component_states(smi_batch *b, const int32_t *components, int3
     SMI_HIP(hipMemcpy(states, d_states, (size_t)total * sizeof(float), hipMemcpyDeviceToHost));
     for (void *p : {(void *)d_sel, (void *)d_off, (void *)d_states}) (void)hipFree(p);
     SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_batch_set_iteration_base(smi_batch *b, const int32_t *base) {
+    SMI_REQUIRE(b != nullptr, "null batch");
+    SMI_REQUIRE(b->n_point == 0 && b->n_shift == 0 && !b->ks.stamp && b->scheme != SMI_SCHEME_FISTA,
+                "smi_batch_set_iteration_base: factorized image components under AMSGrad only");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    if (!base) {
+        if (b->it_base) (void)hipFree(b->it_base);
+        b->it_base = nullptr;
+    } else {
+        if (!b->it_base) SMI_HIP(dev_alloc(&b->it_base, (size_t)b->d.n_blends));
+        SMI_HIP(hipMemcpy(b->it_base, base, b->d.n_blends * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    refresh_view(b);
     return SMI_OK;
 }
 

@@ -286,6 +286,14 @@ struct BatchView {
     // value a failing update stores in state[b]: 3 + the iteration (launch_update stamps it;
     // anything >= 3 means non-finite parameters, finalize_blend explains the iteration)
     int32_t fail_code = 3;
+    // per blend: the iteration counter at which its current adaprox call began (nullptr: 0 for
+    // all).  A blend whose boxes were resized starts anew (blend.py:276-302) while its batch
+    // mates go on: the kernels take the rules of a first step (alpha / 10, vhat = v) and
+    // min_iter from `it - it_base[b]` (smi_batch_set_iteration_base).
+    const int32_t *it_base = nullptr;
+    __device__ __forceinline__ int local_it(int b, int it) const {
+        return it_base ? it - it_base[b] : it;
+    }
 };
 
 void launch_render(const BatchView &v, float *P, hipStream_t s);

@@ -226,7 +226,7 @@ __device__ __forceinline__ void finalize_blend(const BatchView &v, int b, int it
         if (n < v.hist_cap) v.loss_hist[(int64_t)b * v.hist_cap + n] = loss;
         v.n_loss[b] = n + 1;
         v.last_loss[b] = loss;
-        if (check && (n >= 1 || v.have_prev[b]) && it > min_iter &&
+        if (check && (n >= 1 || v.have_prev[b]) && v.local_it(b, it) > min_iter &&
             fabs(loss - prev) < (double)e_rel * fabs(loss))
             atomicCAS(&v.state[b], 0, 1);  // this iteration's update is the last one
     }
@@ -724,6 +724,7 @@ __global__ __launch_bounds__(T) void update_kernel(BatchView v, const float *G, 
                                                    float *g_sed_out, float *g_morph_out,
                                                    int grad_only) {
     const CompCtx c = comp_ctx(v);
+    it = v.local_it(c.b, it);
     // the team is a property of the box, not of the batch: a component gets the same bits
     // whatever else is fitted with it (two launches when a batch holds both kinds)
     // (the same boundary as the register-resident classes: 64 x 59 pixels)
@@ -953,6 +954,7 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
     const CompCtx c = comp_ctx(v);
     if (!(v.c_flags[c.k] & SMI_COMPONENT_POINT_SOURCE)) return;
     if (mode == 0 && v.state[c.b] >= 2) return;
+    it = v.local_it(c.b, it);
     const int lane = c.lane, N = c.N;
     __shared__ double fy[64], fx[64], dfy[64], dfx[64];
     float *us = lds_dyn;
@@ -1469,6 +1471,7 @@ __device__ __forceinline__ void upd_step(const BatchView &v, const float *G, int
     constexpr bool fista = MODE == 2;
     constexpr int kFull = UpdFull<NPL>::value;
     const CompCtx &c = S.c;
+    it = v.local_it(c.b, it);
     const int lane = c.lane, k = S.k, N = c.N;
     float *us = S.us;
     float(&xs)[NPL] = S.xs;
@@ -2056,15 +2059,81 @@ __global__ __launch_bounds__(256) void scatter_states_kernel(BatchView v, const 
 struct PixelArrays {
     float *p[4];
 };
+// keep[k]: 1 the box stays -- the four pixel arrays move to their new offsets; 2 / 3 the box is
+// resized about its centre the way ImageMorphology.update does it (morphology.py:132-207):
+// square boxes, old side ow, new side nw, pad = (nw - ow) / 2.
+//   pad < 0 (shrink_box): the centred slice of image and moments;
+//   pad > 0: the moments are padded with zeros, the image with np.pad(mode="linear_ramp") --
+//   axis 0 over the original columns, then axis 1 over all rows, each ramp
+//   np.linspace(0, edge, pad, endpoint=False) evaluated in float64: i * (edge / pad), or
+//   (i / pad) * edge as soon as one entry of that edge line is 0 (numpy's any_step_zero branch),
+//   rounded to float32.  keep = 3: the host image is a float64 array, so the rows added along
+//   axis 0 enter the ramps along axis 1 unrounded.
+__device__ __forceinline__ double linear_ramp(int i, double edge, int pad, bool any_zero) {
+    return any_zero ? ((double)i / (double)pad) * edge : (double)i * (edge / (double)pad);
+}
 __global__ __launch_bounds__(256) void carry_states_kernel(const int32_t *keep, const int64_t *old_moff,
                                                            const int64_t *new_moff, PixelArrays from,
                                                            PixelArrays to) {
-    const int k = blockIdx.x;
-    if (!keep[k]) return;
+    const int k = blockIdx.x, code = keep[k], tid = threadIdx.x;
+    if (!code) return;
     const int64_t src = old_moff[k], dst = new_moff[k];
     const int N = (int)(old_moff[k + 1] - src);
-    for (int a = 0; a < 4; ++a)
-        for (int i = threadIdx.x; i < N; i += 256) to.p[a][dst + i] = from.p[a][src + i];
+    if (code == 1) {
+        for (int a = 0; a < 4; ++a)
+            for (int i = tid; i < N; i += 256) to.p[a][dst + i] = from.p[a][src + i];
+        return;
+    }
+    const int M = (int)(new_moff[k + 1] - dst);
+    const int ow = (int)(sqrtf((float)N) + 0.5f), nw = (int)(sqrtf((float)M) + 0.5f);
+    const int pad = (nw - ow) / 2;
+    for (int a = pad > 0 ? 1 : 0; a < 4; ++a)
+        for (int i = tid; i < M; i += 256) {
+            const int y = i / nw - pad, x = i % nw - pad;
+            const bool inside = y >= 0 && y < ow && x >= 0 && x < ow;
+            to.p[a][dst + i] = inside ? from.p[a][src + y * ow + x] : 0.f;
+        }
+    if (pad <= 0) return;
+    __shared__ double edge_l[1024], edge_r[1024];
+    const bool wide = code == 3;
+    const float *f = from.p[0] + src;
+    float *t = to.p[0] + dst;
+    int zt = 0, zb = 0;
+    for (int x = tid; x < ow; x += 256) {
+        zt |= f[x] == 0.f;
+        zb |= f[(ow - 1) * ow + x] == 0.f;
+    }
+    zt = __syncthreads_or(zt);
+    zb = __syncthreads_or(zb);
+    for (int i = tid; i < nw * ow; i += 256) {
+        const int y = i / ow, x = i - y * ow;
+        double val;
+        if (y < pad)
+            val = linear_ramp(y, (double)f[x], pad, zt);
+        else if (y >= pad + ow)
+            val = linear_ramp(nw - 1 - y, (double)f[(ow - 1) * ow + x], pad, zb);
+        else
+            val = (double)f[(y - pad) * ow + x];
+        const float r = (float)val;
+        t[y * nw + pad + x] = r;
+        if (x == 0) edge_l[y] = wide ? val : (double)r;
+        if (x == ow - 1) edge_r[y] = wide ? val : (double)r;
+    }
+    __syncthreads();
+    int zl = 0, zr = 0;
+    for (int y = tid; y < nw; y += 256) {
+        zl |= edge_l[y] == 0.0;
+        zr |= edge_r[y] == 0.0;
+    }
+    zl = __syncthreads_or(zl);
+    zr = __syncthreads_or(zr);
+    for (int i = tid; i < nw * 2 * pad; i += 256) {
+        const int y = i / (2 * pad), j = i - y * 2 * pad;
+        if (j < pad)
+            t[y * nw + j] = (float)linear_ramp(j, edge_l[y], pad, zl);
+        else
+            t[y * nw + nw - 1 - (j - pad)] = (float)linear_ramp(j - pad, edge_r[y], pad, zr);
+    }
 }
 
 // data and weights by row pairs for the fused convolution kernel (BatchView::dw); grid.y = plane

@@ -568,6 +568,130 @@ def test_loss_history_of_a_blend_that_goes_non_finite(amd, n_blends):
         b.close()
 
 
+def test_resize_on_the_device_equals_the_host_resize_and_blends_keep_their_own_counters(amd):
+    """smi_batch_update_components with keep = 2 / 3 (the resize of ImageMorphology.update,
+    morphology.py:132-207, carried out by the device: centred slice; zero-padded moments and
+    np.pad(mode="linear_ramp") of the image in float64 -- numpy's two ramp formulas, rows
+    rounded to float32 between the axes or not) against the same arrays made by numpy on the
+    host; then smi_batch_set_iteration_base: blends 1 and 3 start their adaprox call anew at
+    counter 11 while the others go on, in ONE launch per iteration -- the same bits as the
+    two groups stepped in turn with the others paused."""
+    from scarlet_amd import synthetic
+
+    n_blends = 4
+    scenes = synthetic.make_batch(range(4321, 4321 + n_blends))
+    kern = synthetic.psfs()
+    data = np.stack([s["data"] for s in scenes])
+    weights = np.stack([s["weights"] for s in scenes])
+    n = 10 * n_blends
+
+    def specs_of(seds, morphs, origins, steps):
+        return [[amd.ComponentSpec(seds[10 * i + k], morphs[10 * i + k], origins[10 * i + k],
+                                   sed_min_step=scenes[i]["noise_rms"], morph_step=steps[10 * i + k])
+                 for k in range(10)] for i in range(n_blends)]
+
+    origins = [tuple(int(v) for v in s["origins"][k]) for s in scenes for k in range(10)]
+    seds0 = [s["seds"][k] for s in scenes for k in range(10)]
+    morphs0 = [s["morphs"][k].copy() for s in scenes for k in range(10)]
+    # edge lines without a zero (the i * (edge / pad) branch of np.linspace) next to the usual
+    # ones with zeros (the (i / pad) * edge branch)
+    rng = np.random.default_rng(5)
+    for k in (11, 14, 31):
+        morphs0[k] = np.maximum(morphs0[k], rng.uniform(1e-4, 1e-2, morphs0[k].shape).astype(np.float32))
+    steps = [1e-2] * n
+
+    def start():
+        b = amd.BlendBatch(data, weights, specs_of(seds0, morphs0, origins, steps), kernel=kern[2],
+                           max_iter=40)
+        b.step(0, 11, e_rel=1e-3)
+        return b
+
+    # what the device is asked to do: -5 shrink to 31^2, +5 / +10 grow to 51^2 / 61^2
+    grow = {11: 5, 12: -5, 14: 10, 17: 5, 31: 5, 33: -5, 38: 5}
+    wide = {14, 17, 38}  # host image float64: no rounding between the axes
+
+    def image(a, k):
+        d = grow.get(k, 0)
+        if d < 0:
+            return a[-d:d, -d:d]
+        if d > 0:
+            src = a.astype(np.float64) if k in wide else a
+            return np.pad(src, d, mode="linear_ramp").astype(np.float32)
+        return a
+
+    def moment(a, k):
+        d = grow.get(k, 0)
+        return a[-d:d, -d:d] if d < 0 else np.pad(a, d) if d > 0 else a
+
+    keep = np.ones(n, dtype=np.int32)
+    rows = np.array(sorted(grow))
+    keep[rows] = [3 if k in wide else 2 for k in rows]
+    new_origin = np.array([[origins[k][0] - grow[k], origins[k][1] - grow[k]] for k in rows])
+    new_size = np.array([41 + 2 * grow[k] for k in rows])
+
+    def resize(batch):
+        seds, morphs = batch.parameters()
+        mom = batch.moments()
+        batch.update_components(
+            specs_of(seds0, morphs0, origins, steps), keep, [],
+            resized=dict(rows=rows, origin_y=new_origin[:, 0], origin_x=new_origin[:, 1],
+                         size=new_size, morph_step=np.full(rows.size, 5e-3)))
+        s1, m1 = batch.parameters()
+        assert_array_equal(s1, seds)
+        got = batch.moments()
+        for k in range(n):
+            assert_array_equal(m1[k], image(morphs[k], k), err_msg="image %d" % k)
+            for name in ("m_morph", "v_morph", "vhat_morph"):
+                assert_array_equal(got[name][k], moment(mom[name][k], k), err_msg="%s %d" % (name, k))
+        for name in ("m_sed", "v_sed", "vhat_sed"):
+            assert_array_equal(got[name], mom[name])
+        return seds, morphs, mom
+
+    # images as they were set (edge lines without a zero: the other formula of the ramp) ...
+    fresh = amd.BlendBatch(data, weights, specs_of(seds0, morphs0, origins, steps), kernel=kern[2],
+                           max_iter=40)
+    _, morphs, _ = resize(fresh)
+    assert all((morphs[k][[0, -1]] != 0).all() and (morphs[k][:, [0, -1]] != 0).all()
+               for k in (11, 14, 31))
+    fresh.close()
+    # ... and after eleven iterations, moments and all (edges with zeros)
+    live = start()
+    seds, morphs, mom = resize(live)
+    assert (morphs[17][0] == 0).any()
+
+    # blends 1 and 3 (the resized ones) restart at counter 11, all four in one launch ...
+    base = np.array([0, 11, 0, 11], dtype=np.int32)
+    live.set_iteration_base(base)
+    live.step(11, 5, e_rel=1e-3, check_convergence=True)
+    # ... against: the same state, the two groups stepped in turn with the others paused
+    new_specs = specs_of(list(seds), [image(morphs[k], k) for k in range(n)],
+                         [tuple(new_origin[list(rows).index(k)]) if k in grow else origins[k]
+                          for k in range(n)],
+                         [5e-3 if k in grow else 1e-2 for k in range(n)])
+    turn = amd.BlendBatch(data, weights, new_specs, kernel=kern[2], max_iter=40)
+    turn.set_moments(m_sed=mom["m_sed"], v_sed=mom["v_sed"], vhat_sed=mom["vhat_sed"],
+                     m_morph=[moment(a, k) for k, a in enumerate(mom["m_morph"])],
+                     v_morph=[moment(a, k) for k, a in enumerate(mom["v_morph"])],
+                     vhat_morph=[moment(a, k) for k, a in enumerate(mom["vhat_morph"])])
+    turn.set_previous_loss(np.array([h[10] for h in live.loss_history()]))
+    turn.set_states(np.array([0, 2, 0, 2], dtype=np.int32))
+    turn.step(11, 5, e_rel=1e-3, check_convergence=True)
+    turn.set_states(np.array([2, 0, 2, 0], dtype=np.int32))
+    turn.step(0, 5, e_rel=1e-3, check_convergence=True)
+    s1, m1 = live.parameters()
+    s2, m2 = turn.parameters()
+    assert_array_equal(s1, s2)
+    for a, b_ in zip(m1, m2):
+        assert_array_equal(a, b_)
+    for name, arrays in live.moments().items():
+        for a, b_ in zip(arrays, turn.moments()[name]):
+            assert_array_equal(a, b_)
+    for a, b_ in zip(live.loss_history(), turn.loss_history()):
+        assert_array_equal(a[11:16], b_[:5])
+    live.close()
+    turn.close()
+
+
 def test_resize_on_a_live_batch_equals_a_rebuilt_batch(amd):
     """smi_batch_resize_test / smi_batch_get_component_states / smi_batch_update_components:
     the reductions of ImageMorphology.update (morphology.py:132-207) on the device against
