@@ -392,10 +392,8 @@ class BlendBatch:
 
     # -- helpers -----------------------------------------------------------
     def _split_morphs(self, flat):
-        return [
-            flat[self._morph_offsets[k] : self._morph_offsets[k + 1]].reshape(self._shapes[k])
-            for k in range(self.n_components)
-        ]
+        off = self._morph_offsets.tolist()
+        return [flat[off[k]:off[k + 1]].reshape(self._shapes[k]) for k in range(self.n_components)]
 
     @property
     def fft_shape(self):
@@ -719,8 +717,9 @@ class BlendBatch:
             )
         )
 
-    def moments(self):
-        """AMSGrad state: dict with m/v/vhat for seds (arrays) and morphs (lists)."""
+    def moments(self, dtype=np.float32):
+        """AMSGrad state: dict with m/v/vhat for seds (arrays) and morphs (lists); with another
+        ``dtype`` the six downloads are converted as a whole (the entries are views)."""
         ns, nm = (self.n_components, self.C), int(self._morph_offsets[-1])
         bufs = [np.empty(ns, dtype=np.float32) for _ in range(3)] + [
             np.empty(nm, dtype=np.float32) for _ in range(3)
@@ -728,6 +727,8 @@ class BlendBatch:
         _lib.check(
             self._lib.smi_batch_get_moments(self._h, *[_lib.ptr(b, ctypes.c_float) for b in bufs])
         )
+        if dtype != np.float32:
+            bufs = [b.astype(dtype) for b in bufs]
         return dict(
             m_sed=bufs[0], v_sed=bufs[1], vhat_sed=bufs[2],
             m_morph=self._split_morphs(bufs[3]), v_morph=self._split_morphs(bufs[4]),

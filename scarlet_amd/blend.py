@@ -306,7 +306,8 @@ class Blend(CombinedComponent):
                     np.asarray(sed), np.asarray(image), morphology.bbox.origin[-2:],
                     sed_min_step=np.maximum(np.asarray(s_min, dtype=np.float64), s_const),
                     sed_rel_step=s_rel,
-                    morph_step=max(m_const, float(np.max(m_min))),
+                    morph_step=max(m_const, m_min if isinstance(m_min, (int, float))
+                                   else float(np.max(m_min))),
                     morph_rel_step=m_rel,
                     prox_flags=flags["flags"],
                     neighbor_weight=flags["neighbor_weight"] or "angle",
@@ -448,14 +449,19 @@ class Blend(CombinedComponent):
     @staticmethod
     def _download_all(batch, comps):
         seds, morphs = batch.parameters()
-        mom = batch.moments()
+        # (moments as float64 arrays, converted download by download: the Parameters of a
+        # batch hold views)
+        mom = batch.moments(dtype=np.float64)
+        m_sed, v_sed, vhat_sed = mom["m_sed"], mom["v_sed"], mom["vhat_sed"]
+        m_morph, v_morph, vhat_morph = mom["m_morph"], mom["v_morph"], mom["vhat_morph"]
         centers = None
         for k, comp in enumerate(comps):
-            sed = comp.children[0].parameters[0]
-            image = comp.children[1].parameters[0]
+            spectrum, morphology = comp._children
+            sed = spectrum._parameters[0]
+            image = morphology._parameters[0]
             sed[...] = seds[k]
-            sed.m, sed.v, sed.vhat = (mom[n][k].astype(np.float64) for n in ("m_sed", "v_sed", "vhat_sed"))
-            if isinstance(comp.children[1], PointSourceMorphology):
+            sed.m, sed.v, sed.vhat = m_sed[k], v_sed[k], vhat_sed[k]
+            if isinstance(morphology, PointSourceMorphology):
                 if centers is None:
                     centers = batch.centers()
                 image[...] = centers["center"][k]
@@ -468,9 +474,7 @@ class Blend(CombinedComponent):
                 shift[...] = centers["center"][k]
                 shift.m, shift.v, shift.vhat = (centers[n][k].copy() for n in ("m", "v", "vhat"))
             image[...] = morphs[k]
-            image.m, image.v, image.vhat = (
-                mom[n][k].astype(np.float64) for n in ("m_morph", "v_morph", "vhat_morph")
-            )
+            image.m, image.v, image.vhat = m_morph[k], v_morph[k], vhat_morph[k]
 
     # --------------------------------------------------------------------- fit
     def fit(self, max_iter=200, e_rel=1e-3, min_iter=1, noise_factor=0, **alg_kwargs):
@@ -1326,9 +1330,10 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
             ) + morphology._parameters[1:]
             morphology.bbox.origin = tuple(int(o) for o in origin[k])
             morphology.bbox.shape = shape
-        for i in np.unique(blend_of[moved]):
-            for src in group[i].blend.sources:
-                _refresh_boxes(src)
+        if moved.any():
+            sources = [src for r in group for src in r.blend.sources]
+            for j in np.unique(source_of[moved]):
+                _refresh_boxes(sources[j])
         Blend._download_all(batch, flat)
         history = batch.loss_history()
     finally:
