@@ -36,6 +36,7 @@ python "$R/bench.py" --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_live_coun
 for nbl in 128 256 512; do
     python "$R/bench.py" --steps 20 --warmup 5 --no-cpu --no-counters --blends $nbl > "$OUT/${TAG}_bench_shard${nbl}_noprof.json" 2> /dev/null
 done
+python "$R/bench.py" --config cfg5 --steps 40 > "$OUT/${TAG}_bench_cfg5_noprof.json" 2> /dev/null
 python "$R/tools/single_scene.py" 2> "$OUT/single_scene.err" | grep '^{' > "$OUT/${TAG}_bench_single_scene.json"
 # the path a scarlet script calls: Blend objects in, fit_blends, fitted objects out
 python "$R/bench.py" --facade --blends 1024 --steps 100 > "$OUT/${TAG}_bench_facade.json" 2> "$OUT/facade.err"
