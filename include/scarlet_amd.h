@@ -222,6 +222,10 @@ typedef struct smi_components {
                                 /* mean(shift)); NULL = 0.  (The centre of a point source   */
                                 /* takes its rule from morph_step / morph_rel_step: step =  */
                                 /* max(morph_step, rel * mean(centre in frame pixels)).)    */
+    const float *psf_beta;      /* [n_components] point sources on a MoffatPSF model PSF     */
+                                /* (psf.py:145-202): (1 + r^2 / alpha^2)^-beta sampled at    */
+                                /* the pixel centres, alpha in psf_sigma; 0 or NULL = the    */
+                                /* pixel-integrated Gaussian of width psf_sigma              */
 } smi_components;
 
 int smi_batch_create(const smi_batch_desc *desc, int device, smi_batch **out);

@@ -161,12 +161,15 @@ class PointComponent:
     symmetric = False
 
     def __init__(self, sed, center, sigma, boxsize=None, sed_min_step=0.0, center_step=3e-2,
-                 sed_zero=1e-20, center_rel_step=0.0):
+                 sed_zero=1e-20, center_rel_step=0.0, beta=0.0):
         self.sed = sed
         self.center = np.array(center, dtype=np.float64)
         self.sigma = float(sigma)
+        # beta > 0: MoffatPSF(alpha=sigma, beta) instead of the Gaussian (psf.py:145-202)
+        self.beta = float(beta)
         if boxsize is None:
-            boxsize = int(np.ceil(10 * self.sigma))  # psf.py:94-95
+            # psf.py:94-95 (Gaussian), psf.py:170-171 (Moffat)
+            boxsize = int(np.ceil((5 if self.beta > 0 else 10) * self.sigma))
         if boxsize % 2 == 0:
             boxsize += 1  # psf.py:57-58
         self.size = boxsize
@@ -193,7 +196,10 @@ class PointComponent:
         """``GaussianPSF.get_model(offset=)`` for a band-independent sigma
         (psf.py:97-126): separable profile, normalised to unit sum."""
         Y, X = self._axes()
-        image = integrated_gaussian(Y, self.sigma)[:, None] * integrated_gaussian(X, self.sigma)[None, :]
+        if self.beta > 0:  # MoffatPSF._f (psf.py:200-202), sampled at the pixel centres
+            image = (1 + (X[None, :] ** 2 + Y[:, None] ** 2) / self.sigma**2) ** -self.beta
+        else:
+            image = integrated_gaussian(Y, self.sigma)[:, None] * integrated_gaussian(X, self.sigma)[None, :]
         return image / image.sum()
 
     def model_morph(self):
@@ -202,6 +208,15 @@ class PointComponent:
     def center_gradient(self, g_morph):
         """Chain rule d(-logL)/d(center) = sum_yx g_morph * d(morph)/d(center)."""
         Y, X = self._axes()
+        if self.beta > 0:
+            # A = q^-beta with q = 1 + r^2 / alpha^2; d A / d center = -d A / d (grid - offset)
+            q = 1 + (X[None, :] ** 2 + Y[:, None] ** 2) / self.sigma**2
+            A = q**-self.beta
+            d = 2 * self.beta / self.sigma**2 * A / q
+            dAy, dAx = d * Y[:, None], d * X[None, :]
+            S = A.sum()
+            return np.array([(g_morph * (dAy / S - A * dAy.sum() / S**2)).sum(),
+                             (g_morph * (dAx / S - A * dAx.sum() / S**2)).sum()])
         fy, fx = integrated_gaussian(Y, self.sigma), integrated_gaussian(X, self.sigma)
         # d f(Y_j - offset)/d center = -f'(Y_j - offset)
         dfy, dfx = -integrated_gaussian_deriv(Y, self.sigma), -integrated_gaussian_deriv(X, self.sigma)

@@ -451,7 +451,12 @@ def hsc_psf_shift(scarlet):
     print("hsc_psf_shift: logL=%.3f fd=%s" % (out["logL"], fd))
 
 
-def point_source(scarlet):
+def point_source_moffat(scarlet):
+    """The point-source tutorial scene on a MoffatPSF model PSF (psf.py:145-202)."""
+    point_source(scarlet, moffat=(1.6, 2.5))
+
+
+def point_source(scarlet, moffat=None):
     """docs/tutorials/point_source.ipynb: psf_unmatched_sim scene, stars as
     PointSource, galaxies as ExtendedSource; state up to the first gradient."""
     d = np.load("/root/reference/data/psf_unmatched_sim.npz")
@@ -460,7 +465,8 @@ def point_source(scarlet):
     weights = np.ones_like(images) / 2**2
 
     def build(dtype):
-        model_psf = scarlet.GaussianPSF(sigma=0.9)
+        model_psf = scarlet.GaussianPSF(sigma=0.9) if moffat is None else \
+            scarlet.MoffatPSF(alpha=moffat[0], beta=moffat[1], boxsize=15)
         frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters, dtype=dtype)
         obs = scarlet.Observation(
             images, psf=scarlet.ImagePSF(psfs), weights=weights, channels=filters
@@ -528,8 +534,12 @@ def point_source(scarlet):
                 i += 1
     out["fd_dlogL"] = fd
     arrays(sources64, "f64_")
-    np.savez_compressed(os.path.join(OUT, "point_source.npz"), **out)
-    print("point_source: %d sources, logL=%.3f" % (len(sources), out["logL"]))
+    name = "point_source"
+    if moffat is not None:
+        out["moffat"] = np.array(moffat)
+        name = "point_source_moffat"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%s: %d sources, logL=%.3f" % (name, len(sources), out["logL"]))
 
 
 def synthetic_cfg2(scarlet):
@@ -629,7 +639,7 @@ def main(which=None):
     os.makedirs(OUT, exist_ok=True)
     jobs = dict(
         operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
-        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, hsc_shifting=hsc_shifting, lite=lite,
+        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, point_source_moffat=point_source_moffat, hsc_shifting=hsc_shifting, lite=lite,
         hsc_psf_shift=hsc_psf_shift,
         synthetic_cfg2=synthetic_cfg2, init_synthetic=init_synthetic,
     )

@@ -63,7 +63,7 @@ class Components(ctypes.Structure):
         ("center", c_f64p), ("psf_sigma", c_f32p), ("shift_step", c_f32p),
         ("center_floor", c_f32p), ("bg_level", c_f32p), ("fista_step", c_f32p),
         ("sym_strength", c_f32p), ("pos_floor", c_f32p), ("chain_repeat", c_i32p),
-        ("shift_rel_step", c_f32p),
+        ("shift_rel_step", c_f32p), ("psf_beta", c_f32p),
     ]
 
 

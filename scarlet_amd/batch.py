@@ -56,17 +56,20 @@ class ComponentSpec:
 
 class PointSourceSpec(ComponentSpec):
     """A ``PointSource`` (source.py:92-128): spectrum x the model PSF -- a
-    pixel-integrated Gaussian of width ``psf_sigma`` in every band -- evaluated at
-    the free sub-pixel ``center`` (frame pixels).  The box is the PSF box
-    (psf.py:55-66, 93-95) moved to the rounded initial centre
+    pixel-integrated Gaussian of width ``psf_sigma`` in every band, or with ``psf_beta`` > 0
+    the Moffat profile ``(1 + r^2 / psf_sigma^2)^-psf_beta`` sampled at the pixel centres
+    (psf.py:145-202) -- evaluated at the free sub-pixel ``center`` (frame pixels).  The box is
+    the PSF box (psf.py:55-66, 93-95, 170-171) moved to the rounded initial centre
     (morphology.py:494-497) and stays fixed."""
 
     def __init__(self, sed, center, psf_sigma, boxsize=None, sed_min_step=0.0,
-                 sed_rel_step=1e-2, center_step=3e-2, origin=None, center_rel_step=0.0):
+                 sed_rel_step=1e-2, center_step=3e-2, origin=None, center_rel_step=0.0,
+                 psf_beta=0.0):
         self.center = np.array(center, dtype=np.float64).reshape(2)
         self.psf_sigma = float(psf_sigma)
+        self.psf_beta = float(psf_beta)
         if boxsize is None:
-            boxsize = int(np.ceil(10 * self.psf_sigma))
+            boxsize = int(np.ceil((5 if self.psf_beta > 0 else 10) * self.psf_sigma))
         if boxsize % 2 == 0:
             boxsize += 1
         if origin is None:
@@ -230,6 +233,7 @@ class BlendBatch:
             chain_repeat=np.ascontiguousarray([c.chain_repeat for c in part], dtype=np.int32),
             pos_floor=_lib.f32([c.pos_floor for c in part]),
             shift_rel_step=_lib.f32([c.shift_rel_step for c in part]),
+            psf_beta=_lib.f32([getattr(c, "psf_beta", 0.0) for c in part]),
         )
         if rows is None:
             arrays = fields

@@ -24,7 +24,7 @@ from .hoststep import HostParameter
 from .model import UpdateException
 from .model import Model
 from .morphology import ImageMorphology, Morphology, PointSourceMorphology, _edge_pull
-from .psf import GaussianPSF
+from .psf import GaussianPSF, MoffatPSF
 from .parameter import Parameter, relative_step, STD_FROM_V
 from .renderer import ConvolutionRenderer, NullRenderer, ResolutionRenderer
 
@@ -342,11 +342,15 @@ class Blend(CombinedComponent):
     @staticmethod
     def _point_spec(sed, center, morphology):
         """PointSource -> device description; the model PSF must be a pixel-integrated
-        Gaussian with one width for all bands (what the device kernel evaluates)."""
+        Gaussian or a Moffat profile, the same in all bands (what the device kernel
+        evaluates)."""
         psf = morphology.psf
-        if not (isinstance(psf, GaussianPSF) and psf.integrate and psf.is_same):
+        moffat = isinstance(psf, MoffatPSF) and psf.is_same and \
+            bool(np.all(psf.get_parameter(1) == psf.get_parameter(1)[0]))
+        if not (moffat or (isinstance(psf, GaussianPSF) and psf.integrate and psf.is_same)):
             raise NotImplementedError(
-                "point sources need a pixel-integrated GaussianPSF model PSF with one sigma")
+                "point sources need a pixel-integrated GaussianPSF or a MoffatPSF model PSF, "
+                "the same in all bands")
         _plain_2vector(center, "a point-source centre")
         if sed.prior is not None:
             raise NotImplementedError("a prior on the spectrum of a point source")
@@ -361,7 +365,8 @@ class Blend(CombinedComponent):
             boxsize=morphology.bbox.shape[-1],
             sed_min_step=np.maximum(np.asarray(s_min, dtype=np.float64), s_const),
             sed_rel_step=s_rel, center_step=c_const, center_rel_step=c_rel,
-            origin=morphology.bbox.origin[-2:])
+            origin=morphology.bbox.origin[-2:],
+            psf_beta=float(psf.get_parameter(1)[0]) if moffat else 0.0)
         # Parameter(fixed=True): zero gradient for that parameter (blend.py:107-115)
         spec.prox_flags |= (_lib.COMPONENT_FIXED_SED if sed.fixed else 0) | (
             _lib.COMPONENT_FIXED_MORPH if center.fixed else 0)

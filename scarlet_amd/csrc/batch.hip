@@ -211,7 +211,7 @@ struct smi_batch {
     float *g_sed = nullptr, *g_morph = nullptr;
     // point sources: {offset, m, v, vhat} x (y, x) per component, gradient, PSF sigma
     double *pt = nullptr, *g_center = nullptr;
-    float *c_sigma = nullptr;
+    float *c_sigma = nullptr, *c_beta = nullptr;
     int n_point = 0;
     std::vector<double> box_center;  // mean of the box bounds per component (y, x)
     std::vector<char> is_point;
@@ -343,6 +343,7 @@ void refresh_view(smi_batch *b) {
     v.n_point = b->n_point;
     v.pt = b->pt;
     v.c_sigma = b->c_sigma;
+    v.c_beta = b->c_beta;
     v.n_shift = b->n_shift;
     v.max_box_side = b->max_box_side;
     v.morph_param = b->morph_param;
@@ -822,7 +823,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->c_flags, b->c_plan, b->c_moff, b->c_sed_min_step, b->c_sed_rel,
                     b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
-                    b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->morph_param,
+                    b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->c_beta, b->morph_param,
                     b->c_shift_step, b->c_shift_rel, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_pos_floor, b->c_bg_level,
                     b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out, b->it_base,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans, b->work_items};
@@ -1542,7 +1543,7 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
     // point sources: offset of the centre from the mean of the box bounds
     // (morphology.py:503-507), moments zero
     std::vector<double> pt((size_t)n * 8, 0.0);
-    std::vector<float> sigma(n, 0.f);
+    std::vector<float> sigma(n, 0.f), beta(n, 0.f);
     b->box_center.assign((size_t)n * 2, 0.0);
     b->is_point.assign((size_t)n, 0);
     b->n_point = 0;
@@ -1591,9 +1592,14 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
         pt[8 * k] = c->center[2 * k] - b->box_center[2 * k];
         pt[8 * k + 1] = c->center[2 * k + 1] - b->box_center[2 * k + 1];
         sigma[k] = c->psf_sigma[k];
+        if (c->psf_beta) {
+            SMI_REQUIRE(c->psf_beta[k] >= 0.f, "point source with psf_beta < 0");
+            beta[k] = c->psf_beta[k];
+        }
     }
     if ((rc = upload(&b->pt, pt.data(), pt.size()))) return rc;
     if ((rc = upload(&b->c_sigma, sigma.data(), (size_t)n))) return rc;
+    if ((rc = upload(&b->c_beta, beta.data(), (size_t)n))) return rc;
     if (b->g_center) SMI_HIP(hipFree(b->g_center));
     SMI_HIP(dev_alloc(&b->g_center, (size_t)n * 2 + 2));  // never empty: a batch may hold no component
     SMI_HIP(hipMemset(b->g_center, 0, ((size_t)n * 2 + 2) * sizeof(double)));

@@ -240,6 +240,7 @@ struct BatchView {
     int32_t n_point;
     double *pt;
     const float *c_sigma;
+    const float *c_beta;  // > 0: Moffat profile with alpha = c_sigma (point_source_kernel)
     // free Fourier shifts (shift.hip): pt holds {shift y, x, m, v, vhat}; `morph` is the
     // shifted image the model uses, `morph_param` the image parameter; the update
     // kernels read the pulled-back gradient from g_morph_buf / g_sed_buf

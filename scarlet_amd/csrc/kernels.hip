@@ -963,6 +963,21 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
     double off_y = pt[0], off_x = pt[1];
     const float inv_w = 1.0f / (float)c.w;
     int bad = 0;
+    // MoffatPSF (psf.py:145-202): A = (1 + r^2 / alpha^2)^-beta at the pixel centres, not
+    // separable; d A / d centre_y = 2 beta Y / alpha^2 (1 + r^2 / alpha^2)^(-beta - 1)
+    const double beta = (double)v.c_beta[c.k];
+    const bool moffat = beta > 0.0;
+    const double inv_a2 = 1.0 / (sigma * sigma);
+    auto moffat_at = [&](int i, double &A, double &dAy, double &dAx) {
+        const int y = (int)(((float)i + 0.5f) * inv_w);
+        const int x = i - y * c.w;
+        const double Y = (double)(y - c.h / 2) - off_y, X = (double)(x - c.w / 2) - off_x;
+        const double q = 1.0 + (X * X + Y * Y) * inv_a2;
+        A = pow(q, -beta);
+        const double d = 2.0 * beta * inv_a2 * A / q;
+        dAy = d * Y;
+        dAx = d * X;
+    };
 
     auto profiles = [&](bool with_deriv) {
         // FunctionPSF grid (psf.py:60-66): pixel j sits at j - size // 2
@@ -981,22 +996,44 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
     if (mode != 2) {
         const float g_sed = gather_gradient<64>(v, c, G, us);
         __syncthreads();
-        profiles(true);
-        const double Sy = wave_sum(fy[lane]), Sx = wave_sum(fx[lane]);
-        const double dSy = wave_sum(dfy[lane]), dSx = wave_sum(dfx[lane]);
-        const double S = Sy * Sx;
         double gy = 0.0, gx = 0.0;
-        for (int i = lane; i < N; i += 64) {
-            const int y = (int)(((float)i + 0.5f) * inv_w);
-            const int x = i - y * c.w;
-            const double A = fy[y] * fx[x];
-            const double d_y = dfy[y] * fx[x] / S - A * (dSy * Sx) / (S * S);
-            const double d_x = fy[y] * dfx[x] / S - A * (Sy * dSx) / (S * S);
-            gy += (double)us[i] * d_y;
-            gx += (double)us[i] * d_x;
+        if (moffat) {
+            // morph = A / S: g . d morph = (sum g dA) / S - (sum g A) (sum dA) / S^2
+            double S = 0.0, dSy = 0.0, dSx = 0.0, gA = 0.0;
+            for (int i = lane; i < N; i += 64) {
+                double A, dAy, dAx;
+                moffat_at(i, A, dAy, dAx);
+                const double g = (double)us[i];
+                S += A;
+                dSy += dAy;
+                dSx += dAx;
+                gA += g * A;
+                gy += g * dAy;
+                gx += g * dAx;
+            }
+            S = wave_sum(S);
+            dSy = wave_sum(dSy);
+            dSx = wave_sum(dSx);
+            gA = wave_sum(gA);
+            gy = wave_sum(gy) / S - gA * dSy / (S * S);
+            gx = wave_sum(gx) / S - gA * dSx / (S * S);
+        } else {
+            profiles(true);
+            const double Sy = wave_sum(fy[lane]), Sx = wave_sum(fx[lane]);
+            const double dSy = wave_sum(dfy[lane]), dSx = wave_sum(dfx[lane]);
+            const double S = Sy * Sx;
+            for (int i = lane; i < N; i += 64) {
+                const int y = (int)(((float)i + 0.5f) * inv_w);
+                const int x = i - y * c.w;
+                const double A = fy[y] * fx[x];
+                const double d_y = dfy[y] * fx[x] / S - A * (dSy * Sx) / (S * S);
+                const double d_x = fy[y] * dfx[x] / S - A * (Sy * dSx) / (S * S);
+                gy += (double)us[i] * d_y;
+                gx += (double)us[i] * d_x;
+            }
+            gy = wave_sum(gy);
+            gx = wave_sum(gx);
         }
-        gy = wave_sum(gy);
-        gx = wave_sum(gx);
         if (mode == 1) {
             if (lane < c.C) g_sed_out[(int64_t)c.k * c.C + lane] = g_sed;
             if (lane == 0) {
@@ -1040,17 +1077,23 @@ __global__ __launch_bounds__(64) void point_source_kernel(BatchView v, const flo
         }
         bad |= !isfinite(off_y) || !isfinite(off_x);
     }
-    // morphology at the (new) centre: outer product / its sum (psf.py:104-126)
-    profiles(false);
-    double part = 0.0;
-    for (int i = lane; i < N; i += 64) {
+    // morphology at the (new) centre: outer product / its sum (psf.py:104-126), or the
+    // Moffat profile / its sum (psf.py:176-202)
+    if (!moffat) profiles(false);
+    auto value = [&](int i) {
+        if (moffat) {
+            double A, dAy, dAx;
+            moffat_at(i, A, dAy, dAx);
+            return A;
+        }
         const int y = (int)(((float)i + 0.5f) * inv_w);
-        part += fy[y] * fx[i - y * c.w];
-    }
+        return fy[y] * fx[i - y * c.w];
+    };
+    double part = 0.0;
+    for (int i = lane; i < N; i += 64) part += value(i);
     const double total = wave_sum(part);
     for (int i = lane; i < N; i += 64) {
-        const int y = (int)(((float)i + 0.5f) * inv_w);
-        const float z = (float)(fy[y] * fx[i - y * c.w] / total);
+        const float z = (float)(value(i) / total);
         v.morph[c.moff + i] = z;
         bad |= !isfinite(z);
     }

@@ -51,12 +51,15 @@ def point_scene(g, dtype64=False):
     from oracle import pgm
 
     tag = "f64_" if dtype64 else ""
+    # model PSF: GaussianPSF(0.9), or MoffatPSF(alpha, beta, boxsize=15) (point_source_moffat)
+    psf = dict(sigma=0.9) if "moffat" not in g else dict(
+        sigma=float(g["moffat"][0]), beta=float(g["moffat"][1]), boxsize=15)
     comps = []
     for k in range(int(g["n_src"])):
         sed = g["%ssed_%d" % (tag, k)].copy()
         if g["is_star"][k]:
-            comps.append(pgm.PointComponent(sed, g["%scenter_%d" % (tag, k)], 0.9,
-                                            sed_min_step=g["min_step_%d" % k]))
+            comps.append(pgm.PointComponent(sed, g["%scenter_%d" % (tag, k)],
+                                            sed_min_step=g["min_step_%d" % k], **psf))
         else:
             comps.append(pgm.Component(sed, g["%smorph_%d" % (tag, k)].copy(),
                                        g["%sorigin_%d" % (tag, k)],

@@ -212,17 +212,20 @@ def test_fit_forwards_adam_constants(hsc):
         blend.fit(2, no_such_option=1)
 
 
-def test_point_source_tutorial_scene():
+@pytest.mark.parametrize("scene", ["point_source", "point_source_moffat"])
+def test_point_source_tutorial_scene(scene):
     """docs/tutorials/point_source.ipynb through the facade: PointSource /
     ExtendedSource initialisation reproduces the reference's sources (golden), the
-    fit follows the oracle (centres of the stars are free parameters)."""
+    fit follows the oracle (centres of the stars are free parameters); also on a MoffatPSF
+    model PSF (source.py:92-128 takes any ``frame.psf``)."""
     import scarlet_amd as scarlet
     from conftest import golden, point_scene
 
-    g = golden("point_source")
+    g = golden(scene)
     images = g["images"]
     filters = list("ugrizy")
-    model_psf = scarlet.GaussianPSF(sigma=0.9)
+    model_psf = scarlet.GaussianPSF(sigma=0.9) if "moffat" not in g else \
+        scarlet.MoffatPSF(alpha=g["moffat"][0], beta=g["moffat"][1], boxsize=15)
     frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters)
     obs = scarlet.Observation(images, psf=scarlet.ImagePSF(g["psfs"].copy()),
                               weights=np.ones_like(images) / 4, channels=filters).match(frame)

@@ -1498,12 +1498,17 @@ def test_kernel_shift_on_the_device(amd, hsc):
 
 
 # ---------------------------------------------------------------- point sources
+POINT_SCENES = ["point_source", "point_source_moffat"]  # GaussianPSF / MoffatPSF model PSF
+
+
 def _point_batch(amd, g, **kw):
+    psf = dict(psf_sigma=0.9) if "moffat" not in g else dict(
+        psf_sigma=float(g["moffat"][0]), psf_beta=float(g["moffat"][1]), boxsize=15)
     specs = []
     for k in range(int(g["n_src"])):
         if g["is_star"][k]:
-            specs.append(amd.PointSourceSpec(g["sed_%d" % k], g["center_%d" % k], 0.9,
-                                             sed_min_step=g["min_step_%d" % k]))
+            specs.append(amd.PointSourceSpec(g["sed_%d" % k], g["center_%d" % k],
+                                             sed_min_step=g["min_step_%d" % k], **psf))
         else:
             specs.append(amd.ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
                                            sed_min_step=g["min_step_%d" % k]))
@@ -1511,14 +1516,15 @@ def _point_batch(amd, g, **kw):
     return amd.BlendBatch(g["images"][None], w[None], [specs], kernel=g["diff_kernel"], **kw)
 
 
+@pytest.mark.parametrize("scene", POINT_SCENES)
 @pytest.mark.parametrize("path", PATHS)
-def test_point_source_scene_forward_and_gradient(amd, path):
+def test_point_source_scene_forward_and_gradient(amd, path, scene):
     """docs/tutorials/point_source.ipynb scene (3 PointSources + 2 ExtendedSources):
     PSF morphologies, model, rendered image and logL against the reference's golden
     values; gradients (centres included) against the oracle"""
     from conftest import point_scene
 
-    g = golden("point_source")
+    g = golden(scene)
     batch = _point_batch(amd, g, max_iter=4, conv_path=path)
     sc = point_scene(g)
     _, morphs = batch.parameters()
@@ -1544,12 +1550,13 @@ def test_point_source_scene_forward_and_gradient(amd, path):
             assert np.abs(g_morph[k] - grads[k][1]).max() < 2e-5 * np.abs(grads[k][1]).max() + 1e-3, k
 
 
+@pytest.mark.parametrize("scene", POINT_SCENES)
 @pytest.mark.parametrize("path", PATHS)
-def test_point_source_scene_steps(amd, path):
+def test_point_source_scene_steps(amd, path, scene):
     """12 full iterations of the mixed scene: losses, spectra, centres, morphologies"""
     from conftest import point_scene
 
-    g = golden("point_source")
+    g = golden(scene)
     n_it = 12
     batch = _point_batch(amd, g, max_iter=n_it + 1, conv_path=path)
     sc = point_scene(g)
@@ -1613,14 +1620,15 @@ def test_config3_whole_fits_follow_the_oracle(amd):
         assert -losses[i][-1] == logL[i]
 
 
+@pytest.mark.parametrize("scene", POINT_SCENES)
 @pytest.mark.parametrize("path", PATHS)
-def test_point_source_scene_whole_fit_follows_the_oracle(amd, path):
+def test_point_source_scene_whole_fit_follows_the_oracle(amd, path, scene):
     """BASELINE configs[3] (per-band difference kernel, three free point-source centres, two
     extended sources in 71^2 / 81^2 boxes) to convergence against the oracle: same stopping
     iteration, final chi^2 within 1e-5."""
     from conftest import point_scene
 
-    g = golden("point_source")
+    g = golden(scene)
     batch = _point_batch(amd, g, max_iter=100, conv_path=path)
     n_iter, logL = batch.fit(max_iter=100, e_rel=1e-4)
     loss = batch.loss_history()[0]

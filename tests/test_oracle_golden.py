@@ -295,13 +295,15 @@ def test_psf_unmatched_golden():
     assert_allclose(sc.log_likelihood(rendered), g["logL"], rtol=1e-6)
 
 
-def test_point_source_scene_golden():
-    """docs/tutorials/point_source.ipynb scene built by the reference: PSF morphology
-    at a sub-pixel centre (bit-exact), model, rendered image, logL, and the gradient
-    (centres included) against finite differences of the reference's forward."""
+@pytest.mark.parametrize("name", ["point_source", "point_source_moffat"])
+def test_point_source_scene_golden(name):
+    """docs/tutorials/point_source.ipynb scene built by the reference (on its GaussianPSF
+    model PSF, and on a MoffatPSF): PSF morphology at a sub-pixel centre (bit-exact), model,
+    rendered image, logL, and the gradient (centres included) against finite differences of
+    the reference's forward."""
     from conftest import point_scene
 
-    g = golden("point_source")
+    g = golden(name)
     sc = point_scene(g)
     for k, c in enumerate(sc.components):
         assert tuple(c.origin) == tuple(g["origin_%d" % k])
