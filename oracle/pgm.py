@@ -161,9 +161,15 @@ class PointComponent:
     symmetric = False
 
     def __init__(self, sed, center, sigma, boxsize=None, sed_min_step=0.0, center_step=3e-2,
-                 sed_zero=1e-20, center_rel_step=0.0, beta=0.0):
+                 sed_zero=1e-20, center_rel_step=0.0, beta=0.0, image=None):
         self.sed = sed
         self.center = np.array(center, dtype=np.float64)
+        # image: ImagePSF model PSF (psf.py:205-234): the stored image Fourier-shifted by the
+        # offset (fft.shift, fft.py:399-428) -- `sigma` is not used then
+        self.image = None if image is None else np.asarray(image, dtype=np.float64)
+        if image is not None:
+            assert self.image.ndim == 2 and self.image.shape[0] == self.image.shape[1]
+            boxsize, sigma = self.image.shape[0], 0.0
         self.sigma = float(sigma)
         # beta > 0: MoffatPSF(alpha=sigma, beta) instead of the Gaussian (psf.py:145-202)
         self.beta = float(beta)
@@ -195,6 +201,9 @@ class PointComponent:
     def morph(self):
         """``GaussianPSF.get_model(offset=)`` for a band-independent sigma
         (psf.py:97-126): separable profile, normalised to unit sum."""
+        if self.image is not None:
+            offset = self.center - (np.array(self.origin) + self.size / 2)
+            return fftconv.fourier_shift(self.image, offset)
         Y, X = self._axes()
         if self.beta > 0:  # MoffatPSF._f (psf.py:200-202), sampled at the pixel centres
             image = (1 + (X[None, :] ** 2 + Y[:, None] ** 2) / self.sigma**2) ** -self.beta
@@ -207,6 +216,9 @@ class PointComponent:
 
     def center_gradient(self, g_morph):
         """Chain rule d(-logL)/d(center) = sum_yx g_morph * d(morph)/d(center)."""
+        if self.image is not None:
+            offset = self.center - (np.array(self.origin) + self.size / 2)
+            return fftconv.ShiftOperator(self.image.shape, offset).shift_gradient(self.image, g_morph)
         Y, X = self._axes()
         if self.beta > 0:
             # A = q^-beta with q = 1 + r^2 / alpha^2; d A / d center = -d A / d (grid - offset)

@@ -456,7 +456,13 @@ def point_source_moffat(scarlet):
     point_source(scarlet, moffat=(1.6, 2.5))
 
 
-def point_source(scarlet, moffat=None):
+def point_source_image(scarlet):
+    """The point-source tutorial scene on an ImagePSF model PSF (psf.py:205-234): the stored
+    image is Fourier-shifted to the centre."""
+    point_source(scarlet, image=True)
+
+
+def point_source(scarlet, moffat=None, image=False):
     """docs/tutorials/point_source.ipynb: psf_unmatched_sim scene, stars as
     PointSource, galaxies as ExtendedSource; state up to the first gradient."""
     d = np.load("/root/reference/data/psf_unmatched_sim.npz")
@@ -467,6 +473,11 @@ def point_source(scarlet, moffat=None):
     def build(dtype):
         model_psf = scarlet.GaussianPSF(sigma=0.9) if moffat is None else \
             scarlet.MoffatPSF(alpha=moffat[0], beta=moffat[1], boxsize=15)
+        if image:  # a slightly elliptical, off-centre stamp: nothing a profile could stand for
+            yy, xx = np.mgrid[-7:8, -7:8].astype(np.float64)
+            stamp = np.exp(-((yy - 0.2) ** 2 / (2 * 1.0**2) + (xx + 0.1) ** 2 / (2 * 1.2**2)))
+            stamp += 0.05 * (1 + (yy**2 + xx**2) / 4.0) ** -1.5
+            model_psf = scarlet.ImagePSF(stamp)
         frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters, dtype=dtype)
         obs = scarlet.Observation(
             images, psf=scarlet.ImagePSF(psfs), weights=weights, channels=filters
@@ -538,6 +549,9 @@ def point_source(scarlet, moffat=None):
     if moffat is not None:
         out["moffat"] = np.array(moffat)
         name = "point_source_moffat"
+    if image:
+        out["psf_image"] = np.array(model_psf.get_model()[0], dtype=np.float64)
+        name = "point_source_image"
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("%s: %d sources, logL=%.3f" % (name, len(sources), out["logL"]))
 
@@ -639,7 +653,7 @@ def main(which=None):
     os.makedirs(OUT, exist_ok=True)
     jobs = dict(
         operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
-        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, point_source_moffat=point_source_moffat, hsc_shifting=hsc_shifting, lite=lite,
+        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, point_source_moffat=point_source_moffat, point_source_image=point_source_image, hsc_shifting=hsc_shifting, lite=lite,
         hsc_psf_shift=hsc_psf_shift,
         synthetic_cfg2=synthetic_cfg2, init_synthetic=init_synthetic,
     )

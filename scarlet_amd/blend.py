@@ -24,7 +24,7 @@ from .hoststep import HostParameter
 from .model import UpdateException
 from .model import Model
 from .morphology import ImageMorphology, Morphology, PointSourceMorphology, _edge_pull
-from .psf import GaussianPSF, MoffatPSF
+from .psf import GaussianPSF, ImagePSF, MoffatPSF
 from .parameter import Parameter, relative_step, STD_FROM_V
 from .renderer import ConvolutionRenderer, NullRenderer, ResolutionRenderer
 
@@ -347,10 +347,16 @@ class Blend(CombinedComponent):
         psf = morphology.psf
         moffat = isinstance(psf, MoffatPSF) and psf.is_same and \
             bool(np.all(psf.get_parameter(1) == psf.get_parameter(1)[0]))
-        if not (moffat or (isinstance(psf, GaussianPSF) and psf.integrate and psf.is_same)):
+        stamp = None
+        if isinstance(psf, ImagePSF):
+            cube = np.asarray(psf.get_parameter(0))
+            if np.all(cube == cube[0]):
+                stamp = cube[0]
+        if stamp is None and not (
+                moffat or (isinstance(psf, GaussianPSF) and psf.integrate and psf.is_same)):
             raise NotImplementedError(
-                "point sources need a pixel-integrated GaussianPSF or a MoffatPSF model PSF, "
-                "the same in all bands")
+                "point sources need a pixel-integrated GaussianPSF, a MoffatPSF or an ImagePSF "
+                "model PSF, the same in all bands")
         _plain_2vector(center, "a point-source centre")
         if sed.prior is not None:
             raise NotImplementedError("a prior on the spectrum of a point source")
@@ -360,6 +366,21 @@ class Blend(CombinedComponent):
         c_const, c_rel, c_low = (0.0, 0.0, 0.0) if center.fixed and center.step is None else \
             _step_rule(center.step, "center")
         c_const = max(c_const, float(np.max(c_low)))  # (relative_step: max(minimum, factor * mean))
+        if stamp is not None:
+            # ImagePSF.get_model(offset) is fft.shift of the stored image (psf.py:228-234): on
+            # the device a component with a fixed image and a free Fourier shift -- the offset of
+            # the centre from the mean of the box bounds (morphology.py:503-507)
+            if c_rel:
+                raise NotImplementedError("relative_step on the centre of a point source on an ImagePSF")
+            origin = morphology.bbox.origin[-2:]
+            box_center = np.array(origin, dtype=np.float64) + np.array(stamp.shape) / 2
+            return ComponentSpec(
+                np.asarray(sed), stamp, origin,
+                sed_min_step=np.maximum(np.asarray(s_min, dtype=np.float64), s_const),
+                sed_rel_step=s_rel, morph_step=0.0,
+                prox_flags=_lib.COMPONENT_FIXED_MORPH | (_lib.COMPONENT_FIXED_SED if sed.fixed else 0),
+                shift=np.asarray(center, dtype=np.float64) - box_center,
+                shift_step=0.0 if center.fixed else c_const)
         spec = PointSourceSpec(
             np.asarray(sed), np.asarray(center), float(psf.get_parameter(0)[0]),
             boxsize=morphology.bbox.shape[-1],
@@ -470,6 +491,9 @@ class Blend(CombinedComponent):
                 if centers is None:
                     centers = batch.centers()
                 image[...] = centers["center"][k]
+                if batch.has_shift(k):  # on an ImagePSF: the device holds the offset (_point_spec)
+                    bbox = morphology.bbox
+                    image += np.array(bbox.origin[-2:]) + np.array(bbox.shape[-2:]) / 2
                 image.m, image.v, image.vhat = (centers[n][k].copy() for n in ("m", "v", "vhat"))
                 continue
             if batch.has_shift(k):

@@ -54,6 +54,8 @@ def point_scene(g, dtype64=False):
     # model PSF: GaussianPSF(0.9), or MoffatPSF(alpha, beta, boxsize=15) (point_source_moffat)
     psf = dict(sigma=0.9) if "moffat" not in g else dict(
         sigma=float(g["moffat"][0]), beta=float(g["moffat"][1]), boxsize=15)
+    if "psf_image" in g:  # ImagePSF
+        psf = dict(sigma=0.0, image=g["psf_image"])
     comps = []
     for k in range(int(g["n_src"])):
         sed = g["%ssed_%d" % (tag, k)].copy()

@@ -212,7 +212,7 @@ def test_fit_forwards_adam_constants(hsc):
         blend.fit(2, no_such_option=1)
 
 
-@pytest.mark.parametrize("scene", ["point_source", "point_source_moffat"])
+@pytest.mark.parametrize("scene", ["point_source", "point_source_moffat", "point_source_image"])
 def test_point_source_tutorial_scene(scene):
     """docs/tutorials/point_source.ipynb through the facade: PointSource /
     ExtendedSource initialisation reproduces the reference's sources (golden), the
@@ -226,6 +226,8 @@ def test_point_source_tutorial_scene(scene):
     filters = list("ugrizy")
     model_psf = scarlet.GaussianPSF(sigma=0.9) if "moffat" not in g else \
         scarlet.MoffatPSF(alpha=g["moffat"][0], beta=g["moffat"][1], boxsize=15)
+    if "psf_image" in g:
+        model_psf = scarlet.ImagePSF(g["psf_image"].copy())
     frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters)
     obs = scarlet.Observation(images, psf=scarlet.ImagePSF(g["psfs"].copy()),
                               weights=np.ones_like(images) / 4, channels=filters).match(frame)

@@ -1578,6 +1578,72 @@ def test_point_source_scene_steps(amd, path, scene):
                for k, c in enumerate(sc.components) if g["is_star"][k]) > 1e-3
 
 
+@pytest.mark.parametrize("path", PATHS)
+def test_point_sources_on_an_image_psf(amd, path):
+    """PointSource on an ImagePSF model PSF (psf.py:205-234: the stored image Fourier-shifted
+    to the centre): on the device a component with a fixed image and a free Fourier shift =
+    centre - mean(box bounds).  Shifted stamps, model, rendered image and logL against the
+    reference's golden values; gradients (centres included) and twelve full iterations against
+    the oracle; the whole fit stops where the oracle's does."""
+    from conftest import point_scene
+
+    g = golden("point_source_image")
+    stars = np.flatnonzero(g["is_star"])
+    stamp = g["psf_image"].astype(np.float32)
+    box_center = {k: np.asarray(g["origin_%d" % k], dtype=np.float64) + stamp.shape[0] / 2 for k in stars}
+
+    def batch_of(**kw):
+        specs = []
+        for k in range(int(g["n_src"])):
+            if g["is_star"][k]:
+                specs.append(amd.ComponentSpec(
+                    g["sed_%d" % k], stamp, g["origin_%d" % k], sed_min_step=g["min_step_%d" % k],
+                    morph_step=0.0, prox_flags=amd._lib.COMPONENT_FIXED_MORPH,
+                    shift=g["center_%d" % k] - box_center[k], shift_step=3e-2))
+            else:
+                specs.append(amd.ComponentSpec(g["sed_%d" % k], g["morph_%d" % k], g["origin_%d" % k],
+                                               sed_min_step=g["min_step_%d" % k]))
+        w = np.full(g["images"].shape, 0.25, dtype=np.float32)
+        return amd.BlendBatch(g["images"][None], w[None], [specs], kernel=g["diff_kernel"],
+                              conv_path=path, **kw)
+
+    batch = batch_of(max_iter=13)
+    sc = point_scene(g)
+    shifted = batch.model_morphologies()
+    for k in stars:
+        assert np.abs(shifted[k] - g["morph_%d" % k]).max() < 2e-7
+    model, rendered, logL = batch.forward()
+    assert rel_err(model[0], g["model"]) < RTOL
+    assert rel_err(rendered[0], g["rendered"]) < RTOL
+    assert abs(logL[0] - float(g["logL"])) < RTOL * abs(float(g["logL"]))
+    g_sed, g_morph = batch.gradient()
+    g_center = batch.centers()["gradient"]
+    _, grads = sc.loss_and_gradients()
+    sc.loss.clear()
+    for k, c in enumerate(sc.components):
+        assert np.abs(g_sed[k] - grads[k][0]).max() < 2e-5 * max(np.abs(grads[k][0]).max(), 1.0), k
+        got = g_center[k] if g["is_star"][k] else g_morph[k]
+        assert np.abs(got - grads[k][1]).max() < 2e-5 * np.abs(grads[k][1]).max() + 1e-3, k
+    n_it = 12
+    batch.step(0, n_it, e_rel=1e-4)
+    for it in range(n_it):
+        sc.step(it, 1e-4)
+    assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm, rtol=1e-4)
+    sed, _ = batch.parameters()
+    ctr = batch.centers()
+    for k, c in enumerate(sc.components):
+        assert rel_err(sed[k], c.sed) < 5e-4, k
+        if g["is_star"][k]:
+            assert np.abs(ctr["center"][k] + box_center[k] - c.center).max() < 1e-4, k
+            assert_allclose(ctr["vhat"][k], c.vhat_center, rtol=2e-3)
+    assert max(np.abs(sc.components[k].center - g["center_%d" % k]).max() for k in stars) > 1e-3
+    batch.close()
+    whole = batch_of(max_iter=100)
+    n_iter, _ = whole.fit(max_iter=100, e_rel=1e-4)
+    _whole_fit_against_oracle(whole.loss_history()[0], n_iter[0], point_scene(g), 1e-4)
+    whole.close()
+
+
 def _whole_fit_against_oracle(loss, n_iter, sc, e_rel, early=2e-5, whole=5e-4, final=RTOL):
     """same stopping iteration; chi^2 within `early` over the first twelve iterations, `whole`
     through any transient, `final` (north_star's 1e-5) for the result of the fit"""

@@ -295,7 +295,7 @@ def test_psf_unmatched_golden():
     assert_allclose(sc.log_likelihood(rendered), g["logL"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["point_source", "point_source_moffat"])
+@pytest.mark.parametrize("name", ["point_source", "point_source_moffat", "point_source_image"])
 def test_point_source_scene_golden(name):
     """docs/tutorials/point_source.ipynb scene built by the reference (on its GaussianPSF
     model PSF, and on a MoffatPSF): PSF morphology at a sub-pixel centre (bit-exact), model,
