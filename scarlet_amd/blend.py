@@ -151,7 +151,9 @@ class Blend(CombinedComponent):
                                kernels=[None] * C, taken=np.zeros(C, dtype=bool)))
             return layers[-1]
 
-        for obs in self.observations:
+        # (the observation whose kernel carries a free psf_shift becomes the first layer: that
+        # is the one the device moves, smi_batch_set_kernel_shift)
+        for obs in sorted(self.observations, key=lambda o: all(p.fixed for p in o.parameters)):
             r = obs.renderer
             idx = [channels.index(c) for c in obs.channels]
             if type(r) is ResolutionRenderer:
@@ -651,9 +653,11 @@ class Blend(CombinedComponent):
         """``(shift parameter, renderer)`` of the one observation whose
         ``ConvolutionRenderer(psf_shift=...)`` carries the free sub-pixel shift of the
         difference kernel (renderer.py:175-177, 215-228)."""
-        if len(self.observations) != 1:
-            raise NotImplementedError("psf_shift with several observations")
-        obs = self.observations[0]
+        free = [o for o in self.observations if any(not p.fixed for p in o.parameters)]
+        if len(free) != 1:
+            # (one set of kernels moves on the device: the first observation's)
+            raise NotImplementedError("free psf_shifts of several observations")
+        obs = free[0]
         renderer = obs.renderer
         shift = renderer.get_parameter("psf_shift")
         if [id(p) for p in obs.parameters] != [id(shift)] or type(renderer) is not ConvolutionRenderer:
@@ -676,6 +680,9 @@ class Blend(CombinedComponent):
         ``d(-logL)/d(shift) = sum w (m - d) (model (*) dK/ds)``; the shift then takes its
         unconstrained AMSGrad step (step 1e-2) on the host."""
         shift, renderer = self._free_psf_shift()
+        if len(self.observations) != 1:
+            raise NotImplementedError(
+                "a free psf_shift with several observations on a frame beyond the fused convolution")
         obs = self.observations[0]
         alpha0, rel = self._psf_step, self._psf_rel
         self._psf = None  # _specs / _download: no device-side shift in this mode

@@ -1129,7 +1129,9 @@ int smi_batch_set_kernel_shift(smi_batch *b, const float *kernel, int32_t h0, in
     SMI_REQUIRE(b && kernel && fft_shape && shift, "null argument");
     SMI_REQUIRE(b->fused, "a free kernel shift needs the fused convolution path");
     SMI_REQUIRE(b->have_components && b->have_obs, "set the observation and the components first");
-    SMI_REQUIRE(b->layers.empty() && b->lowres.empty(), "a free kernel shift with several observations");
+    // (further observations on the model's grid keep their fixed kernels: the free shift belongs
+    // to the first observation's)
+    SMI_REQUIRE(b->lowres.empty(), "a free kernel shift next to a low-resolution observation");
     SMI_REQUIRE(b->d.kernel_per_blend || b->d.n_blends == 1,
                 "a free kernel shift belongs to one blend: use per-blend kernels");
     const int ph = b->d.kernel_h, pw = b->d.kernel_w;
@@ -1304,7 +1306,7 @@ int smi_batch_add_observation(smi_batch *b, const float *data, const float *weig
     SMI_REQUIRE(b && data && weights && kernel, "null argument");
     SMI_REQUIRE(b->have_obs && b->have_kernel, "add the first observation and its kernel first");
     SMI_REQUIRE(b->fused, "further observations need the fused convolution path");
-    SMI_REQUIRE(!b->ks.stamp, "a free kernel shift with several observations");
+    // (a free kernel shift stays with the first observation: smi_batch_set_kernel_shift)
     SMI_HIP(hipSetDevice(b->device));
     SMI_HIP(hipStreamSynchronize(b->stream));
     const int nb = b->d.n_blends, C = b->d.C;
@@ -1325,11 +1327,22 @@ int smi_batch_add_observation(smi_batch *b, const float *data, const float *weig
     if ((rc = interleave_observation(b, layer.data, layer.weights, &layer.dw))) return rc;
     g_observation_uploads.fetch_add(1);
     // kernel spectrum: the routine of smi_batch_set_kernel, into a buffer of its own
+    // (smi_batch_set_kernel makes the batch's kernel a fixed one: the first observation's free
+    // shift steps aside for the call)
     float2 *first = b->Kt;
     b->Kt = nullptr;
+    const smi::KernelShiftView ks = b->ks;
+    float *ks_resid = b->ks_resid;
+    auto *ks_tmp = b->ks_tmp;
+    b->ks = smi::KernelShiftView{};
+    b->ks_resid = nullptr;
+    b->ks_tmp = nullptr;
     rc = smi_batch_set_kernel(b, kernel);
     layer.Kt = b->Kt;
     b->Kt = first;
+    b->ks = ks;
+    b->ks_resid = ks_resid;
+    b->ks_tmp = ks_tmp;
     if (rc) return rc;
     // log_norm of the layer joins the blend's (observation.py:172-186)
     if (b->include_log_norm) {

@@ -1505,6 +1505,82 @@ def test_two_observations_of_the_same_channels(hsc):
     assert abs(alone.loss[0] - blend.loss[0]) > 1e-3 * abs(blend.loss[0])
 
 
+def test_free_psf_shift_next_to_a_second_observation(hsc):
+    """Blend.fit collects the parameters of ALL observations (blend.py:103-105): an observation
+    whose ConvolutionRenderer carries a free ``psf_shift`` next to a second exposure of three of
+    the bands.  On the device the shifted observation is the first layer (its kernel moves,
+    ``smi_batch_set_kernel_shift``), the other one a further term of the loss
+    (``smi_batch_add_observation``); whichever order the user lists them in.  Against the
+    oracle: losses, the shift, its moments."""
+    import scarlet_amd as scarlet
+    from scarlet_amd.renderer import ConvolutionRenderer
+    from conftest import golden
+    from oracle import pgm
+
+    gp = golden("hsc_psf_shift")
+    filters = list("grizy")
+    frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5),
+                          channels=filters)
+    rng = np.random.default_rng(11)
+    images2 = (hsc["images"][:3] * 0.9 + rng.normal(0, 0.05, hsc["images"][:3].shape)).astype(np.float32)
+    weights2 = (hsc["weights"][:3] * rng.uniform(0.3, 0.6, hsc["weights"][:3].shape)).astype(np.float32)
+    psfs2 = scarlet.GaussianPSF(sigma=(1.6, 1.7, 1.8), boxsize=31).get_model().astype(np.float32)
+
+    def blend_of(shifted_first):
+        obs1 = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                                   weights=hsc["weights"], channels=filters)
+        obs1.match(frame, renderer=ConvolutionRenderer(obs1, frame, psf_shift=gp["psf_shift"].copy()))
+        obs2 = scarlet.Observation(images2, psf=scarlet.ImagePSF(psfs2), weights=weights2,
+                                   channels=filters[:3]).match(frame)
+        comps = []
+        for k in range(int(hsc["n_comp"])):
+            h, w = hsc["morph_%d" % k].shape
+            oy, ox = hsc["origin_%d" % k]
+            box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+            comps.append(scarlet.FactorizedComponent(
+                frame,
+                scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                          min_step=hsc["min_step_%d" % k]),
+                scarlet.ExtendedSourceMorphology(frame, (oy + h // 2, ox + w // 2),
+                                                 hsc["morph_%d" % k].copy(), bbox=box[1:],
+                                                 resizing=False)))
+        return scarlet.Blend(comps, [obs1, obs2] if shifted_first else [obs2, obs1]), obs1, obs2
+
+    blend, obs1, obs2 = blend_of(True)
+    n, logL = blend.fit(12, e_rel=1e-9)
+    assert n == 12 and blend._psf_stepped_on_device and len(blend._extra_layers) == 1
+
+    sc = hsc_scene(hsc)
+    for c in sc.components:
+        c.source = None
+    sc.psf_shift = gp["psf_shift"].copy()
+    data2 = np.zeros(hsc["images"].shape, dtype=np.float32)
+    w2 = np.zeros(hsc["images"].shape, dtype=np.float32)
+    data2[:3], w2[:3] = images2, weights2
+    k2 = np.asarray(obs2.renderer.kernel_image(), dtype=np.float32)
+    ph = max(k2.shape[1], hsc["diff_kernel"].shape[1]) | 1
+    kernel2 = np.zeros((5, ph, ph), dtype=np.float32)
+    kernel2[:, ph // 2, ph // 2] = 1  # unobserved channels: weight zero, any kernel
+    o = ph // 2 - k2.shape[1] // 2
+    kernel2[:3, o:o + k2.shape[1], o:o + k2.shape[2]] = k2
+    sc.extra_observations = [pgm.SameGridObservation(data2, w2, kernel2)]
+    n_ref, _ = sc.fit(12, e_rel=1e-9)
+    assert n_ref == 12
+    off = sc.log_norm + sc.extra_observations[0].log_norm
+    chi, chi_ref = np.array(blend.loss) - off, np.array(sc.loss) - off
+    assert_allclose(chi[0], chi_ref[0], rtol=RTOL)
+    assert_allclose(chi, chi_ref, rtol=2e-4)
+    shift = obs1.parameters[0]
+    assert np.abs(np.asarray(shift) - sc.psf_shift).max() < 2e-5
+    assert np.abs(np.asarray(shift) - gp["psf_shift"]).max() > 1e-3  # it moved
+    assert_allclose(shift.vhat, sc.vhat_psf, rtol=2e-3)
+    # the order of the observations does not matter
+    other, obs1b, _ = blend_of(False)
+    other.fit(12, e_rel=1e-9)
+    assert_allclose(other.loss, blend.loss, rtol=1e-12)
+    assert_allclose(np.asarray(obs1b.parameters[0]), np.asarray(shift), rtol=0, atol=1e-15)
+
+
 def test_user_defined_linear_renderer_matches_the_device_renderer(hsc):
     """Plug-in seam (SURVEY 8b seam 3): ``Observation.match(frame, renderer=<a Renderer
     subclass>)`` (observation.py:59-112).  A user-written Python renderer -- here the PSF
