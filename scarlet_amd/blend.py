@@ -256,10 +256,10 @@ class Blend(CombinedComponent):
                     # (relative_step, parameter.py:126-129: max(minimum, factor * mean))
                     const, rel, low = _step_rule(shift.step, "shift")
                     const = max(const, float(np.max(low)))
-                    if max(image.shape) > 100:
+                    if max(image.shape) > 240:
                         raise NotImplementedError(
                             "a component with a free Fourier shift is limited to boxes of "
-                            "100 pixels a side on the device (got {})".format(image.shape))
+                            "240 pixels a side on the device (got {})".format(image.shape))
                     shift_kw = dict(shift=np.asarray(shift), shift_step=0.0 if shift.fixed else const,
                                     shift_rel_step=0.0 if shift.fixed else rel)
             if shift_kw and (sed.prior is not None or image.prior is not None):

@@ -217,6 +217,7 @@ struct smi_batch {
     std::vector<char> is_point;
     // free Fourier shifts
     int n_shift = 0, max_box_side = 1, max_box_w = 1;
+    float *shift_scratch = nullptr;  // BatchView::shift_scratch
     bool inline_render = true;  // smi_batch_set_inline_render
     float *morph_param = nullptr, *c_shift_step = nullptr, *c_shift_rel = nullptr;
     int32_t *c_shift_fft = nullptr;
@@ -346,6 +347,7 @@ void refresh_view(smi_batch *b) {
     v.c_beta = b->c_beta;
     v.n_shift = b->n_shift;
     v.max_box_side = b->max_box_side;
+    v.shift_scratch = b->shift_scratch;
     v.morph_param = b->morph_param;
     v.g_sed_buf = b->g_sed;
     v.g_morph_buf = b->g_morph;
@@ -825,7 +827,7 @@ int smi_batch_destroy(smi_batch *b) {
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
                     b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->c_beta, b->morph_param,
                     b->c_shift_step, b->c_shift_rel, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_pos_floor, b->c_bg_level,
-                    b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out, b->it_base,
+                    b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out, b->it_base, b->shift_scratch,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans, b->work_items};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -1438,8 +1440,9 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
             SMI_REQUIRE(c->center, "shifting component without its shift (center)");
             SMI_REQUIRE(!(c->prox_flags[k] & SMI_COMPONENT_POINT_SOURCE),
                         "a point source cannot carry a Fourier shift");
-            SMI_REQUIRE(c->box_h[k] <= 100 && c->box_w[k] <= 100,
-                        "shifting component box larger than 100 pixels");
+            // (the FFT lengths of fft.shift, 2 n + 10 rounded up, must fit the 512-entry tables)
+            SMI_REQUIRE(c->box_h[k] <= 240 && c->box_w[k] <= 240,
+                        "shifting component box larger than 240 pixels");
         }
         if (c->prox_flags[k] & SMI_COMPONENT_POINT_SOURCE) {
             SMI_REQUIRE(c->center && c->psf_sigma, "point source without center / psf_sigma");
@@ -1589,6 +1592,12 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
     if ((rc = upload(&b->c_shift_step, shift_step.data(), (size_t)n))) return rc;
     if ((rc = upload(&b->c_shift_rel, shift_rel.data(), (size_t)n))) return rc;
     if ((rc = upload(&b->c_shift_fft, shift_fft.data(), (size_t)n * 2))) return rc;
+    if (b->shift_scratch) {
+        SMI_HIP(hipFree(b->shift_scratch));
+        b->shift_scratch = nullptr;
+    }
+    if (b->n_shift && shift_needs_scratch(max_pix, b->max_box_side))
+        SMI_HIP(dev_alloc(&b->shift_scratch, 4 * (size_t)b->n_morph + 16 * (size_t)n));
     if (b->n_shift) {
         // the uploaded images are the parameters; `morph` becomes the shifted image
         if ((rc = upload(&b->morph_param, c->morph, (size_t)b->n_morph))) return rc;

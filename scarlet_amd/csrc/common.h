@@ -245,6 +245,9 @@ struct BatchView {
     // shifted image the model uses, `morph_param` the image parameter; the update
     // kernels read the pulled-back gradient from g_morph_buf / g_sed_buf
     int32_t n_shift, max_box_side;
+    // boxes beyond the LDS (more than ~100 x 100 pixels): the four image-sized work arrays of
+    // the shift kernels in global memory, 4 N floats per component at 4 c_moff[k] + 16 k
+    float *shift_scratch;
     float *morph_param;
     float *g_sed_buf, *g_morph_buf;
     const float *c_shift_step;
@@ -316,6 +319,7 @@ int launch_update_finalize(const BatchView &v, const float *G, int32_t it, float
 int launch_point_sources(const BatchView &v, const float *G, int32_t it, float e_rel,
                          int32_t prox_max_iter, float *g_sed_out, double *g_center_out,
                          int32_t mode, hipStream_t s);
+bool shift_needs_scratch(int max_box_pixels, int max_box_side);
 int launch_shift_backward(const BatchView &v, const float *G, int32_t it, double *g_shift_out,
                           int32_t grad_only, hipStream_t s);
 int launch_shift_forward(const BatchView &v, int32_t respect_state, hipStream_t s);

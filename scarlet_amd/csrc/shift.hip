@@ -16,8 +16,8 @@
 //
 // FFT lengths are the reference's (fft.py:116-167 with padding 10): the periodic
 // interpolation kernel depends on them.  Everything is evaluated directly (no FFT):
-// a box has at most ~100 pixels per side and the maps are applied as small dense
-// Toeplitz products out of LDS.
+// the maps are applied as small dense Toeplitz products -- out of LDS for boxes of up to ~100
+// pixels per side, with the image-sized work arrays in global memory beyond (up to 240).
 //
 // shift_backward_kernel: gathers d(-logL)/d(shifted image) over the box, pulls it back
 //   to the image (Dr^T g Tx - Di^T g Hx), forms d/d(shift) with the derivative vectors
@@ -100,7 +100,9 @@ struct ShiftLds {
     double *ct, *st, *cb, *sb, *red;
 };
 
-__device__ __forceinline__ ShiftLds carve(unsigned char *base, int Np, int nvec) {
+// `big`: the four image-sized arrays in global memory instead (a workgroup's own region; the
+// barriers between the phases order its accesses), only the vectors in LDS
+__device__ __forceinline__ ShiftLds carve(unsigned char *base, int Np, int nvec, float *big = nullptr) {
     ShiftLds L;
     double *d = reinterpret_cast<double *>(base);
     L.ct = d;
@@ -109,11 +111,11 @@ __device__ __forceinline__ ShiftLds carve(unsigned char *base, int Np, int nvec)
     L.sb = L.cb + 256;
     L.red = L.sb + 256;
     float *f = reinterpret_cast<float *>(L.red + 8);
-    L.g = f;
+    L.g = big ? big : f;
     L.P = L.g + Np;
     L.Pd = L.P + Np;
     L.xs = L.Pd + Np;
-    L.dr = L.xs + Np;
+    L.dr = big ? f : L.xs + Np;
     L.ddr = L.dr + nvec;
     L.tx = L.ddr + nvec;
     L.hx = L.tx + nvec;
@@ -248,8 +250,9 @@ __global__ __launch_bounds__(kT) void shift_backward_kernel(BatchView v, const f
     const int tid = threadIdx.x;
     const int C = v.C, h = v.c_h[k], w = v.c_w[k], N = h * w, oy = v.c_oy[k], ox = v.c_ox[k];
     const int64_t moff = v.c_moff[k];
-    const int Np = (v.max_box_pixels + 3) & ~3;
-    const ShiftLds L = carve(shift_lds, Np, 2 * v.max_box_side);
+    float *big = v.shift_scratch ? v.shift_scratch + 4 * moff + 16 * k : nullptr;
+    const int Np = ((big ? N : v.max_box_pixels) + 3) & ~3;
+    const ShiftLds L = carve(shift_lds, Np, 2 * v.max_box_side, big);
     const float *shifted = v.morph + moff;
     const float *sed = v.sed + (int64_t)k * C;
     double *pt = v.pt + (int64_t)k * 8;
@@ -310,8 +313,9 @@ __global__ __launch_bounds__(kT) void shift_forward_kernel(BatchView v, int resp
     const int tid = threadIdx.x;
     const int h = v.c_h[k], w = v.c_w[k], N = h * w;
     const int64_t moff = v.c_moff[k];
-    const int Np = (v.max_box_pixels + 3) & ~3;
-    const ShiftLds L = carve(shift_lds, Np, 2 * v.max_box_side);
+    float *big = v.shift_scratch ? v.shift_scratch + 4 * moff + 16 * k : nullptr;
+    const int Np = ((big ? N : v.max_box_pixels) + 3) & ~3;
+    const ShiftLds L = carve(shift_lds, Np, 2 * v.max_box_side, big);
     const double *pt = v.pt + (int64_t)k * 8;
     for (int i = tid; i < N; i += kT) L.xs[i] = v.morph_param[moff + i];
     const double2 by = axis_vectors(v.c_shift_fft[2 * k], h, pt[0], false, false,
@@ -435,11 +439,17 @@ size_t stamp_lds_bytes(const KernelShiftView &ks) {
 }
 
 size_t shift_lds_bytes(const BatchView &v) {
-    const size_t Np = (v.max_box_pixels + 3) & ~3;
+    const size_t Np = v.shift_scratch ? 0 : (v.max_box_pixels + 3) & ~3;
     return (512 * 2 + 256 * 2 + 8) * sizeof(double) + (4 * Np + 9 * 2 * (size_t)v.max_box_side) * sizeof(float);
 }
 
 }  // namespace
+
+bool shift_needs_scratch(int max_box_pixels, int max_box_side) {
+    const size_t Np = (max_box_pixels + 3) & ~3;
+    return (512 * 2 + 256 * 2 + 8) * sizeof(double) +
+               (4 * Np + 9 * 2 * (size_t)max_box_side) * sizeof(float) > 160 * 1024;
+}
 
 static int configure_shift_kernels(size_t lds) {
     static size_t cfg_backward[kMaxDevices] = {}, cfg_forward[kMaxDevices] = {};

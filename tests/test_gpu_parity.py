@@ -1767,6 +1767,71 @@ def test_shifting_scene_steps(amd, hsc, path):
     assert max(np.abs(c.shift - g["shift_%d" % k]).max() for k, c in enumerate(sc.components)) > 1e-2
 
 
+def test_free_shift_on_a_box_beyond_the_lds(amd):
+    """A free Fourier shift (ExtendedSource(shifting=True), morphology.py:124-130, 673-676) on a
+    141 x 141 box: the four image-sized work arrays of the shift kernels no longer fit the LDS
+    and live in global memory.  Shifted image, gradients (image pulled back through the shift,
+    the shift itself) and six iterations against the oracle."""
+    from oracle import pgm
+
+    rng = np.random.default_rng(17)
+    C, H, W, n = 3, 160, 150, 141
+    yy, xx = np.mgrid[:n, :n] - n // 2
+    morph = (np.exp(-(yy**2 / (2 * 14.0**2) + xx**2 / (2 * 9.0**2))) +
+             0.3 * np.exp(-((yy - 20) ** 2 + (xx + 12) ** 2) / (2 * 6.0**2))).astype(np.float32)
+    morph /= morph.max()
+    small = np.exp(-((np.mgrid[:21, :21] - 10) ** 2).sum(axis=0) / (2 * 2.5**2)).astype(np.float32)
+    seds = [np.array([3.0, 2.0, 1.0], dtype=np.float32), np.array([1.0, 1.5, 2.5], dtype=np.float32)]
+    origins = [(8, 4), (90, 100)]
+    shifts = [np.array([0.31, -0.27]), np.array([-0.12, 0.2])]
+    kernel = np.zeros((1, 9, 9), dtype=np.float32)
+    g1 = np.exp(-np.arange(-4, 5) ** 2 / (2 * 1.1**2))
+    kernel[0] = np.outer(g1, g1) / np.outer(g1, g1).sum()
+
+    def scene():
+        comps = [pgm.Component(seds[k].copy(), m.copy(), origins[k], sed_min_step=1e-3,
+                               shift=shifts[k].copy())
+                 for k, m in enumerate((morph, small))]
+        return pgm.Scene((C, H, W), data, weights, kernel, comps)
+
+    data = np.zeros((C, H, W), dtype=np.float32)
+    weights = np.full((C, H, W), 4.0, dtype=np.float32)
+    truth = scene()
+    for c, s in zip(truth.components, ([0.6, -0.5], [0.3, 0.1])):
+        c.shift[:] = s
+    data = (truth.render(truth.get_model()) + rng.normal(0, 0.05, (C, H, W))).astype(np.float32)
+    sc = scene()
+    specs = [amd.ComponentSpec(seds[k], m, origins[k], sed_min_step=1e-3, shift=shifts[k])
+             for k, m in enumerate((morph, small))]
+    batch = amd.BlendBatch(data[None], weights[None], [specs], kernel=kernel, max_iter=8)
+    shifted = batch.model_morphologies()
+    for k, c in enumerate(sc.components):
+        assert np.abs(shifted[k] - c.model_morph()).max() < 2e-6, k
+    model, rendered, logL = batch.forward()
+    assert rel_err(model[0], sc.get_model()) < RTOL
+    g_sed, g_morph = batch.gradient()
+    g_shift = batch.centers()["gradient"]
+    _, grads = sc.loss_and_gradients()
+    sc.loss.clear()
+    for k, (s_sed, s_morph) in enumerate(grad_scales(sc)):
+        assert np.abs(g_sed[k] - grads[k][0]).max() < 2 * RTOL * s_sed, k
+        assert np.abs(g_morph[k] - grads[k][1]).max() < 2 * RTOL * s_morph, k
+        assert np.abs(g_shift[k] - grads[k][2]).max() < 2 * RTOL * s_morph * np.sqrt(grads[k][1].size), k
+    n_it = 6
+    batch.step(0, n_it, e_rel=1e-4)
+    for it in range(n_it):
+        sc.step(it, 1e-4)
+    assert_loss_close(batch.loss_history()[0], sc.loss, sc.log_norm, rtol=2e-4)
+    sed, morphs = batch.parameters()
+    st = batch.centers()
+    for k, c in enumerate(sc.components):
+        assert rel_err(sed[k], c.sed) < 1e-3, k
+        assert np.abs(morphs[k] - c.morph).max() < 2e-3, k
+        assert np.abs(st["center"][k] - c.shift).max() < 2e-3, k
+    assert max(np.abs(c.shift - shifts[k]).max() for k, c in enumerate(sc.components)) > 1e-2
+    batch.close()
+
+
 def test_relative_steps_of_centres_shifts_and_the_kernel_shift(amd, hsc):
     """``relative_step`` (parameter.py:126-129: ``max(minimum, factor * X.mean())``) as the step
     rule of a point-source centre, of a free Fourier shift and of ``psf_shift``: eight
