@@ -24,9 +24,9 @@ class ComponentSpec:
         self.sed = np.asarray(sed, dtype=np.float32)
         self.morph = np.ascontiguousarray(morph, dtype=np.float32)
         self.origin = (int(origin[0]), int(origin[1]))
-        self.sed_min_step = np.broadcast_to(
-            np.asarray(sed_min_step, dtype=np.float32), self.sed.shape
-        )
+        step = np.asarray(sed_min_step, dtype=np.float32)
+        self.sed_min_step = step if step.shape == self.sed.shape else \
+            np.broadcast_to(step, self.sed.shape)
         self.sed_rel_step = float(sed_rel_step)
         self.morph_step = float(morph_step)
         self.morph_rel_step = float(morph_rel_step)

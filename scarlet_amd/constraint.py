@@ -223,6 +223,9 @@ _DEVICE_ORDER = (
 )
 
 
+_DEVICE_RANK = {cls: rank for rank, cls in enumerate(_DEVICE_ORDER)}
+
+
 def device_flags(constraint):
     """Translate a constraint (chain) into the fused device chain.
 
@@ -242,9 +245,8 @@ def device_flags(constraint):
         items = [constraint]
     rank = -1
     for c in items:
-        try:
-            r = _DEVICE_ORDER.index(type(c))
-        except ValueError:
+        r = _DEVICE_RANK.get(type(c))
+        if r is None:
             raise NotImplementedError(
                 "constraint {} has no device implementation".format(type(c).__name__)
             )
