@@ -786,9 +786,11 @@ __global__ __launch_bounds__(kThreads) void fused_conv_kernel(BatchView v, const
         const plane_t r_rendered = band_plane(out + band, H * W);
         // data / weights of the first SMI_CONV_PRE columns of the butterfly are requested
         // before the inverse radix-16 pass (their HBM latency hides behind it, the registers
-        // are live across it), the others between its loads and its stores
+        // are live across it), the others between its loads and its stores.  With the 16-byte
+        // loads of BatchView::dw all eight fit (0, 2, 4, 8 measured: conv 0.549 / 0.554 / 0.554 /
+        // 0.543 ms over 100 iterations, 0.598 / 0.599 / 0.600 / 0.589 in the driver window)
 #ifndef SMI_CONV_PRE
-#define SMI_CONV_PRE 0
+#define SMI_CONV_PRE 8
 #endif
         constexpr int kPre = SMI_CONV_PRE < NX1 ? SMI_CONV_PRE : NX1;
         cf dv[NX1], wv[NX1];
