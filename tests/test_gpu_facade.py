@@ -593,6 +593,60 @@ def test_fit_blends_resident_batch_equals_rebuilt_batches_and_single_fits(monkey
         assert one.loss == a[i].loss
 
 
+def test_fit_blends_mixes_device_and_host_resizes(monkeypatch):
+    """Blends of the stock classes have their boxes resized on the device; a blend whose
+    morphologies override ``shrink_box`` (here: by calling the stock one) keeps the host's
+    ``update()`` -- in the same batch, the same launches.  Both against the individual fits and
+    against the batch with every resize on the host (``SCARLET_AMD_FIT_BLENDS=host-resize``)."""
+    import os
+    import sys
+
+    import scarlet_amd as scarlet
+    from scarlet_amd.blend import _device_resize_covers
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    class Mine(scarlet.ExtendedSourceMorphology):
+        def shrink_box(self, image, thresh=0):
+            return super().shrink_box(image, thresh)
+
+    def build():
+        blends = bench.build_facade_blends(0, 12, 0)
+        for i in (3, 8):
+            for src in blends[i].sources:
+                src.children[1].__class__ = Mine
+        return blends
+
+    a = build()
+    assert [_device_resize_covers(b) for b in a] == [i not in (3, 8) for i in range(12)]
+    ra = scarlet.fit_blends(a, 60, e_rel=1e-4)
+    assert scarlet.fit_blends.errors == []
+    monkeypatch.setenv("SCARLET_AMD_FIT_BLENDS", "host-resize")
+    b = build()
+    rb = scarlet.fit_blends(b, 60, e_rel=1e-4)
+    monkeypatch.delenv("SCARLET_AMD_FIT_BLENDS")
+    assert ra == rb
+    resized = {i: 0 for i in range(12)}
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.loss == y.loss
+        for p, q in zip(x.parameters, y.parameters):
+            assert p.shape == q.shape and p.dtype == q.dtype
+            assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
+            if p.m is not None:
+                assert_allclose(p.m, q.m, rtol=0, atol=0)
+                assert_allclose(p.vhat, q.vhat, rtol=0, atol=0)
+            assert callable(p.step) or p.step == q.step
+        for sx, sy in zip(x.sources, y.sources):
+            assert sx.bbox == sy.bbox and sx.children[1].bbox == sy.children[1].bbox
+            resized[i] += tuple(sx.children[1].bbox.shape) != (41, 41)
+    assert resized[3] + resized[8] > 0 and sum(resized.values()) > resized[3] + resized[8]
+    for i in (0, 3, 11):
+        one = build()[i]
+        assert one.fit(60, e_rel=1e-4) == ra[i]
+        assert one.loss == a[i].loss
+
+
 def test_fit_blends_keeps_going_when_one_blend_fails():
     """A blend whose parameters turn non-finite gets ``(n_iter, nan)`` and an entry in
     ``fit_blends.errors``; its loss history ends with the iteration that failed (the loss is
