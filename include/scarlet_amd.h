@@ -460,7 +460,8 @@ int smi_batch_fft_shape(smi_batch *b, int32_t *fft_h, int32_t *fft_w);
  *   resident parameters and moments (their boxes must not have changed) and the others take
  *   theirs from `states`, records in the order of k.  The observation, the kernel, the loss
  *   histories and the per-blend states stay.  Factorized image components under AMSGrad
- *   only.  On an error the batch is left without components.
+ *   only.  A table that fails the argument checks leaves the old one and its state in place;
+ *   after an allocation or transfer error the batch is without components.
  *   keep[k] = 2 / 3: the component keeps its device-resident state and its SQUARE box is resized
  *   about its centre on the device, the way ImageMorphology.update does it on the host
  *   (morphology.py:132-207): the new side is box_h[k] = box_w[k] (sides differ by an even

@@ -1283,7 +1283,9 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
             standard = _standard_size(inner)
             at_hook = hook[blend_of] & resizable
             shrink = at_hook & (standard < size)
-            grow = at_hook & ~shrink & (pull > 0.1 * (1 - 1e-6))
+            # (the device's pull is taken with the constant step of the table: an image with a
+            # step rule of its own is always shown to the host's update())
+            grow = at_hook & ~shrink & ((pull > 0.1 * (1 - 1e-6)) | np.isnan(step))
             restart = np.zeros(nb, dtype=bool)
             keep = np.ones(n_comp, dtype=np.int32)
             states = []

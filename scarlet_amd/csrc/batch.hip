@@ -1410,13 +1410,6 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
                             "1024 pixels a side whose sides differ by an even number");
             }
         }
-        old_moff = b->h_moff;
-        old_px[0] = b->morph;
-        b->morph = nullptr;
-        for (int i = 0; i < 3; ++i) {
-            old_px[1 + i] = b->mom[3 + i];
-            b->mom[3 + i] = nullptr;
-        }
     }
     struct FreeOld {
         float **p;
@@ -1471,6 +1464,17 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
     SMI_REQUIRE(b->n_morph < ((int64_t)1 << 31), "more than 2^31 morphology pixels in one batch");
     b->view.max_box_pixels = max_pix;
 
+    // (every argument check is behind us: only now do the kept pixel arrays leave the batch, so a
+    // refused table leaves the old one and its state in place)
+    if (keep) {
+        old_moff = b->h_moff;
+        old_px[0] = b->morph;
+        b->morph = nullptr;
+        for (int i = 0; i < 3; ++i) {
+            old_px[1 + i] = b->mom[3 + i];
+            b->mom[3 + i] = nullptr;
+        }
+    }
     std::vector<float> zeros_n(n, 0.f), rel(n, 1e-2f);
     std::vector<int32_t> noplan(n, -1);
     int rc;
