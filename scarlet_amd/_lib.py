@@ -249,23 +249,27 @@ def load():
 # ---------------------------------------------------------------------------
 _hw_queues = None  # set by configure()
 _warned = False
+# what the environment said when this module was imported: a value exported later, after the
+# HIP runtime has started, is not what the runtime read (it would make the library assume
+# queues that do not exist)
+_env_at_import = os.environ.get("GPU_MAX_HW_QUEUES")
 
 
 def _hip_started():
-    try:
-        import torch
+    import sys
 
-        return torch.cuda.is_initialized()
-    except ImportError:
-        return False
+    torch = sys.modules.get("torch")  # (not imported yet: it has not started anything)
+    return bool(torch is not None and torch.cuda.is_initialized())
 
 
 def _effective_hw_queues():
     if _hw_queues is not None:
         return _hw_queues
-    # exported by the caller's environment (the shell, a launcher): in effect from the start
+    # exported by the caller's environment (the shell, a launcher): in effect from the start.
+    # A value that appeared after the import counts only while the runtime has not started.
+    value = os.environ.get("GPU_MAX_HW_QUEUES") if not _hip_started() else _env_at_import
     try:
-        return max(1, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+        return max(1, int(value or "4"))
     except ValueError:
         return 4
 
