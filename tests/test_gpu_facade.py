@@ -511,11 +511,12 @@ def test_lite_init_all_sources_main_matches_the_reference(hsc):
     assert all(src.flux.shape[0] == 5 for src in fitted.sources)
 
 
-def test_fit_blends_equals_individual_fits(hsc):
+def test_fit_blends_equals_individual_fits(hsc, monkeypatch):
     """fit_blends: several Blend objects in one device batch that stays on the device for the
     whole call (the resize hooks change its component table in place) give exactly the
-    per-blend results of Blend.fit -- and the observation is uploaded once, not once per
-    hook round"""
+    per-blend results of Blend.fit's own loop (host resize, a new batch after every
+    UpdateException: ``SCARLET_AMD_BLEND_FIT=loop``; by default Blend.fit takes the resident
+    path itself) -- and the observation is uploaded once, not once per hook round"""
     import scarlet_amd as scarlet
     from scarlet_amd import _lib
 
@@ -530,7 +531,13 @@ def test_fit_blends_equals_individual_fits(hsc):
         return blend
 
     single = [make(k) for k in range(3)]
+    monkeypatch.setenv("SCARLET_AMD_BLEND_FIT", "loop")
     want = [b.fit(35, e_rel=1e-5) for b in single]
+    monkeypatch.delenv("SCARLET_AMD_BLEND_FIT")
+    # (and Blend.fit by default: the resident path for one blend)
+    again = [make(k) for k in range(3)]
+    assert [b.fit(35, e_rel=1e-5) for b in again] == want
+    assert all(x.loss == y.loss for x, y in zip(single, again))
     many = [make(k) for k in range(3)]
     boxes = [[tuple(c.children[1].bbox.shape) for c in components_of(b)] for b in many]
     uploads = _lib.load().smi_observation_uploads()
@@ -587,6 +594,7 @@ def test_fit_blends_resident_batch_equals_rebuilt_batches_and_single_fits(monkey
             assert callable(p.step) or p.step == q.step
         resized += sum(tuple(src.children[1].bbox.shape) != (41, 41) for src in x.sources)
     assert resized > 10 and len({r[0] for r in ra}) > 3  # boxes changed, blends stopped apart
+    monkeypatch.setenv("SCARLET_AMD_BLEND_FIT", "loop")  # Blend.fit's own loop, host resize
     for i in (0, 17, 47):
         one = bench.build_facade_blends(i, i + 1, 0)[0]
         assert one.fit(60, e_rel=1e-4) == ra[i]
@@ -641,10 +649,12 @@ def test_fit_blends_mixes_device_and_host_resizes(monkeypatch):
             assert sx.bbox == sy.bbox and sx.children[1].bbox == sy.children[1].bbox
             resized[i] += tuple(sx.children[1].bbox.shape) != (41, 41)
     assert resized[3] + resized[8] > 0 and sum(resized.values()) > resized[3] + resized[8]
-    for i in (0, 3, 11):
-        one = build()[i]
-        assert one.fit(60, e_rel=1e-4) == ra[i]
-        assert one.loss == a[i].loss
+    for mode in ("loop", "resident"):
+        monkeypatch.setenv("SCARLET_AMD_BLEND_FIT", mode)
+        for i in (0, 3, 11):
+            one = build()[i]
+            assert one.fit(60, e_rel=1e-4) == ra[i]
+            assert one.loss == a[i].loss
 
 
 def test_fit_blends_keeps_going_when_one_blend_fails():
