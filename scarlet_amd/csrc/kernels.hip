@@ -1293,6 +1293,28 @@ struct RingLds {
     }
 };
 
+// The same stream read from global memory (L2), for wavefronts that have no staged copy: 256 B
+// per step instead of the slot plan's 2 KB.  Entries are requested four / five steps ahead (an
+// L2 round trip is about three steps).
+template <int P>
+struct RingGlobal {
+    static constexpr int kWeightsAhead = 4, kAddrAhead = 5;
+    rsrc_t r;
+    uint32_t wo, ao;  // this lane's byte offsets inside a step
+    __device__ __forceinline__ RingGlobal(const void *stream, uint32_t bytes, int n_pad, int lane) {
+        r = make_rsrc(stream, bytes);
+        wo = (uint32_t)(lane & 7) * 16u;
+        ao = (uint32_t)(n_pad + kRingAhead) * (128u * P) + (uint32_t)lane * 2u;
+    }
+    __device__ __forceinline__ uint32_t addr(int step, int p) const {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, ao, (step * P + p) * 128, 0);
+    }
+    __device__ __forceinline__ f32x4 weights(int step, int p) const {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, wo, (step * P + p) * 128, 0);
+        return __builtin_bit_cast(f32x4, t);
+    }
+};
+
 // The 16 bytes in front of `us` are the spare cell (idle lanes); n_pad, rmax, perm, centre:
 // the plan's ring_* fields, wave-uniform.  P planes: the lane works on ring m + 8 p (mod 8 P)
 // of its octant in every step, P independent chains.
@@ -1302,12 +1324,12 @@ struct RingLds {
 // operands A, B, C are then one level older (one more entry of the rotation history: c4, and
 // the mirror lane's last but one result g2), and the address words of the stream say which
 // entries are late and which are the axis / diagonal pixel of their ring.
-template <int P, bool LATE = false>
-__device__ __forceinline__ void sweep_ring_loop(float *us, const RingLds<P> &plan, int n_pad,
+template <int P, bool LATE = false, class Plan = RingLds<P>>
+__device__ __forceinline__ void sweep_ring_loop(float *us, const Plan &plan, int n_pad,
                                                 int n_nat, int rmax, uint32_t perm,
                                                 int centre_pix, float one_minus_g, int lane) {
     static_assert(!LATE || P == 1, "late rings: one plane");
-    constexpr int DW = RingLds<P>::kWeightsAhead, DA = RingLds<P>::kAddrAhead;
+    constexpr int DW = Plan::kWeightsAhead, DA = Plan::kAddrAhead;
     // (address words of a stream with late rings carry flags, also while they are prefetched)
     constexpr uint32_t kMask = LATE ? (uint32_t)kRingAddrMask : 0xFFFFFFFFu;
     static_assert(kRingUnroll == 6 && DA < 6 && DW < DA && (P == 1 || P == 2),
@@ -1469,6 +1491,29 @@ __device__ __forceinline__ void sweep_ring(float *us, const SweepPlanDev &pl, co
     else
         sweep_ring_loop<1>(us, RingLds<1>(plan_lds, n_pad, lane), n_pad, n_pad, rmax, perm, centre,
                            one_minus_g, lane);
+}
+
+// a one-plane plan straight from global memory (no staged copy: update_kernel_mixed)
+template <bool kLate>
+__device__ __forceinline__ void sweep_ring_global(float *us, const SweepPlanDev &pl,
+                                                  float one_minus_g, int lane) {
+    const int n_pad = __builtin_amdgcn_readfirstlane(pl.ring_pad);
+    const int n_nat = __builtin_amdgcn_readfirstlane(pl.ring_nat);
+    const int rmax = __builtin_amdgcn_readfirstlane(pl.ring_rmax);
+    const uint32_t perm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.ring_perm);
+    const int centre = __builtin_amdgcn_readfirstlane(pl.ring_centre);
+    const uint32_t bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.ring_bytes);
+    const uint64_t sp = reinterpret_cast<uint64_t>(pl.ring);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sp);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sp >> 32));
+    const void *stream = reinterpret_cast<const void *>((uint64_t)lo | ((uint64_t)hi << 32));
+    const RingGlobal<1> plan(stream, bytes, n_pad, lane);
+    if (kLate && n_nat < n_pad)
+        sweep_ring_loop<1, true, RingGlobal<1>>(us, plan, n_pad, n_nat, rmax, perm, centre,
+                                                one_minus_g, lane);
+    else
+        sweep_ring_loop<1, false, RingGlobal<1>>(us, plan, n_pad, n_pad, rmax, perm, centre,
+                                                 one_minus_g, lane);
 }
 
 // occupancy the register allocator has to reach (waves per SIMD): three arrays of NPL
@@ -1798,7 +1843,8 @@ __device__ __forceinline__ void upd_store(const BatchView &v, UpdState<NPL> &S) 
     if (Team<T>::any(bad) && lane == 0) atomicExch(&v.state[c.b], v.fail_code);  // model.py:153-165
 }
 
-template <int NPL, int MODE, int T = 64>
+// kGlobalRing: components without a staged plan read the ring stream out of L2 (update_kernel_mixed)
+template <int NPL, int MODE, int T = 64, bool kGlobalRing = false>
 __device__ __forceinline__ void update_component(const BatchView &v, const float *G, int it,
                                                  float e_rel, int prox_max_iter, int k,
                                                  float *us, float *sed_new,
@@ -1829,6 +1875,11 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
                     // (boxes beyond 47^2 -- the classes beyond 27 pixels per lane -- have rings
                     // that start late)
                     sweep_ring<1, (NPL > 27)>(S.us, *S.ring, S.plan_lds, S.one_minus_g, S.c.lane);
+                else if (kGlobalRing && T == 64 && S.ring &&
+                         __builtin_amdgcn_readfirstlane(S.ring->ring_planes) == 1)
+                    // (no staged copy -- update_kernel_mixed, small launches: the stream out of L2,
+                    // 256 B a step: 61^2 21.5 k clocks per sweep, 41^2 12.0 k; slot plan 27.4 k, 15.4 k)
+                    sweep_ring_global<(NPL > 27)>(S.us, *S.ring, S.one_minus_g, S.c.lane);
                 else
                     sweep_slots(S.us, S.slots, S.n_slots, S.one_minus_g, S.c.lane);
             }
@@ -1955,15 +2006,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void up
     const int n = v.c_h[k] * v.c_w[k];  // uniform over the wavefront
     float *us = lds_dyn + 4;  // (spare cell of the sweep in front)
     if (n <= 64 * kUpdateNpl[0])
-        update_component<kUpdateNpl[0], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
+        update_component<kUpdateNpl[0], MODE, 64, true>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else if (n <= 64 * kUpdateNpl[1])
-        update_component<kUpdateNpl[1], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
+        update_component<kUpdateNpl[1], MODE, 64, true>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else if (n <= 64 * kUpdateNpl[2])
-        update_component<kUpdateNpl[2], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
+        update_component<kUpdateNpl[2], MODE, 64, true>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else if (n <= 64 * kUpdateNpl[3])
-        update_component<kUpdateNpl[3], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
+        update_component<kUpdateNpl[3], MODE, 64, true>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
     else
-        update_component<kUpdateNpl[4], MODE>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
+        update_component<kUpdateNpl[4], MODE, 64, true>(v, G, it, e_rel, prox_max_iter, k, us, sed_new);
 }
 
 // development aid: shader clocks of `n_rep` sweeps of one plan per wavefront, every wavefront
@@ -1997,7 +2048,9 @@ __global__ void sweep_timing_kernel(const SweepPlanDev *plans, int plan_id, int 
         }
         wave_lds_fence();
         const long long t0 = __builtin_readcyclecounter();
-        if (mode == 2)
+        if (mode == 3)
+            sweep_ring_global<true>(us, pl, one_minus_g, lane);
+        else if (mode == 2)
             sweep_ring<2, true>(us, pl, plan_lds, one_minus_g, lane);
         else
             sweep_slots(us, pl.slots, pl.n_slots, one_minus_g, lane);
@@ -2616,7 +2669,8 @@ int launch_sweep_timing(const SweepPlanDev *d_plans, const SweepPlanDev &host_pl
     const size_t lds = (size_t)waves * (((n + 3) & ~3) + 4) * sizeof(float) +
                        (mode == 2 ? host_plan.ring_bytes : 0);
     SMI_REQUIRE(lds <= 160 * 1024 && waves >= 1 && waves <= 16, "images do not fit the LDS");
-    SMI_REQUIRE(mode == 0 || mode == 2, "mode: 0 slot plan, 2 ring schedule");
+    SMI_REQUIRE(mode == 0 || mode == 2 || (mode == 3 && host_plan.ring_planes == 1),
+                "mode: 0 slot plan, 2 ring schedule, 3 ring schedule with the stream in L2 (one plane)");
     SMI_REQUIRE(mode == 0 ? host_plan.slots != nullptr : host_plan.ring != nullptr, "plan has no such schedule");
     static size_t configured[kMaxDevices] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sweep_timing_kernel), lds, configured))

@@ -29,10 +29,11 @@ batch = BlendBatch(data, weights, comps, kernel=kern[2], max_iter=4)
 n_rep = 20
 images = {}
 big = side > 47
+ring_mode = int(os.environ.get("SWEEP_MODE", "2"))  # 2: stream staged in LDS, 3: read from L2
 for waves, groups in (((1, 1), (1, 256), (4, 256), (6, 256), (6, 1024)) if big else
                       ((1, 1), (1, 256), (4, 256), (8, 256), (12, 256), (12, 1024))):
     row = []
-    for mode in (0, 2):
+    for mode in (0, ring_mode):
         nw = waves * groups
         cyc = np.zeros(nw, dtype=np.int64)
         img = np.zeros((nw, side * side), dtype=np.float32)
@@ -41,6 +42,6 @@ for waves, groups in (((1, 1), (1, 256), (4, 256), (6, 256), (6, 1024)) if big e
                       img.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
         images[mode] = img
         row.append((cyc.mean() / n_rep, cyc.max() / n_rep))
-    same = np.array_equal(images[0].view(np.uint32), images[2].view(np.uint32))
+    same = np.array_equal(images[0].view(np.uint32), images[ring_mode].view(np.uint32))
     print("waves/group %2d groups %4d: slots %6.0f (max %6.0f)  ring, plan in LDS %6.0f (max %6.0f) clocks per sweep, same bits: %s"
           % (waves, groups, row[0][0], row[0][1], row[1][0], row[1][1], same), flush=True)
