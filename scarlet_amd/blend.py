@@ -560,8 +560,10 @@ class Blend(CombinedComponent):
             out, errors = _fit_blends_on([self], self.device, max_iter, e_rel, min_iter,
                                          _from_fit=True, prox_max_iter=prox_max_iter, **opt)
             if out is not None:
+                self._psf_stepped_on_device = False
                 if errors:
                     raise errors[0][1]
+                logger.info("scarlet ran for {0} iterations to logL = {1}".format(*out[0]))
                 return out[0]
 
         it = 0
