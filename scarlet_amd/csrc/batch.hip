@@ -2055,7 +2055,11 @@ static bool inline_render(const smi_batch *b) {
         const char *e = getenv("SMI_INLINE_RENDER");
         return !(e && e[0] == '0');
     }();
-    return allowed && b->inline_render && plain_batch(b) && b->view.render_slots > 0;
+    // (point sources and shifted images are morphologies in `morph` like any other by the time
+    // the convolution runs; further observations, a low-resolution term and a free kernel shift
+    // read the cube)
+    return allowed && b->inline_render && b->fused && b->lowres.empty() && b->layers.empty() &&
+           !b->ks.stamp && b->view.render_slots > 0;
 }
 
 
