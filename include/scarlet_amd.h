@@ -253,8 +253,14 @@ int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32
                         uint16_t *addr, int64_t capacity);
 
 /* data, weights: [n_blends][C][H][W] float32 (observation.py:52-57).  The _device
- * form adopts device buffers (e.g. torch tensors) without copying; they must stay
- * alive and unchanged while the batch uses them. */
+ * form adopts device buffers (e.g. torch tensors) without copying them: log_norm, the loss of
+ * the rocFFT path and further renderers read the caller's buffers, which must stay alive and
+ * UNCHANGED while the batch uses them.  The fused convolution reads a SNAPSHOT taken by this
+ * call -- data and weights interleaved by row pairs, one more copy of the observation in device
+ * memory (8 bytes per pixel and band, also for adopted buffers) -- so an adopted tensor changed
+ * in place is not seen by it: call smi_batch_set_observation_device again to register the new
+ * contents.  The _device form waits for the whole device once (the buffers may have been
+ * written on any stream); the host form only for the batch's stream. */
 int smi_batch_set_observation(smi_batch *b, const float *data, const float *weights);
 int smi_batch_set_observation_device(smi_batch *b, const float *d_data,
                                      const float *d_weights);

@@ -167,33 +167,11 @@ class BlendBatch:
         # monotonicity plans, one per (box shape, weighting); with centre fitting
         # (PROX_FIT_CENTER) nine consecutive ones for the centres around the box centre
         plan_ids = self._plan_ids
-
-        def add_plan(shape, weighting, center):
-            wts, off, didx = operator.monotonic_tables(shape, weighting, center)
-            return _lib.check(
-                lib.smi_batch_add_sweep_plan(
-                    self._h, shape[0], shape[1], _lib.ptr(wts, ctypes.c_double),
-                    _lib.ptr(off, ctypes.c_int32), _lib.ptr(didx, ctypes.c_int32), didx.size,
-                )
-            )
-
         part = flat if rows is None else [flat[k] for k in rows]
         for c in part:
             if c.prox_flags & _lib.PROX_MONOTONIC:
-                fit = bool(c.prox_flags & _lib.PROX_FIT_CENTER)
-                key = (c.morph.shape, c.neighbor_weight, fit)
-                if key in plan_ids:
-                    continue
-                h, w = c.morph.shape
-                if not fit:
-                    plan_ids[key] = add_plan(c.morph.shape, c.neighbor_weight, None)
-                    continue
-                if h < 3 or w < 3:
-                    raise ValueError("centre fitting needs boxes of at least 3x3 pixels")
-                ids = [add_plan(c.morph.shape, c.neighbor_weight, (h // 2 + dy, w // 2 + dx))
-                       for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
-                assert ids == list(range(ids[0], ids[0] + 9))
-                plan_ids[key] = ids[0]
+                self._plan_for(c.morph.shape, c.neighbor_weight,
+                               bool(c.prox_flags & _lib.PROX_FIT_CENTER))
 
         shapes = [c.morph.shape for c in part]
         fields = dict(
@@ -332,6 +310,34 @@ class BlendBatch:
             self._h, ctypes.byref(comps), _lib.ptr(keep, ctypes.c_int32),
             _lib.ptr(_lib.f32(buf), ctypes.c_float)))
 
+    def _plan_for(self, shape, weighting, fit_center):
+        """Id of the monotonicity plan of a (box shape, weighting) pair, registered on first
+        use; with centre fitting (PROX_FIT_CENTER) the first of nine consecutive plans for the
+        centres around the box centre."""
+        shape = (int(shape[0]), int(shape[1]))
+        key = (shape, weighting, bool(fit_center))
+        if key in self._plan_ids:
+            return self._plan_ids[key]
+        lib = self._lib
+
+        def add_plan(center):
+            wts, off, didx = operator.monotonic_tables(shape, weighting, center)
+            return _lib.check(lib.smi_batch_add_sweep_plan(
+                self._h, shape[0], shape[1], _lib.ptr(wts, ctypes.c_double),
+                _lib.ptr(off, ctypes.c_int32), _lib.ptr(didx, ctypes.c_int32), didx.size))
+
+        if not fit_center:
+            self._plan_ids[key] = add_plan(None)
+            return self._plan_ids[key]
+        h, w = shape
+        if h < 3 or w < 3:
+            raise ValueError("centre fitting needs boxes of at least 3x3 pixels")
+        ids = [add_plan((h // 2 + dy, w // 2 + dx)) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+        if ids != list(range(ids[0], ids[0] + 9)):
+            raise RuntimeError("the nine centre plans of a box must be consecutive")
+        self._plan_ids[key] = ids[0]
+        return ids[0]
+
     def _resize_rows(self, flat, rows, origin_y, origin_x, size, morph_step):
         """Table entries of rows whose square boxes the device resizes (``update_components``)."""
         arrays = self._component_arrays
@@ -348,14 +354,9 @@ class BlendBatch:
             self._shapes[k] = shape
             if not c.prox_flags & _lib.PROX_MONOTONIC:
                 continue
-            assert not c.prox_flags & _lib.PROX_FIT_CENTER
-            key = (shape, c.neighbor_weight, False)
-            if key not in self._plan_ids:
-                wts, off, didx = operator.monotonic_tables(shape, c.neighbor_weight, None)
-                self._plan_ids[key] = _lib.check(self._lib.smi_batch_add_sweep_plan(
-                    self._h, n, n, _lib.ptr(wts, ctypes.c_double), _lib.ptr(off, ctypes.c_int32),
-                    _lib.ptr(didx, ctypes.c_int32), didx.size))
-            arrays["sweep_plan"][k] = self._plan_ids[key]
+            # (centre fitting: the nine plans of the new shape, as _pack_components registers them)
+            arrays["sweep_plan"][k] = self._plan_for(
+                shape, c.neighbor_weight, bool(c.prox_flags & _lib.PROX_FIT_CENTER))
 
     def set_iteration_base(self, base):
         """Per blend: the iteration counter at which its current adaprox call began (``None``:

@@ -1077,14 +1077,26 @@ def fit_blends(blends, max_iter=200, e_rel=1e-3, min_iter=1, devices=None, **alg
         # its temporaries (measured: a quarter of the call).  Reference counting still frees
         # everything the loop drops.
         # gc.freeze() takes what exists now out of the collector's generations for the duration
-        # of the call; the collector itself stays on (other threads, callbacks).
+        # of the call; the collector itself stays on (other threads, callbacks).  gc.unfreeze()
+        # empties the WHOLE permanent generation, so the call keeps its hands off when the
+        # application froze objects itself (a pre-fork server) or another fit_blends is running.
         import gc
 
-        gc.freeze()
+        with _freeze_lock:
+            mine = gc.get_freeze_count() == 0 and not _freeze_users[0]
+            if mine:
+                gc.freeze()
+            if mine or _freeze_users[0]:
+                _freeze_users[0] += 1
+                mine = True
         try:
             out, fit_blends.errors = _fit_blends_on(blends, device, **kw)
         finally:
-            gc.unfreeze()
+            if mine:
+                with _freeze_lock:
+                    _freeze_users[0] -= 1
+                    if not _freeze_users[0]:
+                        gc.unfreeze()
         return out
     from concurrent.futures import ThreadPoolExecutor
     from .dist import shard_range
@@ -1182,6 +1194,11 @@ def _fit_group_rebuilt(group, device, max_iter, opt, step_kw):
                     r.base, r.local = len(blend.loss), 0
                 elif state == 2 or r.total >= max_iter:
                     r.result = True
+
+
+# fit_blends calls that share the gc.freeze() of the first of them (see there)
+_freeze_lock = __import__("threading").Lock()
+_freeze_users = [0]
 
 
 def _device_resize_covers(blend):

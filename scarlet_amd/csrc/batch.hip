@@ -955,10 +955,13 @@ int smi_sweep_ring_plan(int32_t h, int32_t w, const double *weights, const int32
     return 1;
 }
 
-// the fused convolution kernel's copy of an observation (common.h: BatchView::dw).  The arrays
-// may have been written by another stream (adopted device buffers): the device is idle first.
+// the fused convolution kernel's copy of an observation (common.h: BatchView::dw).  Adopted
+// device buffers may have been written by another stream: the device is idle first (once per
+// adoption); arrays this library uploaded itself arrived by a blocking copy, and the batch
+// stream has been synchronised by the caller -- no other stream or batch is stalled (a fit
+// with noise_factor > 0 registers an observation every iteration).
 static int interleave_observation(smi_batch *b, const float *d_data, const float *d_weights,
-                                  float4 **dw) {
+                                  float4 **dw, bool adopted = false) {
     if (!b->fused) return SMI_OK;
     const int H = b->d.H, W = b->d.W;
     const int64_t planes = (int64_t)b->d.n_blends * b->d.C;
@@ -969,7 +972,7 @@ static int interleave_observation(smi_batch *b, const float *d_data, const float
         SMI_HIP(dev_alloc(dw, n + 16));
         SMI_HIP(hipMemset(*dw + n, 0, 16 * sizeof(float4)));
     }
-    SMI_HIP(hipDeviceSynchronize());
+    if (adopted) SMI_HIP(hipDeviceSynchronize());
     launch_interleave_obs(d_data, d_weights, *dw, planes, H, W, b->stream);
     return SMI_OK;
 }
@@ -1077,7 +1080,7 @@ int smi_batch_set_observation_device(smi_batch *b, const float *d_data, const fl
     }
     b->data = const_cast<float *>(d_data);
     b->weights = const_cast<float *>(d_weights);
-    if (int rc = interleave_observation(b, b->data, b->weights, &b->dw)) return rc;
+    if (int rc = interleave_observation(b, b->data, b->weights, &b->dw, true)) return rc;
     launch_log_norm(b->weights, b->log_norm, b->d.n_blends, (int64_t)b->d.C * b->d.H * b->d.W,
                     b->stream);
     if (!b->include_log_norm)

@@ -92,6 +92,28 @@ def _device(device=None):
     return "cpu"
 
 
+def comm_info(device=None):
+    """What the LIVE process group looks like, for a bench line to carry: backend
+    ("nccl" = RCCL on ROCm), ``dist.get_world_size()`` and the device of every rank -- one
+    all-gather of a short string per rank, so the record shows that the collective library
+    really saw N ranks.  A single process reports a world of one without a group."""
+    import torch
+
+    name = None
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        name = "cuda:%d %s" % (i, torch.cuda.get_device_name(i))
+    if not _active(1):
+        return {"backend": None, "world_size": 1, "devices": [name]}
+    import torch.distributed as dist
+
+    mine = "%s pid %d" % (name, os.getpid())
+    devices = [bytes(b).decode() for b in all_gather_bytes(mine.encode(), device=device,
+                                                           single_rank_too=True)]
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+            "devices": devices}
+
+
 # ------------------------------------------------------------------ collectives
 def all_gather_bytes(buf, device=None, single_rank_too=False):
     """All-gather one byte string per rank (lengths may differ).  Returns the list of

@@ -118,10 +118,14 @@ def test_the_drivers_eight_rank_command_runs(tmp_path):
     assert eight["n_gpus"] == 8 and eight["scaling"] == "strong"
     assert eight["config"]["blends_per_gpu"] == [8] * 8
     assert "share" in eight["config"]["parallelism"]
+    # the line says what the live process group was: eight ranks, their devices, the backend
+    assert eight["comm"]["world_size"] == 8 and len(eight["comm"]["devices"]) == 8
+    assert eight["comm"]["backend"] == "gloo"  # (RCCL refuses two ranks on one device)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args,
                          capture_output=True, text=True, timeout=900, env=env)
     assert one.returncode == 0, one.stdout[-3000:] + one.stderr[-3000:]
     one = [json.loads(l) for l in one.stdout.splitlines() if l.startswith("{")][0]
+    assert one["comm"]["world_size"] == 1
     assert eight["config"]["mean_logL"] == one["config"]["mean_logL"]
     assert eight["parity"]["checked_blends"] and one["parity"]["checked_blends"]
 

@@ -657,6 +657,55 @@ def test_fit_blends_mixes_device_and_host_resizes(monkeypatch):
             assert one.loss == a[i].loss
 
 
+def test_centre_fitting_with_resizing_on_the_resident_path(monkeypatch):
+    """``MonotonicityConstraint(fit_center_radius=1)`` together with ``resizing=True``: a box
+    resized on the device needs the NINE plans of its new shape (one per candidate centre), as
+    the host resize registers them.  ``Blend.fit`` (resident path by default) and ``fit_blends``
+    against the batch with every resize on the host and against ``Blend.fit``'s own loop."""
+    import os
+    import sys
+
+    import scarlet_amd as scarlet
+    from scarlet_amd.blend import _device_resize_covers
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    def build(lo=0, hi=6):
+        blends = bench.build_facade_blends(lo, hi, 0)
+        for blend in blends:
+            for src in blend.sources:
+                src.children[1].parameters[0].constraint = scarlet.ConstraintChain(
+                    scarlet.MonotonicityConstraint(neighbor_weight="angle", min_gradient=0,
+                                                   fit_center_radius=1),
+                    scarlet.PositivityConstraint(), scarlet.NormalizationConstraint("max"))
+        return blends
+
+    a = build()
+    assert all(_device_resize_covers(b) for b in a)
+    ra = scarlet.fit_blends(a, 45, e_rel=1e-4)
+    assert scarlet.fit_blends.errors == []
+    monkeypatch.setenv("SCARLET_AMD_FIT_BLENDS", "host-resize")
+    b = build()
+    rb = scarlet.fit_blends(b, 45, e_rel=1e-4)
+    monkeypatch.delenv("SCARLET_AMD_FIT_BLENDS")
+    assert ra == rb
+    resized = 0
+    for x, y in zip(a, b):
+        assert x.loss == y.loss
+        for p, q in zip(x.parameters, y.parameters):
+            assert p.shape == q.shape
+            assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
+        resized += sum(tuple(src.children[1].bbox.shape) != (41, 41) for src in x.sources)
+    assert resized > 0
+    for mode in ("loop", "resident"):
+        monkeypatch.setenv("SCARLET_AMD_BLEND_FIT", mode)
+        for i in (0, 5):
+            one = build(i, i + 1)[0]
+            assert one.fit(45, e_rel=1e-4) == ra[i]
+            assert one.loss == a[i].loss
+
+
 def test_fit_blends_keeps_going_when_one_blend_fails():
     """A blend whose parameters turn non-finite gets ``(n_iter, nan)`` and an entry in
     ``fit_blends.errors``; its loss history ends with the iteration that failed (the loss is

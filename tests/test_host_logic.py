@@ -515,7 +515,12 @@ def test_bench_prices_the_bytes_of_survey_8d():
         gather = 4 * 5 * sum(bx)
         assert by["conv"] + by["update"] == by["whole"] + gather
     run = bench.algorithmic_bytes(5, 128, 128, [41 * 41] * 10, 160, 160, 1)
-    assert run["conv"] == 5051760 and run["update"] == 808280  # what the bench line prices
+    # roofline.frac_survey_model prices the 8d model, roofline.frac the bytes a kernel must
+    # move at its fusion boundary: data + weights + parameters in, gradient image out
+    assert run["conv"] == 5051760 and run["update"] == 808280
+    assert run["conv_boundary"] == 1050480 and run["update_boundary"] == run["update"]
+    assert run["conv_boundary"] + run["update_boundary"] - 4 * 5 * 10 * 41 * 41 \
+        - 4 * 5 * 128 * 128 == run["null"]  # = B0 + the gradient image written once and gathered under the boxes
 
 
 def test_resized_component_description_is_what_specs_would_make(hsc):
