@@ -66,6 +66,22 @@ int smi_prox_weighted_monotonic_f64(double *flat_img, const double *weights,
                                     const int32_t *dist_idx, int32_t n_idx,
                                     int32_t n_pix, double min_gradient);
 
+/* The same sweep for n_img independent images of n_pix pixels, every one with tables of its
+ * own, in ONE launch (one workgroup per image): what the initialisation of a scene needs --
+ * each source's detection image made monotonic about that source's centre (source.py:312-333
+ * calls operators_pybind11.cc:14-36 once per source; initialization.py:287-363 loops over the
+ * sources).  images[n_img][n_pix] in place; weights[n_img][n_off][n_pix]; dist_idx[n_img][n_idx];
+ * offsets[n_off] shared.  Image i comes out bit for bit as smi_prox_weighted_monotonic_*(
+ * images[i], weights[i], offsets, n_off, dist_idx[i], n_idx, n_pix, min_gradient) leaves it. */
+int smi_prox_weighted_monotonic_many_f32(int32_t n_img, float *images, int32_t n_pix,
+                                         const float *weights, const int32_t *offsets,
+                                         int32_t n_off, const int32_t *dist_idx, int32_t n_idx,
+                                         float min_gradient);
+int smi_prox_weighted_monotonic_many_f64(int32_t n_img, double *images, int32_t n_pix,
+                                         const double *weights, const int32_t *offsets,
+                                         int32_t n_off, const int32_t *dist_idx, int32_t n_idx,
+                                         double min_gradient);
+
 /* operators_pybind11.cc:39-56.  image[H][W], result[H][W]; taps given as in the
  * reference: values[n_taps] and the four slice-bound vectors. */
 int smi_apply_filter_f32(const float *image, int32_t H, int32_t W,
@@ -492,6 +508,16 @@ int smi_batch_update_components(smi_batch *b, const smi_components *c, const int
 int smi_batch_set_states(smi_batch *b, const int32_t *state);
 int smi_batch_set_iteration_base(smi_batch *b, const int32_t *base);
 int smi_batch_get_progress(smi_batch *b, int32_t *state, int32_t *n_loss);
+/* Per blend: the iteration counter `it` (as passed to smi_batch_step) after whose update the
+ * blend pauses -- it is skipped by the rest of the call like a blend that has stopped (state 2)
+ * -- or NULL: nobody pauses.  One smi_batch_step(it0, n) then takes every blend to ITS next
+ * resize hook (blend.py:196-198: every ten iterations of the blend's own adaprox call) or to
+ * the end of its iteration budget, instead of all blends to the nearest hook of any of them
+ * (a thousand blends whose calls restarted at different times: 12 calls instead of 32).
+ * smi_batch_get_converged: 1 for the blends whose stopping rule (blend.py:294-299) fired since
+ * the last smi_batch_set_pause_at -- what tells a blend that stopped from one that pauses. */
+int smi_batch_set_pause_at(smi_batch *b, const int32_t *it);
+int smi_batch_get_converged(smi_batch *b, int32_t *flag);
 
 /* Number of host-to-device uploads of observation cubes (smi_batch_set_observation and
  * smi_batch_add_observation) this process has made so far: lets a caller -- and the tests --

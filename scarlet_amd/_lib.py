@@ -82,6 +82,16 @@ SYMBOLS = {
         [c_f64p, c_f64p, c_i32p, ctypes.c_int32, c_i32p, ctypes.c_int32, ctypes.c_int32,
          ctypes.c_double],
     ),
+    "smi_prox_weighted_monotonic_many_f32": (
+        ctypes.c_int,
+        [ctypes.c_int32, c_f32p, ctypes.c_int32, c_f32p, c_i32p, ctypes.c_int32, c_i32p,
+         ctypes.c_int32, ctypes.c_float],
+    ),
+    "smi_prox_weighted_monotonic_many_f64": (
+        ctypes.c_int,
+        [ctypes.c_int32, c_f64p, ctypes.c_int32, c_f64p, c_i32p, ctypes.c_int32, c_i32p,
+         ctypes.c_int32, ctypes.c_double],
+    ),
     "smi_apply_filter_f32": (
         ctypes.c_int,
         [c_f32p, ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_int32, c_i32p, c_i32p,
@@ -200,6 +210,8 @@ SYMBOLS = {
     "smi_batch_update_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Components), c_i32p, c_f32p]),
     "smi_batch_set_states": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "smi_batch_set_iteration_base": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
+    "smi_batch_set_pause_at": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
+    "smi_batch_get_converged": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "smi_batch_get_progress": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
 }
 
@@ -243,16 +255,16 @@ def load():
 # (default 4) and streams that share a queue run one after the other.  Eight queues let a
 # small batch -- one GPU's shard of a multi-GPU job -- run four ranges side by side (128
 # blends: 540 k -> 615 k blend-iterations/s).  The HIP runtime reads the variable once, when it
-# starts, and nothing reports the number it took, so the package never changes the environment
-# behind the caller's back: ``configure(hw_queues=8)`` does it on request, before the runtime
-# starts, and the library is told the number that is known to be in effect (4 otherwise).
+# starts, and nothing reports the number it took.  Importing the package therefore ASKS for
+# eight queues -- it exports GPU_MAX_HW_QUEUES=8 -- when the caller's environment says nothing
+# and the runtime has not started yet (a user's 128 .. 767-blend batch then runs four ranges
+# without knowing about ``configure``); a value the caller exported is never touched,
+# ``SCARLET_AMD_HW_QUEUES=keep`` leaves the environment alone, ``configure(hw_queues=n)``
+# sets another number on request.  The library is told the number known to be in effect
+# (4 when the runtime was already up).
 # ---------------------------------------------------------------------------
 _hw_queues = None  # set by configure()
 _warned = False
-# what the environment said when this module was imported: a value exported later, after the
-# HIP runtime has started, is not what the runtime read (it would make the library assume
-# queues that do not exist)
-_env_at_import = os.environ.get("GPU_MAX_HW_QUEUES")
 
 
 def _hip_started():
@@ -260,6 +272,15 @@ def _hip_started():
 
     torch = sys.modules.get("torch")  # (not imported yet: it has not started anything)
     return bool(torch is not None and torch.cuda.is_initialized())
+
+
+if ("GPU_MAX_HW_QUEUES" not in os.environ and os.environ.get("SCARLET_AMD_HW_QUEUES") != "keep"
+        and not _hip_started()):
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# what the environment said when this module was imported: a value exported later, after the
+# HIP runtime has started, is not what the runtime read (it would make the library assume
+# queues that do not exist)
+_env_at_import = os.environ.get("GPU_MAX_HW_QUEUES")
 
 
 def _effective_hw_queues():

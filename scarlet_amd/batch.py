@@ -368,6 +368,22 @@ class BlendBatch:
         assert base.shape == (self.n_blends,)
         _lib.check(self._lib.smi_batch_set_iteration_base(self._h, _lib.ptr(base, ctypes.c_int32)))
 
+    def set_pause_at(self, it):
+        """Per blend: the iteration counter (as passed to ``step``) after whose update the blend
+        pauses for the rest of the call (``None``: nobody pauses); clears ``converged()``."""
+        if it is None:
+            _lib.check(self._lib.smi_batch_set_pause_at(self._h, None))
+            return
+        it = np.ascontiguousarray(it, dtype=np.int32)
+        assert it.shape == (self.n_blends,)
+        _lib.check(self._lib.smi_batch_set_pause_at(self._h, _lib.ptr(it, ctypes.c_int32)))
+
+    def converged(self):
+        """1 per blend whose stopping rule fired since the last ``set_pause_at``."""
+        flag = np.zeros(self.n_blends, dtype=np.int32)
+        _lib.check(self._lib.smi_batch_get_converged(self._h, _lib.ptr(flag, ctypes.c_int32)))
+        return flag
+
     def set_states(self, states):
         """Per-blend state: 0 iterating, 2 finished or paused (skipped by every kernel),
         3 failed."""

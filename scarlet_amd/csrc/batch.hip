@@ -26,6 +26,7 @@
 #include <limits>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <utility>
 
@@ -209,6 +210,8 @@ struct smi_batch {
     float *sed = nullptr, *morph = nullptr;
     float *mom[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float *g_sed = nullptr, *g_morph = nullptr;
+    float *xp_tmp = nullptr;  // BatchView::xp_tmp
+    int n_size_classes = 0;   // size classes of the register-resident update kernels in use
     // point sources: {offset, m, v, vhat} x (y, x) per component, gradient, PSF sigma
     double *pt = nullptr, *g_center = nullptr;
     float *c_sigma = nullptr, *c_beta = nullptr;
@@ -272,6 +275,7 @@ struct smi_batch {
     // per blend
     int32_t *state = nullptr, *zero_state = nullptr, *n_loss = nullptr, *status_out = nullptr;
     int32_t *it_base = nullptr;  // BatchView::it_base (smi_batch_set_iteration_base)
+    int32_t *pause_at = nullptr, *conv_flag = nullptr;  // smi_batch_set_pause_at
     double *loss_hist = nullptr, *last_loss = nullptr, *loss_partial = nullptr;
     // plans
     std::vector<SweepPlanDev> plans;
@@ -324,6 +328,8 @@ void refresh_view(smi_batch *b) {
     v.weights = b->weights;
     v.dw = b->dw;
     v.it_base = b->it_base;
+    v.pause_at = b->pause_at;
+    v.conv_flag = b->conv_flag;
     v.log_norm = b->log_norm;
     v.state = b->state;
     v.n_loss = b->n_loss;
@@ -351,6 +357,8 @@ void refresh_view(smi_batch *b) {
     v.morph_param = b->morph_param;
     v.g_sed_buf = b->g_sed;
     v.g_morph_buf = b->g_morph;
+    v.xp_tmp = b->xp_tmp;
+    v.n_morph_total = b->n_morph;
     v.c_shift_step = b->c_shift_step;
     v.c_shift_rel = b->c_shift_rel;
     v.c_shift_fft = b->c_shift_fft;
@@ -477,6 +485,42 @@ int seam1_sweep(T *flat_img, const T *weights, const int32_t *offsets, int32_t n
 }
 
 template <typename T>
+int seam1_sweep_many(int32_t n_img, T *images, int32_t n_pix, const T *weights,
+                     const int32_t *offsets, int32_t n_off, const int32_t *dist_idx,
+                     int32_t n_idx, T min_gradient) {
+    SMI_REQUIRE(n_img >= 0 && n_pix > 0 && n_off > 0 && n_idx >= 0, "bad sizes");
+    if (n_img == 0) return SMI_OK;
+    SMI_REQUIRE(images && weights && offsets && (dist_idx || n_idx == 0), "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device available");
+        return SMI_ERR_NO_DEVICE;
+    }
+    // the plans on the host cores, a few images per thread (a 128 x 128 plan takes ~1 ms)
+    std::vector<SweepPlanHost> plans(n_img);
+    std::vector<char> ok(n_img, 0);
+    const int n_threads = std::max(1, std::min<int>(n_img, std::min(8u, std::thread::hardware_concurrency())));
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t)
+        pool.emplace_back([&, t] {
+            std::vector<double> w64((size_t)n_off * n_pix);
+            for (int i = t; i < n_img; i += n_threads) {
+                const T *w = weights + (size_t)i * n_off * n_pix;
+                for (size_t q = 0; q < w64.size(); ++q) w64[q] = (double)w[q];
+                ok[i] = build_sweep_plan(n_pix, w64.data(), offsets, n_off,
+                                         dist_idx + (size_t)i * n_idx, n_idx, &plans[i]);
+            }
+        });
+    for (auto &th : pool) th.join();
+    for (int i = 0; i < n_img; ++i)
+        if (!ok[i]) {
+            set_error("malformed monotonicity tables of image " + std::to_string(i));
+            return SMI_ERR_INVALID;
+        }
+    return sweep_many_host_buffers<T>(images, n_img, n_pix, plans, min_gradient);
+}
+
+template <typename T>
 int seam1_filter(const T *image, int32_t H, int32_t W, const T *values, int32_t n_taps,
                  const int32_t *ys, const int32_t *ye, const int32_t *xs, const int32_t *xe,
                  T *result) {
@@ -552,6 +596,20 @@ int smi_prox_weighted_monotonic_f64(double *flat_img, const double *weights,
                                     double min_gradient) {
     return seam1_sweep<double>(flat_img, weights, offsets, n_off, dist_idx, n_idx, n_pix,
                                min_gradient);
+}
+int smi_prox_weighted_monotonic_many_f32(int32_t n_img, float *images, int32_t n_pix,
+                                         const float *weights, const int32_t *offsets,
+                                         int32_t n_off, const int32_t *dist_idx, int32_t n_idx,
+                                         float min_gradient) {
+    return seam1_sweep_many<float>(n_img, images, n_pix, weights, offsets, n_off, dist_idx, n_idx,
+                                   min_gradient);
+}
+int smi_prox_weighted_monotonic_many_f64(int32_t n_img, double *images, int32_t n_pix,
+                                         const double *weights, const int32_t *offsets,
+                                         int32_t n_off, const int32_t *dist_idx, int32_t n_idx,
+                                         double min_gradient) {
+    return seam1_sweep_many<double>(n_img, images, n_pix, weights, offsets, n_off, dist_idx, n_idx,
+                                    min_gradient);
 }
 int smi_apply_filter_f32(const float *image, int32_t H, int32_t W, const float *values,
                          int32_t n_taps, const int32_t *y_start, const int32_t *y_end,
@@ -825,9 +883,9 @@ int smi_batch_destroy(smi_batch *b) {
                     b->c_flags, b->c_plan, b->c_moff, b->c_sed_min_step, b->c_sed_rel,
                     b->c_morph_step, b->c_morph_rel, b->c_min_grad, b->c_lthresh, b->sed,
                     b->morph, b->mom[0], b->mom[1], b->mom[2], b->mom[3], b->mom[4], b->mom[5],
-                    b->g_sed, b->g_morph, b->pt, b->g_center, b->c_sigma, b->c_beta, b->morph_param,
+                    b->g_sed, b->g_morph, b->xp_tmp, b->pt, b->g_center, b->c_sigma, b->c_beta, b->morph_param,
                     b->c_shift_step, b->c_shift_rel, b->c_shift_fft, b->c_center_floor, b->c_sym_strength, b->c_chain_repeat, b->c_pos_floor, b->c_bg_level,
-                    b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out, b->it_base, b->shift_scratch,
+                    b->c_fista_step, b->fista_t, b->have_prev, b->scratch, b->state, b->zero_state, b->n_loss, b->status_out, b->it_base, b->pause_at, b->conv_flag, b->shift_scratch,
                     b->loss_hist, b->last_loss, b->loss_partial, b->d_plans, b->work_items};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -1563,6 +1621,8 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
     if (b->g_morph) SMI_HIP(hipFree(b->g_morph));
     SMI_HIP(dev_alloc(&b->g_sed, (size_t)n * C));
     SMI_HIP(dev_alloc(&b->g_morph, (size_t)b->n_morph));
+    if (b->xp_tmp) SMI_HIP(hipFree(b->xp_tmp));
+    SMI_HIP(dev_alloc(&b->xp_tmp, 2 * (size_t)b->n_morph));
     // point sources: offset of the centre from the mean of the box bounds
     // (morphology.py:503-507), moments zero
     std::vector<double> pt((size_t)n * 8, 0.0);
@@ -1653,6 +1713,8 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
             work.insert(work.end(), items[cls].begin(), items[cls].end());
             base += (int32_t)items[cls].size();
         }
+        b->n_size_classes = 0;
+        for (int cls = 0; cls < kNumUpdateClasses; ++cls) b->n_size_classes += !items[cls].empty();
         work.push_back(-1);  // never empty
         if ((rc = upload(&b->work_items, work.data(), work.size()))) return rc;
         // the plan most monotonic components of a class use: the one its launches stage in LDS
@@ -1782,6 +1844,36 @@ int smi_batch_set_iteration_base(smi_batch *b, const int32_t *base) {
         SMI_HIP(hipMemcpy(b->it_base, base, b->d.n_blends * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_set_pause_at(smi_batch *b, const int32_t *it) {
+    SMI_REQUIRE(b != nullptr, "null batch");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const size_t nb = (size_t)b->d.n_blends;
+    if (!it) {
+        if (b->pause_at) (void)hipFree(b->pause_at);
+        if (b->conv_flag) (void)hipFree(b->conv_flag);
+        b->pause_at = b->conv_flag = nullptr;
+    } else {
+        if (!b->pause_at) {
+            SMI_HIP(dev_alloc(&b->pause_at, nb));
+            SMI_HIP(dev_alloc(&b->conv_flag, nb));
+        }
+        SMI_HIP(hipMemcpy(b->pause_at, it, nb * sizeof(int32_t), hipMemcpyHostToDevice));
+        SMI_HIP(hipMemset(b->conv_flag, 0, nb * sizeof(int32_t)));
+    }
+    refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_get_converged(smi_batch *b, int32_t *flag) {
+    SMI_REQUIRE(b && flag, "null argument");
+    SMI_REQUIRE(b->conv_flag != nullptr, "smi_batch_get_converged follows smi_batch_set_pause_at");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    SMI_HIP(hipMemcpy(flag, b->conv_flag, (size_t)b->d.n_blends * sizeof(int32_t), hipMemcpyDeviceToHost));
     return SMI_OK;
 }
 
@@ -2066,6 +2158,19 @@ static bool inline_render(const smi_batch *b) {
 }
 
 
+// launch_update forks the launches per size class onto streams of their own (BatchView::class_streams)
+static bool class_streams_pay(const smi_batch *b) {
+    static const int forced = [] {  // development aid: 0 never, 1 whenever there are two classes
+        const char *e = getenv("SMI_RANGE_CLASS_STREAMS");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced == 0 || b->n_size_classes < 2) return false;
+    if (forced > 0) return true;
+    // (512 blends of the quickstart scene: four ranges 1 527 k, two ranges with class streams
+    // 1 374 k blend-it/s; 768: 1 541 / 1 507; 1024: 1 510 / 1 620; 2048: 1 670 / 1 758)
+    return g_hw_queues.load(std::memory_order_relaxed) >= 8 && b->d.n_components >= 10000;
+}
+
 // number of blend ranges a step is split into
 static int sub_ranges(const smi_batch *b) {
     if (!plain_batch(b)) return 1;
@@ -2082,6 +2187,11 @@ static int sub_ranges(const smi_batch *b) {
     // 740, 1024: 919 / 857 / 826.
     const int queues = g_hw_queues.load(std::memory_order_relaxed);  // smi_set_hw_queues
     int n = b->n_sub > 0 ? b->n_sub : (nb < 128 ? 1 : (queues >= 8 && nb < 768) ? 4 : 3);
+    // boxes of several size classes (one latency-bound launch per class and range): two ranges
+    // whose class launches run side by side on streams of their own -- 2 x 4 streams on eight
+    // hardware queues (batch of 1024 quickstart blends, k blend-it/s over 100 iterations: three
+    // ranges 1 511, four 1 570, two ranges with class streams 1 617; round 6)
+    if (b->n_sub <= 0 && class_streams_pay(b)) n = 2;
     return std::max(1, std::min(n, nb));
 }
 
@@ -2117,6 +2227,7 @@ static int step_sub_ranges(smi_batch *b, int n_sub, int32_t it0, int32_t n_iter,
     for (int s = 0; s < n_sub; ++s) {
         const int lo = (int)((int64_t)s * nb / n_sub), hi = (int)((int64_t)(s + 1) * nb / n_sub);
         views[s].blend0 = lo;
+        views[s].range_slot = s;
         views[s].nb = hi - lo;
         views[s].comp0 = b->h_comp_start[lo];
         views[s].n_comp = b->h_comp_start[hi] - b->h_comp_start[lo];
@@ -2183,6 +2294,7 @@ int smi_batch_step(smi_batch *b, int32_t it0, int32_t n_iter, float e_rel, int32
     const BatchView &v = b->view;
     const int check = check_convergence != 0;
     const bool timing = b->timing;
+    b->view.class_streams = class_streams_pay(b) ? 1 : 0;
     const int n_sub = sub_ranges(b);
     const bool no_cube = inline_render(b), plain = plain_batch(b);
     if (n_sub > 1) {

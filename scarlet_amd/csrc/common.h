@@ -250,6 +250,11 @@ struct BatchView {
     float *shift_scratch;
     float *morph_param;
     float *g_sed_buf, *g_morph_buf;
+    // register-resident update kernels: the pre-prox image x and the AMSGrad denominator psi of
+    // every pixel, written once per iteration and read back once per proximal sub-iteration
+    // (x at [0, n_morph), psi at [n_morph, 2 n_morph); L2-resident between the two)
+    float *xp_tmp;
+    int64_t n_morph_total;
     const float *c_shift_step;
     const float *c_shift_rel;  // relative_step factor of a free shift (0: constant step)
     const int32_t *c_shift_fft;  // (Fy, Fx) per component, fft.py:116-167 with padding 10
@@ -290,10 +295,20 @@ struct BatchView {
     // value a failing update stores in state[b]: 3 + the iteration (launch_update stamps it;
     // anything >= 3 means non-finite parameters, finalize_blend explains the iteration)
     int32_t fail_code = 3;
+    // which of the concurrent ranges of blends this view is (step_sub_ranges): the launches per
+    // size class of a range fork onto side streams of that range (launch_update)
+    int32_t range_slot = 0;
+    // several size classes in a batch too large for update_kernel_mixed, eight hardware queues:
+    // two ranges whose class launches run side by side (batch.hip: sub_ranges)
+    int32_t class_streams = 0;
     // per blend: the iteration counter at which its current adaprox call began (nullptr: 0 for
     // all).  A blend whose boxes were resized starts anew (blend.py:276-302) while its batch
     // mates go on: the kernels take the rules of a first step (alpha / 10, vhat = v) and
     // min_iter from `it - it_base[b]` (smi_batch_set_iteration_base).
+    // smi_batch_set_pause_at: the iteration after whose update blend b pauses; conv_flag[b] = 1
+    // when the stopping rule fired (finalize_blend)
+    const int32_t *pause_at = nullptr;
+    int32_t *conv_flag = nullptr;
     const int32_t *it_base = nullptr;
     __device__ __forceinline__ int local_it(int b, int it) const {
         return it_base ? it - it_base[b] : it;
@@ -410,6 +425,10 @@ int launch_permute_kernel_spectrum(const float2 *Khat, float2 *Kt, int n_img, in
 
 template <typename T>
 int sweep_host_buffers(T *flat_img, int32_t n_pix, const SweepPlanHost &plan, T min_gradient);
+// n_img images of n_pix pixels, one plan each, one launch (smi_prox_weighted_monotonic_many_*)
+template <typename T>
+int sweep_many_host_buffers(T *images, int32_t n_img, int32_t n_pix,
+                            const std::vector<SweepPlanHost> &plans, T min_gradient);
 template <typename T>
 int apply_filter_host_buffers(const T *image, int32_t H, int32_t W, const T *values,
                               int32_t n_taps, const int32_t *ys, const int32_t *ye,

@@ -226,8 +226,11 @@ __device__ __forceinline__ void finalize_blend(const BatchView &v, int b, int it
         if (n < v.hist_cap) v.loss_hist[(int64_t)b * v.hist_cap + n] = loss;
         v.n_loss[b] = n + 1;
         v.last_loss[b] = loss;
-        if (check && (n >= 1 || v.have_prev[b]) && v.local_it(b, it) > min_iter &&
-            fabs(loss - prev) < (double)e_rel * fabs(loss))
+        const bool stop = check && (n >= 1 || v.have_prev[b]) && v.local_it(b, it) > min_iter &&
+                          fabs(loss - prev) < (double)e_rel * fabs(loss);
+        if (stop && v.conv_flag) v.conv_flag[b] = 1;
+        // (a blend that pauses at its resize hook or at the end of its budget: smi_batch_set_pause_at)
+        if (stop || (v.pause_at && it >= v.pause_at[b]))
             atomicCAS(&v.state[b], 0, 1);  // this iteration's update is the last one
     }
 }
@@ -1517,9 +1520,17 @@ __device__ __forceinline__ void sweep_ring_global(float *us, const SweepPlanDev 
 }
 
 // occupancy the register allocator has to reach (waves per SIMD): three arrays of NPL
-// registers + the sweep's prefetch; without the cap the scheduler trades waves for ILP
+// registers (one for the teams, UpdState) + the sweep's prefetch; without the cap the
+// scheduler trades waves for ILP
+#ifndef SMI_XP_TEAM
+#define SMI_XP_TEAM 1
+#endif
+constexpr bool update_xp(int team) { return SMI_XP_TEAM && team > 64; }  // (UpdState)
+constexpr int update_waves(int npl, int team) {
+    return npl <= 16 ? 4 : npl <= 27 ? (update_xp(team) ? 4 : 3) : 2;
+}
 #ifndef SMI_WAVES
-#define SMI_WAVES __attribute__((amdgpu_waves_per_eu(NPL <= 16 ? 4 : NPL <= 27 ? 3 : 2)))
+#define SMI_WAVES __attribute__((amdgpu_waves_per_eu(update_waves(NPL, T))))
 #endif
 // MODE 0: Blend.fit, 1: lite with AdaproxParameter, 2: lite with FistaParameter
 //
@@ -1528,11 +1539,22 @@ __device__ __forceinline__ void sweep_ring_global(float *us, const SweepPlanDev 
 // The components of a launch all belong to one size class (`work` lists them class by
 // class, common.h), so the per-pixel loops carry no bounds for the first kFull slots and a
 // small box never runs through a large box's loops.
-template <int NPL>
+// XP (the four-wavefront teams): the pre-prox image x and the denominators psi live in global
+// memory between the AMSGrad step and the sub-iterations (BatchView::xp_tmp, read back a few
+// pixels ahead of their use), so that a lane carries ONE array of NPL registers -- z -- through
+// the sub-iterations instead of three: 128 instead of 168 registers for the 71^2 / 81^2 boxes,
+// four workgroups per CU instead of three while three of a team's four wavefronts idle
+// through every sweep (cfg 4: update 0.516 -> 0.46 ms).  Same bits.  The one-wavefront classes
+// keep all three in registers: they are bound by throughput, not by residency, and the extra
+// stores and the read-back cost them 12 % (cfg 3: update 0.334 -> 0.374 ms at three or four
+// wavefronts per SIMD alike; NOTEBOOK round 6).
+template <int NPL, bool XP>
 struct UpdState {
     CompCtx c;
     int k, flags, plan_id, bad, ctr, n_slots;
-    float xs[NPL], rs[NPL], zs[NPL];
+    float xs[XP ? 1 : NPL], rs[XP ? 1 : NPL], zs[NPL];
+    float rpmax;      // XP: psi is stored unscaled
+    bool fista_prox;  // XP, FISTA: the candidate is z itself
     float alpha, pmax, t_old;
     bool monotonic, fit_center;
     const SweepSlotEntry *slots;
@@ -1554,16 +1576,25 @@ struct UpdFull {
 // proximal sub-iterations
 template <int NPL, int MODE, int T>
 __device__ __forceinline__ void upd_step(const BatchView &v, const float *G, int it, float e2,
-                                         int prox_max_iter, UpdState<NPL> &S) {
+                                         int prox_max_iter, UpdState<NPL, update_xp(T)> &S) {
     constexpr bool LITE = MODE != 0;
     constexpr bool fista = MODE == 2;
+    constexpr bool XP = update_xp(T);
     constexpr int kFull = UpdFull<NPL>::value;
     const CompCtx &c = S.c;
     it = v.local_it(c.b, it);
     const int lane = c.lane, k = S.k, N = c.N;
     float *us = S.us;
-    float(&xs)[NPL] = S.xs;
-    float(&rs)[NPL] = S.rs;
+    // (XP: xs holds the gradient, then x, and is dead after this phase)
+    float xs_local[NPL], rs_local[NPL];
+    auto &xs = [&]() -> float(&)[NPL] {
+        if constexpr (XP) return xs_local;
+        else return S.xs;
+    }();
+    auto &rs = [&]() -> float(&)[NPL] {  // (XP: never touched)
+        if constexpr (XP) return rs_local;
+        else return S.rs;
+    }();
     float(&zs)[NPL] = S.zs;
     const int flags = S.flags = v.c_flags[k];
     const int plan_id = S.plan_id = v.c_plan[k];
@@ -1645,15 +1676,26 @@ __device__ __forceinline__ void upd_step(const BatchView &v, const float *G, int
     const float alpha = fmaxf(v.c_morph_step[k], v.c_morph_rel[k] * (Team<T>::sum(msum) / (float)N));
     float pmax = 0.f;
     const rsrc_t r_m = make_rsrc(v.m_morph + c.moff, nbytes);
+    const rsrc_t r_x = make_rsrc(v.xp_tmp + c.moff, nbytes);
+    const rsrc_t r_p = make_rsrc(v.xp_tmp + v.n_morph_total + c.moff, nbytes);
+    S.fista_prox = fista;
     if (fista) {
         const float step = v.c_fista_step[k] / ssum2;
+        if constexpr (XP) {
+            // (candidate = z - 0 * (z - x) = z: nothing to keep beside z)
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) rs[j] = buf_load(r_m, (uint32_t)(lane + T * j) * 4u);
+            for (int j = 0; j < NPL; ++j) zs[j] = buf_load(r_m, (uint32_t)(lane + T * j) * 4u);
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            xs[j] = rs[j] - step * xs[j];
-            rs[j] = 0.f;
-            zs[j] = xs[j];
+            for (int j = 0; j < NPL; ++j) zs[j] = zs[j] - step * xs[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) rs[j] = buf_load(r_m, (uint32_t)(lane + T * j) * 4u);
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                xs[j] = rs[j] - step * xs[j];
+                rs[j] = 0.f;
+                zs[j] = xs[j];
+            }
         }
         pmax = 1.f;
     } else {
@@ -1703,8 +1745,15 @@ __device__ __forceinline__ void upd_step(const BatchView &v, const float *G, int
                     zs[j] = xs[j];
                     // slots beyond the box: x = z = 0 (loads returned 0), psi must not count
                     const bool in_box = j < kFull || lane + T * j < N;
-                    rs[j] = in_box ? psi : 0.f;
-                    pmax = fmaxf(pmax, rs[j]);
+                    if constexpr (XP) {
+                        const float rj = in_box ? psi : 0.f;
+                        buf_store(r_x, off, xs[j]);
+                        buf_store(r_p, off, rj);
+                        pmax = fmaxf(pmax, rj);
+                    } else {
+                        rs[j] = in_box ? psi : 0.f;
+                        pmax = fmaxf(pmax, rs[j]);
+                    }
                 }
             }
 #pragma unroll
@@ -1719,8 +1768,11 @@ __device__ __forceinline__ void upd_step(const BatchView &v, const float *G, int
         pmax = Team<T>::max(pmax);
     }
     const float rpmax = 1.f / pmax;
+    S.rpmax = rpmax;
+    if constexpr (!XP) {
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) rs[j] = rs[j] * rpmax;
+        for (int j = 0; j < NPL; ++j) rs[j] = rs[j] * rpmax;
+    }
     S.alpha = alpha;
     S.pmax = pmax;
 
@@ -1744,15 +1796,64 @@ __device__ __forceinline__ void upd_step(const BatchView &v, const float *G, int
 
 // candidate of a proximal sub-iteration into the LDS image
 template <int NPL, int T>
-__device__ __forceinline__ void upd_prox_begin(UpdState<NPL> &S) {
+__device__ __forceinline__ void upd_prox_begin(const BatchView &v, UpdState<NPL, update_xp(T)> &S) {
     const int lane = S.c.lane;
+    if constexpr (update_xp(T)) {
+        if (S.fista_prox) {
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) S.us[lane + T * j] = S.zs[j] - S.rs[j] * (S.zs[j] - S.xs[j]);
+            for (int j = 0; j < NPL; ++j) S.us[lane + T * j] = S.zs[j];
+            return;
+        }
+        // x and psi back from memory (written by this lane in upd_step), CH pixels per lane at a
+        // time, the next group requested before this one is used
+        const uint32_t nbytes = (uint32_t)S.c.N * 4u;
+        const rsrc_t r_x = make_rsrc(v.xp_tmp + S.c.moff, nbytes);
+        const rsrc_t r_p = make_rsrc(v.xp_tmp + v.n_morph_total + S.c.moff, nbytes);
+        constexpr int CH = NPL <= 8 ? NPL : 8;
+        const float rpmax = S.rpmax;
+        float cx[CH], cp[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const uint32_t off = (uint32_t)(lane + T * u) * 4u;
+            cx[u] = buf_load(r_x, off);
+            cp[u] = buf_load(r_p, off);
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < NPL; j0 += CH) {
+            float nx[CH], np[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                nx[u] = np[u] = 0.f;
+                if (j0 + CH + u < NPL) {
+                    const uint32_t off = (uint32_t)(lane + T * (j0 + CH + u)) * 4u;
+                    nx[u] = buf_load(r_x, off);
+                    np[u] = buf_load(r_p, off);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = j0 + u;
+                if (j < NPL) {
+                    const float r = cp[u] * rpmax;
+                    S.us[lane + T * j] = S.zs[j] - r * (S.zs[j] - cx[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                cx[u] = nx[u];
+                cp[u] = np[u];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) S.us[lane + T * j] = S.zs[j] - S.rs[j] * (S.zs[j] - S.xs[j]);
+    }
 }
 
 // MonotonicityConstraint(fit_center_radius=1): the plan of this sub-iteration
-template <int NPL>
-__device__ __forceinline__ void upd_prox_plan(const BatchView &v, UpdState<NPL> &S) {
+template <int NPL, bool XP>
+__device__ __forceinline__ void upd_prox_plan(const BatchView &v, UpdState<NPL, XP> &S) {
     if (S.fit_center) {
         const int centre = __builtin_amdgcn_readfirstlane(fit_center_index(S.us, S.c));
         const SweepPlanDev &pl = v.plans[S.plan_id + centre];
@@ -1764,7 +1865,8 @@ __device__ __forceinline__ void upd_prox_plan(const BatchView &v, UpdState<NPL> 
 
 // rest of the chain after the sweep, convergence test; true when the sub-iterations end
 template <int NPL, int MODE, int T>
-__device__ __forceinline__ bool upd_prox_end(const BatchView &v, float e2, UpdState<NPL> &S) {
+__device__ __forceinline__ bool upd_prox_end(const BatchView &v, float e2,
+                                             UpdState<NPL, update_xp(T)> &S) {
     constexpr bool LITE = MODE != 0;
     constexpr int kFull = UpdFull<NPL>::value;
     const CompCtx &c = S.c;
@@ -1812,7 +1914,7 @@ __device__ __forceinline__ bool upd_prox_end(const BatchView &v, float e2, UpdSt
 
 // parameters back to memory, finite check
 template <int NPL, int MODE, int T>
-__device__ __forceinline__ void upd_store(const BatchView &v, UpdState<NPL> &S) {
+__device__ __forceinline__ void upd_store(const BatchView &v, UpdState<NPL, update_xp(T)> &S) {
     constexpr bool fista = MODE == 2;
     const CompCtx &c = S.c;
     const int lane = c.lane;
@@ -1851,7 +1953,7 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
                                                  const SweepPlanDev *staged = nullptr,
                                                  const char *plan_lds = nullptr, int tid = -1) {
     constexpr bool fista = MODE == 2;
-    UpdState<NPL> S;
+    UpdState<NPL, update_xp(T)> S;
     S.k = k;
     S.staged = staged;
     S.plan_lds = plan_lds;
@@ -1865,9 +1967,9 @@ __device__ __forceinline__ void update_component(const BatchView &v, const float
     upd_step<NPL, MODE, T>(v, G, it, e2, prox_max_iter, S);
     team_fence<T>();  // the offsets parked in `us` have been consumed
     for (int tau = 0; tau < prox_max_iter; ++tau) {
-        upd_prox_begin<NPL, T>(S);
+        upd_prox_begin<NPL, T>(v, S);
         team_fence<T>();
-        upd_prox_plan<NPL>(v, S);
+        upd_prox_plan(v, S);
         if (S.monotonic) {
             // one wavefront sweeps (the steps are sequential and at most 64 pixels wide)
             if (T == 64 || threadIdx.x < 64) {
@@ -1911,7 +2013,7 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 // 128 blends 553 -> 613, 256 blends 749 -> 772, 512 blends (1280 components per range)
 // 872 -> 810: hence kUpdatePackLimit = 1024 components.
 constexpr int update_pack_max(int npl, int team) {
-    return team != 64 ? 1 : 4 * (npl <= 16 ? 4 : npl <= 27 ? 3 : 2);
+    return team != 64 ? 1 : 4 * update_waves(npl, team);
 }
 // With `stage_plan` >= 0 the workgroup first copies that plan's ring stream into the LDS behind
 // its images (common.h: RingPlanHost): the sweeps of the components that use the plan -- in a
@@ -2311,6 +2413,31 @@ __global__ __launch_bounds__(64) void sweep_kernel(T *img, int n_pix, const int3
     for (int i = lane; i < n_pix; i += 64) img[i] = buf[i];
 }
 
+// One workgroup per image, every image with a plan of its own inside the concatenated plan
+// arrays (smi_prox_weighted_monotonic_many_*: the detection images of a scene's sources).
+struct SweepManyDesc {
+    int64_t level_off, entry_off, term_off;  // into level_start / pix, cnt / nbr, wt
+    int32_t n_levels, n_entries;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void sweep_many_kernel(T *images, int n_pix,
+                                                         const SweepManyDesc *desc,
+                                                         const int32_t *level_start,
+                                                         const int32_t *pix, const int32_t *cnt,
+                                                         const int32_t *nbr, const T *wt,
+                                                         T one_minus_g) {
+    const SweepManyDesc d = desc[blockIdx.x];
+    T *buf = reinterpret_cast<T *>(lds_dyn);
+    T *img = images + (int64_t)blockIdx.x * n_pix;
+    const int t = threadIdx.x;
+    for (int i = t; i < n_pix; i += 256) buf[i] = img[i];
+    __syncthreads();
+    sweep_levels<T, T, 256>(buf, level_start + d.level_off, d.n_levels, d.n_entries,
+                            pix + d.entry_off, cnt + d.entry_off, nbr + d.term_off,
+                            wt + d.term_off, one_minus_g, t);
+    for (int i = t; i < n_pix; i += 256) img[i] = buf[i];
+}
+
 // The same sweep for images beyond the LDS (initialisation runs it on the whole detection
 // image, e.g. 282 x 282 doubles): one workgroup of 1024 threads working in global memory,
 // level by level; a workgroup-scope fence + barrier makes a level's writes visible to the
@@ -2582,14 +2709,25 @@ int launch_update(const BatchView &v_in, const float *G, int32_t it, float e_rel
             const char *e = getenv("SMI_CLASS_STREAMS");
             return e ? atoi(e) : -1;
         }();
-        const bool side_by_side = classes > 1 && (class_streams < 0 ? v.n_comp <= kMixedUpdateLimit
-                                                                    : class_streams > 0);
+        const bool side_by_side =
+            classes > 1 && (class_streams < 0 ? (v.n_comp <= kMixedUpdateLimit || v.class_streams)
+                                              : class_streams > 0);
+        // (ONE set of side streams per host thread, shared by the concurrent ranges of blends: the
+        // launches of a class from two ranges queue up behind each other on that class's stream.
+        // Side streams per range -- eight streams busy at once -- were measured: 1 616 k -> 1 300 k
+        // blend-it/s on the 1024-blend quickstart batch.  SMI_SIDE_PER_RANGE=1 brings them back.)
         struct Side {
             hipStream_t stream[kNumUpdateClasses] = {};
             hipEvent_t fork = nullptr, join[kNumUpdateClasses] = {};
             int device = -1;
         };
-        static thread_local Side side;
+        constexpr int kSideSlots = 4;
+        static thread_local Side sides[kSideSlots];
+        static const bool per_range = [] {  // development aid
+            const char *e = getenv("SMI_SIDE_PER_RANGE");
+            return e && atoi(e) != 0;
+        }();
+        Side &side = sides[per_range && v.range_slot >= 0 && v.range_slot < kSideSlots ? v.range_slot : 0];
         int n_side = 0;
         if (side_by_side) {
             int dev = 0;
@@ -2783,6 +2921,58 @@ int sweep_host_buffers(T *flat_img, int32_t n_pix, const SweepPlanHost &plan, T 
 }
 template int sweep_host_buffers<float>(float *, int32_t, const SweepPlanHost &, float);
 template int sweep_host_buffers<double>(double *, int32_t, const SweepPlanHost &, double);
+
+template <typename T>
+int sweep_many_host_buffers(T *images, int32_t n_img, int32_t n_pix,
+                            const std::vector<SweepPlanHost> &plans, T min_gradient) {
+    const size_t lds = (size_t)n_pix * sizeof(T);
+    if (lds > 160 * 1024) {  // beyond the LDS: image by image in global memory
+        for (int i = 0; i < n_img; ++i)
+            if (int rc = sweep_host_buffers<T>(images + (size_t)i * n_pix, n_pix, plans[i], min_gradient))
+                return rc;
+        return SMI_OK;
+    }
+    std::vector<SweepManyDesc> desc(n_img);
+    std::vector<int32_t> ls, pix, cnt, nbr;
+    std::vector<T> wt;
+    for (int i = 0; i < n_img; ++i) {
+        const SweepPlanHost &p = plans[i];
+        desc[i].level_off = (int64_t)ls.size();
+        desc[i].entry_off = (int64_t)pix.size();
+        desc[i].term_off = (int64_t)nbr.size();
+        desc[i].n_levels = p.n_entries ? (int32_t)p.level_start.size() - 1 : 0;
+        desc[i].n_entries = p.n_entries;
+        if (!p.n_entries) continue;
+        ls.insert(ls.end(), p.level_start.begin(), p.level_start.end());
+        pix.insert(pix.end(), p.pix.begin(), p.pix.end());
+        cnt.insert(cnt.end(), p.cnt.begin(), p.cnt.end());
+        nbr.insert(nbr.end(), p.nbr.begin(), p.nbr.end());
+        for (double w : p.wt) wt.push_back((T)w);
+    }
+    if (pix.empty()) return SMI_OK;
+    DevBuf<T> d_img, d_wt;
+    DevBuf<int32_t> d_ls, d_pix, d_cnt, d_nbr;
+    DevBuf<SweepManyDesc> d_desc;
+    SMI_HIP(d_img.upload(images, (size_t)n_img * n_pix));
+    SMI_HIP(d_wt.upload(wt.data(), wt.size()));
+    SMI_HIP(d_ls.upload(ls.data(), ls.size()));
+    SMI_HIP(d_pix.upload(pix.data(), pix.size()));
+    SMI_HIP(d_cnt.upload(cnt.data(), cnt.size()));
+    SMI_HIP(d_nbr.upload(nbr.data(), nbr.size()));
+    SMI_HIP(d_desc.upload(desc.data(), desc.size()));
+    auto kern = sweep_many_kernel<T>;
+    SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_img), dim3(256), lds, 0, d_img.p, n_pix, d_desc.p, d_ls.p,
+                       d_pix.p, d_cnt.p, d_nbr.p, d_wt.p, (T)1 - min_gradient);
+    SMI_HIP(hipGetLastError());
+    SMI_HIP(hipMemcpy(images, d_img.p, (size_t)n_img * n_pix * sizeof(T), hipMemcpyDeviceToHost));
+    return SMI_OK;
+}
+template int sweep_many_host_buffers<float>(float *, int32_t, int32_t,
+                                            const std::vector<SweepPlanHost> &, float);
+template int sweep_many_host_buffers<double>(double *, int32_t, int32_t,
+                                             const std::vector<SweepPlanHost> &, double);
 
 template <typename T>
 int apply_filter_host_buffers(const T *image, int32_t H, int32_t W, const T *values,

@@ -132,6 +132,41 @@ def _native_sweep(X, weights, offsets, didx, min_gradient):
     return X
 
 
+def prox_weighted_monotonic_many(images, centers, neighbor_weight="flat", min_gradient=0.1):
+    """``prox_weighted_monotonic(shape, neighbor_weight, min_gradient, center=centers[i])``
+    applied to ``images[i]`` for every i, in ONE launch through the C ABI
+    (``smi_prox_weighted_monotonic_many_*``): the detection images of a scene's sources, each
+    made monotonic about its own centre (source.py:312-333 inside the loop of
+    initialization.py:287-363).  ``images`` (n, H, W), float32 or float64, C-contiguous, is
+    modified in place and returned; every image comes out bit for bit as the single
+    operator leaves it."""
+    lib = _lib.load()
+    if images.ndim != 3 or not images.flags.c_contiguous:
+        raise ValueError("prox_weighted_monotonic_many needs a C-contiguous (n, H, W) array")
+    n, h, w = images.shape
+    if len(centers) != n:
+        raise ValueError("one centre per image")
+    if n == 0:
+        return images
+    if images.dtype == np.float32:
+        fn, ct = lib.smi_prox_weighted_monotonic_many_f32, _lib.ctypes.c_float
+    elif images.dtype == np.float64:
+        fn, ct = lib.smi_prox_weighted_monotonic_many_f64, _lib.ctypes.c_double
+    else:
+        raise TypeError("prox_weighted_monotonic_many: float32 or float64 array required")
+    shape = (h, w)
+    weights = np.empty((n, 8, h * w), dtype=images.dtype)
+    didx = np.empty((n, h * w - 1), dtype=np.int32)
+    for i, center in enumerate(centers):
+        weights[i] = getRadialMonotonicWeights(shape, neighbor_weight=neighbor_weight, center=center)
+        didx[i] = sort_by_radius(shape, center)[1:]
+    off = _lib.i32(getOffsets(w)[0])
+    _lib.check(fn(n, _lib.ptr(images, ct), h * w, _lib.ptr(weights, ct),
+                  _lib.ptr(off, _lib.ctypes.c_int32), off.size,
+                  _lib.ptr(didx, _lib.ctypes.c_int32), didx.shape[1], float(min_gradient)))
+    return images
+
+
 def _prox_weighted_monotonic(X, step, weights, didx, offsets, min_gradient=0.1):
     """Force a radially monotonic profile; ``X`` is modified in place."""
     return _native_sweep(X, weights, offsets, didx, min_gradient)

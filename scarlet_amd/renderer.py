@@ -121,8 +121,32 @@ class ConvolutionRenderer(Renderer):
         equations of ``initialization.set_spectra_to_match`` (condition numbers of several
         hundred).  Not used by the fitting loop."""
         model_ = np.asarray(self.map_channels(model), dtype=np.float64)
-        kernel = np.asarray(self.kernel_image(*parameters), dtype=np.float64)
-        out = fft.convolve(fft.Fourier(model_), kernel, axes=(1, 2)).image
+        if self.get_parameter("psf_shift", *parameters) is not None:
+            kernel = fft.Fourier(np.asarray(self.kernel_image(*parameters), dtype=np.float64))
+        else:
+            # (the kernel's transforms are kept with it: one per FFT shape, not one per call)
+            kernel = getattr(self, "_kernel_float64", None)
+            if kernel is None:
+                kernel = self._kernel_float64 = fft.Fourier(
+                    np.asarray(self.kernel_image(), dtype=np.float64))
+        # A component's model is zero outside its box: convolve the part of the frame the
+        # kernel can reach from there (zero-boundary convolution: the same sums, on a
+        # transform a fraction of the frame's size) and leave the rest zero.
+        out = None
+        rows = np.flatnonzero(model_.any(axis=(0, 2)))
+        cols = np.flatnonzero(model_.any(axis=(0, 1)))
+        if rows.size == 0:
+            out = np.zeros(model_.shape, dtype=np.float64)
+        else:
+            hy, hx = kernel.shape[-2] // 2 + 1, kernel.shape[-1] // 2 + 1
+            y0, y1 = max(rows[0] - hy, 0), min(rows[-1] + 1 + hy, model_.shape[1])
+            x0, x1 = max(cols[0] - hx, 0), min(cols[-1] + 1 + hx, model_.shape[2])
+            if 2 * (y1 - y0) * (x1 - x0) <= model_.shape[1] * model_.shape[2]:
+                out = np.zeros(model_.shape, dtype=np.float64)
+                cut = np.ascontiguousarray(model_[:, y0:y1, x0:x1])
+                out[:, y0:y1, x0:x1] = fft.convolve(fft.Fourier(cut), kernel, axes=(1, 2)).image
+        if out is None:
+            out = fft.convolve(fft.Fourier(model_), kernel, axes=(1, 2)).image
         data_sl, model_sl = self.slices
         if out[model_sl].shape == tuple(self.data_frame.shape):
             return out[model_sl]

@@ -104,32 +104,44 @@ class SingleExtendedSource(FactorizedComponent):
     def __init__(self, model_frame, sky_coord, observations, thresh=1.0, shifting=False,
                  resizing=True, boxsize=None):
         observations = _as_sequence(observations)
-        per_obs = init.get_pixel_spectrum(sky_coord, observations, concat=False)
+        # (init_all_sources sweeps the detection images of all its sources in one launch)
+        ready = init.prepared_detection(sky_coord, observations)
+        if ready is not None:
+            per_obs, coadd, coadd_rms, symmetrised, swept = ready
+        else:
+            per_obs = init.get_pixel_spectrum(sky_coord, observations, concat=False)
+            coadd, coadd_rms = init.build_initialization_image(observations, spectra=per_obs)
+            symmetrised = swept = None
         spectrum = TabulatedSpectrum(model_frame, np.concatenate(per_obs).reshape(-1),
                                      min_step=_noise_rms(observations))
-        coadd, coadd_rms = init.build_initialization_image(observations, spectra=per_obs)
         image, bbox = self.init_morph(model_frame, sky_coord, coadd, coadd_rms, thresh=thresh,
                                       symmetric=True, monotonic="flat", min_grad=0,
-                                      boxsize=boxsize)
+                                      boxsize=boxsize, _swept=swept)
         morphology = _fitted_morphology(model_frame, sky_coord, image, bbox, shifting, resizing)
         super().__init__(model_frame, spectrum, morphology)
         self.center = morphology.center
 
     @staticmethod
     def init_morph(frame, sky_coord, detect, detect_std, thresh=1, symmetric=True,
-                   monotonic="flat", min_grad=0, boxsize=None):
+                   monotonic="flat", min_grad=0, boxsize=None, _swept=None):
         """Cut-out of the detection image around the source: symmetrised and made
         monotonic about the nearest pixel, trimmed at ``thresh * detect_std``,
-        peak-normalised and never narrower than the model PSF."""
+        peak-normalised and never narrower than the model PSF.  ``_swept``: the symmetrised,
+        monotonic profile when ``init_all_sources`` has prepared it (symmetric, 'flat'
+        weights, no minimal gradient)."""
         pixel = _nearest_pixel(frame, sky_coord)
-        profile = detect.copy()
-        if symmetric:
-            profile = operator.prox_uncentered_symmetry(profile, 0, center=pixel, algorithm="sdss")
-        if monotonic:
-            weights = "angle" if monotonic is True else monotonic
-            sweep = operator.prox_weighted_monotonic(profile.shape, neighbor_weight=weights,
-                                                     center=pixel, min_gradient=min_grad)
-            profile = sweep(np.ascontiguousarray(profile), 0).reshape(profile.shape)
+        if _swept is not None and symmetric and monotonic == "flat" and min_grad == 0:
+            profile = _swept.copy()
+        else:
+            profile = detect.copy()
+            if symmetric:
+                profile = operator.prox_uncentered_symmetry(profile, 0, center=pixel,
+                                                            algorithm="sdss")
+            if monotonic:
+                weights = "angle" if monotonic is True else monotonic
+                sweep = operator.prox_weighted_monotonic(profile.shape, neighbor_weight=weights,
+                                                         center=pixel, min_gradient=min_grad)
+                profile = sweep(np.ascontiguousarray(profile), 0).reshape(profile.shape)
         image, bbox = init.trim_morphology(pixel, profile, bg_thresh=detect_std * thresh,
                                            boxsize=boxsize)
         if image.sum() > 0:

@@ -170,6 +170,44 @@ def test_quickstart_initialisation_matches_reference(hsc):
     assert logL > logL0 and n <= 100
 
 
+def test_initialisation_sweeps_all_detection_images_in_one_launch(hsc, monkeypatch):
+    """``init_all_sources`` prepares every source's detection image -- coadd, symmetrised,
+    monotonic about the source's pixel -- ahead of the loop over the sources with ONE call of
+    the many-image sweep and no per-source sweep, and gives exactly the sources of the
+    per-source path (``ExtendedSource`` built one by one)."""
+    import scarlet_amd as scarlet
+    from scarlet_amd import initialization, operator
+
+    filters = list("grizy")
+    frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5), channels=filters)
+    obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                              weights=hsc["weights"], channels=filters).match(frame)
+    centers = [tuple(c) for c in hsc["centers"]]
+    calls = {"many": 0, "one": 0}
+    many, one = operator.prox_weighted_monotonic_many, operator._native_sweep
+
+    def count_many(*a, **k):
+        calls["many"] += 1
+        return many(*a, **k)
+
+    def count_one(*a, **k):
+        calls["one"] += 1
+        return one(*a, **k)
+
+    monkeypatch.setattr(operator, "prox_weighted_monotonic_many", count_many)
+    monkeypatch.setattr(operator, "_native_sweep", count_one)
+    kw = dict(max_components=2, min_snr=50, thresh=1, fallback=True, silent=True, set_spectra=False)
+    batched, _ = initialization.init_all_sources(frame, centers, obs, **kw)
+    assert calls == {"many": 1, "one": 0} and not initialization._prepared
+    single = [initialization.init_source(frame, c, obs, thresh=1, max_components=2, min_snr=50)
+              for c in centers]
+    assert calls["many"] == 1 and calls["one"] >= len(centers)
+    for a, b in zip(components_of(scarlet.Blend(batched, obs)), components_of(scarlet.Blend(single, obs))):
+        assert a.children[1].bbox == b.children[1].bbox
+        for p, q in zip(a.parameters, b.parameters):
+            assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
+
+
 def test_two_observations_equal_one(hsc):
     """the same scene observed as (g,r,i) and (z,y) by two Observations gives the same
     fit as the single 5-band Observation (loss summed over observations, blend.py:265-271)"""
@@ -704,6 +742,47 @@ def test_centre_fitting_with_resizing_on_the_resident_path(monkeypatch):
             one = build(i, i + 1)[0]
             assert one.fit(45, e_rel=1e-4) == ra[i]
             assert one.loss == a[i].loss
+
+
+def test_blends_pause_at_their_own_hooks_and_give_the_lockstep_results(monkeypatch):
+    """``fit_blends`` lets every blend run to ITS next resize hook (or the end of its budget)
+    inside one device call -- the device pauses it there, ``smi_batch_set_pause_at`` -- instead of
+    stopping all blends at the nearest hook of any of them.  Same results as the lock-step
+    rounds (``SCARLET_AMD_FIT_BLENDS=lockstep``), bit for bit, in fewer device calls."""
+    import os
+    import sys
+
+    import scarlet_amd as scarlet
+    from scarlet_amd import BlendBatch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    calls = {"n": 0}
+    step = BlendBatch.step
+
+    def counting(self, *a, **k):
+        calls["n"] += 1
+        return step(self, *a, **k)
+
+    monkeypatch.setattr(BlendBatch, "step", counting)
+    n = 40
+    a = bench.build_facade_blends(0, n, 0)
+    ra = scarlet.fit_blends(a, 57, e_rel=1e-4, min_iter=3)
+    own = calls["n"]
+    monkeypatch.setenv("SCARLET_AMD_FIT_BLENDS", "lockstep")
+    calls["n"] = 0
+    b = bench.build_facade_blends(0, n, 0)
+    rb = scarlet.fit_blends(b, 57, e_rel=1e-4, min_iter=3)
+    assert ra == rb and own < calls["n"]
+    assert len({r[0] for r in ra}) > 3 and max(r[0] for r in ra) == 57
+    for x, y in zip(a, b):
+        assert x.loss == y.loss
+        for p, q in zip(x.parameters, y.parameters):
+            assert p.shape == q.shape
+            assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
+            if p.m is not None:
+                assert_allclose(p.v, q.v, rtol=0, atol=0)
 
 
 def test_fit_blends_keeps_going_when_one_blend_fails():

@@ -74,6 +74,31 @@ def test_sweep_bit_exact_beyond_the_lds(amd, dtype, shape, center):
         assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("dtype,shape", [(np.float64, (58, 48)), (np.float32, (128, 128)),
+                                         (np.float64, (128, 128)), (np.float32, (7, 9)),
+                                         (np.float64, (150, 150))])
+def test_many_sweeps_in_one_launch_equal_the_single_sweeps(amd, dtype, shape):
+    """``smi_prox_weighted_monotonic_many_*``: the detection images of a scene's sources, each
+    about a centre of its own (on the edge and in a corner too), made monotonic in one launch --
+    bit for bit what the one-image entry point and the oracle give image by image.  150 x 150
+    doubles are beyond the LDS: that call falls back to image-by-image launches."""
+    from oracle import proxops
+
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    n = 6
+    centers = [(int(rng.integers(0, shape[0])), int(rng.integers(0, shape[1]))) for _ in range(n - 2)]
+    centers += [(0, 0), (shape[0] - 1, shape[1] // 2)]
+    for mode, g in (("flat", 0.0), ("angle", 0.1)):
+        x0 = rng.random((n,) + shape).astype(dtype)
+        got = amd.operator.prox_weighted_monotonic_many(x0.copy(), centers, mode, g)
+        for i, c in enumerate(centers):
+            w, didx, off = proxops.monotonic_operator(shape, mode, c)
+            assert_array_equal(got[i], proxops.sweep(x0[i].copy(), w, off, didx, g))
+            one = amd.operator.prox_weighted_monotonic(shape, mode, g, center=c)
+            assert_array_equal(got[i], one(x0[i].copy(), 0))
+    assert amd.operator.prox_weighted_monotonic_many(x0[:0].copy(), [], "flat", 0).shape[0] == 0
+
+
 def test_sweep_reference_known_answers(amd):
     """reference tests/test_constraint.py:92-135 through the product classes"""
     from test_oracle_golden import MONO_NEAREST, MONO_ANGLE, MONO_ANGLE_G25

@@ -647,10 +647,35 @@ def test_bench_names_the_dominant_kernel_from_the_library_path():
     assert bench.dominant_kernel(full, "none", by) == ("update_kernel_reg", by["update"], 0.3353)
 
 
+def test_importing_the_package_asks_for_eight_hardware_queues():
+    """A fresh process that says nothing about GPU_MAX_HW_QUEUES gets 8 exported by the
+    import (before the HIP runtime can have started); a value of the caller's stays, and
+    SCARLET_AMD_HW_QUEUES=keep leaves the environment alone."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import scarlet_amd; "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), scarlet_amd.configure())" % root)
+
+    def run(**env):
+        base = {k: v for k, v in os.environ.items()
+                if k not in ("GPU_MAX_HW_QUEUES", "SCARLET_AMD_HW_QUEUES")}
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                             env=dict(base, **env), timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.split()[-2:]
+
+    assert run() == ["8", "8"]
+    assert run(GPU_MAX_HW_QUEUES="2") == ["2", "2"]
+    assert run(SCARLET_AMD_HW_QUEUES="keep") == ["None", "4"]
+
+
 def test_configure_sets_the_hardware_queues_only_on_request(monkeypatch):
-    """Loading the library leaves the environment alone; ``configure(hw_queues=8)`` sets
-    GPU_MAX_HW_QUEUES while the HIP runtime has not started, warns and changes nothing once
-    it has, and the library is told the number in effect."""
+    """``configure(hw_queues=8)`` sets GPU_MAX_HW_QUEUES while the HIP runtime has not started,
+    warns and changes nothing once it has, and the library is told the number in effect
+    (``load()`` itself leaves the environment alone)."""
     import os
     import warnings
 
@@ -660,6 +685,8 @@ def test_configure_sets_the_hardware_queues_only_on_request(monkeypatch):
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
     monkeypatch.setattr(_lib, "_hw_queues", None)
     monkeypatch.setattr(_lib, "_warned", False)
+    # (a process whose environment was left alone: SCARLET_AMD_HW_QUEUES=keep)
+    monkeypatch.setattr(_lib, "_env_at_import", None)
     lib = _lib.load()
     assert "GPU_MAX_HW_QUEUES" not in os.environ
     assert scarlet_amd.configure() == 4
