@@ -327,6 +327,12 @@ int smi_batch_get_centers(smi_batch *b, double *center, double *m, double *v, do
                           double *gradient);
 int smi_batch_set_center_moments(smi_batch *b, const double *m, const double *v,
                                  const double *vhat);
+/* New values [n_components][2] for the point-source centres / free shifts (entries of other
+ * components are ignored); the morphologies that enter the model follow.  For a 2-vector the
+ * host steps itself -- a prior, a constraint or a step callable on it (blend.py:120-145 treats
+ * every Parameter alike): its device step is 0, the host takes the step from the gradient of
+ * smi_batch_get_centers and writes the result back here. */
+int smi_batch_set_centers(smi_batch *b, const double *center);
 int smi_batch_get_model_morphology(smi_batch *b, float *morph);
 int smi_batch_set_parameters(smi_batch *b, const float *sed, const float *morph);
 

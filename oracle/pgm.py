@@ -474,17 +474,37 @@ class Scene:
         blend.py:165-180 (amsgrad, prox_max_iter=10)."""
         _, grads = self.loss_and_gradients()
         # all steps are evaluated on the pre-update parameters (blend.py:135-138)
+        # A free 2-vector (centre, shift, psf_shift) is a Parameter like any other
+        # (blend.py:120-145): `vec_rules[name]`, if set on the component / scene, holds
+        # {"prior": f(x) -> array added to the gradient (blend.py:120-131), "prox": f(x, step),
+        # "step": f(x, it=...)} for it.
+        def rules(owner, name):
+            return (getattr(owner, "vec_rules", None) or {}).get(name, {})
+
+        def vec_alpha(owner, name, x, default):
+            fn = rules(owner, name).get("step")
+            return default if fn is None else fn(x, it=it)
+
+        def vec_grad(owner, name, x, g):
+            fn = rules(owner, name).get("prior")
+            return g if fn is None else g + fn(x)
+
         alphas = [(c.sed_step(it),
-                   relative_step(c.center, c.center_rel_step, c.center_step)
+                   vec_alpha(c, "center", c.center,
+                             relative_step(c.center, c.center_rel_step, c.center_step))
                    if isinstance(c, PointComponent) else c.morph_step)
                   for c in self.components]
         shift_alphas = [None if getattr(c, "shift", None) is None else
-                        relative_step(c.shift, c.shift_rel_step, c.shift_step) for c in self.components]
+                        vec_alpha(c, "shift", c.shift,
+                                  relative_step(c.shift, c.shift_rel_step, c.shift_step))
+                        for c in self.components]
         if self.psf_shift is not None:
-            psf_alpha = relative_step(self.psf_shift, self.psf_shift_rel_step, self.psf_shift_step)
+            psf_alpha = vec_alpha(self, "psf_shift", self.psf_shift,
+                                  relative_step(self.psf_shift, self.psf_shift_rel_step,
+                                                self.psf_shift_step))
         if self.psf_shift is not None:
             # the renderer's parameter comes after the sources' in X (blend.py:103-105)
-            g_psf = self.g_psf_shift
+            g_psf = vec_grad(self, "psf_shift", self.psf_shift, self.g_psf_shift)
         for c, (g_sed, g_morph, *g_shift), (a_sed, a_morph), a_shift in zip(
                 self.components, grads, alphas, shift_alphas):
             adaprox_update(
@@ -492,10 +512,11 @@ class Scene:
                 e_rel, prox_max_iter, b1, b2, eps,
             )
             if isinstance(c, PointComponent):
-                # the centre has no constraint (source.py:115): plain AMSGrad step
+                # the centre has no constraint by default (source.py:115): plain AMSGrad step
                 adaprox_update(
-                    it, c.center, g_morph, c.m_center, c.v_center, c.vhat_center, a_morph,
-                    None, e_rel, prox_max_iter, b1, b2, eps,
+                    it, c.center, vec_grad(c, "center", c.center, g_morph), c.m_center,
+                    c.v_center, c.vhat_center, a_morph, rules(c, "center").get("prox"), e_rel,
+                    prox_max_iter, b1, b2, eps,
                 )
                 continue
             adaprox_update(
@@ -504,12 +525,13 @@ class Scene:
             )
             if g_shift:
                 adaprox_update(
-                    it, c.shift, g_shift[0], c.m_shift, c.v_shift, c.vhat_shift, a_shift,
-                    None, e_rel, prox_max_iter, b1, b2, eps,
+                    it, c.shift, vec_grad(c, "shift", c.shift, g_shift[0]), c.m_shift, c.v_shift,
+                    c.vhat_shift, a_shift, rules(c, "shift").get("prox"), e_rel, prox_max_iter,
+                    b1, b2, eps,
                 )
         if self.psf_shift is not None:
             adaprox_update(it, self.psf_shift, g_psf, self.m_psf, self.v_psf, self.vhat_psf, psf_alpha,
-                           None, e_rel, prox_max_iter, b1, b2, eps)
+                           rules(self, "psf_shift").get("prox"), e_rel, prox_max_iter, b1, b2, eps)
 
     def check_parameters(self):
         """``Model.check_parameters`` (model.py:153-165)."""

@@ -162,6 +162,7 @@ SYMBOLS = {
     "smi_batch_set_parameters": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p]),
     "smi_batch_get_centers": (ctypes.c_int, [ctypes.c_void_p] + [c_f64p] * 5),
     "smi_batch_set_center_moments": (ctypes.c_int, [ctypes.c_void_p] + [c_f64p] * 3),
+    "smi_batch_set_centers": (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
     "smi_batch_get_model_morphology": (ctypes.c_int, [ctypes.c_void_p, c_f32p]),
     "smi_batch_set_scheme": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "smi_batch_get_fista_state": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f64p]),

@@ -698,6 +698,12 @@ class BlendBatch:
         )
         return out
 
+    def set_centers(self, center):
+        """New point-source centres (frame pixels) / free shifts, (n_components, 2); rows of
+        other components are ignored.  The morphologies that enter the model follow."""
+        center = np.ascontiguousarray(center, dtype=np.float64).reshape(self.n_components, 2)
+        _lib.check(self._lib.smi_batch_set_centers(self._h, _lib.ptr(center, ctypes.c_double)))
+
     def set_center_moments(self, m=None, v=None, vhat=None):
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 2)
                 for a in (m, v, vhat)]

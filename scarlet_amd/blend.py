@@ -20,7 +20,7 @@ from .batch import BlendBatch, ComponentSpec, PointSourceSpec
 from .bbox import overlapped_slices
 from .component import CombinedComponent, FactorizedComponent
 from .constraint import PositivityConstraint, device_flags
-from .hoststep import HostParameter
+from .hoststep import HostParameter, HostVector
 from .model import UpdateException
 from .model import Model
 from .morphology import ImageMorphology, Morphology, PointSourceMorphology, _edge_pull
@@ -70,12 +70,30 @@ def _adaprox_options(alg_kwargs):
     return prox_max_iter, opt
 
 
-def _plain_2vector(p, what):
-    """A free 2-vector on the device (shift, point-source centre, psf_shift) takes the bare
-    AMSGrad step of the reference's defaults (morphology.py:673-676, source.py:115,
-    renderer.py:175-177): no prior, no constraint."""
-    if p.prior is not None or p.constraint is not None:
-        raise NotImplementedError("priors / constraints on {}".format(what))
+def _vector_rule(p, what):
+    """``(on_device, rule)`` of a free 2-vector (shift, point-source centre, psf_shift).  The
+    device takes the bare AMSGrad step of the reference's defaults (morphology.py:673-676,
+    source.py:115, renderer.py:175-177); a vector with a prior, a constraint or a step callable
+    of the user's is stepped on the host from the device's gradient (hoststep.HostVector), like
+    any other parameter the device cannot express (blend.py:120-145).  ``rule`` = (constant,
+    relative factor, minimum), or the callable."""
+    if p.fixed and p.step is None:
+        return True, (0.0, 0.0, 0.0)
+    try:
+        rule = _step_rule(p.step, what)
+    except NotImplementedError:
+        return False, p.step
+    return p.prior is None and p.constraint is None, rule
+
+
+def _rule(p, what):
+    """step rule of a parameter, or the callable itself if it is user code"""
+    if p.fixed and p.step is None:
+        return (0.0, 0.0, 0.0)  # never used (blend.py:107-115)
+    try:
+        return _step_rule(p.step, what)
+    except NotImplementedError:
+        return p.step
 
 
 def _step_rule(step, what):
@@ -243,7 +261,11 @@ class Blend(CombinedComponent):
             if isinstance(morphology, PointSourceMorphology):
                 if self._scheme_args()[0] != "amsgrad":
                     raise NotImplementedError("point sources with another scheme than amsgrad")
-                specs.append(self._point_spec(sed, image, morphology))
+                on_device, rule = _vector_rule(image, "center")
+                if not on_device:  # a prior / constraint / step callable on the centre
+                    self._host.append((k, HostVector(image, rule)))
+                    rule = (0.0, 0.0, 0.0)
+                specs.append(self._point_spec(sed, image, morphology, rule))
                 continue
             shift_kw = {}
             if getattr(morphology, "shifting", False):
@@ -251,10 +273,13 @@ class Blend(CombinedComponent):
                 # the reference's default for a bare ImageMorphology, morphology.py:113 --
                 # is the identity; a fixed non-zero one is applied with step 0
                 shift = morphology.parameters[1]
-                _plain_2vector(shift, "a shift parameter")
                 if not shift.fixed or np.any(np.asarray(shift) != 0):
                     # (relative_step, parameter.py:126-129: max(minimum, factor * mean))
-                    const, rel, low = _step_rule(shift.step, "shift")
+                    on_device, rule = _vector_rule(shift, "shift")
+                    if not on_device:  # the host steps it: the device keeps it where it is
+                        self._host.append((k, HostVector(shift, rule)))
+                        rule = (0.0, 0.0, 0.0)
+                    const, rel, low = rule
                     const = max(const, float(np.max(low)))
                     if max(image.shape) > 240:
                         raise NotImplementedError(
@@ -265,16 +290,7 @@ class Blend(CombinedComponent):
             if shift_kw and (sed.prior is not None or image.prior is not None):
                 raise NotImplementedError("priors on a component with a free Fourier shift")
 
-            def rule(p, what):
-                """step rule of a parameter, or the callable itself if it is user code"""
-                if p.fixed and p.step is None:
-                    return (0.0, 0.0, 0.0)  # never used (blend.py:107-115)
-                try:
-                    return _step_rule(p.step, what)
-                except NotImplementedError:
-                    return p.step
-
-            sed_rule, morph_rule = rule(sed, "spectrum"), rule(image, "morphology")
+            sed_rule, morph_rule = _rule(sed, "spectrum"), _rule(image, "morphology")
             # the spectrum kernel applies PositivityConstraint(1e-20) (spectrum.py:54-56)
             free_form = isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20
             # a prior is user code: its gradient joins the likelihood's on the host
@@ -327,25 +343,56 @@ class Blend(CombinedComponent):
     def _scheme_args(self):
         return getattr(self, "_scheme", ("amsgrad", 0.25))
 
+    def _host_gradients(self, batch, comps):
+        """(g_sed, g_morph, g_vec) at the parameters of this iteration for the parameters the
+        host steps; g_vec = gradients of the free 2-vectors when one of them is the host's."""
+        g_sed, g_morph = batch.gradient()
+        g_vec = None
+        if any(hp.kind == "vec" for _, hp in self._host):
+            g_vec = batch.centers()["gradient"]
+            # a point source on an ImagePSF is a stamp with a free shift on the device: the
+            # device holds the offset of the centre from the middle of its box (_point_spec)
+            self._vec_offset = {}
+            for k, hp in self._host:
+                if hp.kind != "vec":
+                    continue
+                morphology = comps[k].children[1]
+                if isinstance(morphology, PointSourceMorphology) and batch.has_shift(k):
+                    bbox = morphology.bbox
+                    self._vec_offset[k] = np.array(bbox.origin[-2:]) + np.array(bbox.shape[-2:]) / 2
+                else:
+                    self._vec_offset[k] = 0.0
+        return g_sed, g_morph, g_vec
+
     def _host_update(self, batch, local, grads, e_rel, prox_max_iter, opt):
         """The host's share of iteration ``local``: AMSGrad + proximal sub-iterations of
         the parameters in ``self._host`` from the gradients the device gathered before its
         own update, then the new values go back to the device."""
-        g_sed, g_morph = grads
+        g_sed, g_morph, g_vec = grads
         seds, morphs = batch.parameters()
+        centers = None
         for k, hp in self._host:
             if hp.kind == "sed":
                 seds[k] = hp.update(local, g_sed[k], e_rel, prox_max_iter, **opt)
+            elif hp.kind == "vec":
+                # a free 2-vector (shift / centre) with a prior, a constraint or a step callable
+                if centers is None:
+                    centers = batch.centers()["center"]
+                centers[k] = hp.update(local, g_vec[k], e_rel, prox_max_iter, **opt) - self._vec_offset[k]
             else:
                 morphs[k] = hp.update(local, g_morph[k], e_rel, prox_max_iter, **opt)
             hp.store()
-        batch.set_parameters(seds, morphs)
+        if any(hp.kind != "vec" for _, hp in self._host):
+            batch.set_parameters(seds, morphs)
+        if centers is not None:
+            batch.set_centers(centers)
 
     @staticmethod
-    def _point_spec(sed, center, morphology):
+    def _point_spec(sed, center, morphology, center_rule):
         """PointSource -> device description; the model PSF must be a pixel-integrated
         Gaussian or a Moffat profile, the same in all bands (what the device kernel
-        evaluates)."""
+        evaluates).  ``center_rule``: (constant, relative factor, minimum) of the centre's
+        step on the device -- zeros for a centre the host steps (``_vector_rule``)."""
         psf = morphology.psf
         moffat = isinstance(psf, MoffatPSF) and psf.is_same and \
             bool(np.all(psf.get_parameter(1) == psf.get_parameter(1)[0]))
@@ -359,14 +406,12 @@ class Blend(CombinedComponent):
             raise NotImplementedError(
                 "point sources need a pixel-integrated GaussianPSF, a MoffatPSF or an ImagePSF "
                 "model PSF, the same in all bands")
-        _plain_2vector(center, "a point-source centre")
         if sed.prior is not None:
             raise NotImplementedError("a prior on the spectrum of a point source")
         if not (isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20):
             raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
         s_const, s_rel, s_min = _step_rule(sed.step, "spectrum")
-        c_const, c_rel, c_low = (0.0, 0.0, 0.0) if center.fixed and center.step is None else \
-            _step_rule(center.step, "center")
+        c_const, c_rel, c_low = center_rule
         c_const = max(c_const, float(np.max(c_low)))  # (relative_step: max(minimum, factor * mean))
         if stamp is not None:
             # ImagePSF.get_model(offset) is fft.shift of the stored image (psf.py:228-234): on
@@ -548,6 +593,16 @@ class Blend(CombinedComponent):
                 raise NotImplementedError(
                     "user-defined constraints / steps together with a free psf_shift")
             self._psf = self._free_psf_shift()
+            if self._psf_host is not None:
+                if noise_factor:
+                    raise NotImplementedError(
+                        "noise_factor > 0 with a host-stepped psf_shift (prior, constraint or "
+                        "step callable on it)")
+                try:
+                    return self._fit_with_psf_shift(max_iter, e_rel, min_iter, prox_max_iter, opt,
+                                                    callback)
+                finally:
+                    self._psf, self._psf_stepped_on_device = None, False
         extra = () if self._psf is None else (self._psf[0],)
 
         if (not free and scheme == "amsgrad" and callback is None and not noise_factor
@@ -597,7 +652,7 @@ class Blend(CombinedComponent):
                         self._draw_noise(batch, noise_factor)
                     # plug-in seam: gradients at the parameters of this iteration for the
                     # parameters the host updates (hoststep.py)
-                    grads = batch.gradient() if self._host else None
+                    grads = self._host_gradients(batch, comps) if self._host else None
                     batch.step(local, n, e_rel=e_rel, min_iter=min_iter,
                                prox_max_iter=prox_max_iter, check_convergence=True)
                     active, err = batch.status()
@@ -680,9 +735,11 @@ class Blend(CombinedComponent):
             raise NotImplementedError("only ConvolutionRenderer(psf_shift=...) has free parameters")
         if tuple(obs.shape) != tuple(self.frame.shape) or list(obs.channels) != list(self.frame.channels):
             raise NotImplementedError("psf_shift needs an observation on the model frame")
-        _plain_2vector(shift, "psf_shift")
-        # (relative_step, parameter.py:126-129: max(minimum, factor * mean(shift)))
-        const, self._psf_rel, low = _step_rule(shift.step, "psf_shift")
+        # (relative_step, parameter.py:126-129: max(minimum, factor * mean(shift)); a prior, a
+        # constraint or a step callable on the shift: the host steps it, _fit_with_psf_shift)
+        on_device, rule = _vector_rule(shift, "psf_shift")
+        self._psf_host = None if on_device else HostVector(shift, rule)
+        const, self._psf_rel, low = rule if on_device else (0.0, 0.0, 0.0)
         self._psf_step = max(const, float(np.max(low)))
         return shift, renderer
 
@@ -714,10 +771,9 @@ class Blend(CombinedComponent):
             out[:, oy:oy + k.shape[1], ox:ox + k.shape[2]] = k
             return out
 
-        for name in ("m", "v", "vhat"):
-            if getattr(shift, name) is None:
-                setattr(shift, name, np.zeros(2))
-        b1, b2, eps = opt["b1"], opt["b2"], opt["eps"]
+        # (the step itself: hoststep.HostVector -- amsgrad_pair of the device in float64, plus
+        # the shift's prior / constraint / step callable if it has any)
+        stepper = getattr(self, "_psf_host", None) or HostVector(shift, (alpha0, rel, 0.0))
         it = 0
         while it < max_iter:
             comps = _flatten(self.sources)
@@ -740,13 +796,9 @@ class Blend(CombinedComponent):
                     batch.set_kernel(stamp(renderer.kernel_image()))
                     batch.step(local, 1, e_rel=e_rel, min_iter=min_iter,
                                prox_max_iter=prox_max_iter, check_convergence=True)
-                    # AMSGrad without constraint (lite/parameters.py:274-291)
-                    shift.m = (1 - b1) * g + b1 * shift.m
-                    shift.v = (1 - b2) * g * g + b2 * shift.v
-                    shift.vhat = shift.v.copy() if local == 0 else np.maximum(shift.vhat, shift.v)
-                    alpha = max(alpha0, rel * float(np.mean(np.asarray(shift))))
-                    upd = alpha * shift.m / np.sqrt(np.maximum(shift.vhat, eps))
-                    shift[...] = np.asarray(shift) - (upd / 10 if local == 0 else upd)
+                    # AMSGrad (lite/parameters.py:274-291), sub-iterations if it is constrained
+                    stepper.update(local, g, e_rel, prox_max_iter, **opt)
+                    stepper.store()
                     batch.set_kernel(stamp(renderer.kernel_image()))
                     active, err = batch.status()
                     done = len(batch.loss_history()[0])
@@ -1245,6 +1297,7 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
         np.stack([r.obs[0] for r in group]), np.stack([r.obs[1] for r in group]), specs,
         kernel=None if kernel is None else np.stack([r.obs[2] for r in group]),
         max_iter=max(max_iter, 1), device=device)
+    write_back, wrote = None, False
     try:
         flat = [c for cs in comps for c in cs]
         n_comp = len(flat)
@@ -1278,6 +1331,30 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
             [np.full(len(_flatten([src])), j) for j, src in
              enumerate(src for r in group for src in r.blend.sources)]).astype(np.int64) \
             if n_comp else np.zeros(0, dtype=np.int64)
+        def write_back():
+            """Device -> Python objects: new image Parameters (morphology.py:155-163, 180-193)
+            and boxes of the components the device has resized, then all values, moments and
+            the losses recorded since the fit began."""
+            for k in np.flatnonzero(moved):
+                morphology = flat[k].children[1]
+                image = morphology.parameters[0]
+                shape = tuple(batch._shapes[k])
+                morphology._parameters = (
+                    Parameter(np.zeros(shape, dtype=image.dtype), name=image.name, prior=image.prior,
+                              constraint=image.constraint, step=float(step[k]), fixed=image.fixed),
+                ) + morphology._parameters[1:]
+                morphology.bbox.origin = tuple(int(o) for o in origin[k])
+                morphology.bbox.shape = shape
+            if moved.any():
+                sources = [src for r in group for src in r.blend.sources]
+                for j in np.unique(source_of[moved]):
+                    _refresh_boxes(sources[j])
+            Blend._download_all(batch, flat)
+            history = batch.loss_history()
+            n_loss = batch.progress()[1]
+            for i, r in enumerate(group):
+                r.blend.loss.extend(history[i][:n_loss[i]])
+
         pushed = None  # what the device holds as per-blend states / counter bases
         lockstep = os.environ.get("SCARLET_AMD_FIT_BLENDS") == "lockstep"
         while True:
@@ -1399,28 +1476,21 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
             base[restart] = prior[restart] + count[restart]
             local[restart] = 0
             state[restart & (state == 2)] = 0
-        # the Python objects of the components the device has resized: new image Parameters
-        # (morphology.py:155-163, 180-193) and boxes; the values follow with the download
-        for k in np.flatnonzero(moved):
-            morphology = flat[k].children[1]
-            image = morphology.parameters[0]
-            shape = tuple(batch._shapes[k])
-            morphology._parameters = (
-                Parameter(np.zeros(shape, dtype=image.dtype), name=image.name, prior=image.prior,
-                          constraint=image.constraint, step=float(step[k]), fixed=image.fixed),
-            ) + morphology._parameters[1:]
-            morphology.bbox.origin = tuple(int(o) for o in origin[k])
-            morphology.bbox.shape = shape
-        if moved.any():
-            sources = [src for r in group for src in r.blend.sources]
-            for j in np.unique(source_of[moved]):
-                _refresh_boxes(sources[j])
-        Blend._download_all(batch, flat)
-        history = batch.loss_history()
+        write_back()
+        wrote = True
+    except BaseException:
+        # a launch or a host hook raised: what the device holds -- boxes it resized, parameters,
+        # moments, the losses of the iterations that ran -- still reaches the Python objects, so
+        # that no blend is left with a box its Parameters do not fit
+        if write_back is not None and not wrote:
+            try:
+                write_back()
+            except Exception:
+                pass
+        raise
     finally:
         batch.close()
     for i, r in enumerate(group):
-        r.blend.loss.extend(history[i][:count[i]])
         r.base, r.local = int(base[i]), int(local[i])
         r.result = (ArithmeticError("parameters of the blend are not finite")
                     if state[i] == 3 else True)
@@ -1515,8 +1585,10 @@ def _fit_blends_on(blends, device, max_iter=200, e_rel=1e-3, min_iter=1, _from_f
             # smi_batch_add_observation): such a blend is fitted by itself, like
             # [b.fit() for b in blends] would (scarlet/testing/api.py:216-224)
             solo.add(i)
+    for i, b in enumerate(blends):
+        if i in solo or i not in observed:
             continue
-        described[i] = b._specs(_flatten(b.sources))  # (once: 20 us per component)
+        described[i] = b._specs(_flatten(b.sources))  # (once: 15 us per component)
         if b._host:
             solo.add(i)
     if solo and _from_fit:

@@ -1928,6 +1928,30 @@ int smi_batch_get_centers(smi_batch *b, double *center, double *m, double *v, do
     return SMI_OK;
 }
 
+int smi_batch_set_centers(smi_batch *b, const double *center) {
+    SMI_REQUIRE(b && b->have_components && center, "components not set / null argument");
+    SMI_HIP(hipSetDevice(b->device));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    const int n = b->d.n_components;
+    if (!n) return SMI_OK;
+    std::vector<double> pt((size_t)n * 8);
+    SMI_HIP(hipMemcpy(pt.data(), b->pt, pt.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k) {
+        const bool free2 = b->is_point[k] || b->is_shift[k];
+        if (!free2) continue;  // (entries of other components are ignored)
+        for (int a = 0; a < 2; ++a)
+            pt[8 * k + a] = center[2 * k + a] - (b->is_point[k] ? b->box_center[2 * k + a] : 0.0);
+    }
+    SMI_HIP(hipMemcpy(b->pt, pt.data(), pt.size() * sizeof(double), hipMemcpyHostToDevice));
+    // what enters the model follows: the PSF at the new centre, the image at the new shift
+    const BatchView v = unmasked_view(b);
+    int rc;
+    if ((rc = launch_point_sources(v, nullptr, 0, 0.f, 0, nullptr, nullptr, 2, b->stream))) return rc;
+    if ((rc = launch_shift_forward(v, 0, b->stream))) return rc;
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
 int smi_batch_set_center_moments(smi_batch *b, const double *m, const double *v,
                                  const double *vhat) {
     SMI_REQUIRE(b && b->have_components, "components not set");

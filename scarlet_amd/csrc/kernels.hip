@@ -2444,24 +2444,75 @@ __global__ __launch_bounds__(256) void sweep_many_kernel(T *images, int n_pix,
 // next one (one CU, one L1).
 template <typename T>
 __global__ __launch_bounds__(1024) void sweep_global_kernel(T *image, const int32_t *level_start,
-                                                            int n_levels, int E,
+                                                            int n_levels, int E, int max_terms,
                                                             const int32_t *pix, const int32_t *cnt,
                                                             const int32_t *nbr, const T *wt,
                                                             T one_minus_g) {
+    // Round 6: the plan entries of level l + 1 are requested before level l is applied (one
+    // entry per thread and level in registers; a level of a 282 x 282 image has at most ~800
+    // pixels), so a level costs the image's own round trip through L2 and the fence, not the
+    // plan's on top: 2.9 -> 1.x ms for the 282 x 282 doubles of the multi-resolution set-up.
+    constexpr int kTerms = 8;  // offsets of operators_pybind11.cc:14-36
     volatile T *img = image;
+    struct Entry {
+        int p, n;
+        int nb[kTerms];
+        T w[kTerms];
+    };
+    auto load = [&](int q, Entry &e) {
+        e.p = pix[q];
+        e.n = cnt[q];
+#pragma unroll
+        for (int j = 0; j < kTerms; ++j)
+            if (j < max_terms) {
+                e.nb[j] = nbr[(int64_t)j * E + q];
+                e.w[j] = wt[(int64_t)j * E + q];
+            }
+    };
+    auto apply = [&](const Entry &e) {
+        T ref = 0;
+#pragma unroll
+        for (int j = 0; j < kTerms; ++j)
+            if (j < e.n) ref = add_rn(ref, mul_rn((T)img[e.nb[j]], e.w[j]));
+        const T lim = mul_rn(ref, one_minus_g);
+        if (lim < img[e.p]) img[e.p] = lim;
+    };
+    if (n_levels <= 0) return;
+    const int t = (int)threadIdx.x;
+    if (max_terms > kTerms) {  // tables with more than eight offsets: entry by entry
+        for (int l = 0; l < n_levels; ++l) {
+            for (int q = level_start[l] + t; q < level_start[l + 1]; q += 1024) {
+                T ref = 0;
+                for (int j = 0; j < cnt[q]; ++j)
+                    ref = add_rn(ref, mul_rn((T)img[nbr[(int64_t)j * E + q]], wt[(int64_t)j * E + q]));
+                const T lim = mul_rn(ref, one_minus_g);
+                if (lim < img[pix[q]]) img[pix[q]] = lim;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        return;
+    }
+    int s = level_start[0], e = level_start[1];
+    Entry cur{}, nxt{};
+    bool have = s + t < e;
+    if (have) load(s + t, cur);
     for (int l = 0; l < n_levels; ++l) {
-        const int s = level_start[l], e = level_start[l + 1];
-        for (int q = s + (int)threadIdx.x; q < e; q += 1024) {
-            const int p = pix[q];
-            const int n = cnt[q];
-            T ref = 0;
-            for (int j = 0; j < n; ++j)
-                ref = add_rn(ref, mul_rn(img[nbr[(int64_t)j * E + q]], wt[(int64_t)j * E + q]));
-            const T lim = mul_rn(ref, one_minus_g);
-            if (lim < img[p]) img[p] = lim;
+        const int e_next = l + 1 < n_levels ? level_start[l + 2] : e;
+        const bool have_next = l + 1 < n_levels && e + t < e_next;
+        if (have_next) load(e + t, nxt);
+        if (have) apply(cur);
+        for (int q = s + t + 1024; q < e; q += 1024) {
+            Entry more{};
+            load(q, more);
+            apply(more);
         }
         __threadfence_block();
         __syncthreads();
+        cur = nxt;
+        have = have_next;
+        s = e;
+        e = e_next;
     }
 }
 
@@ -2875,13 +2926,58 @@ void launch_crop(const float *P, float *out, int32_t n_img, int32_t H, int32_t W
 }
 
 // ---- seam 1: host-buffer entry points --------------------------------------
+// Device buffers of the host-buffer entry points (seam 1).  A call of the reference's sweep
+// needs seven of them for a few hundred microseconds; hipMalloc / hipFree cost more than the
+// kernel (a 128 x 128 image: 2.1 ms per call, most of it the allocator), so freed blocks are
+// kept -- per host thread and device, by power-of-two size, up to 512 MB -- and handed out again.
+// The entry points are synchronous: a block is idle when its call has returned.
+struct PoolBlock {
+    void *p;
+    size_t cap;
+    int dev;
+};
+static thread_local std::vector<PoolBlock> seam_pool;
+static thread_local size_t seam_pool_bytes = 0;
+constexpr size_t kSeamPoolLimit = (size_t)512 << 20;
+
+static hipError_t pool_alloc(void **p, size_t bytes, size_t *cap) {
+    size_t want = 256;
+    while (want < bytes) want <<= 1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (size_t i = 0; i < seam_pool.size(); ++i)
+        if (seam_pool[i].cap == want && seam_pool[i].dev == dev) {
+            *p = seam_pool[i].p;
+            *cap = want;
+            seam_pool_bytes -= want;
+            seam_pool.erase(seam_pool.begin() + (long)i);
+            return hipSuccess;
+        }
+    *cap = want;
+    return hipMalloc(p, want);
+}
+
+static void pool_free(void *p, size_t cap) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (cap > kSeamPoolLimit / 4 || seam_pool_bytes + cap > kSeamPoolLimit) {
+        (void)hipFree(p);
+        return;
+    }
+    seam_pool.push_back({p, cap, dev});
+    seam_pool_bytes += cap;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
+    size_t cap = 0;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p, cap);
     }
-    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)); }
+    hipError_t alloc(size_t n) {
+        return pool_alloc(reinterpret_cast<void **>(&p), n * sizeof(T), &cap);
+    }
     hipError_t upload(const T *h, size_t n) {
         hipError_t e = alloc(n > 0 ? n : 1);
         if (e != hipSuccess || n == 0) return e;
@@ -2913,7 +3009,8 @@ int sweep_host_buffers(T *flat_img, int32_t n_pix, const SweepPlanHost &plan, T 
                            plan.n_entries, d_pix.p, d_cnt.p, d_nbr.p, d_wt.p, omg);
     } else {
         hipLaunchKernelGGL(sweep_global_kernel<T>, dim3(1), dim3(1024), 0, 0, d_img.p, d_ls.p,
-                           n_levels, plan.n_entries, d_pix.p, d_cnt.p, d_nbr.p, d_wt.p, omg);
+                           n_levels, plan.n_entries, plan.max_terms, d_pix.p, d_cnt.p, d_nbr.p,
+                           d_wt.p, omg);
     }
     SMI_HIP(hipGetLastError());
     SMI_HIP(hipMemcpy(flat_img, d_img.p, (size_t)n_pix * sizeof(T), hipMemcpyDeviceToHost));

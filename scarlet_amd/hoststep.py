@@ -157,3 +157,68 @@ class HostParameter:
     def store(self):
         """Leave the moments on the Parameter like the device path does (float64)."""
         self.p.m, self.p.v, self.p.vhat = (a.astype(np.float64) for a in (self.m, self.v, self.vhat))
+
+
+class HostVector:
+    """A free 2-vector -- the sub-pixel shift of an image, the centre of a point source, a
+    renderer's ``psf_shift`` -- that carries a ``Prior``, a constraint or a step callable:
+    the reference treats it like every other ``Parameter`` (blend.py:120-145), the device
+    only knows the bare AMSGrad step of the defaults (morphology.py:673-676, source.py:115,
+    renderer.py:175-177).  Such a vector keeps a device step of 0; the host takes its step
+    from the device's gradient in float64 -- ``amsgrad_pair`` of csrc/shift.hip operation by
+    operation, so a vector without any of the three moves exactly as on the device -- and
+    writes the result back (``smi_batch_set_centers`` / the kernel of the observation).
+
+    step: ``(constant, relative factor, minimum)`` of a built-in rule, or the user's callable
+    """
+
+    kind = "vec"
+
+    def __init__(self, parameter, step):
+        self.p = parameter
+        self.step = step
+        for name in ("m", "v", "vhat"):
+            value = getattr(parameter, name)
+            setattr(self, name, np.zeros(2) if value is None else np.array(value, dtype=np.float64))
+
+    def alpha(self, it):
+        if callable(self.step):
+            return np.asarray(self.step(self.p, it=it), dtype=np.float64)
+        const, rel, minimum = self.step
+        x = np.asarray(self.p, dtype=np.float64)
+        # (relative_step, parameter.py:126-129: max(minimum, factor * mean), on the pre-update value)
+        return max(max(float(const), float(np.max(minimum))), float(rel) * 0.5 * float(x[0] + x[1]))
+
+    def update(self, it, g, e_rel, prox_max_iter, b1, b2, eps):
+        p = self.p
+        x0 = np.array(p, dtype=np.float64)
+        g = np.zeros(2) if p.fixed else np.asarray(g, dtype=np.float64).reshape(2)
+        if p.prior is not None and not p.fixed:
+            # what the prior returns for the current value joins the gradient (blend.py:120-131)
+            g = g + np.asarray(p.prior(np.asarray(p).view(np.ndarray)), dtype=np.float64)
+        alpha = self.alpha(it)
+        self.m = (1.0 - b1) * g + b1 * self.m
+        self.v = (1.0 - b2) * g * g + b2 * self.v
+        self.vhat = self.v.copy() if it == 0 else np.maximum(self.vhat, self.v)
+        psi = np.sqrt(np.maximum(self.vhat, eps))
+        upd = alpha * self.m / psi
+        if it == 0:
+            upd = upd / 10.0
+        x = x0 - upd
+        z = x
+        prox = p.constraint
+        if prox is not None:
+            pmax = psi.max()
+            gamma = alpha / pmax
+            z = x.copy()
+            for _ in range(prox_max_iter):
+                zn = np.asarray(prox(z - psi / pmax * (z - x), gamma), dtype=np.float64)
+                done = np.sum((zn - z) ** 2) <= e_rel ** 2 * np.sum(z ** 2)
+                z = zn
+                if done:
+                    break
+        p[...] = z
+        return z
+
+    def store(self):
+        self.p.m, self.p.v, self.p.vhat = self.m.copy(), self.v.copy(), self.vhat.copy()

@@ -88,14 +88,20 @@ def getRadialMonotonicWeights(shape, neighbor_weight="flat", center=None):
     Y = (np.arange(h) - py)[:, None] * np.ones((1, w), dtype=int)
     X = (np.arange(w) - px)[None, :] * np.ones((h, 1), dtype=int)
     r2 = X * X + Y * Y
-    to_peak = np.arctan2(-Y, -X)
+    flat = neighbor_weight == "flat"
+    to_peak = None if flat else np.arctan2(-Y, -X)
     cosw = np.zeros((8, h, w))
     for i, (dy, dx) in enumerate(NEIGHBOR_COORDS):
         ny, nx = Y + dy, X + dx
         inside = (ny + py >= 0) & (ny + py < h) & (nx + px >= 0) & (nx + px < w)
         nearer = (nx * nx + ny * ny) < r2
         valid = inside & nearer
-        cosw[i][valid] = np.cos(to_peak[valid] - np.arctan2(float(dy), float(dx)))
+        if flat:
+            # every neighbour that counts gets weight 1 below: its cosine (never exactly zero
+            # for a strictly nearer neighbour -- pi / 2 is no float) need not be evaluated
+            cosw[i][valid] = 1.0
+        else:
+            cosw[i][valid] = np.cos(to_peak[valid] - np.arctan2(float(dy), float(dx)))
     cosw = cosw.reshape(8, h * w)
     if neighbor_weight == "nearest":
         out = np.zeros_like(cosw)

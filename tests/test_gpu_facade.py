@@ -307,6 +307,153 @@ def test_point_source_tutorial_scene(scene):
 
 
 
+def test_priors_constraints_and_step_callables_on_free_2_vectors(hsc):
+    """A free 2-vector is a ``Parameter`` like any other (blend.py:120-145): a prior, a
+    constraint or a step callable on a point source's centre, on the Fourier shift of an
+    extended source or on a renderer's ``psf_shift`` is taken by the host from the device's
+    gradient (hoststep.HostVector; rounds 1 - 5 refused them).  Each against the oracle with the
+    same rule, step by step; a rule that changes nothing reproduces the device's own step."""
+    import scarlet_amd as scarlet
+    from scarlet_amd.initialization import init_all_sources
+    from scarlet_amd.renderer import ConvolutionRenderer
+    from conftest import golden, point_scene, shifting_scene
+
+    class Pull(scarlet.Prior):
+        """gradient of a quadratic well about ``x0`` (what the reference adds to the
+        likelihood's gradient is whatever ``prior(x)`` returns, blend.py:120-131)"""
+        def __init__(self, x0, k):
+            self.x0, self.k = np.array(x0, dtype=float), k
+
+        def __call__(self, x):
+            return self.k * (np.asarray(x) - self.x0)
+
+        def grad(self, x):
+            return self(x)
+
+    class Within(scarlet.Constraint):
+        def __init__(self, x0, r):
+            self.x0, self.r = np.array(x0, dtype=float), r
+
+        def __call__(self, X, step):
+            X[...] = np.clip(X, self.x0 - self.r, self.x0 + self.r)
+            return X
+
+    def halving(X, it=0):
+        return 0.05 / (1 + it // 3)
+
+    # -- point sources: constraint + step callable on one centre, a prior on another
+    g = golden("point_source")
+    images = g["images"]
+    filters = list("ugrizy")
+    frame = scarlet.Frame(images.shape, psf=scarlet.GaussianPSF(sigma=0.9), channels=filters)
+    obs = scarlet.Observation(images, psf=scarlet.ImagePSF(g["psfs"].copy()),
+                              weights=np.ones_like(images) / 4, channels=filters).match(frame)
+
+    def sources_of():
+        out = []
+        for k in range(int(g["n_src"])):
+            cls = scarlet.PointSource if g["is_star"][k] else scarlet.ExtendedSource
+            out.append(cls(frame, tuple(g["sky"][k]), obs))
+        return out
+
+    stars = [k for k in range(int(g["n_src"])) if g["is_star"][k]]
+    assert len(stars) >= 2
+    sources = sources_of()
+    c0 = np.array(sources[stars[0]].children[1].parameters[0])
+    c1 = np.array(sources[stars[1]].children[1].parameters[0])
+    p0 = sources[stars[0]].children[1].parameters[0]
+    p0.constraint, p0.step = Within(c0, 0.02), halving
+    sources[stars[1]].children[1].parameters[0].prior = Pull(c1 + 0.3, 50.0)
+    blend = scarlet.Blend(sources, obs)
+    n, _ = blend.fit(9, e_rel=1e-6)
+    assert sorted(k for k, hp in blend._host if hp.kind == "vec") == stars[:2]
+    sc = point_scene(g)
+    sc.components[stars[0]].vec_rules = {"center": dict(
+        prox=lambda x, step: np.clip(x, c0 - 0.02, c0 + 0.02), step=halving)}
+    sc.components[stars[1]].vec_rules = {"center": dict(prior=lambda x: 50.0 * (x - (c1 + 0.3)))}
+    n_ref, _ = sc.fit(9, e_rel=1e-6)
+    assert n == n_ref == 9
+    assert_allclose(np.array(blend.loss) - sc.log_norm, np.array(sc.loss) - sc.log_norm, rtol=1e-4)
+    for k in stars[:2]:
+        center = sources[k].children[1].parameters[0]
+        assert np.abs(np.asarray(center) - sc.components[k].center).max() < 1e-5
+        assert center.m is not None and center.std.shape == (2,)
+    assert np.abs(np.asarray(p0) - c0).max() <= 0.02 + 1e-12  # the constraint held ...
+    plain = sources_of()
+    scarlet.Blend(plain, obs).fit(9, e_rel=1e-6)
+    assert np.abs(np.asarray(plain[stars[0]].children[1].parameters[0]) - c0).max() > 0.02  # ... and bit
+    # a step callable that returns the default step: the host's step is the device's (from the
+    # gradient of a separate float32 evaluation: to float32 rounding)
+    same = sources_of()
+    for k in stars:
+        same[k].children[1].parameters[0].step = lambda X, it=0: 3e-2
+    scarlet.Blend(same, obs).fit(9, e_rel=1e-6)
+    for k in stars:
+        assert np.abs(np.asarray(same[k].children[1].parameters[0])
+                      - np.asarray(plain[k].children[1].parameters[0])).max() < 2e-5
+
+    # -- the Fourier shift of an extended source under a prior
+    gs = golden("hsc_shifting")
+    filters = list("grizy")
+    frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5), channels=filters)
+    obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                              weights=hsc["weights"], channels=filters).match(frame)
+    srcs, _ = init_all_sources(frame, [tuple(c) for c in gs["centers"]], obs, max_components=2,
+                               min_snr=50, thresh=1, fallback=True, silent=True, set_spectra=True,
+                               shifting=True)
+    blend = scarlet.Blend(srcs, obs)
+    comps = components_of(blend)
+    for comp in comps:
+        comp.children[1].resizing = False
+    s0 = np.array(comps[0].children[1].parameters[1])
+    comps[0].children[1].parameters[1].prior = Pull(s0 - 0.2, 2000.0)
+    n, _ = blend.fit(7, e_rel=1e-6)
+    sc = shifting_scene(gs, hsc)
+    sc.components[0].vec_rules = {"shift": dict(prior=lambda x: 2000.0 * (x - (s0 - 0.2)))}
+    n_ref, _ = sc.fit(7, e_rel=1e-6)
+    assert n == n_ref == 7
+    assert_allclose(np.array(blend.loss) - sc.log_norm, np.array(sc.loss) - sc.log_norm, rtol=3e-4)
+    for comp, c in zip(comps, sc.components):
+        assert np.abs(np.asarray(comp.children[1].parameters[1]) - c.shift).max() < 2e-4
+    free = shifting_scene(gs, hsc)  # (the prior is in force: without it the shift ends elsewhere)
+    free.fit(7, e_rel=1e-6)
+    assert np.abs(free.components[0].shift - sc.components[0].shift).max() > 5e-3
+
+    # -- psf_shift under a constraint
+    gp = golden("hsc_psf_shift")
+    obs = scarlet.Observation(hsc["images"], psf=scarlet.ImagePSF(hsc["psfs"].copy()),
+                              weights=hsc["weights"], channels=filters)
+    obs.match(frame, renderer=ConvolutionRenderer(obs, frame, psf_shift=gp["psf_shift"].copy()))
+    shift = obs.parameters[0]
+    shift.constraint = Within(gp["psf_shift"], 0.015)
+    comps = []
+    for k in range(int(hsc["n_comp"])):
+        h, w = hsc["morph_%d" % k].shape
+        oy, ox = hsc["origin_%d" % k]
+        box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+        comps.append(scarlet.FactorizedComponent(
+            frame,
+            scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                      min_step=hsc["min_step_%d" % k]),
+            scarlet.ExtendedSourceMorphology(frame, (oy + h // 2, ox + w // 2),
+                                             hsc["morph_%d" % k].copy(), bbox=box[1:],
+                                             resizing=False)))
+    blend = scarlet.Blend(comps, obs)
+    n, _ = blend.fit(6, e_rel=1e-9)
+    sc = hsc_scene(hsc)
+    for c in sc.components:
+        c.source = None
+    sc.psf_shift = gp["psf_shift"].copy()
+    lo, hi = gp["psf_shift"] - 0.015, gp["psf_shift"] + 0.015
+    sc.vec_rules = {"psf_shift": dict(prox=lambda x, step: np.clip(x, lo, hi))}
+    n_ref, _ = sc.fit(6, e_rel=1e-9)
+    assert n == n_ref == 6
+    assert_allclose(np.array(blend.loss) - sc.log_norm, np.array(sc.loss) - sc.log_norm, rtol=1e-4)
+    assert np.abs(np.asarray(shift) - sc.psf_shift).max() < 2e-5
+    assert np.abs(np.asarray(shift) - gp["psf_shift"]).max() <= 0.015 + 1e-12
+    assert shift.m is not None
+
+
 def test_relative_step_on_psf_shift_through_the_facade(hsc):
     """``Parameter.step = partial(relative_step, factor=..., minimum=...)`` (parameter.py:126-129)
     on ``psf_shift``: ``Blend.fit`` hands the rule to the device and follows the oracle with
@@ -783,6 +930,45 @@ def test_blends_pause_at_their_own_hooks_and_give_the_lockstep_results(monkeypat
             assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
             if p.m is not None:
                 assert_allclose(p.v, q.v, rtol=0, atol=0)
+
+
+def test_an_error_in_the_middle_of_fit_blends_leaves_consistent_objects(monkeypatch):
+    """A hook round that raises (here: the second ``update_components`` of the batch): the boxes
+    the device has resized so far, the parameters, moments and the losses of the iterations
+    that ran still reach the Python objects before the batch is closed -- every image fits its
+    box, every blend has its losses -- and the error propagates."""
+    import os
+    import sys
+
+    import scarlet_amd as scarlet
+    from scarlet_amd import BlendBatch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    calls = {"n": 0}
+    update = BlendBatch.update_components
+
+    def failing(self, *a, **k):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise RuntimeError("injected")
+        return update(self, *a, **k)
+
+    monkeypatch.setattr(BlendBatch, "update_components", failing)
+    blends = bench.build_facade_blends(0, 24, 0)
+    with pytest.raises(RuntimeError, match="injected"):
+        scarlet.fit_blends(blends, 60, e_rel=1e-4)
+    resized = 0
+    for blend in blends:
+        assert len(blend.loss) >= 11 and np.all(np.isfinite(blend.loss))
+        for src in blend.sources:
+            morphology = src.children[1]
+            image = morphology.parameters[0]
+            assert tuple(image.shape) == tuple(morphology.bbox.shape)
+            assert image.m is not None and image.m.shape == image.shape
+            resized += tuple(image.shape) != (41, 41)
+    assert resized > 0
 
 
 def test_fit_blends_keeps_going_when_one_blend_fails():

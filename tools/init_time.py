@@ -130,11 +130,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scenes", type=int, default=4)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--profile", action="store_true", help="cProfile of one cfg-2 scene's initialisation")
     args = ap.parse_args()
     import scarlet_amd as scarlet  # noqa: F401
 
     counter = Seam1Counter()
     measure(quickstart, counter, repeats=1, fit_iters=5)  # library load, plan caches, first launches
+    if args.profile:
+        import cProfile
+        import pstats
+        from scarlet_amd import initialization as init
+
+        measure(lambda: synthetic_scene(1234), counter, repeats=1, fit_iters=2)
+        frame, obs, centers, kw = synthetic_scene(1235)
+        prof = cProfile.Profile()
+        prof.enable()
+        init.init_all_sources(frame, centers, obs, fallback=True, silent=True, set_spectra=True, **kw)
+        prof.disable()
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(40)
+        return
     out = dict(what="init_all_sources (SURVEY 8f-2) beside Blend.fit(100, e_rel=1e-4) per scene; best "
                     "of 3; seam1_* = calls of the monotonic sweep through the C ABI during source "
                     "construction (count, images swept, bytes moved host<->device incl. tables, wall ms "
