@@ -555,6 +555,9 @@ def main():
     ap.add_argument("--loop", default="blend", choices=["blend", "lite-adaprox", "lite-fista"],
                     help="ablation: run the scarlet.lite loop (LiteBlend.fit semantics) on the "
                          "same scenes instead of Blend.fit's")
+    ap.add_argument("--ramp-ms", type=float, default=150.0,
+                    help="milliseconds of untimed iterations before the warm-up (GPU clocks up "
+                         "after the idle set-up; 0: none)")
     ap.add_argument("--no-counters", action="store_true",
                     help="do not re-run under rocprofv3 for the HBM byte counters (roofline.traffic "
                          "then comes from the committed profiles/hbm_traffic.json)")
@@ -631,7 +634,26 @@ def main():
     def run(it0, n):
         batch.step(it0, n, e_rel=e_rel, prox_max_iter=prox_max_iter, check_convergence=False)
 
-    # W untimed warm-up iterations, then the state of iteration 0 again
+    def ramp(ms):
+        """Keep the GPU busy with this batch's own iterations for `ms` milliseconds (state back
+        to iteration 0 afterwards).  The driver's W = 5 warm-up iterations last 4.5 ms, the
+        set-up before them (scene construction, uploads) and the oracle check before the
+        roofline pass leave the GPU idle for seconds, and the power management needs ~20 ms of
+        load to raise the clocks again: ten back-to-back windows of 20 iterations run at
+        1 076 k, then 1 187 k blend-it/s each (tools/clock_ramp.py,
+        profiles/r06_clock_ramp.txt).  What `value` should say is the rate of a fit, which
+        lasts hundreds of iterations."""
+        if ms <= 0:
+            return
+        t_end = time.perf_counter() + ms * 1e-3
+        while time.perf_counter() < t_end:
+            run(0, max(Wm, 5))
+            torch.cuda.synchronize()
+        fresh()
+
+    # the clocks up (not a warm-up of anything the timed region reuses), then W untimed
+    # warm-up iterations, then the state of iteration 0 again
+    ramp(args.ramp_ms)
     run(0, Wm)
     torch.cuda.synchronize()
     it0 = 0
@@ -674,6 +696,7 @@ def main():
     # launch there says nothing about the kernel; `value` is not affected by this pass.
     ranges_timed = batch.sub_ranges()
     if not args.steady:
+        ramp(args.ramp_ms)  # (the oracle check above left the GPU idle)
         fresh()
     batch.set_sub_ranges(1)
     batch.enable_timing(True)  # HIP events around every phase, on the batch stream
@@ -882,6 +905,13 @@ def main():
                                "blend%s" % (world, K, " (ranks share GPUs over gloo: functional "
                                             "check, not a scaling point)" if share else ""),
                 "sub_ranges_per_gpu": ranges_timed,
+                "clock_ramp_ms": args.ramp_ms,
+                "clock_ramp_note": "untimed iterations of this batch before the W warm-up "
+                                   "iterations and before the roofline pass, state restored: the "
+                                   "GPU idles for seconds during set-up and needs ~20 ms of load "
+                                   "to raise its clocks (profiles/r06_clock_ramp.txt: first "
+                                   "20-iteration window 1 076 k, every later one 1 187 k "
+                                   "blend-it/s); --ramp-ms 0 measures the cold window",
                 "mean_logL": float(np.mean(rec["logL"])),
             },
             "roofline": roofline,

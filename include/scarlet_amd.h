@@ -524,6 +524,14 @@ int smi_batch_get_progress(smi_batch *b, int32_t *state, int32_t *n_loss);
  * the last smi_batch_set_pause_at -- what tells a blend that stopped from one that pauses. */
 int smi_batch_set_pause_at(smi_batch *b, const int32_t *it);
 int smi_batch_get_converged(smi_batch *b, int32_t *flag);
+/* What a round of fit_blends sends and fetches, in one call each (stream-ordered copies through
+ * a pinned staging buffer: two synchronisations per round instead of eight small blocking
+ * copies -- a single scene's fit has eight rounds of ~2 ms).  smi_batch_set_round = set_states +
+ * set_iteration_base + set_pause_at (a NULL array is left as it is on the device);
+ * smi_batch_get_round = get_progress + get_converged. */
+int smi_batch_set_round(smi_batch *b, const int32_t *state, const int32_t *base,
+                        const int32_t *pause_at);
+int smi_batch_get_round(smi_batch *b, int32_t *state, int32_t *n_loss, int32_t *converged);
 
 /* Number of host-to-device uploads of observation cubes (smi_batch_set_observation and
  * smi_batch_add_observation) this process has made so far: lets a caller -- and the tests --

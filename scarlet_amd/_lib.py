@@ -213,6 +213,8 @@ SYMBOLS = {
     "smi_batch_set_iteration_base": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "smi_batch_set_pause_at": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "smi_batch_get_converged": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
+    "smi_batch_set_round": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p, c_i32p]),
+    "smi_batch_get_round": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p, c_i32p]),
     "smi_batch_get_progress": (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p]),
 }
 

@@ -384,6 +384,26 @@ class BlendBatch:
         _lib.check(self._lib.smi_batch_get_converged(self._h, _lib.ptr(flag, ctypes.c_int32)))
         return flag
 
+    def set_round(self, states=None, base=None, pause_at=None):
+        """``set_states`` + ``set_iteration_base`` + ``set_pause_at`` in one call (``None``:
+        left as it is on the device)."""
+        arrs = []
+        for a in (states, base, pause_at):
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=np.int32)
+                assert a.shape == (self.n_blends,)
+            arrs.append(a)
+        _lib.check(self._lib.smi_batch_set_round(
+            self._h, *[_lib.ptr(a, ctypes.c_int32) for a in arrs]))
+
+    def round(self):
+        """``progress()`` and ``converged()`` in one call: (state, losses recorded, stopped by
+        its own rule) per blend; blocks until the steps are done."""
+        out = [np.zeros(self.n_blends, dtype=np.int32) for _ in range(3)]
+        _lib.check(self._lib.smi_batch_get_round(
+            self._h, *[_lib.ptr(a, ctypes.c_int32) for a in out]))
+        return out
+
     def set_states(self, states):
         """Per-blend state: 0 iterating, 2 finished or paused (skipped by every kernel),
         3 failed."""

@@ -1376,15 +1376,14 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
             n = int(quota[live].max())
             now_push = (np.where(frozen & (state == 0), 2, state).astype(np.int32),
                         np.where(live, g - local, 0))
-            if pushed is None or not np.array_equal(pushed[0], now_push[0]):
-                batch.set_states(now_push[0])
-            if pushed is None or not np.array_equal(pushed[1], now_push[1]):
-                batch.set_iteration_base(now_push[1])
-            batch.set_pause_at(np.where(live, g + quota - 1, -1))
+            batch.set_round(
+                now_push[0] if pushed is None or not np.array_equal(pushed[0], now_push[0]) else None,
+                now_push[1] if pushed is None or not np.array_equal(pushed[1], now_push[1]) else None,
+                np.where(live, g + quota - 1, -1))
             batch.step(g, n, check_convergence=True, **step_kw)
             g += n
-            now, cnt = batch.progress()
-            stopped = batch.converged() != 0
+            now, cnt, stopped = batch.round()
+            stopped = stopped != 0
             done = cnt - count
             count = cnt.astype(np.int64)
             local[live] += done[live]

@@ -276,6 +276,7 @@ struct smi_batch {
     int32_t *state = nullptr, *zero_state = nullptr, *n_loss = nullptr, *status_out = nullptr;
     int32_t *it_base = nullptr;  // BatchView::it_base (smi_batch_set_iteration_base)
     int32_t *pause_at = nullptr, *conv_flag = nullptr;  // smi_batch_set_pause_at
+    int32_t *h_round = nullptr;  // pinned staging of smi_batch_set_round / get_round, 3 x n_blends
     double *loss_hist = nullptr, *last_loss = nullptr, *loss_partial = nullptr;
     // plans
     std::vector<SweepPlanDev> plans;
@@ -892,6 +893,7 @@ int smi_batch_destroy(smi_batch *b) {
     for (auto e : b->events) (void)hipEventDestroy(e);
     for (auto e : b->sub_events) (void)hipEventDestroy(e);
     for (auto st : b->sub_streams) (void)hipStreamDestroy(st);
+    if (b->h_round) (void)hipHostFree(b->h_round);
     for (auto *l : b->lowres) lowres_destroy(l);
     for (auto &l : b->layers)
         for (void *p : {(void *)l.data, (void *)l.weights, (void *)l.Kt, (void *)l.dw})
@@ -1865,6 +1867,60 @@ int smi_batch_set_pause_at(smi_batch *b, const int32_t *it) {
         SMI_HIP(hipMemset(b->conv_flag, 0, nb * sizeof(int32_t)));
     }
     refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_set_round(smi_batch *b, const int32_t *state, const int32_t *base,
+                        const int32_t *pause_at) {
+    SMI_REQUIRE(b != nullptr, "null batch");
+    SMI_REQUIRE(!base || (b->n_point == 0 && b->n_shift == 0 && !b->ks.stamp && b->scheme != SMI_SCHEME_FISTA),
+                "smi_batch_set_round: iteration bases for factorized image components under AMSGrad only");
+    SMI_HIP(hipSetDevice(b->device));
+    const size_t nb = (size_t)b->d.n_blends, bytes = nb * sizeof(int32_t);
+    bool grew = false;
+    if (!b->h_round) SMI_HIP(hipHostMalloc((void **)&b->h_round, 3 * bytes, hipHostMallocDefault));
+    if (base && !b->it_base) {
+        SMI_HIP(dev_alloc(&b->it_base, nb));
+        grew = true;
+    }
+    if (pause_at && !b->pause_at) {
+        SMI_HIP(dev_alloc(&b->pause_at, nb));
+        SMI_HIP(dev_alloc(&b->conv_flag, nb));
+        grew = true;
+    }
+    // (the staging buffer may still feed the copies of the last call)
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    if (state) {
+        memcpy(b->h_round, state, bytes);
+        SMI_HIP(hipMemcpyAsync(b->state, b->h_round, bytes, hipMemcpyHostToDevice, b->stream));
+    }
+    if (base) {
+        memcpy(b->h_round + nb, base, bytes);
+        SMI_HIP(hipMemcpyAsync(b->it_base, b->h_round + nb, bytes, hipMemcpyHostToDevice, b->stream));
+    }
+    if (pause_at) {
+        memcpy(b->h_round + 2 * nb, pause_at, bytes);
+        SMI_HIP(hipMemcpyAsync(b->pause_at, b->h_round + 2 * nb, bytes, hipMemcpyHostToDevice, b->stream));
+        SMI_HIP(hipMemsetAsync(b->conv_flag, 0, bytes, b->stream));
+    }
+    if (grew) refresh_view(b);
+    return SMI_OK;
+}
+
+int smi_batch_get_round(smi_batch *b, int32_t *state, int32_t *n_loss, int32_t *converged) {
+    SMI_REQUIRE(b && state && n_loss, "null argument");
+    SMI_REQUIRE(!converged || b->conv_flag, "smi_batch_get_round: converged follows a pause_at");
+    SMI_HIP(hipSetDevice(b->device));
+    const size_t nb = (size_t)b->d.n_blends, bytes = nb * sizeof(int32_t);
+    if (!b->h_round) SMI_HIP(hipHostMalloc((void **)&b->h_round, 3 * bytes, hipHostMallocDefault));
+    SMI_HIP(hipMemcpyAsync(b->h_round, b->state, bytes, hipMemcpyDeviceToHost, b->stream));
+    SMI_HIP(hipMemcpyAsync(b->h_round + nb, b->n_loss, bytes, hipMemcpyDeviceToHost, b->stream));
+    if (converged)
+        SMI_HIP(hipMemcpyAsync(b->h_round + 2 * nb, b->conv_flag, bytes, hipMemcpyDeviceToHost, b->stream));
+    SMI_HIP(hipStreamSynchronize(b->stream));
+    for (size_t i = 0; i < nb; ++i) state[i] = std::min(b->h_round[i], 3);
+    memcpy(n_loss, b->h_round + nb, bytes);
+    if (converged) memcpy(converged, b->h_round + 2 * nb, bytes);
     return SMI_OK;
 }
 

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the rocprofv3 summaries behind bench.py's roofline object on the GPU box and leave
 # them under gpurun_out/<tag>/ (copy the CSVs / JSON you want judged into profiles/).
-#   gpurun -- 'bash tools/collect_profiles.sh r05'
+#   gpurun -- 'bash tools/collect_profiles.sh r06'
 # Kernel trace and counters are separate runs (gpurun refuses --pmc with trace domains other
 # than --kernel-trace; counters in passes of their own as MI355X_MICROARCH.md prescribes).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -22,6 +22,7 @@ stats() {  # name, bench arguments
 stats single_range --steps 100 --warmup 10 --no-cpu --sub-ranges 1
 stats default --steps 100 --warmup 10 --no-cpu
 stats cfg1 --config cfg1 --steps 100 --warmup 10 --no-cpu --sub-ranges 1
+stats cfg1_default --config cfg1 --steps 100 --warmup 10 --no-cpu   # two ranges, class streams
 stats cfg4 --config cfg4 --steps 100 --warmup 10 --no-cpu
 stats cfg5 --config cfg5 --steps 40
 stats driver --steps 20 --warmup 5   # the command the driver runs at round end
@@ -38,6 +39,15 @@ for nbl in 128 256 512; do
 done
 python "$R/bench.py" --config cfg5 --steps 40 > "$OUT/${TAG}_bench_cfg5_noprof.json" 2> /dev/null
 python "$R/tools/single_scene.py" 2> "$OUT/single_scene.err" | grep '^{' > "$OUT/${TAG}_bench_single_scene.json"
+# the driver's window cold (no clock ramp) beside the default, and the ramp itself
+python "$R/bench.py" --steps 20 --warmup 5 --ramp-ms 0 --no-cpu --no-counters > "$OUT/${TAG}_bench_driver_cold.json" 2> /dev/null
+python "$R/tools/clock_ramp.py" > "$OUT/${TAG}_clock_ramp.txt" 2> /dev/null
+# initialisation beside the fit, a small shard's enqueue time
+python "$R/tools/init_time.py" --scenes 4 --out "$OUT/${TAG}_init.json" > /dev/null 2> "$OUT/init.err"
+python "$R/tools/launch_overhead.py" --blends 128 > "$OUT/${TAG}_launch_overhead_128.txt" 2> /dev/null
+for cfg in cfg1 cfg4; do
+    python "$R/bench.py" --config $cfg --steps 100 --warmup 10 --no-cpu --no-counters > "$OUT/${TAG}_bench_${cfg}_noprof.json" 2> /dev/null
+done
 # the path a scarlet script calls: Blend objects in, fit_blends, fitted objects out
 python "$R/bench.py" --facade --blends 1024 --steps 100 > "$OUT/${TAG}_bench_facade.json" 2> "$OUT/facade.err"
 
