@@ -262,10 +262,24 @@ class Blend(CombinedComponent):
                 if self._scheme_args()[0] != "amsgrad":
                     raise NotImplementedError("point sources with another scheme than amsgrad")
                 on_device, rule = _vector_rule(image, "center")
+                if on_device and rule[1] and isinstance(morphology.psf, ImagePSF):
+                    # (a stamp with a free Fourier shift on the device holds the OFFSET of the
+                    # centre: a relative_step rule on the centre itself is the host's)
+                    on_device = False
                 if not on_device:  # a prior / constraint / step callable on the centre
                     self._host.append((k, HostVector(image, rule)))
                     rule = (0.0, 0.0, 0.0)
-                specs.append(self._point_spec(sed, image, morphology, rule))
+                # the spectrum like any other spectrum: PositivityConstraint(1e-20) and a
+                # built-in step on the device, anything else (a prior, another constraint, a
+                # step callable) stepped on the host from the device's gradient
+                sed_rule = _rule(sed, "spectrum")
+                free_form = isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20
+                sed_on_device = not callable(sed_rule) and sed.prior is None and (
+                    free_form or (sed.fixed and sed.constraint is None and np.all(np.asarray(sed) > 1e-20)))
+                if not sed_on_device:
+                    self._host.append((k, HostParameter(sed, "sed", sed_rule, *self._scheme_args())))
+                    sed_rule = (0.0, 0.0, 0.0)
+                specs.append(self._point_spec(sed, image, morphology, rule, sed_rule, sed_on_device))
                 continue
             shift_kw = {}
             if getattr(morphology, "shifting", False):
@@ -388,11 +402,12 @@ class Blend(CombinedComponent):
             batch.set_centers(centers)
 
     @staticmethod
-    def _point_spec(sed, center, morphology, center_rule):
+    def _point_spec(sed, center, morphology, center_rule, sed_rule, sed_on_device=True):
         """PointSource -> device description; the model PSF must be a pixel-integrated
         Gaussian or a Moffat profile, the same in all bands (what the device kernel
         evaluates).  ``center_rule``: (constant, relative factor, minimum) of the centre's
-        step on the device -- zeros for a centre the host steps (``_vector_rule``)."""
+        step on the device -- zeros for a centre the host steps (``_vector_rule``); ``sed_rule``
+        likewise for the spectrum (``sed_on_device`` False: the host steps it)."""
         psf = morphology.psf
         moffat = isinstance(psf, MoffatPSF) and psf.is_same and \
             bool(np.all(psf.get_parameter(1) == psf.get_parameter(1)[0]))
@@ -406,26 +421,21 @@ class Blend(CombinedComponent):
             raise NotImplementedError(
                 "point sources need a pixel-integrated GaussianPSF, a MoffatPSF or an ImagePSF "
                 "model PSF, the same in all bands")
-        if sed.prior is not None:
-            raise NotImplementedError("a prior on the spectrum of a point source")
-        if not (isinstance(sed.constraint, PositivityConstraint) and sed.constraint.zero == 1e-20):
-            raise NotImplementedError("spectrum constraint must be PositivityConstraint(1e-20)")
-        s_const, s_rel, s_min = _step_rule(sed.step, "spectrum")
+        s_const, s_rel, s_min = sed_rule
+        sed_fixed = sed.fixed or not sed_on_device
         c_const, c_rel, c_low = center_rule
         c_const = max(c_const, float(np.max(c_low)))  # (relative_step: max(minimum, factor * mean))
         if stamp is not None:
             # ImagePSF.get_model(offset) is fft.shift of the stored image (psf.py:228-234): on
             # the device a component with a fixed image and a free Fourier shift -- the offset of
             # the centre from the mean of the box bounds (morphology.py:503-507)
-            if c_rel:
-                raise NotImplementedError("relative_step on the centre of a point source on an ImagePSF")
             origin = morphology.bbox.origin[-2:]
             box_center = np.array(origin, dtype=np.float64) + np.array(stamp.shape) / 2
             return ComponentSpec(
                 np.asarray(sed), stamp, origin,
                 sed_min_step=np.maximum(np.asarray(s_min, dtype=np.float64), s_const),
                 sed_rel_step=s_rel, morph_step=0.0,
-                prox_flags=_lib.COMPONENT_FIXED_MORPH | (_lib.COMPONENT_FIXED_SED if sed.fixed else 0),
+                prox_flags=_lib.COMPONENT_FIXED_MORPH | (_lib.COMPONENT_FIXED_SED if sed_fixed else 0),
                 shift=np.asarray(center, dtype=np.float64) - box_center,
                 shift_step=0.0 if center.fixed else c_const)
         spec = PointSourceSpec(
@@ -436,7 +446,7 @@ class Blend(CombinedComponent):
             origin=morphology.bbox.origin[-2:],
             psf_beta=float(psf.get_parameter(1)[0]) if moffat else 0.0)
         # Parameter(fixed=True): zero gradient for that parameter (blend.py:107-115)
-        spec.prox_flags |= (_lib.COMPONENT_FIXED_SED if sed.fixed else 0) | (
+        spec.prox_flags |= (_lib.COMPONENT_FIXED_SED if sed_fixed else 0) | (
             _lib.COMPONENT_FIXED_MORPH if center.fixed else 0)
         return spec
 

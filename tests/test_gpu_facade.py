@@ -392,6 +392,18 @@ def test_priors_constraints_and_step_callables_on_free_2_vectors(hsc):
         assert np.abs(np.asarray(same[k].children[1].parameters[0])
                       - np.asarray(plain[k].children[1].parameters[0])).max() < 2e-5
 
+    # the spectrum of a point source is a spectrum like any other: a prior on it (here one that
+    # adds nothing) sends it to the host, which reproduces the device's spectrum step
+    flat = sources_of()
+    for k in stars:
+        flat[k].children[0].parameters[0].prior = Pull(0.0, 0.0)
+    with_prior = scarlet.Blend(flat, obs)
+    with_prior.fit(9, e_rel=1e-6)
+    assert sorted(k for k, hp in with_prior._host if hp.kind == "sed") == stars
+    for k in stars:
+        assert_allclose(np.asarray(flat[k].children[0].parameters[0]),
+                        np.asarray(plain[k].children[0].parameters[0]), rtol=2e-5)
+
     # -- the Fourier shift of an extended source under a prior
     gs = golden("hsc_shifting")
     filters = list("grizy")
