@@ -48,7 +48,8 @@ from .component import (  # noqa: F401
     CubeComponent,
     CombinedComponent,
 )
-from .blend import Blend, fit_blends  # noqa: F401
+from .blend import Blend  # noqa: F401
+from .fitting import fit_blends  # noqa: F401
 from .source import (  # noqa: F401
     ExtendedSource,
     SingleExtendedSource,
