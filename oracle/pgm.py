@@ -168,8 +168,10 @@ class PointComponent:
         # offset (fft.shift, fft.py:399-428) -- `sigma` is not used then
         self.image = None if image is None else np.asarray(image, dtype=np.float64)
         if image is not None:
-            assert self.image.ndim == 2 and self.image.shape[0] == self.image.shape[1]
-            boxsize, sigma = self.image.shape[0], 0.0
+            # (a cube: an ImagePSF that differs between the bands -- the morphology is then a
+            # cube too, one Fourier-shifted stamp per band, morphology.py:476-513)
+            assert self.image.ndim in (2, 3) and self.image.shape[-2] == self.image.shape[-1]
+            boxsize, sigma = self.image.shape[-1], 0.0
         self.sigma = float(sigma)
         # beta > 0: MoffatPSF(alpha=sigma, beta) instead of the Gaussian (psf.py:145-202)
         self.beta = float(beta)
@@ -218,7 +220,10 @@ class PointComponent:
         """Chain rule d(-logL)/d(center) = sum_yx g_morph * d(morph)/d(center)."""
         if self.image is not None:
             offset = self.center - (np.array(self.origin) + self.size / 2)
-            return fftconv.ShiftOperator(self.image.shape, offset).shift_gradient(self.image, g_morph)
+            op = fftconv.ShiftOperator(self.image.shape[-2:], offset)
+            if self.image.ndim == 3:  # g_morph: (C, h, w), the band's spectrum already in it
+                return sum(op.shift_gradient(img, g) for img, g in zip(self.image, g_morph))
+            return op.shift_gradient(self.image, g_morph)
         Y, X = self._axes()
         if self.beta > 0:
             # A = q^-beta with q = 1 + r^2 / alpha^2; d A / d center = -d A / d (grid - offset)
@@ -323,7 +328,7 @@ class Scene:
         """``overlapped_slices(frame.bbox, comp.bbox)`` on the two spatial axes
         (bbox.py:279-301; component.py:59-61)."""
         H, W = self.frame_shape[1:]
-        h, w = comp.morph.shape
+        h, w = comp.morph.shape[-2:]
         y0, x0 = comp.origin
         ylo, yhi = max(y0, 0), min(y0 + h, H)
         xlo, xhi = max(x0, 0), min(x0 + w, W)
@@ -351,7 +356,8 @@ class Scene:
         for group in self._groups():
             if len(group) == 1:
                 c = group[0]
-                boxed = c.sed[:, None, None] * c.model_morph()[None, :, :]
+                mm = c.model_morph()
+                boxed = c.sed[:, None, None] * (mm if mm.ndim == 3 else mm[None, :, :])
                 fs, bs = self.box_slices(c)
                 full[fs] += boxed[bs]
                 continue
@@ -426,12 +432,17 @@ class Scene:
         ``sum_yx G*morph`` and ``sum_c sed*G`` (lite/models.py:206-216)."""
         out = []
         for c in self.components:
-            h, w = c.morph.shape
+            h, w = c.morph.shape[-2:]
             boxed = np.zeros((self.frame_shape[0], h, w), dtype=np.float64)
             fs, bs = self.box_slices(c)
             boxed[bs] = G[fs]
-            g_sed = np.einsum("cyx,yx->c", boxed, c.model_morph())
-            g_morph = np.einsum("c,cyx->yx", c.sed, boxed)
+            mm = c.model_morph()
+            if mm.ndim == 3:  # a point source on a band-dependent model PSF
+                g_sed = np.einsum("cyx,cyx->c", boxed, mm)
+                g_morph = c.sed[:, None, None] * boxed
+            else:
+                g_sed = np.einsum("cyx,yx->c", boxed, mm)
+                g_morph = np.einsum("c,cyx->yx", c.sed, boxed)
             fixed_sed, fixed_morph = getattr(c, "fixed", (False, False))
             if fixed_sed:
                 g_sed = np.zeros_like(g_sed)

@@ -462,6 +462,13 @@ def point_source_image(scarlet):
     point_source(scarlet, image=True)
 
 
+def point_source_bands(scarlet):
+    """The same scene on an ImagePSF model PSF that DIFFERS between the bands (a cube of six
+    stamps of growing width: source.py:92-128 takes any ``frame.psf``; the morphology of a
+    point source is then a cube, morphology.py:476-513)."""
+    point_source(scarlet, image="bands")
+
+
 def point_source(scarlet, moffat=None, image=False):
     """docs/tutorials/point_source.ipynb: psf_unmatched_sim scene, stars as
     PointSource, galaxies as ExtendedSource; state up to the first gradient."""
@@ -477,6 +484,11 @@ def point_source(scarlet, moffat=None, image=False):
             yy, xx = np.mgrid[-7:8, -7:8].astype(np.float64)
             stamp = np.exp(-((yy - 0.2) ** 2 / (2 * 1.0**2) + (xx + 0.1) ** 2 / (2 * 1.2**2)))
             stamp += 0.05 * (1 + (yy**2 + xx**2) / 4.0) ** -1.5
+            if image == "bands":  # one stamp per band, the redder the wider
+                stamp = np.stack([
+                    np.exp(-((yy - 0.2) ** 2 / (2 * (0.85 + 0.07 * c) ** 2)
+                             + (xx + 0.1) ** 2 / (2 * (1.05 + 0.06 * c) ** 2)))
+                    + 0.05 * (1 + (yy**2 + xx**2) / 4.0) ** -1.5 for c in range(len(filters))])
             model_psf = scarlet.ImagePSF(stamp)
         frame = scarlet.Frame(images.shape, psf=model_psf, channels=filters, dtype=dtype)
         obs = scarlet.Observation(
@@ -512,7 +524,8 @@ def point_source(scarlet, moffat=None, image=False):
                 out["min_step_%d" % k] = np.asarray(spectrum.parameters[0].step.keywords["minimum"])
             if isinstance(src, scarlet.PointSource):
                 out["%scenter_%d" % (tag, k)] = np.array(morphology.parameters[0])
-                out["%smorph_%d" % (tag, k)] = np.array(morphology.get_model()[0])
+                full = np.array(morphology.get_model())
+                out["%smorph_%d" % (tag, k)] = full if image == "bands" else full[0]
             else:
                 out["%smorph_%d" % (tag, k)] = np.array(morphology.parameters[0])
 
@@ -552,6 +565,9 @@ def point_source(scarlet, moffat=None, image=False):
     if image:
         out["psf_image"] = np.array(model_psf.get_model()[0], dtype=np.float64)
         name = "point_source_image"
+    if image == "bands":
+        out["psf_image"] = np.array(model_psf.get_model(), dtype=np.float64)
+        name = "point_source_bands"
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("%s: %d sources, logL=%.3f" % (name, len(sources), out["logL"]))
 
@@ -653,7 +669,7 @@ def main(which=None):
     os.makedirs(OUT, exist_ok=True)
     jobs = dict(
         operator_tables=operator_tables, fft_psf=fft_psf, render_loss=render_loss,
-        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, point_source_moffat=point_source_moffat, point_source_image=point_source_image, hsc_shifting=hsc_shifting, lite=lite,
+        hsc_cosmos_35=hsc_cosmos_35, psf_unmatched=psf_unmatched, point_source=point_source, point_source_moffat=point_source_moffat, point_source_image=point_source_image, point_source_bands=point_source_bands, hsc_shifting=hsc_shifting, lite=lite,
         hsc_psf_shift=hsc_psf_shift,
         synthetic_cfg2=synthetic_cfg2, init_synthetic=init_synthetic,
     )

@@ -19,7 +19,7 @@ from .batch import BlendBatch, ComponentSpec, PointSourceSpec
 from .bbox import overlapped_slices
 from .component import CombinedComponent, FactorizedComponent
 from .constraint import PositivityConstraint, device_flags
-from .hoststep import HostParameter, HostVector
+from .hoststep import HostBandSource, HostParameter, HostVector
 from .model import UpdateException
 from .morphology import PointSourceMorphology
 from .psf import GaussianPSF, ImagePSF, MoffatPSF
@@ -33,12 +33,62 @@ class _HostSteppedShift(Exception):
     """the batch cannot step the kernel shift on the device (no fused convolution)"""
 
 
+def _band_dependent_psf(comp):
+    """True for a point source whose model PSF is an ImagePSF that differs between the bands."""
+    morphology = comp.children[1]
+    if not isinstance(morphology, PointSourceMorphology) or not isinstance(morphology.psf, ImagePSF):
+        return False
+    cube = np.asarray(morphology.psf.get_parameter(0))
+    return cube.ndim == 3 and cube.shape[0] > 1 and not np.all(cube == cube[0])
+
+
+def _band_components(src):
+    """The device's stand-ins for a point source on a band-dependent ImagePSF
+    (``hoststep.HostBandSource``): per band a factorized component -- that band's spectrum
+    entry, the others zero, times that band's stamp under a free Fourier shift -- whose
+    Parameters are fixed as far as the device is concerned.  Built once per source."""
+    cached = getattr(src, "_band_stand_ins", None)
+    if cached is not None:
+        return cached
+    from .morphology import ImageMorphology
+    from .parameter import Parameter
+    from .spectrum import TabulatedSpectrum
+
+    spectrum, morphology = src.children
+    cube = np.asarray(morphology.psf.get_parameter(0), dtype=np.float64)
+    sed, center = spectrum.parameters[0], morphology.parameters[0]
+    assert cube.shape[0] == sed.shape[0], "one stamp of the model PSF per band of the spectrum"
+    box = morphology.bbox[-2:]
+    middle = np.array(box.origin, dtype=np.float64) + np.array(box.shape) / 2
+    out = []
+    for c in range(cube.shape[0]):
+        values = np.zeros(sed.shape, dtype=np.float64)
+        values[c] = sed[c]
+        comp = FactorizedComponent(
+            src.frame,
+            TabulatedSpectrum(src.frame, Parameter(values, name="spectrum", fixed=True),
+                              bbox=spectrum.bbox),
+            ImageMorphology(src.frame, Parameter(cube[c].copy(), name="image", fixed=True),
+                            bbox=box.copy(), shifting=True,
+                            shift=Parameter(np.asarray(center, dtype=np.float64) - middle,
+                                            name="shift", step=0.0),
+                            resizing=False))
+        comp._band_of = (src, c, middle)
+        out.append(comp)
+    src._band_stand_ins = out
+    return out
+
+
 def _flatten(sources):
-    """FactorizedComponents of the scene in parameter order."""
+    """FactorizedComponents of the scene in parameter order (a point source on a band-dependent
+    ImagePSF as its per-band stand-ins, ``_band_components``)."""
     out = []
     for src in sources:
         if isinstance(src, FactorizedComponent):
-            out.append(src)
+            if _band_dependent_psf(src):
+                out.extend(_band_components(src))
+            else:
+                out.append(src)
         elif isinstance(src, CombinedComponent):
             if src.operation != "add":
                 # (the reference's own 'multiply' model is identically zero: its accumulator starts
@@ -256,6 +306,29 @@ class Blend(CombinedComponent):
             spectrum, morphology = comp.children
             sed = spectrum.parameters[0]
             image = morphology.parameters[0]
+            if getattr(comp, "_band_of", None) is not None:
+                # stand-in of a point source on a band-dependent ImagePSF: fixed on the device,
+                # the source's spectrum and centre are the host's (HostBandSource)
+                src, c, middle = comp._band_of
+                real_sed, real_center = src.children[0].parameters[0], src.children[1].parameters[0]
+                if self._scheme_args()[0] != "amsgrad":
+                    raise NotImplementedError("point sources with another scheme than amsgrad")
+                values = np.zeros(real_sed.shape)
+                values[c] = real_sed[c]
+                sed[...] = values
+                shift = morphology.parameters[1]
+                shift[...] = np.asarray(real_center, dtype=np.float64) - middle
+                if c == 0:
+                    _, center_rule = _vector_rule(real_center, "center")
+                    self._host.append((k, HostBandSource(
+                        real_sed, real_center, _rule(real_sed, "spectrum"), center_rule, middle,
+                        real_sed.shape[0])))
+                specs.append(ComponentSpec(
+                    np.asarray(sed), np.asarray(image), morphology.bbox.origin[-2:],
+                    sed_min_step=0.0, sed_rel_step=0.0, morph_step=0.0,
+                    prox_flags=_lib.COMPONENT_FIXED_MORPH | _lib.COMPONENT_FIXED_SED,
+                    shift=np.asarray(shift, dtype=np.float64), shift_step=0.0))
+                continue
             if isinstance(morphology, PointSourceMorphology):
                 if self._scheme_args()[0] != "amsgrad":
                     raise NotImplementedError("point sources with another scheme than amsgrad")
@@ -360,7 +433,7 @@ class Blend(CombinedComponent):
         host steps; g_vec = gradients of the free 2-vectors when one of them is the host's."""
         g_sed, g_morph = batch.gradient()
         g_vec = None
-        if any(hp.kind == "vec" for _, hp in self._host):
+        if any(hp.kind in ("vec", "band") for _, hp in self._host):
             g_vec = batch.centers()["gradient"]
             # a point source on an ImagePSF is a stamp with a free shift on the device: the
             # device holds the offset of the centre from the middle of its box (_point_spec)
@@ -391,6 +464,17 @@ class Blend(CombinedComponent):
                 if centers is None:
                     centers = batch.centers()["center"]
                 centers[k] = hp.update(local, g_vec[k], e_rel, prox_max_iter, **opt) - self._vec_offset[k]
+            elif hp.kind == "band":
+                # a point source on a band-dependent ImagePSF: its C stand-ins k .. k + C - 1
+                if centers is None:
+                    centers = batch.centers()["center"]
+                rows = range(k, k + hp.n_bands)
+                new_sed, offset = hp.update(local, [g_sed[j] for j in rows], [g_vec[j] for j in rows],
+                                            e_rel, prox_max_iter, **opt)
+                for c, j in enumerate(rows):
+                    seds[j] = np.zeros_like(seds[j])
+                    seds[j][c] = new_sed[c]
+                    centers[j] = offset
             else:
                 morphs[k] = hp.update(local, g_morph[k], e_rel, prox_max_iter, **opt)
             hp.store()

@@ -222,3 +222,39 @@ class HostVector:
 
     def store(self):
         self.p.m, self.p.v, self.p.vhat = self.m.copy(), self.v.copy(), self.vhat.copy()
+
+
+class HostBandSource:
+    """A ``PointSource`` on an ``ImagePSF`` model PSF that DIFFERS between the bands
+    (source.py:92-128 takes any ``frame.psf``; the morphology is then a cube, one stamp per
+    band Fourier-shifted to the centre, morphology.py:476-513).  A device component is a
+    spectrum x ONE image, so the device fits such a source as C components -- band c's spectrum
+    entry (the others zero) x band c's stamp under a Fourier shift -- with device steps of 0,
+    and the host steps the source's two Parameters from the gathered gradients:
+
+        d/d sed[c]   = g_sed of band component c, entry c
+        d/d center   = sum over the band components of their shift gradients
+
+    the spectrum with ``HostParameter`` (float32, the spectrum kernel's arithmetic), the centre
+    with ``HostVector`` (float64, the device's ``amsgrad_pair``).
+    """
+
+    kind = "band"
+
+    def __init__(self, sed, center, sed_step, center_step, box_center, n_bands):
+        self.sed = HostParameter(sed, "sed", sed_step)
+        self.vec = HostVector(center, center_step)
+        self.box_center = np.asarray(box_center, dtype=np.float64)
+        self.n_bands = int(n_bands)
+        self.p = center  # (finite check of the fit loop)
+
+    def update(self, it, g_sed_rows, g_vec_rows, e_rel, prox_max_iter, **opt):
+        g_sed = np.array([g_sed_rows[c][c] for c in range(self.n_bands)], dtype=np.float32)
+        g_vec = np.sum(np.asarray(g_vec_rows, dtype=np.float64), axis=0)
+        sed = self.sed.update(it, g_sed, e_rel, prox_max_iter, **opt)
+        center = self.vec.update(it, g_vec, e_rel, prox_max_iter, **opt)
+        return sed, center - self.box_center
+
+    def store(self):
+        self.sed.store()
+        self.vec.store()

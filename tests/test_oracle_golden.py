@@ -295,10 +295,12 @@ def test_psf_unmatched_golden():
     assert_allclose(sc.log_likelihood(rendered), g["logL"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["point_source", "point_source_moffat", "point_source_image"])
+@pytest.mark.parametrize("name", ["point_source", "point_source_moffat", "point_source_image",
+                                  "point_source_bands"])
 def test_point_source_scene_golden(name):
     """docs/tutorials/point_source.ipynb scene built by the reference (on its GaussianPSF
-    model PSF, and on a MoffatPSF): PSF morphology at a sub-pixel centre (bit-exact), model,
+    model PSF, on a MoffatPSF, on an ImagePSF and on an ImagePSF that differs between the
+    bands -- the morphology is a cube then): PSF morphology at a sub-pixel centre (bit-exact), model,
     rendered image, logL, and the gradient (centres included) against finite differences of
     the reference's forward."""
     from conftest import point_scene
