@@ -314,6 +314,10 @@ class Scene:
         self.psf_shift = None if psf_shift is None else np.array(psf_shift, dtype=np.float64)
         self.m_psf, self.v_psf, self.vhat_psf = np.zeros(2), np.zeros(2), np.zeros(2)
         self.psf_shift_step, self.psf_shift_rel_step = psf_shift_step, psf_shift_rel_step
+        # several observations with a free psf_shift each (blend.py:103-105 collects every
+        # observation's parameters): `psf_groups` = [dict(bands=[...], shift=array(2), step=1e-2)],
+        # one per observation -- its channels of the merged cube and its own shift
+        self.psf_groups = None
         self.frame_shape = tuple(frame_shape)
         self.dtype = dtype
         self.data = data
@@ -386,6 +390,11 @@ class Scene:
     def shifted_kernel(self):
         """The difference kernel, Fourier-shifted by ``psf_shift`` and cropped back to
         its stamp (renderer.py:220-228 -> fft.py:399-428)."""
+        if self.psf_groups:
+            out = np.array(self.kernel, copy=True)
+            for g in self.psf_groups:
+                out[g["bands"]] = fftconv.fourier_shift(self.kernel[g["bands"]], g["shift"]).astype(out.dtype)
+            return out
         if self.psf_shift is None:
             return self.kernel
         return fftconv.fourier_shift(self.kernel, self.psf_shift).astype(self.kernel.dtype)
@@ -398,11 +407,17 @@ class Scene:
     def psf_shift_gradient(self, model, rendered):
         """d(-logL)/d(psf_shift) = sum w (m - d) * (model (*) d kernel / d shift)."""
         r = self.weights * (rendered - self.data)
-        op = fftconv.ShiftOperator(self.kernel.shape[1:], self.psf_shift)
-        dk = [np.stack([d[a] for d in (op.derivative_images(k.astype(np.float64))
-                                       for k in self.kernel)]) for a in range(2)]
-        return np.array([np.sum(r * fftconv.convolve(model, d.astype(self.kernel.dtype),
-                                                     axes=(1, 2))) for d in dk])
+
+        def gradient(bands, shift):
+            op = fftconv.ShiftOperator(self.kernel.shape[1:], shift)
+            dk = [np.stack([d[a] for d in (op.derivative_images(k.astype(np.float64))
+                                           for k in self.kernel[bands])]) for a in range(2)]
+            return np.array([np.sum(r[bands] * fftconv.convolve(
+                model[bands], d.astype(self.kernel.dtype), axes=(1, 2))) for d in dk])
+
+        if self.psf_groups:
+            return [gradient(g["bands"], g["shift"]) for g in self.psf_groups]
+        return gradient(slice(None), self.psf_shift)
 
     @property
     def log_norm(self):
@@ -474,7 +489,7 @@ class Scene:
             loss = loss + term
             G = G + obs.adjoint(upstream, self.frame_shape[0])
         self.loss.append(loss)
-        if self.psf_shift is not None:
+        if self.psf_shift is not None or self.psf_groups:
             self.g_psf_shift = self.psf_shift_gradient(model, rendered)
         return loss, self.parameter_gradients(G)
 
@@ -513,6 +528,9 @@ class Scene:
             psf_alpha = vec_alpha(self, "psf_shift", self.psf_shift,
                                   relative_step(self.psf_shift, self.psf_shift_rel_step,
                                                 self.psf_shift_step))
+        if self.psf_groups:  # (steps on the pre-update shifts, like every other step)
+            group_alphas = [relative_step(g["shift"], g.get("rel", 0.0), g.get("step", 1e-2))
+                            for g in self.psf_groups]
         if self.psf_shift is not None:
             # the renderer's parameter comes after the sources' in X (blend.py:103-105)
             g_psf = vec_grad(self, "psf_shift", self.psf_shift, self.g_psf_shift)
@@ -543,6 +561,12 @@ class Scene:
         if self.psf_shift is not None:
             adaprox_update(it, self.psf_shift, g_psf, self.m_psf, self.v_psf, self.vhat_psf, psf_alpha,
                            rules(self, "psf_shift").get("prox"), e_rel, prox_max_iter, b1, b2, eps)
+        if self.psf_groups:
+            for g, alpha, grad in zip(self.psf_groups, group_alphas, self.g_psf_shift):
+                for name in ("m", "v", "vhat"):
+                    g.setdefault(name, np.zeros(2))
+                adaprox_update(it, g["shift"], grad, g["m"], g["v"], g["vhat"], alpha, None, e_rel,
+                               prox_max_iter, b1, b2, eps)
 
     def check_parameters(self):
         """``Model.check_parameters`` (model.py:153-165)."""

@@ -684,6 +684,14 @@ class Blend(CombinedComponent):
             if self._host:
                 raise NotImplementedError(
                     "user-defined constraints / steps together with a free psf_shift")
+            if sum(any(not p.fixed for p in o.parameters) for o in self.observations) > 1:
+                # one set of kernels moves on the device: the free shifts of SEVERAL
+                # observations (blend.py:103-105 collects every observation's parameters)
+                # are stepped on the host
+                if noise_factor:
+                    raise NotImplementedError("noise_factor > 0 with free psf_shifts of several observations")
+                return self._fit_with_psf_shifts(max_iter, e_rel, min_iter, prox_max_iter, opt,
+                                                 callback)
             self._psf = self._free_psf_shift()
             if self._psf_host is not None:
                 if noise_factor:
@@ -929,6 +937,125 @@ class Blend(CombinedComponent):
         for p in self.parameters + (shift,):
             if p.v is not None:
                 p.std = STD_FROM_V
+        return len(self.loss), -self.loss[-1]
+
+    def _fit_with_psf_shifts(self, max_iter, e_rel, min_iter, prox_max_iter, opt, callback):
+        """Free ``psf_shift``s of SEVERAL observations (blend.py:103-105: the parameters of
+        every observation join the sources' in ``X``).  The device moves one set of kernels,
+        so here every shift is the host's: the observations -- on the model's grid, each with
+        channels of its own -- are merged into one cube as usual (``_observation``), per
+        iteration the device runs its step with every kernel at its current shift, and for
+        each free shift two more forward renders with that observation's ``dK/ds`` in its
+        channels (zero kernels elsewhere) give ``d(-logL)/ds = sum w (m - d) (model (*) dK/ds)``
+        over its channels; the shifts take their AMSGrad steps (``hoststep.HostVector``: also
+        with a prior, a constraint or a step callable) and the merged kernel cube is rebuilt."""
+        channels = list(self.frame.channels)
+        C = self.frame.C
+        movers = []
+        for obs in self.observations:
+            free = [p for p in obs.parameters if not p.fixed]
+            if not free:
+                continue
+            renderer = obs.renderer
+            shift = renderer.get_parameter("psf_shift")
+            if [id(p) for p in obs.parameters] != [id(shift)] or type(renderer) is not ConvolutionRenderer:
+                raise NotImplementedError("only ConvolutionRenderer(psf_shift=...) has free parameters")
+            _, rule = _vector_rule(shift, "psf_shift")
+            movers.append((obs, renderer, shift, [channels.index(c) for c in obs.channels],
+                           HostVector(shift, rule)))
+
+        def merged():
+            """(data, weights, kernel cube with C bands) at the current shifts"""
+            self._psf = True  # (lets _observation accept free renderer parameters)
+            try:
+                data, weights, kernel = self._observation()
+            finally:
+                self._psf = None
+            if self._lowres or self._extra_layers or kernel is None:
+                raise NotImplementedError(
+                    "free psf_shifts of several observations need observations on the model's "
+                    "grid with channels of their own")
+            kernel = np.asarray(kernel, dtype=np.float32)
+            return data, weights, (np.repeat(kernel, C, axis=0) if kernel.shape[0] == 1 else kernel)
+
+        data, weights, kernel = merged()
+        ph, pw = kernel.shape[-2:]
+
+        def derivative_cube(idx, dk):
+            """dK/ds of one observation in its channels, zero kernels in the others"""
+            dk = np.asarray(dk, dtype=np.float32)
+            cube = np.zeros((C, ph, pw), dtype=np.float32)
+            oy, ox = ph // 2 - dk.shape[1] // 2, pw // 2 - dk.shape[2] // 2
+            for j, c in enumerate(idx):
+                cube[c, oy:oy + dk.shape[1], ox:ox + dk.shape[2]] = dk[j if dk.shape[0] > 1 else 0]
+            return cube
+
+        shifts = tuple(m[2] for m in movers)
+        w64 = weights.astype(np.float64)
+        it = 0
+        while it < max_iter:
+            comps = _flatten(self.sources)
+            batch = BlendBatch(data[None], weights[None], [self._specs(comps)], kernel=kernel,
+                               max_iter=max(max_iter - it, 1), device=self.device)
+            self._upload_state(batch, comps)
+            batch.set_optimizer(**opt)
+            restart = False
+            try:
+                local = 0
+                while it + local < max_iter and not restart:
+                    _, rendered, _ = batch.forward(model=False)
+                    resid = w64 * (rendered[0] - data)
+                    grads = []
+                    for obs, renderer, shift, idx, stepper in movers:
+                        g = np.zeros(2)
+                        for a, dk in enumerate(renderer.kernel_derivatives()):
+                            batch.set_kernel(derivative_cube(idx, dk))
+                            g[a] = np.sum(resid[idx] * batch.forward(model=False)[1][0][idx])
+                        grads.append(g)
+                    batch.set_kernel(kernel)
+                    batch.step(local, 1, e_rel=e_rel, min_iter=min_iter,
+                               prox_max_iter=prox_max_iter, check_convergence=True)
+                    for (obs, renderer, shift, idx, stepper), g in zip(movers, grads):
+                        stepper.update(local, g, e_rel, prox_max_iter, **opt)
+                        stepper.store()
+                    kernel = merged()[2]
+                    batch.set_kernel(kernel)
+                    active, err = batch.status()
+                    done = len(batch.loss_history()[0])
+                    if err >= 0 or not all(np.all(np.isfinite(np.asarray(s))) for s in shifts):
+                        self.loss.extend(batch.loss_history()[0])
+                        self._download(batch, comps)
+                        raise ArithmeticError("parameters of the blend are not finite")
+                    hook = done == local + 1 and done > 1 and (done - 1) % 10 == 0
+                    local = done
+                    if hook:
+                        self._download(batch, comps)
+                        for src in self.sources:
+                            try:
+                                src.update()
+                            except UpdateException:
+                                restart = True
+                    if active == 0 and not restart:
+                        break
+                    if callback is not None and not restart:
+                        if not hook:
+                            self._download(batch, comps)
+                        try:
+                            callback(*self.parameters, *shifts, it=local - 1)
+                        except StopIteration:
+                            break
+                self.loss.extend(batch.loss_history()[0])
+                if not restart:
+                    self._download(batch, comps)
+            finally:
+                batch.close()
+            if not restart:
+                break
+            it = len(self.loss)
+        for p in self.parameters + shifts:
+            if p.v is not None:
+                p.std = STD_FROM_V
+        self._psf_stepped_on_device = False
         return len(self.loss), -self.loss[-1]
 
     def _host_render_ops(self):

@@ -1978,6 +1978,59 @@ def test_free_psf_shift_next_to_a_second_observation(hsc):
     assert_allclose(np.asarray(obs1b.parameters[0]), np.asarray(shift), rtol=0, atol=1e-15)
 
 
+def test_free_psf_shifts_of_two_observations(hsc):
+    """``Blend.fit`` collects the parameters of EVERY observation (blend.py:103-105): two
+    observations -- bands g, r, i of one instrument, z, y of another -- whose
+    ``ConvolutionRenderer``s each carry a free ``psf_shift``.  The device moves one set of
+    kernels, so both shifts are stepped on the host (``Blend._fit_with_psf_shifts``; round 5
+    refused).  Against the oracle with one shift per group of bands: losses, both shifts."""
+    import scarlet_amd as scarlet
+    from scarlet_amd.renderer import ConvolutionRenderer
+    from conftest import golden
+
+    gp = golden("hsc_psf_shift")
+    filters = list("grizy")
+    frame = scarlet.Frame(hsc["images"].shape, psf=scarlet.GaussianPSF(sigma=(0.8,) * 5),
+                          channels=filters)
+    s1, s2 = gp["psf_shift"].copy(), np.array([-0.12, 0.07])
+    obs1 = scarlet.Observation(hsc["images"][:3], psf=scarlet.ImagePSF(hsc["psfs"][:3].copy()),
+                               weights=hsc["weights"][:3], channels=filters[:3])
+    obs1.match(frame, renderer=ConvolutionRenderer(obs1, frame, psf_shift=s1.copy()))
+    obs2 = scarlet.Observation(hsc["images"][3:], psf=scarlet.ImagePSF(hsc["psfs"][3:].copy()),
+                               weights=hsc["weights"][3:], channels=filters[3:])
+    obs2.match(frame, renderer=ConvolutionRenderer(obs2, frame, psf_shift=s2.copy()))
+    comps = []
+    for k in range(int(hsc["n_comp"])):
+        h, w = hsc["morph_%d" % k].shape
+        oy, ox = hsc["origin_%d" % k]
+        box = scarlet.Box((5, h, w), origin=(0, int(oy), int(ox)))
+        comps.append(scarlet.FactorizedComponent(
+            frame,
+            scarlet.TabulatedSpectrum(frame, hsc["sed_%d" % k].copy(), bbox=box[0],
+                                      min_step=hsc["min_step_%d" % k]),
+            scarlet.ExtendedSourceMorphology(frame, (oy + h // 2, ox + w // 2),
+                                             hsc["morph_%d" % k].copy(), bbox=box[1:],
+                                             resizing=False)))
+    blend = scarlet.Blend(comps, [obs1, obs2])
+    seen = []
+    n, _ = blend.fit(8, e_rel=1e-9, callback=lambda *X, it: seen.append((it, len(X))))
+    assert n == 8 and seen[0] == (0, len(blend.parameters) + 2)  # both shifts behind the sources'
+
+    sc = hsc_scene(hsc)
+    for c in sc.components:
+        c.source = None
+    sc.psf_groups = [dict(bands=[0, 1, 2], shift=s1.copy(), step=1e-2),
+                     dict(bands=[3, 4], shift=s2.copy(), step=1e-2)]
+    n_ref, _ = sc.fit(8, e_rel=1e-9)
+    assert n_ref == 8
+    assert_allclose(np.array(blend.loss) - sc.log_norm, np.array(sc.loss) - sc.log_norm, rtol=2e-4)
+    for obs, start, group in ((obs1, s1, sc.psf_groups[0]), (obs2, s2, sc.psf_groups[1])):
+        shift = obs.parameters[0]
+        assert np.abs(np.asarray(shift) - group["shift"]).max() < 3e-5
+        assert np.abs(np.asarray(shift) - start).max() > 1e-3  # it moved
+        assert shift.m is not None and shift.std.shape == (2,)
+
+
 def test_user_defined_linear_renderer_matches_the_device_renderer(hsc):
     """Plug-in seam (SURVEY 8b seam 3): ``Observation.match(frame, renderer=<a Renderer
     subclass>)`` (observation.py:59-112).  A user-written Python renderer -- here the PSF
