@@ -127,9 +127,8 @@ def _vector_rule(p, what):
     relative factor, minimum), or the callable."""
     if p.fixed and p.step is None:
         return True, (0.0, 0.0, 0.0)
-    try:
-        rule = _step_rule(p.step, what)
-    except NotImplementedError:
+    rule = _step_rule(p.step, what)
+    if rule is None:
         return False, p.step
     return p.prior is None and p.constraint is None, rule
 
@@ -138,26 +137,26 @@ def _rule(p, what):
     """step rule of a parameter, or the callable itself if it is user code"""
     if p.fixed and p.step is None:
         return (0.0, 0.0, 0.0)  # never used (blend.py:107-115)
-    try:
-        return _step_rule(p.step, what)
-    except NotImplementedError:
-        return p.step
+    rule = _step_rule(p.step, what)
+    return p.step if rule is None else rule
 
 
 def _step_rule(step, what):
-    """(constant, relative factor, minimum) of a Parameter.step."""
+    """(constant, relative factor, minimum) of a Parameter.step, or None for a rule the device
+    does not have (a step callable of the user's, ``relative_step`` along an axis of an
+    image): that parameter is stepped on the host."""
     if isinstance(step, partial) and step.func is relative_step:
         kw = step.keywords
         axis = kw.get("axis")
         # (the mean of a spectrum along its only axis is its mean: parameter.py:126-129)
         along_all = axis is None or (what == "spectrum" and axis in (0, -1, (0,), (-1,)))
         if not along_all or step.args:
-            raise NotImplementedError("relative_step along an axis of an image: stepped on the host")
+            return None
         return 0.0, float(kw.get("factor", 0.1)), kw.get("minimum", 0)
     if step is relative_step:
         return 0.0, 0.1, 0
     if callable(step):
-        raise NotImplementedError("custom step callables for {} cannot run on the device".format(what))
+        return None
     return float(step), 0.0, 0
 
 
@@ -822,6 +821,15 @@ class Blend(CombinedComponent):
         n_seen = int(np.count_nonzero(noisy_weights))
         batch.add_loss_constant(-0.5 * n_seen * np.log(noise_factor + 1.0))
 
+    @staticmethod
+    def _psf_shift_of(obs):
+        """(renderer, shift) of an observation whose only parameter is its renderer's psf_shift"""
+        renderer = obs.renderer
+        shift = renderer.get_parameter("psf_shift")
+        if [id(p) for p in obs.parameters] != [id(shift)] or type(renderer) is not ConvolutionRenderer:
+            raise NotImplementedError("only ConvolutionRenderer(psf_shift=...) has free parameters")
+        return renderer, shift
+
     def _free_psf_shift(self):
         """``(shift parameter, renderer)`` of the one observation whose
         ``ConvolutionRenderer(psf_shift=...)`` carries the free sub-pixel shift of the
@@ -831,10 +839,7 @@ class Blend(CombinedComponent):
             # (one set of kernels moves on the device: the first observation's)
             raise NotImplementedError("free psf_shifts of several observations")
         obs = free[0]
-        renderer = obs.renderer
-        shift = renderer.get_parameter("psf_shift")
-        if [id(p) for p in obs.parameters] != [id(shift)] or type(renderer) is not ConvolutionRenderer:
-            raise NotImplementedError("only ConvolutionRenderer(psf_shift=...) has free parameters")
+        renderer, shift = self._psf_shift_of(obs)
         if tuple(obs.shape) != tuple(self.frame.shape) or list(obs.channels) != list(self.frame.channels):
             raise NotImplementedError("psf_shift needs an observation on the model frame")
         # (relative_step, parameter.py:126-129: max(minimum, factor * mean(shift)); a prior, a
@@ -956,10 +961,7 @@ class Blend(CombinedComponent):
             free = [p for p in obs.parameters if not p.fixed]
             if not free:
                 continue
-            renderer = obs.renderer
-            shift = renderer.get_parameter("psf_shift")
-            if [id(p) for p in obs.parameters] != [id(shift)] or type(renderer) is not ConvolutionRenderer:
-                raise NotImplementedError("only ConvolutionRenderer(psf_shift=...) has free parameters")
+            renderer, shift = self._psf_shift_of(obs)
             _, rule = _vector_rule(shift, "psf_shift")
             movers.append((obs, renderer, shift, [channels.index(c) for c in obs.channels],
                            HostVector(shift, rule)))
