@@ -276,6 +276,7 @@ struct smi_batch {
     int32_t *state = nullptr, *zero_state = nullptr, *n_loss = nullptr, *status_out = nullptr;
     int32_t *it_base = nullptr;  // BatchView::it_base (smi_batch_set_iteration_base)
     int32_t *pause_at = nullptr, *conv_flag = nullptr;  // smi_batch_set_pause_at
+    std::vector<char> plan_shared;  // plans[i] belongs to the plan cache (smi_batch_add_sweep_plan)
     int32_t *h_round = nullptr;  // pinned staging of smi_batch_set_round / get_round, 3 x n_blends
     double *loss_hist = nullptr, *last_loss = nullptr, *loss_partial = nullptr;
     // plans
@@ -302,6 +303,7 @@ void refresh_view(smi_batch *b) {
     v.Fy = b->Py;
     v.Fx = b->Px;
     v.n_comp = b->d.n_components;
+    v.n_comp_total = b->d.n_components;
     v.comp_start = b->comp_start;
     v.c_blend = b->c_blend;
     v.c_oy = b->c_oy;
@@ -869,7 +871,9 @@ int smi_batch_destroy(smi_batch *b) {
         }
         plans_leave(b->device, b->Fy, b->Fx, b->plans_shared);
     }
-    for (auto &pl : b->plans) {
+    for (size_t i = 0; i < b->plans.size(); ++i) {
+        auto &pl = b->plans[i];
+        if (i < b->plan_shared.size() && b->plan_shared[i]) continue;  // (the plan cache's)
         (void)hipFree(pl.level_start);
         (void)hipFree(pl.pix);
         (void)hipFree(pl.cnt);
@@ -907,11 +911,57 @@ int smi_batch_destroy(smi_batch *b) {
     return SMI_OK;
 }
 
+// Sweep plans by content.  A plan -- level plan, slot entries, ring stream: ~1 MB for a 61 x 61
+// box -- depends on the tables alone, and every fit of a scene asks for the same three or four
+// (a scene's Blend.fit spent 1 ms of its 18 building and uploading them).  The device copies
+// are therefore kept per device under a hash of the tables and shared by all batches; they are
+// never freed (at most kPlanCacheLimit of them; beyond that a batch owns its plans again).
+namespace {
+constexpr size_t kPlanCacheLimit = 512;
+struct PlanKey {
+    int device, h, w, n_idx;
+    uint64_t hash;
+    bool operator<(const PlanKey &o) const {
+        return std::tie(device, h, w, n_idx, hash) < std::tie(o.device, o.h, o.w, o.n_idx, o.hash);
+    }
+};
+std::mutex g_sweep_plans_mu;
+std::map<PlanKey, SweepPlanDev> g_sweep_plans;
+
+uint64_t fnv1a(const void *p, size_t n, uint64_t h) {
+    // (eight bytes at a time: the tables are a few hundred KB)
+    const uint64_t *q = static_cast<const uint64_t *>(p);
+    for (size_t i = 0; i < n / 8; ++i) h = (h ^ q[i]) * 1099511628211ull;
+    const unsigned char *t = static_cast<const unsigned char *>(p) + (n / 8) * 8;
+    for (size_t i = 0; i < n % 8; ++i) h = (h ^ t[i]) * 1099511628211ull;
+    return h;
+}
+}  // namespace
+
 int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *weights,
                              const int32_t *offsets, const int32_t *dist_idx, int32_t n_idx) {
     SMI_REQUIRE(b && weights && offsets, "null argument");
     SMI_REQUIRE(h > 0 && w > 0, "empty box");
     SMI_HIP(hipSetDevice(b->device));
+    static const bool use_cache = [] {  // development aid: SMI_PLAN_CACHE=0
+        const char *e = getenv("SMI_PLAN_CACHE");
+        return !e || atoi(e) != 0;
+    }();
+    PlanKey key{b->device, h, w, n_idx, 1469598103934665603ull};
+    if (use_cache) {
+        key.hash = fnv1a(weights, (size_t)8 * h * w * sizeof(double), key.hash);
+        key.hash = fnv1a(offsets, 8 * sizeof(int32_t), key.hash);
+        if (n_idx > 0) key.hash = fnv1a(dist_idx, (size_t)n_idx * sizeof(int32_t), key.hash);
+        std::lock_guard<std::mutex> lock(g_sweep_plans_mu);
+        auto hit = g_sweep_plans.find(key);
+        if (hit != g_sweep_plans.end()) {
+            b->plans.push_back(hit->second);
+            b->plan_shared.push_back(1);
+            if (hit->second.n_levels > b->max_levels) b->max_levels = hit->second.n_levels;
+            if (int rc = upload_plans(b)) return rc;
+            return (int)b->plans.size() - 1;
+        }
+    }
     SweepPlanHost hp;
     if (!build_sweep_plan(h * w, weights, offsets, 8, dist_idx, n_idx, &hp)) return SMI_ERR_INVALID;
     SweepPlanDev dp;
@@ -989,7 +1039,14 @@ int smi_batch_add_sweep_plan(smi_batch *b, int32_t h, int32_t w, const double *w
         dp.ring_perm = rp.perm;
         dp.ring_bytes = (uint32_t)stream.size();
     }
+    bool shared = false;
+    if (use_cache) {
+        std::lock_guard<std::mutex> lock(g_sweep_plans_mu);
+        if (g_sweep_plans.size() < kPlanCacheLimit)
+            shared = g_sweep_plans.emplace(key, dp).second;  // (the cache owns the device copies now)
+    }
     b->plans.push_back(dp);
+    b->plan_shared.push_back(shared ? 1 : 0);
     if (dp.n_levels > b->max_levels) b->max_levels = dp.n_levels;
     if ((rc = upload_plans(b))) return rc;
     return (int)b->plans.size() - 1;

@@ -202,6 +202,7 @@ struct SweepPlanDev {
 struct BatchView {
     int32_t nb, C, H, W, Fy, Fx;  // Fy=H, Fx=W for the NullRenderer
     int32_t n_comp;
+    int32_t n_comp_total;  // components of the whole batch (n_comp: of this range of blends)
     // components (device, SoA)
     const int32_t *comp_start;  // nb + 1
     const int32_t *c_blend, *c_oy, *c_ox, *c_h, *c_w, *c_flags, *c_plan;

@@ -2094,8 +2094,15 @@ __global__ __launch_bounds__(T * update_pack_max(NPL, T)) SMI_WAVES void update_
 // per class -> this kernel): 16 blends 50 -> 103, 128: 340 -> 567, 512: 857 -> 1003, 768:
 // 1027 -> 1062, 1024: 1159 -> 1145 (three ranges of 3413 components: the occupancy of the
 // small classes starts to count), hence kMixedUpdateLimit.
-template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void update_kernel_mixed(
+// WAVES = wavefronts per SIMD the register allocator aims at.  2: 256 registers, 244 - 268 B of
+// scratch.  1 (round 6): the whole register file of a SIMD for one wavefront -- what does not
+// fit the 256 architectural registers is parked in accumulation registers (110 - 119 of them,
+// v_accvgpr moves) instead of scratch memory: no spill traffic on the chain of a lone blend.
+// Quickstart Blend.fit(100, 1e-4) 18.5 -> 17.2 ms, 16 quickstart blends 124 k -> 135 k
+// blend-it/s, 128 blends 765 k -> 782 k; 256 blends 1 224 k -> 1 040 k: a batch of more than
+// ~1 000 components needs the second wavefront per SIMD (launch_update picks).
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void update_kernel_mixed(
     BatchView v, const float *G, int it, float e_rel, int prox_max_iter, int n_finalize,
     int min_iter, int check) {
     __shared__ float sed_new[64];
@@ -2738,15 +2745,26 @@ int launch_update(const BatchView &v_in, const float *G, int32_t it, float e_rel
             pending_finalize.on = false;
             const int n_fin = fin.on ? v.nb : 0;
             const dim3 grid(v.n_comp + n_fin);
-            if (v.scheme == SMI_SCHEME_FISTA)
-                hipLaunchKernelGGL(update_kernel_mixed<2>, grid, dim3(64), lds, s, v, G, it,
-                                   e_rel, prox_max_iter, n_fin, fin.min_iter, fin.check);
-            else if (v.lite)
-                hipLaunchKernelGGL(update_kernel_mixed<1>, grid, dim3(64), lds, s, v, G, it,
-                                   e_rel, prox_max_iter, n_fin, fin.min_iter, fin.check);
-            else
-                hipLaunchKernelGGL(update_kernel_mixed<0>, grid, dim3(64), lds, s, v, G, it,
-                                   e_rel, prox_max_iter, n_fin, fin.min_iter, fin.check);
+            static const int one_wave_limit = [] {  // development aid
+                const char *e = getenv("SMI_MIXED_ONE_WAVE");
+                return e ? atoi(e) : 1024;
+            }();
+            const bool lone = v.n_comp_total <= one_wave_limit;  // (one wavefront per SIMD suffices)
+#define SMI_MIXED(MODE)                                                                          \
+    if (lone)                                                                                    \
+        hipLaunchKernelGGL((update_kernel_mixed<MODE, 1>), grid, dim3(64), lds, s, v, G, it,     \
+                           e_rel, prox_max_iter, n_fin, fin.min_iter, fin.check);                \
+    else                                                                                         \
+        hipLaunchKernelGGL((update_kernel_mixed<MODE, 2>), grid, dim3(64), lds, s, v, G, it,     \
+                           e_rel, prox_max_iter, n_fin, fin.min_iter, fin.check)
+            if (v.scheme == SMI_SCHEME_FISTA) {
+                SMI_MIXED(2);
+            } else if (v.lite) {
+                SMI_MIXED(1);
+            } else {
+                SMI_MIXED(0);
+            }
+#undef SMI_MIXED
             return SMI_OK;
         }
         // one launch per size class that has components in this range of blends, the
