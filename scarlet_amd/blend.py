@@ -85,7 +85,8 @@ def _flatten(sources):
     out = []
     for src in sources:
         if isinstance(src, FactorizedComponent):
-            if _band_dependent_psf(src):
+            # (the rare case is told apart by one type check per component)
+            if isinstance(src._children[1], PointSourceMorphology) and _band_dependent_psf(src):
                 out.extend(_band_components(src))
             else:
                 out.append(src)
