@@ -56,7 +56,7 @@ def _band_components(src):
 
     spectrum, morphology = src.children
     cube = np.asarray(morphology.psf.get_parameter(0), dtype=np.float64)
-    sed, center = spectrum.parameters[0], morphology.parameters[0]
+    sed, center = spectrum._parameters[0], morphology._parameters[0]
     assert cube.shape[0] == sed.shape[0], "one stamp of the model PSF per band of the spectrum"
     box = morphology.bbox[-2:]
     middle = np.array(box.origin, dtype=np.float64) + np.array(box.shape) / 2
@@ -304,19 +304,19 @@ class Blend(CombinedComponent):
         self._host = []
         for k, comp in enumerate(comps):
             spectrum, morphology = comp.children
-            sed = spectrum.parameters[0]
-            image = morphology.parameters[0]
+            sed = spectrum._parameters[0]
+            image = morphology._parameters[0]
             if getattr(comp, "_band_of", None) is not None:
                 # stand-in of a point source on a band-dependent ImagePSF: fixed on the device,
                 # the source's spectrum and centre are the host's (HostBandSource)
                 src, c, middle = comp._band_of
-                real_sed, real_center = src.children[0].parameters[0], src.children[1].parameters[0]
+                real_sed, real_center = src.children[0]._parameters[0], src.children[1]._parameters[0]
                 if self._scheme_args()[0] != "amsgrad":
                     raise NotImplementedError("point sources with another scheme than amsgrad")
                 values = np.zeros(real_sed.shape)
                 values[c] = real_sed[c]
                 sed[...] = values
-                shift = morphology.parameters[1]
+                shift = morphology._parameters[1]
                 shift[...] = np.asarray(real_center, dtype=np.float64) - middle
                 if c == 0:
                     _, center_rule = _vector_rule(real_center, "center")
@@ -357,7 +357,7 @@ class Blend(CombinedComponent):
                 # Fourier sub-pixel shift (morphology.py:124-130).  A fixed zero shift --
                 # the reference's default for a bare ImageMorphology, morphology.py:113 --
                 # is the identity; a fixed non-zero one is applied with step 0
-                shift = morphology.parameters[1]
+                shift = morphology._parameters[1]
                 if not shift.fixed or np.any(np.asarray(shift) != 0):
                     # (relative_step, parameter.py:126-129: max(minimum, factor * mean))
                     on_device, rule = _vector_rule(shift, "shift")
@@ -566,7 +566,7 @@ class Blend(CombinedComponent):
     @staticmethod
     def _upload_state(batch, comps):
         """Warm start: the AMSGrad moments stored on the Parameters (blend.py:153-163)."""
-        params = [(c.children[0].parameters[0], c.children[1].parameters[0]) for c in comps]
+        params = [(c.children[0]._parameters[0], c.children[1]._parameters[0]) for c in comps]
         point = [isinstance(c.children[1], PointSourceMorphology) for c in comps]
 
         def state(p, name, shape):
@@ -592,7 +592,7 @@ class Blend(CombinedComponent):
             if point[k]:
                 vec[k] = params[k][1]
             elif batch.has_shift(k):
-                vec[k] = c.children[1].parameters[1]
+                vec[k] = c.children[1]._parameters[1]
         if any(p is not None and p.m is not None and p.v is not None and p.vhat is not None
                for p in vec):
             batch.set_center_moments(
@@ -620,6 +620,18 @@ class Blend(CombinedComponent):
         m_sed, v_sed, vhat_sed = mom["m_sed"], mom["v_sed"], mom["vhat_sed"]
         m_morph, v_morph, vhat_morph = mom["m_morph"], mom["v_morph"], mom["vhat_morph"]
         centers = None
+        shifted = (np.asarray(batch._flags) & _lib.COMPONENT_SHIFTING).astype(bool).tolist()
+        if not any(shifted) and not any(isinstance(c._children[1], PointSourceMorphology) for c in comps):
+            # images only (a thousand blends: ten thousand components): nothing but assignments
+            for k, comp in enumerate(comps):
+                spectrum, morphology = comp._children
+                sed = spectrum._parameters[0]
+                image = morphology._parameters[0]
+                sed[...] = seds[k]
+                sed.m, sed.v, sed.vhat = m_sed[k], v_sed[k], vhat_sed[k]
+                image[...] = morphs[k]
+                image.m, image.v, image.vhat = m_morph[k], v_morph[k], vhat_morph[k]
+            return
         for k, comp in enumerate(comps):
             spectrum, morphology = comp._children
             sed = spectrum._parameters[0]
@@ -638,7 +650,7 @@ class Blend(CombinedComponent):
             if batch.has_shift(k):
                 if centers is None:
                     centers = batch.centers()
-                shift = comp.children[1].parameters[1]
+                shift = comp.children[1]._parameters[1]
                 shift[...] = centers["center"][k]
                 shift.m, shift.v, shift.vhat = (centers[n][k].copy() for n in ("m", "v", "vhat"))
             image[...] = morphs[k]

@@ -238,7 +238,7 @@ def device_flags(constraint):
                center_floor=1e-6, sym_strength=1.0, chain_repeat=1)
     if constraint is None:
         return out
-    if isinstance(constraint, ConstraintChain):
+    if type(constraint) is ConstraintChain or isinstance(constraint, ConstraintChain):
         out["chain_repeat"] = int(constraint.repeat)
         items = list(constraint.constraints)
     else:
@@ -257,7 +257,8 @@ def device_flags(constraint):
                 )
             )
         rank = r
-        if isinstance(c, MonotonicityConstraint):
+        t = type(c)  # (exact types: _DEVICE_RANK has no entry for subclasses)
+        if t is MonotonicityConstraint:
             if c.fit_center_radius > 1:
                 raise NotImplementedError("fit_center_radius > 1 is not supported on the device")
             out["flags"] |= _lib.PROX_MONOTONIC
@@ -267,22 +268,22 @@ def device_flags(constraint):
                 out["flags"] |= _lib.PROX_MONO_MASK
             out["neighbor_weight"] = c.neighbor_weight
             out["min_gradient"] = float(c.min_gradient)
-        elif isinstance(c, SymmetryConstraint):
+        elif t is SymmetryConstraint:
             out["flags"] |= _lib.PROX_SYMMETRY
             out["sym_strength"] = float(c.strength)
-        elif isinstance(c, (L0Constraint, L1Constraint)):
+        elif t is L0Constraint or t is L1Constraint:
             if out["flags"] & (_lib.PROX_L0 | _lib.PROX_L1):
                 raise NotImplementedError("L0 and L1 constraints in one chain")
             if c.type == "relative":
                 out["flags"] |= _lib.PROX_L_RELATIVE
-            out["flags"] |= _lib.PROX_L0 if isinstance(c, L0Constraint) else _lib.PROX_L1
+            out["flags"] |= _lib.PROX_L0 if t is L0Constraint else _lib.PROX_L1
             out["l_thresh"] = float(c.thresh)
-        elif isinstance(c, PositivityConstraint):
+        elif t is PositivityConstraint:
             out["flags"] |= _lib.PROX_POSITIVE
             out["zero"] = float(c.zero)
-        elif isinstance(c, CenterOnConstraint):
+        elif t is CenterOnConstraint:
             out["flags"] |= _lib.PROX_CENTER_ON
             out["center_floor"] = float(c.tiny)
-        elif isinstance(c, NormalizationConstraint):
+        elif t is NormalizationConstraint:
             out["flags"] |= _lib.PROX_NORM_MAX if c.type == "max" else _lib.PROX_NORM_SUM
     return out

@@ -266,13 +266,14 @@ _freeze_lock = __import__("threading").Lock()
 _freeze_users = [0]
 
 
-def _device_resize_covers(blend):
+def _device_resize_covers(blend, flat=None):
     """True when the device can also carry out every resize below ``blend``
     (``smi_batch_update_components`` with keep = 2 / 3): stock ``shrink_box``, odd square boxes,
-    a constant step on float32 / float64 images."""
-    for c in _flatten(blend.sources):
+    a constant step on float32 / float64 images.  ``flat``: the blend's components, if the
+    caller has them already."""
+    for c in (_flatten(blend.sources) if flat is None else flat):
         morphology = c.children[1]
-        image = morphology.parameters[0]
+        image = morphology._parameters[0]
         h, w = morphology.bbox.shape[-2:]
         if (type(morphology).shrink_box is not Morphology.shrink_box or h != w or h % 2 == 0
                 or h > 1000 or image.dtype not in (np.float32, np.float64)):
@@ -326,23 +327,25 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
         frozen = np.zeros(nb, dtype=bool)  # out of iterations
         g = 0  # the batch's iteration counter: blend i is at g - (its counter base) = local[i]
         # per component: may update() act, and does the device test stand for it
-        resizable = np.array([bool(c.children[1].resizing) and not c.children[1].parameters[0].fixed
+        resizable = np.array([bool(c.children[1].resizing) and not c.children[1]._parameters[0].fixed
                               for c in flat])
         blend_of = np.repeat(np.arange(nb), np.diff(first))
         # blends the device resizes by itself, and what the host tracks for their components
-        on_device = np.array([_device_resize_covers(r.blend) for r in group])
+        on_device = np.array([_device_resize_covers(r.blend, cs) for r, cs in zip(group, comps)])
         if os.environ.get("SCARLET_AMD_FIT_BLENDS") == "host-resize":  # development aid: A/B runs
             on_device[:] = False
         origin = np.array([c.children[1].bbox.origin[-2:] for c in flat], dtype=np.int64).reshape(-1, 2)
-        step = np.array([float(c.children[1].parameters[0].step)
-                         if isinstance(c.children[1].parameters[0].step, (int, float)) else np.nan
+        step = np.array([float(c.children[1]._parameters[0].step)
+                         if isinstance(c.children[1]._parameters[0].step, (int, float)) else np.nan
                          for c in flat])
-        wide = np.array([c.children[1].parameters[0].dtype == np.float64 for c in flat])
+        wide = np.array([c.children[1]._parameters[0].dtype == np.float64 for c in flat])
         moved = np.zeros(n_comp, dtype=bool)
         # (update() of a source stops at its first child that resizes, component.py:172-185)
+        # (a source is one factorized component or a combined one: no second walk through the tree
+        # for the common case)
         source_of = np.concatenate(
-            [np.full(len(_flatten([src])), j) for j, src in
-             enumerate(src for r in group for src in r.blend.sources)]).astype(np.int64) \
+            [np.full(1 if isinstance(src, FactorizedComponent) else len(_flatten([src])), j)
+             for j, src in enumerate(src for r in group for src in r.blend.sources)]).astype(np.int64) \
             if n_comp else np.zeros(0, dtype=np.int64)
         def write_back():
             """Device -> Python objects: new image Parameters (morphology.py:155-163, 180-193)
@@ -350,7 +353,7 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
             the losses recorded since the fit began."""
             for k in np.flatnonzero(moved):
                 morphology = flat[k].children[1]
-                image = morphology.parameters[0]
+                image = morphology._parameters[0]
                 shape = tuple(batch._shapes[k])
                 morphology._parameters = (
                     Parameter(np.zeros(shape, dtype=image.dtype), name=image.name, prior=image.prior,
@@ -461,7 +464,7 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
                 for k, rec in zip(idx, batch.component_states(idx)):
                     _record_to_parameters(flat[k], rec)
                 changed = set()
-                images = {i: [c.children[1].parameters[0] for c in comps[i]] for i in visit}
+                images = {i: [c.children[1]._parameters[0] for c in comps[i]] for i in visit}
                 for i, src, k, below in calls:
                     try:
                         src.update()
@@ -476,7 +479,7 @@ def _fit_group_resident(group, device, max_iter, opt, step_kw):
                     comps[i] = _flatten(group[i].blend.sources)
                     flat[first[i]:first[i + 1]] = comps[i]
                     for j, c in enumerate(comps[i]):
-                        if c.children[1].parameters[0] is before[j]:
+                        if c.children[1]._parameters[0] is before[j]:
                             continue
                         specs[i][j] = _resized_spec(specs[i][j], c)
                         keep[first[i] + j] = 0
@@ -517,7 +520,7 @@ def _resized_spec(spec, comp):
     import copy
 
     morphology = comp.children[1]
-    image = morphology.parameters[0]
+    image = morphology._parameters[0]
     new = copy.copy(spec)
     new.morph = np.asarray(image, dtype=np.float32)
     new.origin = tuple(int(o) for o in morphology.bbox.origin[-2:])
@@ -528,8 +531,8 @@ def _resized_spec(spec, comp):
 def _record_to_parameters(comp, rec):
     """A state record of the device (``BlendBatch.component_states``) into the Parameters of
     a factorized component: values in place, moments as float64 arrays."""
-    sed = comp.children[0].parameters[0]
-    image = comp.children[1].parameters[0]
+    sed = comp.children[0]._parameters[0]
+    image = comp.children[1]._parameters[0]
     sed[...] = rec["sed"]
     sed.m, sed.v, sed.vhat = (rec[n].astype(np.float64) for n in ("m_sed", "v_sed", "vhat_sed"))
     image[...] = rec["morph"]
@@ -538,8 +541,8 @@ def _record_to_parameters(comp, rec):
 
 
 def _parameters_to_record(comp):
-    sed = comp.children[0].parameters[0]
-    image = comp.children[1].parameters[0]
+    sed = comp.children[0]._parameters[0]
+    image = comp.children[1]._parameters[0]
     return dict(sed=np.asarray(sed), m_sed=sed.m, v_sed=sed.v, vhat_sed=sed.vhat,
                 morph=np.asarray(image), m_morph=image.m, v_morph=image.v, vhat_morph=image.vhat)
 
