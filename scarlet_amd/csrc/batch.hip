@@ -1680,8 +1680,18 @@ static int set_components_impl(smi_batch *b, const smi_components *c, const int3
     if (b->g_morph) SMI_HIP(hipFree(b->g_morph));
     SMI_HIP(dev_alloc(&b->g_sed, (size_t)n * C));
     SMI_HIP(dev_alloc(&b->g_morph, (size_t)b->n_morph));
-    if (b->xp_tmp) SMI_HIP(hipFree(b->xp_tmp));
-    SMI_HIP(dev_alloc(&b->xp_tmp, 2 * (size_t)b->n_morph));
+    if (b->xp_tmp) {
+        SMI_HIP(hipFree(b->xp_tmp));
+        b->xp_tmp = nullptr;
+    }
+    {
+        // (only the four-wavefront teams keep x and psi there: boxes beyond the largest
+        // one-wavefront class)
+        bool teams = false;
+        for (int k = 0; k < n && !teams; ++k)
+            teams = update_class(c->box_h[k] * c->box_w[k]) >= kNumSmallClasses;
+        if (teams) SMI_HIP(dev_alloc(&b->xp_tmp, 2 * (size_t)b->n_morph));
+    }
     // point sources: offset of the centre from the mean of the box bounds
     // (morphology.py:503-507), moments zero
     std::vector<double> pt((size_t)n * 8, 0.0);
