@@ -653,6 +653,21 @@ def main():
 
     # the clocks up (not a warm-up of anything the timed region reuses), then W untimed
     # warm-up iterations, then the state of iteration 0 again
+    cold = None
+    if args.ramp_ms > 0 and not args.steady:
+        # the same protocol without the ramp first (rounds 1-5 measured this window): reported
+        # beside `value` as config.cold_window_value, never as `value`
+        run(0, Wm)
+        torch.cuda.synchronize()
+        fresh()
+        torch.cuda.synchronize()
+        sdist.barrier()
+        t0 = time.perf_counter()
+        run(0, K)
+        torch.cuda.synchronize()
+        sdist.barrier()
+        cold = n_total * K / sdist.max_over_ranks(time.perf_counter() - t0)
+        fresh()
     ramp(args.ramp_ms)
     run(0, Wm)
     torch.cuda.synchronize()
@@ -906,6 +921,7 @@ def main():
                                             "check, not a scaling point)" if share else ""),
                 "sub_ranges_per_gpu": ranges_timed,
                 "clock_ramp_ms": args.ramp_ms,
+                "cold_window_value": None if cold is None else round(cold, 1),
                 "clock_ramp_note": "untimed iterations of this batch before the W warm-up "
                                    "iterations and before the roofline pass, state restored: the "
                                    "GPU idles for seconds during set-up and needs ~20 ms of load "
