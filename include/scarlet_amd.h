@@ -549,7 +549,14 @@ int smi_batch_conv_path_used(smi_batch *b, int32_t *path);
  * shifted along y to every low-resolution row (renderer.py:341-353), and
  * Pt[Fx][Fx*n_b], the transposed operator that shifts a padded model row to every
  * low-resolution column (renderer.py:498-505).  A rendering of a padded model cube
- * [C][Fy][Fx] is two dense products per band, out[C][n_a][n_b]. */
+ * [C][Fy][Fx] is the linear map out[C][n_a][n_b] = A . (model . Pt) per band.
+ *
+ * The reference's shift is a phase ramp between a real transform and its inverse on the
+ * padded grid (renderer.py:414-476), i.e. Pt is circulant along x: Pt[x'][x][b] =
+ * s_b[(x - x') mod Fx].  smi_resampler_create checks that, and then evaluates the same map
+ * through transforms along x of the model rows, the operator rows (made once, on the
+ * device, in float64) and s_b -- path 1, "spectral": 1/25 of the arithmetic and 1/5 of the
+ * HBM traffic of the two dense products (path 0), which stay for any other Pt. */
 typedef struct smi_resampler smi_resampler;
 int smi_resampler_create(const float *A, const float *Pt, int32_t C, int32_t n_a, int32_t n_b,
                          int32_t Fy, int32_t Fx, smi_resampler **out);
@@ -558,6 +565,11 @@ int smi_resampler_render(smi_resampler *r, const float *model, float *out);
  * over n_rep repetitions without host transfers (benchmark of BASELINE config 5) */
 int smi_resampler_time(smi_resampler *r, int32_t n_rep, double *ms_per_render);
 int smi_resampler_destroy(smi_resampler *r);
+/* which evaluation the resampler uses: 0 = two dense products per band, 1 = spectral.
+ * smi_resampler_set_path(r, 0) switches a spectral resampler to the dense products (the
+ * parity tests compare the two); path 1 is refused for an operator that is not circulant. */
+int smi_resampler_get_path(smi_resampler *r, int32_t *path);
+int smi_resampler_set_path(smi_resampler *r, int32_t path);
 
 /* The low-resolution observation as a further term of a fit (Blend._loss_func sums the
  * log-likelihoods of all observations, blend.py:265-271; Observation.get_log_likelihood,

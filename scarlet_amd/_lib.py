@@ -131,6 +131,8 @@ SYMBOLS = {
     "smi_resampler_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32,
                                           ctypes.POINTER(ctypes.c_double)]),
     "smi_resampler_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "smi_resampler_get_path": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "smi_resampler_set_path": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "smi_batch_attach_lowres": (
         ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i32p, c_f32p, c_f32p, ctypes.c_double]
     ),

@@ -661,6 +661,17 @@ int smi_resampler_time(smi_resampler *r, int32_t n_rep, double *ms_per_render) {
     return resampler_time(r->impl, n_rep, ms_per_render);
 }
 
+int smi_resampler_get_path(smi_resampler *r, int32_t *path) {
+    SMI_REQUIRE(r && r->impl && path, "null argument");
+    *path = resampler_get_path(r->impl);
+    return SMI_OK;
+}
+
+int smi_resampler_set_path(smi_resampler *r, int32_t path) {
+    SMI_REQUIRE(r && r->impl, "null argument");
+    return resampler_set_path(r->impl, path);
+}
+
 static constexpr int kMaxLowRes = 8;
 
 int smi_batch_attach_lowres(smi_batch *b, smi_resampler *r, const int32_t *channels,

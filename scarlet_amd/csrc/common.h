@@ -380,6 +380,8 @@ int resampler_create(const float *A, const float *Pt, int C, int n_a, int n_b, i
                      Resampler **out);
 int resampler_render(Resampler *r, const float *model, float *out);
 int resampler_time(Resampler *r, int n_rep, double *ms_per_render);
+int resampler_get_path(const Resampler *r);
+int resampler_set_path(Resampler *r, int path);
 void resampler_destroy(Resampler *r);
 struct LowRes;
 int lowres_create(Resampler *r, const int32_t *channels, const float *data, const float *weights,

@@ -19,7 +19,10 @@
 // tiles are summed in double by a second kernel -- that keeps the renderings within
 // ~1e-7 of the reference's float64 evaluation and gives a small output enough workgroups
 // to fill the chip.  The bands of an observation are one batched launch.
+#include <algorithm>
+#include <cmath>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -200,9 +203,15 @@ int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float
          int64_t strideC, int n_batch, double *scratch, size_t scratch_elems, int M, int N, int K,
          hipStream_t s) {
     // one MFMA tile per wavefront along a dimension of up to 96 (see the kernel)
-    const int tm = M <= 96 ? 1 : 2, tn = N <= 96 ? 1 : 2;
+    int tm = M <= 96 ? 1 : 2, tn = N <= 96 ? 1 : 2;
+    auto n_tiles = [&](int a, int b) {
+        return ((M + 64 * a - 1) / (64 * a)) * ((N + 64 * b - 1) / (64 * b)) * n_batch;
+    };
+    // (a product of a few hundred rows and columns -- the transforms of the spectral path --
+    // is 45 workgroups in 128 x 128 tiles and 125 in 64 x 64 tiles)
+    if (n_tiles(tm, tn) * std::max(1, (K + kSliceTerms - 1) / kSliceTerms) < 200) tm = tn = 1;
     const int bm = 64 * tm, bn = 64 * tn;
-    const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * n_batch;
+    const int tiles = n_tiles(tm, tn);
     // slices of ~kSliceTerms terms (float32 accumulation length); fewer when the tiles
     // alone fill the chip several times over and the partials would not fit the scratch.
     // (Round 4: fewer, longer slices -- 18 instead of 47 for the 300 x 300 x 15 000 product, 61
@@ -248,54 +257,355 @@ void launch_transpose(const float *in, float *out, int rows, int cols, hipStream
                        s, in, out, rows, cols);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The spectral path.  The reference shifts the padded model along x by a phase ramp between
+// a real transform and its inverse on the padded grid (renderer.py:414-476), so the shift
+// operator of a low-resolution column b is a circulant matrix: P[x', x, b] = s_b[(x - x') mod
+// F_x].  With the transforms along x of the model rows, of the operator rows and of s_b
+// (hat = sum_x . exp(-2 pi i k x / F_x), k <= F_x / 2, w_k = 1 for k = 0 and the Nyquist
+// term, else 2), Parseval's identity turns the two dense products into
+//
+//   Mh[y, k]   = hat(model[y, :])[k]                           F_y x F_x x (F_x + 2)
+//   G[a, k]    = sum_y conj(E[a, y, k]) Mh[y, k]               E = hat(A[a, y, :]), read once
+//   out[a, b]  = Re sum_k beta[b, k] G[a, k]                   beta = w_k hat(s_b)[k] / F_x
+//
+// -- the same linear map (exact in exact arithmetic; checked against the dense products on
+// every fixture pair), 3.2 GFLOP -> 0.13 GFLOP per 300 x 300 band and 90 MB of E through HBM
+// instead of 450 MB of shifted models.  The adjoint runs the transposed chain:
+//
+//   Gbar[a, k] = sum_b resid[a, b] conj(beta[b, k])
+//   Mbar[y, k] = sum_a Gbar[a, k] E[a, y, k]
+//   g[y, x]    = sum_k Re(Mbar[y, k]) cos(2 pi k x / F_x) - Im(Mbar[y, k]) sin(2 pi k x / F_x)
+//
+// E is made on the device at set-up from the float32 operator the caller hands over, in
+// float64 (row_dft_kernel); the sums over y, a, b and k run in float64 as well, the two
+// transforms along x on the matrix cores (gemm above, K = F_x or F_x + 2 terms in float32).
+// An operator Pt that is not circulant keeps the dense products.
+// ---------------------------------------------------------------------------------------
+
+// out[row][k] = scale_k sum_x in[row][x] tw[(k x) mod Fx], k < Kx; tw[j] = exp(-2 pi i j / Fx)
+// in float64.  hermitian != 0: scale_k = w_k / Fx (the beta table), else 1.
+__global__ __launch_bounds__(256) void row_dft_kernel(const float *in, const double2 *tw,
+                                                      float2 *out, int Fx, int Kx, int hermitian) {
+    extern __shared__ double dft_sm[];
+    double *row = dft_sm;
+    double2 *t = reinterpret_cast<double2 *>(dft_sm + ((Fx + 1) & ~1));
+    const int64_t r = blockIdx.x;
+    for (int x = threadIdx.x; x < Fx; x += 256) {
+        row[x] = (double)in[r * Fx + x];
+        t[x] = tw[x];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < Kx; k += 256) {
+        double re = 0.0, im = 0.0;
+        int j = 0;
+        for (int x = 0; x < Fx; ++x) {
+            const double a = row[x];
+            const double2 w = t[j];
+            re = fma(a, w.x, re);
+            im = fma(a, w.y, im);
+            j += k;
+            if (j >= Fx) j -= Fx;
+        }
+        if (hermitian) {
+            const double sc = ((k == 0 || 2 * k == Fx) ? 1.0 : 2.0) / (double)Fx;
+            re *= sc;
+            im *= sc;
+        }
+        out[r * Kx + k] = make_float2((float)re, (float)im);
+    }
+}
+
+// One workgroup per (low-resolution row a, band c): G[k] = sum_y conj(E[c][a][y][k]) Mh[c][y][k]
+// (wavefront w takes the rows y = w, w + 16, ..., four loads of E in flight per lane; lanes
+// along k, so a wavefront reads 512 contiguous bytes of E per row), the sixteen partial sums
+// combined in a fixed order, then out[c][a][b] = Re sum_k beta[b][k] G[k] by sixteen lanes
+// per column b.  E is read exactly once per rendering.
+__global__ __launch_bounds__(1024) void spectral_forward_kernel(const float2 *E, const float2 *Mh,
+                                                                const float2 *beta, float *out,
+                                                                int n_a, int n_b, int Fy, int Kx) {
+    extern __shared__ double2 fwd_sm[];
+    double2 *red = fwd_sm;         // [16][64]
+    double2 *G = fwd_sm + 16 * 64;  // [Kx]
+    const int a = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float2 *Ea = E + ((int64_t)c * n_a + a) * Fy * Kx;
+    const float2 *Mc = Mh + (int64_t)c * Fy * Kx;
+    for (int k0 = 0; k0 < Kx; k0 += 64) {
+        const int k = k0 + lane;
+        double re = 0.0, im = 0.0;
+        if (k < Kx) {
+            auto term = [&](float2 e, float2 m) {
+                re = fma((double)e.x, (double)m.x, re);
+                re = fma((double)e.y, (double)m.y, re);
+                im = fma((double)e.x, (double)m.y, im);
+                im = fma(-(double)e.y, (double)m.x, im);
+            };
+            int y = w;
+            for (; y + 48 < Fy; y += 64) {
+                const float2 e0 = Ea[(int64_t)y * Kx + k], e1 = Ea[(int64_t)(y + 16) * Kx + k];
+                const float2 e2 = Ea[(int64_t)(y + 32) * Kx + k], e3 = Ea[(int64_t)(y + 48) * Kx + k];
+                const float2 m0 = Mc[(int64_t)y * Kx + k], m1 = Mc[(int64_t)(y + 16) * Kx + k];
+                const float2 m2 = Mc[(int64_t)(y + 32) * Kx + k], m3 = Mc[(int64_t)(y + 48) * Kx + k];
+                term(e0, m0);
+                term(e1, m1);
+                term(e2, m2);
+                term(e3, m3);
+            }
+            for (; y < Fy; y += 16) term(Ea[(int64_t)y * Kx + k], Mc[(int64_t)y * Kx + k]);
+        }
+        red[w * 64 + lane] = make_double2(re, im);
+        __syncthreads();
+        if (w == 0 && k < Kx) {
+            double sr = 0.0, si = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                sr += red[q * 64 + lane].x;
+                si += red[q * 64 + lane].y;
+            }
+            G[k] = make_double2(sr, si);
+        }
+        __syncthreads();
+    }
+    const int part = tid & 15;
+    for (int b0 = 0; b0 < n_b; b0 += 64) {
+        const int b = b0 + (tid >> 4);
+        double t = 0.0;
+        if (b < n_b)
+            for (int k = part; k < Kx; k += 16) {
+                const float2 bt = beta[(int64_t)b * Kx + k];
+                const double2 g = G[k];
+                t = fma((double)bt.x, g.x, t);
+                t = fma(-(double)bt.y, g.y, t);
+            }
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (b < n_b && part == 0) out[((int64_t)c * n_a + a) * n_b + b] = (float)t;
+    }
+}
+
+// Gbar[ca][k] = sum_b resid[ca][b] conj(beta[b][k]); one workgroup per (band, row a)
+__global__ __launch_bounds__(256) void spectral_gbar_kernel(const float *resid, const float2 *beta,
+                                                            float2 *Gbar, int n_b, int Kx) {
+    extern __shared__ float gbar_sm[];
+    const int64_t ca = blockIdx.x;
+    for (int b = threadIdx.x; b < n_b; b += 256) gbar_sm[b] = resid[ca * n_b + b];
+    __syncthreads();
+    for (int k = threadIdx.x; k < Kx; k += 256) {
+        double re = 0.0, im = 0.0;
+        for (int b = 0; b < n_b; ++b) {
+            const float2 bt = beta[(int64_t)b * Kx + k];
+            const double r = (double)gbar_sm[b];
+            re = fma(r, (double)bt.x, re);
+            im = fma(-r, (double)bt.y, im);
+        }
+        Gbar[ca * Kx + k] = make_float2((float)re, (float)im);
+    }
+}
+
+// Mbar[c][y][k] = sum_a Gbar[c][a][k] E[c][a][y][k]; one workgroup of four wavefronts per
+// (model row y, band c), wavefront w takes a = w, w + 4, ...
+__global__ __launch_bounds__(256) void spectral_adjoint_kernel(const float2 *E, const float2 *Gbar,
+                                                               float2 *Mbar, int n_a, int Fy,
+                                                               int Kx) {
+    __shared__ double2 red[4][64];
+    const int y = blockIdx.x, c = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float2 *Ec = E + ((int64_t)c * n_a * Fy + y) * Kx;
+    const float2 *Gc = Gbar + (int64_t)c * n_a * Kx;
+    const int64_t sa = (int64_t)Fy * Kx;
+    for (int k0 = 0; k0 < Kx; k0 += 64) {
+        const int k = k0 + lane;
+        double re = 0.0, im = 0.0;
+        if (k < Kx) {
+            auto term = [&](float2 g, float2 e) {
+                re = fma((double)g.x, (double)e.x, re);
+                re = fma(-(double)g.y, (double)e.y, re);
+                im = fma((double)g.x, (double)e.y, im);
+                im = fma((double)g.y, (double)e.x, im);
+            };
+            int a = w;
+            for (; a + 12 < n_a; a += 16) {
+                const float2 e0 = Ec[a * sa + k], e1 = Ec[(a + 4) * sa + k];
+                const float2 e2 = Ec[(a + 8) * sa + k], e3 = Ec[(a + 12) * sa + k];
+                const float2 g0 = Gc[(int64_t)a * Kx + k], g1 = Gc[(int64_t)(a + 4) * Kx + k];
+                const float2 g2 = Gc[(int64_t)(a + 8) * Kx + k], g3 = Gc[(int64_t)(a + 12) * Kx + k];
+                term(g0, e0);
+                term(g1, e1);
+                term(g2, e2);
+                term(g3, e3);
+            }
+            for (; a < n_a; a += 4) term(Gc[(int64_t)a * Kx + k], Ec[a * sa + k]);
+        }
+        red[w][lane] = make_double2(re, im);
+        __syncthreads();
+        if (w == 0 && k < Kx) {
+            const double sr = (red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x);
+            const double si = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
+            Mbar[((int64_t)c * Fy + y) * Kx + k] = make_float2((float)sr, (float)si);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 struct Resampler {
     int C = 0, n_a = 0, n_b = 0, Fy = 0, Fx = 0;
     float *A = nullptr;    // [C][n_a][Fy * Fx]
     float *Pt = nullptr;   // [Fx][Fx * n_b]  (transposed shift operator, shared by the bands)
-    float *model = nullptr, *B = nullptr, *out = nullptr;  // B: [C][Fy * Fx * n_b]
+    float *model = nullptr, *out = nullptr;
+    // dense products (made on first use: an operator Pt that is not circulant, or asked for)
+    float *B = nullptr;    // [C][Fy * Fx * n_b]
     double *scratch = nullptr;
     size_t scratch_elems = 0;
     float *At = nullptr;   // [C][Fy * Fx][n_a]: A transposed (left operand of the adjoint)
-    float *P = nullptr;    // [Fx * n_b][Fx]: built when a fit attaches the resampler (adjoint)
+    float *P = nullptr;    // [Fx * n_b][Fx]
+    // spectral path
+    int path = 0;          // 0: dense products, 1: spectral
+    bool spectral = false; // Pt is circulant and the tables below exist
+    int Kx = 0;            // Fx / 2 + 1
+    float2 *E = nullptr;    // [C][n_a][Fy][Kx]: transforms along x of the operator rows
+    float2 *beta = nullptr; // [n_b][Kx]
+    float *Wx = nullptr;    // [Fx][2 Kx]: cos, -sin interleaved (forward transform as a product)
+    float *WxT = nullptr;   // [2 Kx][Fx]
+    float2 *Mh = nullptr;   // [C][Fy][Kx]: transforms of the model rows / Mbar of the adjoint
+    float2 *Gbar = nullptr; // [C][n_a][Kx]
+    double *sscratch = nullptr;  // slice partials of the two transforms when Fx > kSliceTerms
+    size_t sscratch_elems = 0;
 };
+
+namespace {
+
+// P[x', x, b] == P[0, (x - x') mod Fx, b] for all entries (to float32 rounding of the largest)?
+bool circulant_along_x(const float *Pt, int Fx, int n_b) {
+    float top = 0.f;
+    for (size_t i = 0; i < (size_t)Fx * n_b; ++i) top = std::max(top, std::fabs(Pt[i]));
+    const float tol = 4e-7f * top;
+    for (int xp = 1; xp < Fx; ++xp) {
+        const float *row = Pt + (size_t)xp * Fx * n_b;
+        for (int x = 0; x < Fx; ++x) {
+            int d = x - xp;
+            if (d < 0) d += Fx;
+            const float *a = row + (size_t)x * n_b, *b = Pt + (size_t)d * n_b;
+            for (int q = 0; q < n_b; ++q)
+                if (!(std::fabs(a[q] - b[q]) <= tol)) return false;
+        }
+    }
+    return true;
+}
+
+int build_dense(Resampler *r) {
+    if (r->B) return SMI_OK;
+    const size_t plane = (size_t)r->Fy * r->Fx;
+    const size_t nA = (size_t)r->C * r->n_a * plane, nB = (size_t)r->C * plane * r->n_b;
+    // double partials of the sliced products: out (n_a x n_b, thousands of slices) and
+    // the model-sized results of the adjoint (F_y x F_x, ~100 slices), all bands at once
+    const size_t slices_out = (plane + kSliceTerms - 1) / kSliceTerms + 1;
+    const size_t slices_g = ((size_t)r->Fx * r->n_b + kSliceTerms - 1) / kSliceTerms + 1;
+    r->scratch_elems = (size_t)r->C * std::max((size_t)r->n_a * r->n_b * slices_out,
+                                               plane * slices_g);
+    SMI_HIP(hipMalloc((void **)&r->B, nB * sizeof(float)));
+    SMI_HIP(hipMalloc((void **)&r->scratch, r->scratch_elems * sizeof(double)));
+    // At[C][Fy Fx][n_a]: the left operand of the adjoint's first product; P: its second
+    SMI_HIP(hipMalloc((void **)&r->At, nA * sizeof(float)));
+    for (int c = 0; c < r->C; ++c)
+        launch_transpose(r->A + (size_t)c * r->n_a * plane, r->At + (size_t)c * r->n_a * plane,
+                         r->n_a, (int)plane, nullptr);
+    SMI_HIP(hipMalloc((void **)&r->P, (size_t)r->Fx * r->Fx * r->n_b * sizeof(float)));
+    launch_transpose(r->Pt, r->P, r->Fx, r->Fx * r->n_b, nullptr);
+    SMI_HIP(hipGetLastError());
+    SMI_HIP(hipDeviceSynchronize());
+    return SMI_OK;
+}
+
+int build_spectral(Resampler *r, const float *Pt_host) {
+    const int Fx = r->Fx, Fy = r->Fy, Kx = Fx / 2 + 1, n_a = r->n_a, n_b = r->n_b, C = r->C;
+    r->Kx = Kx;
+    const double step = 2.0 * 3.14159265358979323846 / (double)Fx;
+    std::vector<double2> tw(Fx);
+    for (int j = 0; j < Fx; ++j) tw[j] = make_double2(std::cos(step * j), -std::sin(step * j));
+    std::vector<float> Wx((size_t)Fx * 2 * Kx), WxT((size_t)2 * Kx * Fx), S((size_t)n_b * Fx);
+    for (int x = 0; x < Fx; ++x)
+        for (int k = 0; k < Kx; ++k) {
+            const double2 w = tw[(int)(((int64_t)k * x) % Fx)];
+            Wx[(size_t)x * 2 * Kx + 2 * k] = WxT[(size_t)(2 * k) * Fx + x] = (float)w.x;
+            Wx[(size_t)x * 2 * Kx + 2 * k + 1] = WxT[(size_t)(2 * k + 1) * Fx + x] = (float)w.y;
+        }
+    for (int b = 0; b < n_b; ++b)  // s_b[x] = P[x' = 0][x][b]
+        for (int x = 0; x < Fx; ++x) S[(size_t)b * Fx + x] = Pt_host[(size_t)x * n_b + b];
+    double2 *d_tw = nullptr;
+    float *d_S = nullptr;
+    SMI_HIP(hipMalloc((void **)&d_tw, Fx * sizeof(double2)));
+    SMI_HIP(hipMalloc((void **)&d_S, S.size() * sizeof(float)));
+    SMI_HIP(hipMalloc((void **)&r->E, (size_t)C * n_a * Fy * Kx * sizeof(float2)));
+    SMI_HIP(hipMalloc((void **)&r->beta, (size_t)n_b * Kx * sizeof(float2)));
+    SMI_HIP(hipMalloc((void **)&r->Wx, Wx.size() * sizeof(float)));
+    SMI_HIP(hipMalloc((void **)&r->WxT, WxT.size() * sizeof(float)));
+    SMI_HIP(hipMalloc((void **)&r->Mh, (size_t)C * Fy * Kx * sizeof(float2)));
+    SMI_HIP(hipMalloc((void **)&r->Gbar, (size_t)C * n_a * Kx * sizeof(float2)));
+    const size_t slices = (size_t)(std::max(Fx, 2 * Kx) + kSliceTerms - 1) / kSliceTerms + 1;
+    r->sscratch_elems = (size_t)C * Fy * std::max(Fx, 2 * Kx) * slices;
+    SMI_HIP(hipMalloc((void **)&r->sscratch, r->sscratch_elems * sizeof(double)));
+    SMI_HIP(hipMemcpy(d_tw, tw.data(), Fx * sizeof(double2), hipMemcpyHostToDevice));
+    SMI_HIP(hipMemcpy(d_S, S.data(), S.size() * sizeof(float), hipMemcpyHostToDevice));
+    SMI_HIP(hipMemcpy(r->Wx, Wx.data(), Wx.size() * sizeof(float), hipMemcpyHostToDevice));
+    SMI_HIP(hipMemcpy(r->WxT, WxT.data(), WxT.size() * sizeof(float), hipMemcpyHostToDevice));
+    const size_t lds = (size_t)((Fx + 1) & ~1) * sizeof(double) + (size_t)Fx * sizeof(double2);
+    hipLaunchKernelGGL(row_dft_kernel, dim3((unsigned)((size_t)C * n_a * Fy)), dim3(256), lds,
+                       nullptr, r->A, d_tw, r->E, Fx, Kx, 0);
+    hipLaunchKernelGGL(row_dft_kernel, dim3(n_b), dim3(256), lds, nullptr, d_S, d_tw, r->beta, Fx,
+                       Kx, 1);
+    SMI_HIP(hipGetLastError());
+    SMI_HIP(hipDeviceSynchronize());
+    (void)hipFree(d_tw);
+    (void)hipFree(d_S);
+    r->spectral = true;
+    return SMI_OK;
+}
+
+}  // namespace
 
 int resampler_create(const float *A, const float *Pt, int C, int n_a, int n_b, int Fy, int Fx,
                      Resampler **out) {
     auto *r = new Resampler;
     r->C = C; r->n_a = n_a; r->n_b = n_b; r->Fy = Fy; r->Fx = Fx;
     const size_t nA = (size_t)C * n_a * Fy * Fx, nP = (size_t)Fx * Fx * n_b;
-    const size_t nB = (size_t)C * Fy * Fx * n_b;
-    // double partials of the sliced products: out (n_a x n_b, thousands of slices) and
-    // the model-sized results of the adjoint (F_y x F_x, ~100 slices), all bands at once
-    const size_t slices_out = ((size_t)Fy * Fx + kSliceTerms - 1) / kSliceTerms + 1;
-    const size_t slices_g = ((size_t)Fx * n_b + kSliceTerms - 1) / kSliceTerms + 1;
-    r->scratch_elems = (size_t)C * std::max((size_t)n_a * n_b * slices_out,
-                                            (size_t)Fy * Fx * slices_g);
     *out = r;
     SMI_HIP(hipMalloc((void **)&r->A, nA * sizeof(float)));
     SMI_HIP(hipMalloc((void **)&r->Pt, nP * sizeof(float)));
     SMI_HIP(hipMalloc((void **)&r->model, (size_t)C * Fy * Fx * sizeof(float)));
-    SMI_HIP(hipMalloc((void **)&r->B, nB * sizeof(float)));
     SMI_HIP(hipMalloc((void **)&r->out, (size_t)C * n_a * n_b * sizeof(float)));
-    SMI_HIP(hipMalloc((void **)&r->scratch, r->scratch_elems * sizeof(double)));
     SMI_HIP(hipMemcpy(r->A, A, nA * sizeof(float), hipMemcpyHostToDevice));
     SMI_HIP(hipMemcpy(r->Pt, Pt, nP * sizeof(float), hipMemcpyHostToDevice));
-    // At[C][Fy Fx][n_a]: the left operand of the adjoint's first product
-    SMI_HIP(hipMalloc((void **)&r->At, nA * sizeof(float)));
-    for (int c = 0; c < C; ++c)
-        launch_transpose(r->A + (size_t)c * n_a * Fy * Fx, r->At + (size_t)c * n_a * Fy * Fx, n_a,
-                         Fy * Fx, nullptr);
-    SMI_HIP(hipGetLastError());
-    SMI_HIP(hipDeviceSynchronize());
+    // (the transform tables of a row live in LDS: 24 bytes per column)
+    if (Fx <= 2048 && circulant_along_x(Pt, Fx, n_b)) {
+        const int rc = build_spectral(r, Pt);
+        if (rc) return rc;
+        r->path = 1;
+        return SMI_OK;
+    }
+    return build_dense(r);
+}
+
+int resampler_get_path(const Resampler *r) { return r->path; }
+
+int resampler_set_path(Resampler *r, int path) {
+    SMI_REQUIRE(path == 0 || path == 1, "path is 0 (dense products) or 1 (spectral)");
+    SMI_REQUIRE(path == 0 || r->spectral,
+                "the shift operator of this resampler is not circulant: dense products only");
+    if (path == 0) {
+        const int rc = build_dense(r);
+        if (rc) return rc;
+    }
+    r->path = path;
     return SMI_OK;
 }
 
 void resampler_destroy(Resampler *r) {
     if (!r) return;
     for (void *p : {(void *)r->A, (void *)r->Pt, (void *)r->model, (void *)r->B, (void *)r->out,
-                    (void *)r->scratch, (void *)r->At, (void *)r->P})
+                    (void *)r->scratch, (void *)r->At, (void *)r->P, (void *)r->E,
+                    (void *)r->beta, (void *)r->Wx, (void *)r->WxT, (void *)r->Mh,
+                    (void *)r->Gbar, (void *)r->sscratch})
         if (p) (void)hipFree(p);
     delete r;
 }
@@ -303,12 +613,43 @@ void resampler_destroy(Resampler *r) {
 // r->model (device, padded) -> r->out, on stream s; all bands in one launch per product
 static int resampler_forward(Resampler *r, hipStream_t s) {
     const int64_t plane = (int64_t)r->Fy * r->Fx;
+    if (r->path == 1) {
+        const int Kx = r->Kx;
+        int rc = gemm(r->model, plane, r->Wx, 0, reinterpret_cast<float *>(r->Mh),
+                      (int64_t)r->Fy * 2 * Kx, r->C, r->sscratch, r->sscratch_elems, r->Fy, 2 * Kx,
+                      r->Fx, s);
+        if (rc) return rc;
+        const size_t lds = (size_t)(16 * 64 + Kx) * sizeof(double2);
+        hipLaunchKernelGGL(spectral_forward_kernel, dim3(r->n_a, r->C), dim3(1024), lds, s, r->E,
+                           r->Mh, r->beta, r->out, r->n_a, r->n_b, r->Fy, Kx);
+        return SMI_OK;
+    }
     int rc = gemm(r->model, plane, r->Pt, 0, r->B, plane * r->n_b, r->C, r->scratch,
                   r->scratch_elems, r->Fy, r->Fx * r->n_b, r->Fx, s);
     if (rc) return rc;
     return gemm(r->A, (int64_t)r->n_a * plane, r->B, plane * r->n_b, r->out,
                 (int64_t)r->n_a * r->n_b, r->C, r->scratch, r->scratch_elems, r->n_a, r->n_b,
                 (int)plane, s);
+}
+
+// gradient of the padded bands from the weighted residual [C][n_a][n_b] (the transposed chain)
+static int resampler_adjoint(Resampler *r, const float *resid, float *gpad, hipStream_t s) {
+    const int64_t plane = (int64_t)r->Fy * r->Fx;
+    if (r->path == 1) {
+        const int Kx = r->Kx;
+        hipLaunchKernelGGL(spectral_gbar_kernel, dim3(r->C * r->n_a), dim3(256),
+                           r->n_b * sizeof(float), s, resid, r->beta, r->Gbar, r->n_b, Kx);
+        hipLaunchKernelGGL(spectral_adjoint_kernel, dim3(r->Fy, r->C), dim3(256), 0, s, r->E,
+                           r->Gbar, r->Mh, r->n_a, r->Fy, Kx);
+        return gemm(reinterpret_cast<float *>(r->Mh), (int64_t)r->Fy * 2 * Kx, r->WxT, 0, gpad,
+                    plane, r->C, r->sscratch, r->sscratch_elems, r->Fy, r->Fx, 2 * Kx, s);
+    }
+    int rc = gemm(r->At, (int64_t)r->n_a * plane, resid, (int64_t)r->n_a * r->n_b, r->B,
+                  plane * r->n_b, r->C, r->scratch, r->scratch_elems, (int)plane, r->n_b, r->n_a,
+                  s);
+    if (rc) return rc;
+    return gemm(r->B, plane * r->n_b, r->P, 0, gpad, plane, r->C, r->scratch, r->scratch_elems,
+                r->Fy, r->Fx, r->Fx * r->n_b, s);
 }
 
 int resampler_render(Resampler *r, const float *model, float *out) {
@@ -439,12 +780,6 @@ int lowres_create(Resampler *r, const int32_t *channels, const float *data, cons
     SMI_HIP(hipMemcpy(l->data, data, n * sizeof(float), hipMemcpyHostToDevice));
     SMI_HIP(hipMemcpy(l->weights, weights, n * sizeof(float), hipMemcpyHostToDevice));
     SMI_HIP(hipMemset(l->term, 0, sizeof(double)));
-    if (!r->P) {  // transposed shift operator for the adjoint
-        SMI_HIP(hipMalloc((void **)&r->P, (size_t)r->Fx * r->Fx * r->n_b * sizeof(float)));
-        launch_transpose(r->Pt, r->P, r->Fx, r->Fx * r->n_b, nullptr);
-        SMI_HIP(hipGetLastError());
-        SMI_HIP(hipDeviceSynchronize());
-    }
     return SMI_OK;
 }
 
@@ -460,11 +795,7 @@ int lowres_evaluate(LowRes *l, const float *P, int Py, int Px, int backward, hip
     hipLaunchKernelGGL(lowres_residual_kernel, dim3(1), dim3(1024), 0, s, r->out, l->data,
                        l->weights, l->resid, n, l->log_norm, l->term);
     if (!backward) return SMI_OK;
-    rc = gemm(r->At, (int64_t)r->n_a * plane, l->resid, (int64_t)r->n_a * r->n_b, r->B,
-              (int64_t)plane * r->n_b, r->C, r->scratch, r->scratch_elems, plane, r->n_b, r->n_a, s);
-    if (rc) return rc;
-    return gemm(r->B, (int64_t)plane * r->n_b, r->P, 0, l->gpad, plane, r->C, r->scratch,
-                r->scratch_elems, r->Fy, r->Fx, r->Fx * r->n_b, s);
+    return resampler_adjoint(r, l->resid, l->gpad, s);
 }
 
 void lowres_add_gradient(LowRes *l, float *Q, int Py, int Px, hipStream_t s) {

@@ -166,7 +166,8 @@ class ResolutionRenderer(Renderer):
     shifted along y to every low-resolution row (``_resconv_op``).  The per-call part --
     shifting the padded model along x to every low-resolution column and contracting
     with the operator (renderer.py:478-545) -- is linear in the model; it runs on the
-    GPU as two dense products per band (``smi_resampler_*``).  Rotated grids are not
+    GPU (``smi_resampler_*``), through transforms along x since the shift operator is
+    circulant, or as two dense products per band (``device_path``).  Rotated grids are not
     supported."""
 
     def __init__(self, data_frame, model_frame, padding=10):
@@ -268,6 +269,21 @@ class ResolutionRenderer(Renderer):
                 ctypes.byref(handle)))
             self._device = (lib, handle, (C, n_a, n_b))
         return self._device
+
+    def device_path(self, path=None):
+        """How the device evaluates the operator: 1 = through transforms along x (the shift
+        operator the reference builds is circulant), 0 = two dense products per band.
+        ``device_path(0)`` switches to the dense products (parity checks)."""
+        import ctypes
+
+        from . import _lib
+
+        lib, handle, _ = self._resampler()
+        if path is not None:
+            _lib.check(lib.smi_resampler_set_path(handle, int(path)))
+        now = ctypes.c_int32(-1)
+        _lib.check(lib.smi_resampler_get_path(handle, ctypes.byref(now)))
+        return now.value
 
     def get_model(self, *parameters):
         def transform(model, *parameters):

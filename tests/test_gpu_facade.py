@@ -1218,6 +1218,76 @@ def test_multiresolution_render_matches_the_reference():
     print("largest deviation from the reference rendering: %.2e of the peak" % worst)
 
 
+def test_spectral_and_dense_evaluation_of_the_resampling_operator_agree():
+    """The shift operator the reference builds (renderer.py:414-476: a phase ramp between a
+    real transform and its inverse on the padded grid) is circulant along x, so the library
+    evaluates A . (model . Pt) through transforms along x (path 1); the two dense products
+    per band (path 0) are the same linear map.  Renderings of fixture pairs by both paths
+    against the reference's rendering and against each other; an operator that is not
+    circulant keeps the dense products and cannot be switched."""
+    import ctypes
+
+    import scarlet_amd as scarlet
+    from conftest import golden
+    from scarlet_amd import _lib
+
+    g = golden("multiresolution")
+
+    def wcs(k):
+        w = scarlet.LinearWCS(g["crpix_%d" % k], g["crval_%d" % k], g["pc_%d" % k], g["cdelt_%d" % k])
+        w.array_shape = g["crpix_%d" % k] * 2
+        return w
+
+    worst = {0: 0.0, 1: 0.0, "between": 0.0}
+    for tag in ("1_3_union", "1_4_intersection", "2_4_intersection", "3_4_union", "0_2_union"):
+        if tag not in list(g["pairs"]):
+            continue
+        i, j, coverage = tag.split("_")
+        i, j = int(i), int(j)
+        obs_hr = scarlet.Observation(g["image_%d" % i][None], wcs=wcs(i),
+                                     psf=scarlet.ImagePSF(g["psf_%d" % i]), channels=["lr"])
+        obs_lr = scarlet.Observation(g["image_%d" % j][None], wcs=wcs(j),
+                                     psf=scarlet.ImagePSF(g["psf_%d" % j]), channels=["hr"])
+        scarlet.Frame.from_observations([obs_lr, obs_hr], obs_id=1, coverage=coverage)
+        r = obs_lr.renderer
+        assert r.device_path() == 1, tag
+        ref = g["rendered_%s" % tag]
+        out = {}
+        for path in (1, 0, 1):
+            assert r.device_path(path) == path
+            out[path] = obs_lr.render(g["image_%d" % i][None])
+            dev = np.abs(out[path] - ref).max() / np.abs(ref).max()
+            worst[path] = max(worst[path], dev)
+            assert dev < 1e-5, (tag, path)
+        between = np.abs(out[0] - out[1]).max() / np.abs(ref).max()
+        worst["between"] = max(worst["between"], between)
+        assert between < 1e-6, tag
+    print("deviation from the reference rendering: spectral %.2e, dense %.2e of the peak; "
+          "between the two %.2e" % (worst[1], worst[0], worst["between"]))
+    # a shift operator that is not circulant
+    rng = np.random.default_rng(5)
+    A = rng.normal(0, 1, (1, 5, 12 * 10)).astype(np.float32)
+    Pt = rng.normal(0, 1, (10, 10 * 7)).astype(np.float32)
+    lib = _lib.load()
+    handle = ctypes.c_void_p()
+    _lib.check(lib.smi_resampler_create(_lib.ptr(A, ctypes.c_float), _lib.ptr(Pt, ctypes.c_float),
+                                        1, 5, 7, 12, 10, ctypes.byref(handle)))
+    try:
+        path = ctypes.c_int32(-1)
+        _lib.check(lib.smi_resampler_get_path(handle, ctypes.byref(path)))
+        assert path.value == 0
+        assert lib.smi_resampler_set_path(handle, 1) != 0
+        padded = rng.normal(0, 1, (1, 12, 10)).astype(np.float32)
+        out = np.empty((1, 5, 7), np.float32)
+        _lib.check(lib.smi_resampler_render(handle, _lib.ptr(padded, ctypes.c_float),
+                                            _lib.ptr(out, ctypes.c_float)))
+        ref = np.einsum("ak,kb->ab", A[0].astype(np.float64),
+                        (padded[0].astype(np.float64) @ Pt.astype(np.float64)).reshape(120, 7))
+        assert np.abs(out[0] - ref).max() < 2e-6 * np.abs(ref).max()
+    finally:
+        lib.smi_resampler_destroy(handle)
+
+
 def _lowres_operators(lowres):
     """Dense device operators from the ORACLE's matrices (independent of the facade's
     set-up): A [C][n_a][Fy Fx], Pt [Fx][Fx n_b]."""

@@ -4,7 +4,8 @@ docs/tutorials/multiresolution.ipynb) for ``bench.py --config cfg5``:
 * forward rendering of a high-resolution image into a low-resolution observation
   (``ResolutionRenderer``; SURVEY.md 8d: "forward render only"): the fixture pair the
   survey timed on the reference (131^2 -> 78^2, 128 ms per render on one CPU core), device
-  time of the two dense products on the matrix cores against the f32 MFMA peak;
+  time through transforms along x (the operator's transforms read once: HBM roofline) and,
+  beside it, as the two dense products on the matrix cores against the f32 MFMA peak;
 * one fit of the tutorial scene (5-band 50^2 HSC cut-out + 250^2 HST cut-out, model frame
   6 x 282 x 282, four sources): iterations per second.
 
@@ -37,17 +38,31 @@ def render_pair(scarlet, g, i, j, n_rep):
     r = obs_lr.renderer
     rendered = obs_lr.render(g["image_%d" % i][None])
     lib, handle, (C, n_a, n_b) = r._resampler()
-    ms = ctypes.c_double()
     from scarlet_amd import _lib
-    _lib.check(lib.smi_resampler_time(handle, n_rep, ctypes.byref(ms)))
     Fy, Fx = r._fft_shape
-    flops = C * (2.0 * Fy * Fx * Fx * n_b + 2.0 * n_a * n_b * Fy * Fx)
+    Kx = Fx // 2 + 1
     ref = g["rendered_%d_%d_union" % (i, j)]
     err = float(np.abs(rendered - ref).max() / np.abs(ref).max())
-    return dict(ms=ms.value, flops=flops, shape=(C, n_a, n_b, int(Fy), int(Fx)), err=err)
+    path = r.device_path()
+    ms = {}
+    for p in ((1, 0) if path == 1 else (0,)):  # the dense products beside the spectral path
+        r.device_path(p)
+        obs_lr.render(g["image_%d" % i][None])
+        t = ctypes.c_double()
+        _lib.check(lib.smi_resampler_time(handle, n_rep, ctypes.byref(t)))
+        ms[p] = t.value
+    r.device_path(path)
+    # dense: two products per band.  spectral: the transform of the model rows as a product,
+    # the contraction with the operator's transforms (8 flops per complex term) and the sum
+    # over k; its HBM bytes are the operator's transforms, read once, + model in + rendering out
+    flops = C * (2.0 * Fy * Fx * Fx * n_b + 2.0 * n_a * n_b * Fy * Fx)
+    flops_spectral = C * (2.0 * Fy * Fx * 2 * Kx + 8.0 * n_a * Fy * Kx + 4.0 * n_a * n_b * Kx)
+    bytes_spectral = C * (8.0 * n_a * Fy * Kx + 4.0 * Fy * Fx + 4.0 * n_a * n_b) + 8.0 * n_b * Kx
+    return dict(path=path, ms=ms[path], ms_dense=ms[0], flops=flops, flops_spectral=flops_spectral,
+                bytes_spectral=bytes_spectral, shape=(C, n_a, n_b, int(Fy), int(Fx)), err=err)
 
 
-def tutorial_fit(scarlet, g, n_iter):
+def tutorial_fit(scarlet, g, n_iter, path=None):
     def wcs(tag, n):
         return scarlet.TanWCS(g["crpix_" + tag], g["crval_" + tag], g["pc_" + tag],
                               g["cdelt_" + tag], array_shape=(n, n))
@@ -64,6 +79,8 @@ def tutorial_fit(scarlet, g, n_iter):
     sources = [scarlet.ExtendedSource(frame, sky, observations, thresh=0.1)
                for sky in obs_hst.get_sky_coord(g["pixel_hst"])]
     scarlet.initialization.set_spectra_to_match(sources, observations)
+    if path is not None:
+        obs_hsc.renderer.device_path(path)
     scarlet.Blend(sources, observations).fit(3, e_rel=1e-9)  # operators, plans, kernels resident
     blend = scarlet.Blend(sources, observations)
     t0 = time.perf_counter()
@@ -75,7 +92,8 @@ def tutorial_fit(scarlet, g, n_iter):
     # per iteration: rendering + its transpose (two products each)
     flops = 2 * C * (2.0 * Fy * Fx * Fx * n_b + 2.0 * n_a * n_b * Fy * Fx)
     return dict(n=n, seconds=dt, frame=tuple(int(v) for v in frame.shape), logL=float(logL),
-                flops_per_iteration=flops, shape=(C, n_a, n_b, int(Fy), int(Fx)))
+                flops_per_iteration=flops, shape=(C, n_a, n_b, int(Fy), int(Fx)),
+                path=r.device_path())
 
 
 def main(args):
@@ -87,8 +105,39 @@ def main(args):
     golden = os.path.join(ROOT, "tests", "golden")
     pair = render_pair(scarlet, np.load(os.path.join(golden, "multiresolution.npz")), 0, 1,
                        max(args.steps, 10))
-    fit = tutorial_fit(scarlet, np.load(os.path.join(golden, "multires_tutorial.npz")), args.steps)
-    tflops = pair["flops"] / (pair["ms"] * 1e-3) / 1e12
+    tutorial = np.load(os.path.join(golden, "multires_tutorial.npz"))
+    fit = tutorial_fit(scarlet, tutorial, args.steps)
+    fit_dense = tutorial_fit(scarlet, tutorial, args.steps, path=0) if fit["path"] == 1 else fit
+    tflops_dense = pair["flops"] / (pair["ms_dense"] * 1e-3) / 1e12
+    dense = {
+        "what": "the same rendering as two dense products per band on the matrix cores "
+                "(smi_resampler_set_path(r, 0); the path of an operator that is not circulant)",
+        "ms_per_render": round(pair["ms_dense"], 4), "flops_per_render": pair["flops"],
+        "achieved": round(tflops_dense, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tflops_dense / F32_MFMA_PEAK_TFLOPS, 5),
+        "fit_ms_per_step": round(1e3 * fit_dense["seconds"] / fit_dense["n"], 4),
+        "fit_flops_per_iteration": fit["flops_per_iteration"],
+    }
+    if pair["path"] == 1:
+        gbs = pair["bytes_spectral"] / (pair["ms"] * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(gbs / 8000.0, 5), "traffic": None,
+            "kernel": "spectral_forward_kernel (+ gemm_mfma_kernel for the transform of the model "
+                      "rows): one ResolutionRenderer rendering through transforms along x -- the "
+                      "operator's transforms are read once (%.1f MB); three dependent launches, "
+                      "latency-bound at this size" % (pair["bytes_spectral"] / 1e6),
+            "bytes_per_render": pair["bytes_spectral"], "flops_per_render": pair["flops_spectral"],
+            "ms_per_render": round(pair["ms"], 4),
+            "dense_equivalent_tflops": round(pair["flops"] / (pair["ms"] * 1e-3) / 1e12, 2),
+            "measured": "HIP events around %d back-to-back renderings of the resident model"
+                        % max(args.steps, 10),
+            "dense_products": dense,
+        }
+    else:
+        roofline = dict(dense, bound="mfma", traffic=None,
+                        kernel="gemm_mfma_kernel (+ reduce_slices_kernel): one ResolutionRenderer "
+                               "rendering = two batched products")
     line = {
         "metric": "PGM iters/sec over batched blends; achieved HBM GB/s vs roofline",
         "value": round(fit["n"] / fit["seconds"], 1),
@@ -104,19 +153,11 @@ def main(args):
                         "convolution; Blend.fit through the facade (host hook every 10 "
                         "iterations included)" % (fit["frame"], fit["shape"]),
             "iterations": fit["n"],
+            "resampler_path": "spectral" if fit["path"] == 1 else "dense products",
             "render_pair": "fixture images 0 -> 1 (131^2 -> 78^2), operators %s, deviation "
                            "from the reference's rendering %.1e of the peak" % (pair["shape"], pair["err"]),
         },
-        "roofline": {
-            "bound": "mfma", "achieved": round(tflops, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
-            "kernel": "gemm_mfma_kernel (+ reduce_slices_kernel): one ResolutionRenderer "
-                      "rendering = two batched products",
-            "flops_per_render": pair["flops"], "ms_per_render": round(pair["ms"], 4),
-            "measured": "HIP events around %d back-to-back renderings of the resident model"
-                        % max(args.steps, 10),
-            "fit_flops_per_iteration": fit["flops_per_iteration"],
-        },
+        "roofline": roofline,
         "cpu_baseline": {
             "value": round(1e3 / 128.0, 2), "unit": "renders/s", "cores": 1, "kind": "reference",
             "sample": "the reference's own ResolutionRenderer.render on this pair, 128 ms on one "

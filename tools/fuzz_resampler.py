@@ -1,5 +1,6 @@
 """The multi-resolution operators with random sizes (non-square FFT shapes, n_a != n_b,
-sizes off the GEMM tiles) and random dense operators, GPU against NumPy in float64:
+sizes off the GEMM tiles) and random operators -- dense ones (two products per band) and circulant shift operators
+(the spectral path) in turn --, GPU against NumPy in float64:
 smi_resampler_render, and the low-resolution term's loss and gradient through
 smi_batch_attach_lowres on a NullRenderer batch.  Development aid.
 
@@ -27,11 +28,18 @@ for n in range(n_cases):
     n_a, n_b = int(rng.integers(1, 40)), int(rng.integers(1, 40))
     A = rng.normal(0, 1, (C, n_a, Fy * Fx)).astype(np.float32)
     P = rng.normal(0, 1, (Fx, n_b, Fx)).astype(np.float32)  # P[x, b, x']
+    if n % 2:  # a circulant shift operator (what the reference builds): the spectral path
+        kern = rng.normal(0, 1, (n_b, Fx)).astype(np.float32)
+        idx = (np.arange(Fx)[:, None] - np.arange(Fx)[None, :]) % Fx  # [x, x']
+        P = np.ascontiguousarray(kern[:, idx].transpose(1, 0, 2))
     Pt = np.ascontiguousarray(P.transpose(2, 0, 1).reshape(Fx, Fx * n_b))
     handle = ctypes.c_void_p()
     _lib.check(lib.smi_resampler_create(_lib.ptr(A, ctypes.c_float), _lib.ptr(Pt, ctypes.c_float),
                                         C, n_a, n_b, Fy, Fx, ctypes.byref(handle)))
-    desc = "C=%d frame %dx%d F=%dx%d n_a=%d n_b=%d" % (C, H, W, Fy, Fx, n_a, n_b)
+    path = ctypes.c_int32(-1)
+    _lib.check(lib.smi_resampler_get_path(handle, ctypes.byref(path)))
+    assert path.value == n % 2, "path %d for case %d" % (path.value, n)
+    desc = "C=%d frame %dx%d F=%dx%d n_a=%d n_b=%d path=%d" % (C, H, W, Fy, Fx, n_a, n_b, path.value)
 
     def render64(padded):
         shifted = np.einsum("cyz,xbz->cyxb", padded.astype(np.float64), P.astype(np.float64))
