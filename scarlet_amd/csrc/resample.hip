@@ -49,14 +49,14 @@ constexpr int kSliceTerms = 320; // float32 accumulation length inside a slice
 // the last 64 rows of the third tile row are not computed).  The LDS tiles are double
 // buffered: global loads of tile k + 1 are in flight during the products of tile k, their
 // LDS stores go to the other buffer, one barrier per tile.
-template <int TM, int TN>
+template <int TM, int TN, int BK = kBK>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t strideA,
                                                         const float *B, int64_t strideB,
                                                         float *C, int64_t strideC, double *Cpart,
                                                         int M, int N, int K, int kslice,
                                                         int n_slices) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    __shared__ float As[2][kBK][BM + kPad], Bs[2][kBK][BN + kPad];
+    __shared__ float As[2][BK][BM + kPad], Bs[2][BK][BN + kPad];
     const int batch = blockIdx.z / n_slices, z = blockIdx.z - batch * n_slices;
     A += batch * strideA;
     B += batch * strideB;
@@ -65,16 +65,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t 
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     const int k_lo = z * kslice, k_hi = min(K, k_lo + kslice);
 
-    // global -> registers -> LDS.  A tile: BM rows x 16 k, thread t takes k = t % 16 of
-    // the rows t / 16 + 16 q (a row's 16 floats are one 64-byte segment); B tile: 16 k x
-    // BN columns, thread t takes column t % BN of the rows t / BN + (256 / BN) q.
-    constexpr int QA = BM / 16, QB = BN / 16, RB = 256 / BN;
-    const int a_k = tid & 15, a_r = tid >> 4, b_n = tid % BN, b_k = tid / BN;
+    // global -> registers -> LDS.  A tile: BM rows x BK k, thread t takes k = t % BK of
+    // the rows t / BK + (256 / BK) q (a row's BK floats are one 64- or 128-byte segment); B
+    // tile: BK k x BN columns, thread t takes column t % BN of the rows t / BN + (256 / BN) q.
+    constexpr int RA = 256 / BK, QA = BM / RA, RB = 256 / BN, QB = BK / RB;
+    const int a_k = tid % BK, a_r = tid / BK, b_n = tid % BN, b_k = tid / BN;
     float ra[QA], rb[QB];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
-            const int m = m0 + a_r + 16 * q, k = k0 + a_k;
+            const int m = m0 + a_r + RA * q, k = k0 + a_k;
             ra[q] = (m < M && k < k_hi) ? A[(int64_t)m * K + k] : 0.f;
         }
 #pragma unroll
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t 
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < QA; ++q) As[buf][a_k][a_r + 16 * q] = ra[q];
+        for (int q = 0; q < QA; ++q) As[buf][a_k][a_r + RA * q] = ra[q];
 #pragma unroll
         for (int q = 0; q < QB; ++q) Bs[buf][b_k + RB * q][b_n] = rb[q];
     };
@@ -112,16 +112,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float *A, int64_t 
     stage(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = k_lo; k0 < k_hi; k0 += kBK) {
-        const bool more = k0 + kBK < k_hi;
-        if (more) fetch(k0 + kBK);  // in flight during the products
+    for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
+        const bool more = k0 + BK < k_hi;
+        if (more) fetch(k0 + BK);  // in flight during the products
         // operand layout of v_mfma_f32_32x32x2_f32: lane l holds A[i = l & 31][k = l >> 5]
         // and B[k = l >> 5][j = l & 31]
         if (any) {
             const int kk = lane >> 5, ij = lane & 31;
             auto products = [&](auto all_on) {
 #pragma unroll
-                for (int ks = 0; ks < kBK; ks += 2) {
+                for (int ks = 0; ks < BK; ks += 2) {
                     float a[TM], b[TN];
 #pragma unroll
                     for (int i = 0; i < TM; ++i) a[i] = As[buf][ks + kk][wm + 32 * i + ij];
@@ -209,7 +209,8 @@ int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float
     };
     // (a product of a few hundred rows and columns -- the transforms of the spectral path --
     // is 45 workgroups in 128 x 128 tiles and 125 in 64 x 64 tiles)
-    if (n_tiles(tm, tn) * std::max(1, (K + kSliceTerms - 1) / kSliceTerms) < 200) tm = tn = 1;
+    const bool few = n_tiles(tm, tn) * std::max(1, (K + kSliceTerms - 1) / kSliceTerms) < 200;
+    if (few) tm = tn = 1;
     const int bm = 64 * tm, bn = 64 * tn;
     const int tiles = n_tiles(tm, tn);
     // slices of ~kSliceTerms terms (float32 accumulation length); fewer when the tiles
@@ -230,7 +231,12 @@ int gemm(const float *A, int64_t strideA, const float *B, int64_t strideB, float
 #define SMI_GEMM(TM, TN)                                                                         \
     hipLaunchKernelGGL((gemm_mfma_kernel<TM, TN>), grid, dim3(256), 0, s, A, strideA, B, strideB, \
                        C, strideC, part, M, N, K, kslice, n_slices)
-    if (tm == 1 && tn == 1) SMI_GEMM(1, 1);
+    // (a workgroup alone on its CU waits for every k-tile's loads: twice the depth per tile
+    // where the grid does not fill the chip)
+    if (few)
+        hipLaunchKernelGGL((gemm_mfma_kernel<1, 1, 2 * kBK>), grid, dim3(256), 0, s, A, strideA, B,
+                           strideB, C, strideC, part, M, N, K, kslice, n_slices);
+    else if (tm == 1 && tn == 1) SMI_GEMM(1, 1);
     else if (tm == 1) SMI_GEMM(1, 2);
     else if (tn == 1) SMI_GEMM(2, 1);
     else SMI_GEMM(2, 2);

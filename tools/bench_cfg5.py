@@ -149,8 +149,8 @@ def main(args):
         "config": {
             "workload": "configs[4]: multi-resolution tutorial scene, 1 blend, model frame %s, "
                         "5-band 50x50 observation through a ResolutionRenderer (operators "
-                        "C, n_a, n_b, Fy, Fx = %s) + 250x250 observation through the fused "
-                        "convolution; Blend.fit through the facade (host hook every 10 "
+                        "C, n_a, n_b, Fy, Fx = %s) + 250x250 observation through the rocFFT "
+                        "convolution (a frame beyond the fused kernel's 160^2); Blend.fit through the facade (host hook every 10 "
                         "iterations included)" % (fit["frame"], fit["shape"]),
             "iterations": fit["n"],
             "resampler_path": "spectral" if fit["path"] == 1 else "dense products",
