@@ -357,6 +357,57 @@ def test_multiresolution_frames_and_renderer_setup():
         assert obs_lr.renderer._resconv_op.shape == (1, n_lr, int(np.prod(g["fft_shape_%s" % tag])))
 
 
+def test_the_reference_shift_operator_is_circulant_and_the_spectral_form_is_the_same_map():
+    """What the library's spectral evaluation of the resampling operator rests on
+    (resample.hip): the x-shift the reference applies to the padded model
+    (renderer.py:414-476) is a circulant matrix, and with transforms along x Parseval's
+    identity gives A . (model . Pt) and its transpose exactly.  Host operators of a fixture
+    pair, float64 NumPy; no GPU."""
+    g = golden("multiresolution")
+
+    def wcs(k):
+        w = scarlet.LinearWCS(g["crpix_%d" % k], g["crval_%d" % k], g["pc_%d" % k], g["cdelt_%d" % k])
+        w.array_shape = g["crpix_%d" % k] * 2
+        return w
+
+    i, j = 1, 4
+    obs_hr = scarlet.Observation(g["image_%d" % i][None], wcs=wcs(i),
+                                 psf=scarlet.ImagePSF(g["psf_%d" % i]), channels=["lr"])
+    obs_lr = scarlet.Observation(g["image_%d" % j][None], wcs=wcs(j),
+                                 psf=scarlet.ImagePSF(g["psf_%d" % j]), channels=["hr"])
+    scarlet.Frame.from_observations([obs_lr, obs_hr], obs_id=1, coverage="intersection")
+    r = obs_lr.renderer
+    Fy, Fx = r._fft_shape
+    n_b = r.other_shifts.shape[1]
+    P = r._shift_along(np.eye(Fx)[None], -r.other_shifts[1], axis=2)[0]  # [x', x, b]
+    kern = P[0]  # s_b[x] = P[0, x, b]
+    idx = (np.arange(Fx)[None, :] - np.arange(Fx)[:, None]) % Fx  # [x', x] -> (x - x') mod Fx
+    assert np.abs(P - kern[idx]).max() < 1e-14 * np.abs(P).max()
+    P32 = P.astype(np.float32)
+    assert np.array_equal(P32, P32[0][idx])  # what smi_resampler_create checks
+    A = r._resconv_op[0].reshape(-1, Fy, Fx).astype(np.float64)
+    rng = np.random.default_rng(3)
+    model = np.zeros((Fy, Fx))
+    model[10:70, 25:90] = rng.random((60, 65))
+    dense = np.einsum("ayx,yxb->ab", A, np.einsum("yp,pxb->yxb", model, P))
+    Kx = Fx // 2 + 1
+    w = np.full(Kx, 2.0)
+    w[0] = 1.0
+    if Fx % 2 == 0:
+        w[-1] = 1.0
+    E = np.fft.rfft(A, axis=2)
+    beta = w * np.fft.rfft(kern, axis=0).T / Fx  # [b, k]
+    G = np.einsum("ayk,yk->ak", np.conj(E), np.fft.rfft(model, axis=1))
+    assert np.abs(np.real(G @ beta.T) - dense).max() < 1e-12 * np.abs(dense).max()
+    # the transposed chain
+    resid = rng.normal(size=dense.shape)
+    g_dense = np.einsum("ab,ayx,pxb->yp", resid, A, P)
+    Mbar = np.einsum("ak,ayk->yk", resid @ np.conj(beta), E)
+    W = np.exp(-2j * np.pi * np.outer(np.arange(Fx), np.arange(Kx)) / Fx)
+    g_spec = Mbar.real @ W.real.T + Mbar.imag @ W.imag.T
+    assert np.abs(g_spec - g_dense).max() < 1e-12 * np.abs(g_dense).max()
+
+
 def test_tan_wcs_matches_astropy():
     """Gnomonic WCS against astropy's conversions (golden: the two cut-outs of the
     multi-resolution tutorial, whose reference pixels lie 1800 to 30000 pixels outside the
