@@ -4,7 +4,7 @@ sizes off the GEMM tiles) and random operators -- dense ones (two products per b
 smi_resampler_render, and the low-resolution term's loss and gradient through
 smi_batch_attach_lowres on a NullRenderer batch.  Development aid.
 
-    python tools/fuzz_resampler.py [n_cases] [seed]
+    python tools/fuzz_resampler.py [n_cases] [seed]      (FUZZ_BIG=1: frames of 100 .. 260 pixels)
 """
 import ctypes
 import os
@@ -26,6 +26,11 @@ for n in range(n_cases):
     H, W = int(rng.integers(8, 70)), int(rng.integers(8, 70))
     Fy, Fx = H + int(rng.integers(0, 30)), W + int(rng.integers(0, 30))
     n_a, n_b = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    if os.environ.get("FUZZ_BIG"):  # several 64-lane chunks of k, more than 64 columns b
+        C = 1
+        H, W = int(rng.integers(100, 220)), int(rng.integers(130, 260))
+        Fy, Fx = H + int(rng.integers(0, 40)), W + int(rng.integers(0, 40))
+        n_a, n_b = int(rng.integers(30, 110)), int(rng.integers(50, 90))
     A = rng.normal(0, 1, (C, n_a, Fy * Fx)).astype(np.float32)
     P = rng.normal(0, 1, (Fx, n_b, Fx)).astype(np.float32)  # P[x, b, x']
     if n % 2:  # a circulant shift operator (what the reference builds): the spectral path
@@ -58,17 +63,21 @@ for n in range(n_cases):
         Cm = C + 1  # one model channel the low-resolution observation does not see
         channels = sorted(rng.choice(Cm, C, replace=False).tolist())
         sed = rng.uniform(0.5, 2, Cm).astype(np.float32)
-        morph = rng.random((H, W)).astype(np.float32)
+        # (a component box the update kernels hold in LDS: the whole frame up to 70 pixels)
+        bh, bw = min(H, 70), min(W, 70)
+        oy, ox = int(rng.integers(0, H - bh + 1)), int(rng.integers(0, W - bw + 1))
+        morph = rng.random((bh, bw)).astype(np.float32)
         data = rng.normal(0, 1, (C, n_a, n_b)).astype(np.float32)
         weights = rng.uniform(0.5, 2, (C, n_a, n_b)).astype(np.float32)
         weights[rng.random(weights.shape) < 0.1] = 0
         batch = BlendBatch(np.zeros((1, Cm, H, W), np.float32), np.zeros((1, Cm, H, W), np.float32),
-                           [[ComponentSpec(sed, morph, (0, 0), prox_flags=0)]], kernel=None, max_iter=2)
+                           [[ComponentSpec(sed, morph, (oy, ox), prox_flags=0)]], kernel=None, max_iter=2)
         batch.attach_lowres(handle, channels, data, weights, 1.25)
         _, _, logL = batch.forward()
         g_sed, g_morph = batch.gradient()
         batch.close()
-        model = sed[:, None, None].astype(np.float64) * morph[None].astype(np.float64)
+        model = np.zeros((Cm, H, W))
+        model[:, oy:oy + bh, ox:ox + bw] = sed[:, None, None].astype(np.float64) * morph[None].astype(np.float64)
         y0, x0 = (Fy - H + 1) // 2, (Fx - W + 1) // 2
         pad = np.zeros((C, Fy, Fx))
         pad[:, y0:y0 + H, x0:x0 + W] = model[channels]
@@ -78,6 +87,7 @@ for n in range(n_cases):
         gpad = np.einsum("cyxb,xbz->cyz", back, P.astype(np.float64))
         G = np.zeros((Cm, H, W))
         G[channels] = gpad[:, y0:y0 + H, x0:x0 + W]
+        G = G[:, oy:oy + bh, ox:ox + bw]
         ref_sed = np.einsum("cyx,yx->c", G, morph)
         ref_morph = np.einsum("c,cyx->yx", sed, G)
         dev["loss"] = abs(-logL[0] - loss) / abs(loss)
