@@ -172,8 +172,9 @@ def init_source(frame, center, observations, thresh=1, max_components=1, min_com
 
 # Detection images of a scene's sources, swept in one launch ahead of the loop over the sources
 # (``prepare_detection_sweeps``): key -> (pixel spectra, coadd, coadd rms, symmetrised
-# profile, the same profile made monotonic about the source's pixel).  ``SingleExtendedSource``
-# looks its centre up here before it computes them itself.
+# profile, the same profile made monotonic about the source's pixel, the trimming threshold the
+# swept profile is good for -- None: any).  ``SingleExtendedSource`` looks its centre up here
+# before it computes them itself.
 _prepared = {}
 
 
@@ -185,13 +186,28 @@ def _prepared_key(sky_coord, observations):
     return coord + tuple(id(obs) for obs in observations)
 
 
-def prepare_detection_sweeps(frame, centers, observations):
+# Half-width of the window about a source's pixel in which its detection image is swept first
+# (prepare_detection_sweeps); frames that are not much larger are swept whole.
+SWEEP_WINDOW = 32
+
+
+def prepare_detection_sweeps(frame, centers, observations, thresh=None):
     """What every ``SingleExtendedSource`` of the scene starts from -- the spectrum-weighted
     coadd about its centre, symmetrised and made monotonic (source.py:312-333) -- for ALL
     centres at once: the host part per centre, then ONE launch of the monotonic sweep for all
     of them (``operator.prox_weighted_monotonic_many``) instead of a host -> GPU -> host round
     trip per source.  Same arithmetic, same bits as the per-source path; centres the
-    preparation cannot serve (outside the frame, a failing pixel spectrum) are left to it."""
+    preparation cannot serve (outside the frame, a failing pixel spectrum) are left to it.
+
+    With ``thresh`` (the caller's trimming threshold) the sweep runs in a window of
+    ``2 SWEEP_WINDOW + 1`` pixels about the centre first.  The sweep bounds a pixel by the mean
+    of its neighbours CLOSER to the centre ('flat' weights, no minimal gradient), and every
+    closer neighbour of a pixel of a centred square lies in the square: inside the window the
+    result is the full frame's, bit for bit, and every pixel outside is at most the largest
+    value on the window's rim.  If that is at or below the smallest trimming threshold of the
+    frame, ``trim_morphology`` zeroes everything outside whatever its value: the window's sweep
+    IS the source's profile (tables of 65^2 instead of the frame's pixels, the same for every
+    centre away from the border).  Otherwise the centre is swept on the whole frame."""
     from . import operator
 
     observations = _as_tuple(observations)
@@ -213,15 +229,50 @@ def prepare_detection_sweeps(frame, centers, observations):
         rows.append((key, per_obs, coadd, coadd_rms, pixel, np.ascontiguousarray(profile)))
     if not rows:
         return 0
-    by_shape = {}
-    for r in rows:
-        by_shape.setdefault((r[5].shape, r[5].dtype.str), []).append(r)
-    for group in by_shape.values():
-        swept = np.stack([r[5] for r in group])
-        operator.prox_weighted_monotonic_many(swept, [tuple(int(v) for v in r[4]) for r in group],
-                                              neighbor_weight="flat", min_gradient=0)
-        for r, out in zip(group, swept):
-            _prepared[r[0]] = (r[1], r[2], r[3], r[5], out)
+
+    def sweep(images_and_centres):
+        """[(image, centre)] -> the swept images, one launch per image shape"""
+        out = [None] * len(images_and_centres)
+        by_shape = {}
+        for n, (image, _) in enumerate(images_and_centres):
+            by_shape.setdefault((image.shape, image.dtype.str), []).append(n)
+        for group in by_shape.values():
+            swept = np.stack([images_and_centres[n][0] for n in group])
+            operator.prox_weighted_monotonic_many(
+                swept, [tuple(int(v) for v in images_and_centres[n][1]) for n in group],
+                neighbor_weight="flat", min_gradient=0)
+            for n, image in zip(group, swept):
+                out[n] = image
+        return out
+
+    R = SWEEP_WINDOW
+    H, W = rows[0][5].shape
+    windowed = thresh is not None and thresh >= 0 and max(H, W) > 2 * R + 1 + R // 2
+    whole = list(range(len(rows)))
+    if windowed:
+        cuts = []
+        for r in rows:
+            py, px = int(r[4][0]), int(r[4][1])
+            y0, y1, x0, x1 = max(py - R, 0), min(py + R + 1, H), max(px - R, 0), min(px + R + 1, W)
+            cuts.append((y0, y1, x0, x1))
+        swept = sweep([(np.ascontiguousarray(r[5][y0:y1, x0:x1]), (r[4][0] - y0, r[4][1] - x0))
+                       for r, (y0, y1, x0, x1) in zip(rows, cuts)])
+        whole = []
+        for n, (r, (y0, y1, x0, x1), win) in enumerate(zip(rows, cuts, swept)):
+            rim = [edge for cut, edge in ((y0 > 0, win[0]), (y1 < H, win[-1]),
+                                          (x0 > 0, win[:, 0]), (x1 < W, win[:, -1])) if cut]
+            floor = thresh * float(np.min(r[3]))  # smallest trimming threshold of the frame
+            if rim and not max(float(np.max(e)) for e in rim) <= floor:
+                whole.append(n)  # (NaNs land here too)
+                continue
+            full = np.zeros_like(r[5])
+            full[y0:y1, x0:x1] = win
+            _prepared[r[0]] = (r[1], r[2], r[3], r[5], full, thresh)
+    if whole:
+        swept = sweep([(rows[n][5].copy(), rows[n][4]) for n in whole])
+        for n, out in zip(whole, swept):
+            r = rows[n]
+            _prepared[r[0]] = (r[1], r[2], r[3], r[5], out, None)
     return len(rows)
 
 
@@ -242,7 +293,7 @@ def init_all_sources(frame, centers, observations, thresh=1, max_components=1,
     try:
         # (all sources' detection images through the monotonic sweep in one launch)
         if max_components > 0 and len(centers) > 1:
-            prepare_detection_sweeps(frame, centers, observations)
+            prepare_detection_sweeps(frame, centers, observations, thresh=thresh)
         return _init_all_sources(frame, centers, observations, thresh, max_components,
                                  min_components, min_snr, shifting, resizing, boxsize, fallback,
                                  silent, set_spectra)

@@ -138,6 +138,9 @@ def _native_sweep(X, weights, offsets, didx, min_gradient):
     return X
 
 
+_MANY_TABLES = {}
+
+
 def prox_weighted_monotonic_many(images, centers, neighbor_weight="flat", min_gradient=0.1):
     """``prox_weighted_monotonic(shape, neighbor_weight, min_gradient, center=centers[i])``
     applied to ``images[i]`` for every i, in ONE launch through the C ABI
@@ -164,8 +167,17 @@ def prox_weighted_monotonic_many(images, centers, neighbor_weight="flat", min_gr
     weights = np.empty((n, 8, h * w), dtype=images.dtype)
     didx = np.empty((n, h * w - 1), dtype=np.int32)
     for i, center in enumerate(centers):
-        weights[i] = getRadialMonotonicWeights(shape, neighbor_weight=neighbor_weight, center=center)
-        didx[i] = sort_by_radius(shape, center)[1:]
+        # (windows about sources away from the border share one shape and one centre)
+        key = (shape, neighbor_weight, (int(center[0]), int(center[1])), images.dtype.str)
+        tables = _MANY_TABLES.get(key)
+        if tables is None:
+            tables = (getRadialMonotonicWeights(shape, neighbor_weight=neighbor_weight,
+                                                center=center).astype(images.dtype),
+                      sort_by_radius(shape, center)[1:].astype(np.int32))
+            if len(_MANY_TABLES) >= 32:
+                _MANY_TABLES.clear()
+            _MANY_TABLES[key] = tables
+        weights[i], didx[i] = tables
     off = _lib.i32(getOffsets(w)[0])
     _lib.check(fn(n, _lib.ptr(images, ct), h * w, _lib.ptr(weights, ct),
                   _lib.ptr(off, _lib.ctypes.c_int32), off.size,

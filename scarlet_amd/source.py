@@ -107,7 +107,9 @@ class SingleExtendedSource(FactorizedComponent):
         # (init_all_sources sweeps the detection images of all its sources in one launch)
         ready = init.prepared_detection(sky_coord, observations)
         if ready is not None:
-            per_obs, coadd, coadd_rms, symmetrised, swept = ready
+            per_obs, coadd, coadd_rms, symmetrised, swept, good_for = ready
+            if good_for is not None and not thresh >= good_for:
+                swept = None  # (swept in a window that a lower threshold may look beyond)
         else:
             per_obs = init.get_pixel_spectrum(sky_coord, observations, concat=False)
             coadd, coadd_rms = init.build_initialization_image(observations, spectra=per_obs)

@@ -208,6 +208,58 @@ def test_initialisation_sweeps_all_detection_images_in_one_launch(hsc, monkeypat
             assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
 
 
+def test_initialisation_sweeps_windows_about_the_sources_and_gives_the_same_sources(monkeypatch):
+    """On a frame much larger than the sources (the benchmark's 128^2 scenes) the prepared
+    sweep runs in a 65^2 window about every source's pixel (initialization.SWEEP_WINDOW): the
+    result inside is the full frame's bit for bit and what lies outside is below the trimming
+    threshold, so the sources equal those of the per-source path (whole-frame sweeps) exactly.
+    With a window of 7^2 pixels the rim lies inside the sources and fails the test: those
+    centres are swept whole, in a second launch, with the same sources again."""
+    import scarlet_amd as scarlet
+    from scarlet_amd import initialization, operator, synthetic
+
+    kern = synthetic.psfs()
+    channels = list("grizy")
+    many = operator.prox_weighted_monotonic_many
+    for seed in (1234, 1237):
+        s = synthetic.make_blend(seed, kernel=kern)
+        frame = scarlet.Frame((5, synthetic.H, synthetic.W),
+                              psf=scarlet.GaussianPSF(sigma=(synthetic.SIGMA_MODEL,) * 5), channels=channels)
+        obs = scarlet.Observation(s["data"], psf=scarlet.ImagePSF(np.repeat(kern[0], 5, axis=0)),
+                                  weights=s["weights"], channels=channels).match(frame)
+        centers = [(float(o[0] + m.shape[0] // 2), float(o[1] + m.shape[1] // 2))
+                   for o, m in zip(s["origins"], s["morphs"])]
+        for thresh, half in ((1, 32), (1, 3)):
+            monkeypatch.setattr(initialization, "SWEEP_WINDOW", half)
+            shapes = []
+
+            def record(images, *a, **k):
+                shapes.append(images.shape)
+                return many(images, *a, **k)
+
+            monkeypatch.setattr(operator, "prox_weighted_monotonic_many", record)
+            batched, _ = initialization.init_all_sources(frame, centers, obs, max_components=1,
+                                                         min_snr=50, thresh=thresh, silent=True,
+                                                         set_spectra=False)
+            monkeypatch.setattr(operator, "prox_weighted_monotonic_many", many)
+            side = 2 * initialization.SWEEP_WINDOW + 1
+            assert shapes and all(max(sh[1:]) <= side for sh in shapes if sh[1:] != (synthetic.H, synthetic.W))
+            whole = sum(sh[0] for sh in shapes if sh[1:] == (synthetic.H, synthetic.W))
+            if half == 32:
+                assert whole < len(centers), "no source of the scene was served by its window"
+            else:
+                assert whole == len(centers)
+            single = [initialization.init_source(frame, c, obs, thresh=thresh, max_components=1,
+                                                 min_snr=50) for c in centers]
+            a_comps = components_of(scarlet.Blend(batched, obs))
+            b_comps = components_of(scarlet.Blend(single, obs))
+            assert len(a_comps) == len(b_comps)
+            for a, b in zip(a_comps, b_comps):
+                assert a.children[1].bbox == b.children[1].bbox
+                for p, q in zip(a.parameters, b.parameters):
+                    assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
+
+
 def test_two_observations_equal_one(hsc):
     """the same scene observed as (g,r,i) and (z,y) by two Observations gives the same
     fit as the single 5-band Observation (loss summed over observations, blend.py:265-271)"""
