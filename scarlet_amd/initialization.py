@@ -191,6 +191,47 @@ def _prepared_key(sky_coord, observations):
 SWEEP_WINDOW = 32
 
 
+def _window(pixel, shape):
+    R = SWEEP_WINDOW
+    py, px = int(pixel[0]), int(pixel[1])
+    return max(py - R, 0), min(py + R + 1, shape[0]), max(px - R, 0), min(px + R + 1, shape[1])
+
+
+def _window_pays(shape, thresh):
+    R = SWEEP_WINDOW
+    return thresh is not None and thresh >= 0 and max(shape) > 2 * R + 1 + R // 2
+
+
+def _rim_below(win, cut, shape, floor):
+    """The largest value on the sides of the window that have frame beyond them is at or
+    below ``floor`` (NaNs: no)."""
+    y0, y1, x0, x1 = cut
+    rim = [edge for beyond, edge in ((y0 > 0, win[0]), (y1 < shape[0], win[-1]),
+                                     (x0 > 0, win[:, 0]), (x1 < shape[1], win[:, -1])) if beyond]
+    return not rim or max(float(np.max(e)) for e in rim) <= floor
+
+
+def sweep_in_window(profile, pixel, thresh, detect_std):
+    """One image through the windowed sweep of ``prepare_detection_sweeps`` ('flat' weights,
+    no minimal gradient): the swept profile with zeros outside the window, or None where the
+    window does not pay or its rim is brighter than the smallest trimming threshold."""
+    from . import operator
+
+    if not _window_pays(profile.shape, thresh):
+        return None
+    if not (0 <= pixel[0] < profile.shape[0] and 0 <= pixel[1] < profile.shape[1]):
+        return None
+    cut = y0, y1, x0, x1 = _window(pixel, profile.shape)
+    win = np.ascontiguousarray(profile[y0:y1, x0:x1])[None]
+    operator.prox_weighted_monotonic_many(win, [(int(pixel[0]) - y0, int(pixel[1]) - x0)],
+                                          neighbor_weight="flat", min_gradient=0)
+    if not _rim_below(win[0], cut, profile.shape, thresh * float(np.min(detect_std))):
+        return None
+    full = np.zeros_like(profile)
+    full[y0:y1, x0:x1] = win[0]
+    return full
+
+
 def prepare_detection_sweeps(frame, centers, observations, thresh=None):
     """What every ``SingleExtendedSource`` of the scene starts from -- the spectrum-weighted
     coadd about its centre, symmetrised and made monotonic (source.py:312-333) -- for ALL
@@ -245,28 +286,20 @@ def prepare_detection_sweeps(frame, centers, observations, thresh=None):
                 out[n] = image
         return out
 
-    R = SWEEP_WINDOW
-    H, W = rows[0][5].shape
-    windowed = thresh is not None and thresh >= 0 and max(H, W) > 2 * R + 1 + R // 2
+    shape = rows[0][5].shape
     whole = list(range(len(rows)))
-    if windowed:
-        cuts = []
-        for r in rows:
-            py, px = int(r[4][0]), int(r[4][1])
-            y0, y1, x0, x1 = max(py - R, 0), min(py + R + 1, H), max(px - R, 0), min(px + R + 1, W)
-            cuts.append((y0, y1, x0, x1))
+    if _window_pays(shape, thresh):
+        cuts = [_window(r[4], shape) for r in rows]
         swept = sweep([(np.ascontiguousarray(r[5][y0:y1, x0:x1]), (r[4][0] - y0, r[4][1] - x0))
                        for r, (y0, y1, x0, x1) in zip(rows, cuts)])
         whole = []
-        for n, (r, (y0, y1, x0, x1), win) in enumerate(zip(rows, cuts, swept)):
-            rim = [edge for cut, edge in ((y0 > 0, win[0]), (y1 < H, win[-1]),
-                                          (x0 > 0, win[:, 0]), (x1 < W, win[:, -1])) if cut]
-            floor = thresh * float(np.min(r[3]))  # smallest trimming threshold of the frame
-            if rim and not max(float(np.max(e)) for e in rim) <= floor:
-                whole.append(n)  # (NaNs land here too)
+        for n, (r, cut, win) in enumerate(zip(rows, cuts, swept)):
+            # (floor: the smallest trimming threshold of the frame)
+            if not _rim_below(win, cut, shape, thresh * float(np.min(r[3]))):
+                whole.append(n)
                 continue
             full = np.zeros_like(r[5])
-            full[y0:y1, x0:x1] = win
+            full[cut[0]:cut[1], cut[2]:cut[3]] = win
             _prepared[r[0]] = (r[1], r[2], r[3], r[5], full, thresh)
     if whole:
         swept = sweep([(rows[n][5].copy(), rows[n][4]) for n in whole])

@@ -141,9 +141,17 @@ class SingleExtendedSource(FactorizedComponent):
                                                             algorithm="sdss")
             if monotonic:
                 weights = "angle" if monotonic is True else monotonic
-                sweep = operator.prox_weighted_monotonic(profile.shape, neighbor_weight=weights,
-                                                         center=pixel, min_gradient=min_grad)
-                profile = sweep(np.ascontiguousarray(profile), 0).reshape(profile.shape)
+                windowed = None
+                if weights == "flat" and min_grad == 0:
+                    # (a window about the pixel where its rim proves the rest lies below the
+                    # trimming threshold: initialization.prepare_detection_sweeps)
+                    windowed = init.sweep_in_window(profile, pixel, thresh, detect_std)
+                if windowed is not None:
+                    profile = windowed
+                else:
+                    sweep = operator.prox_weighted_monotonic(profile.shape, neighbor_weight=weights,
+                                                             center=pixel, min_gradient=min_grad)
+                    profile = sweep(np.ascontiguousarray(profile), 0).reshape(profile.shape)
         image, bbox = init.trim_morphology(pixel, profile, bg_thresh=detect_std * thresh,
                                            boxsize=boxsize)
         if image.sum() > 0:

@@ -249,15 +249,21 @@ def test_initialisation_sweeps_windows_about_the_sources_and_gives_the_same_sour
                 assert whole < len(centers), "no source of the scene was served by its window"
             else:
                 assert whole == len(centers)
-            single = [initialization.init_source(frame, c, obs, thresh=thresh, max_components=1,
-                                                 min_snr=50) for c in centers]
-            a_comps = components_of(scarlet.Blend(batched, obs))
-            b_comps = components_of(scarlet.Blend(single, obs))
-            assert len(a_comps) == len(b_comps)
-            for a, b in zip(a_comps, b_comps):
-                assert a.children[1].bbox == b.children[1].bbox
-                for p, q in zip(a.parameters, b.parameters):
-                    assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
+            # the sources one by one: through the same window logic, and swept whole
+            one_by_one = [initialization.init_source(frame, c, obs, thresh=thresh, max_components=1,
+                                                     min_snr=50) for c in centers]
+            with monkeypatch.context() as m:
+                m.setattr(initialization, "sweep_in_window", lambda *a, **k: None)
+                whole_frame = [initialization.init_source(frame, c, obs, thresh=thresh,
+                                                          max_components=1, min_snr=50) for c in centers]
+            b_comps = components_of(scarlet.Blend(whole_frame, obs))
+            for other in (batched, one_by_one):
+                a_comps = components_of(scarlet.Blend(other, obs))
+                assert len(a_comps) == len(b_comps)
+                for a, b in zip(a_comps, b_comps):
+                    assert a.children[1].bbox == b.children[1].bbox
+                    for p, q in zip(a.parameters, b.parameters):
+                        assert_allclose(np.asarray(p), np.asarray(q), rtol=0, atol=0)
 
 
 def test_two_observations_equal_one(hsc):
